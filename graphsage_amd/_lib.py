@@ -1,0 +1,121 @@
+"""ctypes binding of libgraphsage_amd.so (the C ABI declared in include/graphsage_amd.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a kernel reports an
+error, a GraphsageAmdError is raised.  torch is used only as the owner of device memory.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_C", "libgraphsage_amd.so")
+
+ACT_IDENTITY = 0
+ACT_RELU = 1
+
+
+class GraphsageAmdError(RuntimeError):
+    pass
+
+
+_P = c_void_p  # every device pointer crosses the boundary as void*
+
+# name -> (argtypes) ; every function returns int except gs_last_error / gs_abi_version
+_PROTOS = {
+    "gs_device_info": [POINTER(c_int), POINTER(c_int), ctypes.c_char_p, c_int],
+    "gs_sample_padded": [_P, c_int64, c_int32, _P, c_int64, _P, c_int32, _P, _P],
+    "gs_sample_uniform_csr": [_P, _P, c_int64, c_int32, _P, c_int64, c_int32, c_uint64, c_uint64, _P, c_uint32,
+                              c_int64, _P, _P],
+    "gs_select_batch": [_P, c_int64, _P, c_int64, _P, _P],
+    "gs_advance_counter": [_P, c_uint64, _P],
+    "gs_gather_rows": [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
+    "gs_gather_mean_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P],
+    "gs_mean_bwd": [_P, c_int64, c_int64, c_int32, c_int32, c_float, _P, c_int64, _P, c_int64, c_int, _P],
+    "gs_sage_dense_fwd": [_P, c_int64, _P, c_int32, _P, c_int64, _P, c_int32, c_int64, _P, c_int64, _P, c_int64,
+                          c_int32, c_int, c_int, _P, _P, c_int64, _P],
+    "gs_dense_wgrad": [_P, c_int64, _P, c_int32, _P, c_int64, c_int32, c_int32, c_int64, c_int32, _P, c_int64, _P],
+    "gs_dense_dgrad": [_P, c_int64, c_int32, c_int32, c_int64, _P, c_int64, c_int32, _P, c_int64, c_int, _P],
+    "gs_act_bwd": [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P],
+    "gs_colsum_slabs": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P],
+    "gs_gemm_f32": [c_int, c_int, c_int64, c_int32, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int, _P, c_int64, _P],
+    "gs_segment_max_fwd": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P],
+    "gs_segment_max_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P],
+    "gs_l2norm_fwd": [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P],
+    "gs_l2norm_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
+    "gs_class_loss": [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int, _P, _P, c_int64, _P, c_int64, _P],
+    "gs_reduce_slabs": [_P, c_int32, c_int64, c_int32, c_int32, c_int64, c_float, _P, c_int64, _P, c_int64, c_int, _P],
+    "gs_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P],
+    "gs_sum_scaled": [_P, c_int64, c_float, _P, c_int, _P],
+    "gs_sumsq_scaled": [_P, c_int64, c_float, _P, c_int, _P],
+    "gs_stream_create": [POINTER(c_void_p)],
+    "gs_stream_destroy": [_P],
+    "gs_stream_sync": [_P],
+    "gs_capture_begin": [_P],
+    "gs_capture_end": [_P, POINTER(c_void_p)],
+    "gs_graph_launch": [_P, _P],
+    "gs_graph_destroy": [_P],
+    "gs_event_create": [POINTER(c_void_p)],
+    "gs_event_record": [_P, _P],
+    "gs_event_elapsed_ms": [_P, _P, POINTER(c_float)],
+    "gs_event_destroy": [_P],
+    "gs_build_csr_host": [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int64, POINTER(c_int64)],
+}
+
+EXPORTED_SYMBOLS = sorted(list(_PROTOS.keys()) + ["gs_last_error", "gs_abi_version"])
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Load (building first if hipcc is available and the sources changed) and return the CDLL."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception as e:  # no hipcc on this box: fall through to the prebuilt library check
+            if not os.path.exists(LIB_PATH):
+                raise GraphsageAmdError("libgraphsage_amd.so is missing and could not be built: %s" % e)
+    if not os.path.exists(LIB_PATH):
+        raise GraphsageAmdError("HIP extension not found at %s (run python -m graphsage_amd.build)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.gs_last_error.restype = c_char_p
+    lib.gs_last_error.argtypes = []
+    lib.gs_abi_version.restype = c_int
+    lib.gs_abi_version.argtypes = []
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gs_last_error()
+        raise GraphsageAmdError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Refuses CPU tensors: no CPU fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GraphsageAmdError("graphsage_amd kernels need device (HIP) tensors; got a CPU tensor")
+    return t.data_ptr()
+
+
+def host_ptr(a):
+    """Pointer of a contiguous numpy array (host-side entry points only)."""
+    if a is None:
+        return None
+    return a.ctypes.data

@@ -1,0 +1,173 @@
+// K2: feature-row gather fused with the segmented mean (HBM-bound; the roofline-defining kernel).
+//
+// Work decomposition: one WAVE per (output row, 64-float4 column chunk).  The s neighbor ids of the
+// row are loaded once by lanes 0..s-1 and broadcast through v_readlane (SGPR row base + per-lane
+// 16-byte column offset), so every neighbor row is fetched as full 1-KiB wave loads = 8 whole
+// 128-byte lines when the table's leading dimension is a multiple of 32 floats (F=602 -> ld=608).
+// U independent 16-B loads per lane are issued before the first add (>= 8 KiB in flight per wave,
+// >= 32 waves per CU), the [n*s, d] gathered tensor of models.py:299 never exists.
+// Summation order is j = 0..s-1, fixed => results are deterministic run to run.
+#include "gs_common.h"
+
+__device__ __forceinline__ f32x4 gs_mask_tail(f32x4 v, int col, int d) {
+    // zero the elements at logical column >= d (only the last float4 of a row can be partial)
+    if (col + 3 >= d) {
+        if (col + 0 >= d) v.x = 0.f;
+        if (col + 1 >= d) v.y = 0.f;
+        if (col + 2 >= d) v.z = 0.f;
+        if (col + 3 >= d) v.w = 0.f;
+    }
+    return v;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restrict__ X, int64_t ldx,
+                                                          const int32_t* __restrict__ idx, int64_t n, int32_t s,
+                                                          int32_t d, const float* __restrict__ S, int64_t lds_,
+                                                          const int32_t* __restrict__ sidx, float* __restrict__ out,
+                                                          int64_t ldo, float scale, int32_t chunks) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_items = n * (int64_t)chunks;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_items) return;  // wave-uniform
+    const int64_t row = w / chunks;
+    const int c = (int)(w - row * chunks);
+    const int col = (c * 64 + lane) * 4;
+    const bool active = col < d;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int jb = 0; jb < s; jb += 64) {
+        const int cnt = min(64, s - jb);  // uniform
+        int32_t my = 0;
+        if (lane < cnt) my = idx ? idx[row * s + jb + lane] : (int32_t)(row * s + jb + lane);
+        if (active) {
+            int j = 0;
+            for (; j + U <= cnt; j += U) {
+                f32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int32_t r = __builtin_amdgcn_readlane(my, j + u);
+                    v[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + col);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc += v[u];
+            }
+            if (j < cnt) {
+                // remainder batch: load everything (index clamped), select afterwards -- keeps the
+                // loads unconditional so they stay in flight together.
+                f32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = min(j + u, cnt - 1);
+                    const int32_t r = __builtin_amdgcn_readlane(my, jj);
+                    v[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + col);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float m = (j + u < cnt) ? 1.f : 0.f;
+                    acc += v[u] * m;
+                }
+            }
+        }
+    }
+    if (active) {
+        if (S) {
+            const int64_t sr = sidx ? (int64_t)sidx[row] : row;
+            acc += *reinterpret_cast<const f32x4*>(S + sr * lds_ + col);
+        }
+        acc *= scale;
+        acc = gs_mask_tail(acc, col, d);
+        *reinterpret_cast<f32x4*>(out + row * ldo + col) = acc;
+    }
+}
+
+static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
+                              const float* S, int64_t ld_self, const int32_t* sidx, float* out, int64_t ldo,
+                              float scale, hipStream_t st) {
+    const int d4 = (d + 3) / 4;
+    const int chunks = (d4 + 63) / 64;
+    const int64_t n_items = n * (int64_t)chunks;
+    const int64_t blocks = gs_ceil_div(n_items, 4);
+    GS_REQUIRE(blocks < (1ll << 31), "gather: grid too large (%lld blocks)", (long long)blocks);
+    if (s >= 8)
+        hipLaunchKernelGGL(gather_mean_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, idx, n, s, d, S,
+                           ld_self, sidx, out, ldo, scale, chunks);
+    else if (s >= 4)
+        hipLaunchKernelGGL(gather_mean_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, idx, n, s, d, S,
+                           ld_self, sidx, out, ldo, scale, chunks);
+    else
+        hipLaunchKernelGGL(gather_mean_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, idx, n, s, d, S,
+                           ld_self, sidx, out, ldo, scale, chunks);
+    GS_LAUNCH_CHECK("gather_mean_kernel");
+    return GS_OK;
+}
+
+extern "C" int gs_gather_mean_fwd(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
+                                  const float* self_src, int64_t ld_self, const int32_t* self_idx, float* mean,
+                                  int64_t ldm, void* stream) {
+    GS_CHECK_MAT(X, ldx, "gs_gather_mean_fwd X");
+    GS_CHECK_MAT(mean, ldm, "gs_gather_mean_fwd mean");
+    GS_REQUIRE(n >= 0 && s > 0 && d > 0, "gs_gather_mean_fwd: bad sizes n=%lld s=%d d=%d", (long long)n, s, d);
+    const int d4x4 = ((d + 3) / 4) * 4;
+    GS_REQUIRE(ldx >= d4x4 && ldm >= d4x4, "gs_gather_mean_fwd: ld must be >= round_up(d,4)");
+    if (self_src) {
+        GS_CHECK_MAT(self_src, ld_self, "gs_gather_mean_fwd self");
+        GS_REQUIRE(ld_self >= d4x4, "gs_gather_mean_fwd: ld_self must be >= round_up(d,4)");
+    }
+    GS_REQUIRE(n * (int64_t)s < (1ll << 31) || idx, "gs_gather_mean_fwd: contiguous mode needs n*s < 2^31");
+    if (n == 0) return GS_OK;
+    const float scale = self_src ? 1.0f / (float)(s + 1) : 1.0f / (float)s;
+    return launch_gather_mean(X, ldx, idx, n, s, d, self_src, ld_self, self_idx, mean, ldm, scale,
+                              (hipStream_t)stream);
+}
+
+extern "C" int gs_gather_rows(const float* X, int64_t ldx, const int32_t* ids, int64_t n, int32_t d, float* out,
+                              int64_t ldo, void* stream) {
+    GS_CHECK_MAT(X, ldx, "gs_gather_rows X");
+    GS_CHECK_MAT(out, ldo, "gs_gather_rows out");
+    GS_REQUIRE(ids && n >= 0 && d > 0, "gs_gather_rows: bad args");
+    const int d4x4 = ((d + 3) / 4) * 4;
+    GS_REQUIRE(ldx >= d4x4 && ldo >= d4x4, "gs_gather_rows: ld must be >= round_up(d,4)");
+    if (n == 0) return GS_OK;
+    return launch_gather_mean(X, ldx, ids, n, 1, d, nullptr, 0, nullptr, out, ldo, 1.0f, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ backward of the segmented mean
+__global__ __launch_bounds__(256) void mean_bwd_kernel(const float* __restrict__ d_mean, int64_t ldd, int64_t rows,
+                                                       int32_t s, int32_t d, float scale,
+                                                       const float* __restrict__ mask_y, int64_t ldy,
+                                                       float* __restrict__ d_neigh, int64_t ldn, int accumulate) {
+    const int d4 = (d + 3) / 4;
+    const int64_t total = rows * (int64_t)d4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / d4;
+        const int col = (int)(t - r * d4) * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(d_mean + (r / s) * ldd + col) * scale;
+        if (mask_y) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(mask_y + r * ldy + col);
+            g.x = y.x > 0.f ? g.x : 0.f;
+            g.y = y.y > 0.f ? g.y : 0.f;
+            g.z = y.z > 0.f ? g.z : 0.f;
+            g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(d_neigh + r * ldn + col);
+        if (accumulate) g += *dst;
+        *dst = gs_mask_tail(g, col, d);
+    }
+}
+
+extern "C" int gs_mean_bwd(const float* d_mean, int64_t ldd, int64_t n, int32_t s, int32_t d, float scale,
+                           const float* mask_y, int64_t ldy, float* d_neigh, int64_t ldn, int accumulate,
+                           void* stream) {
+    GS_CHECK_MAT(d_mean, ldd, "gs_mean_bwd d_mean");
+    GS_CHECK_MAT(d_neigh, ldn, "gs_mean_bwd d_neigh");
+    if (mask_y) GS_CHECK_MAT(mask_y, ldy, "gs_mean_bwd mask_y");
+    GS_REQUIRE(n >= 0 && s > 0 && d > 0, "gs_mean_bwd: bad sizes");
+    if (n == 0) return GS_OK;
+    const int64_t total = n * (int64_t)s * ((d + 3) / 4);
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(mean_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_mean, ldd, n * (int64_t)s,
+                       s, d, scale, mask_y, ldy, d_neigh, ldn, accumulate);
+    GS_LAUNCH_CHECK("mean_bwd_kernel");
+    return GS_OK;
+}

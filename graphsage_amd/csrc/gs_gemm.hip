@@ -1,0 +1,458 @@
+// K3 / K4 / K6: fp32 dense contractions on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32:
+// a k-ordered fmaf chain, so results stay inside the 1e-4 parity budget without any bf16 split).
+//
+// One kernel template covers every contraction on the hot path:
+//   NN  out = self·W            forward            A k-contiguous,  B n-contiguous
+//   TN  dW  = A^T·dZ            weight gradient    A m-contiguous (row-gathered over k),  B n-contiguous
+//   NT  dX  = dZ·W^T            input gradient     A k-contiguous,  B k-contiguous
+// Both operands are staged through LDS as DIRECT float4 copies of the global tile (no transposes):
+//   k-contiguous source  -> LDS [row][32+4]  read back with one ds_read_b128 per 4 k-steps
+//   row-contiguous source-> LDS [32][rows]   read back with ds_read_b32 (lanes = consecutive rows)
+// The MFMA consumes k in the order (k0 + 4*(lane>>5) + i): A and B use the same permutation of the
+// 8-wide k group, which only re-orders the fp32 summation.
+// Block = 256 threads = 4 waves (2x2), block tile BM x BN (64x64 or 128x128), BK = 32, register
+// prefetch of the next tile overlaps the MFMAs.  blockIdx -> tile mapping is XCD-aware: the tiles that
+// share an A row panel run on the same XCD (same L2).  Up to two (A, B, K) terms per launch give the
+// SAGE "[self·W_self || mean·W_neigh]" (concat) or "self·W_self + mean·W_neigh" (add) in ONE kernel,
+// with bias + relu fused in the epilogue.  Split-K writes per-slice slabs (deterministic, no atomics).
+#include "gs_common.h"
+
+struct GemmTerm {
+    const float* A;
+    const int32_t* a_idx;  // gathers source rows of A (nullable)
+    const float* B;
+    int64_t lda, ldb;
+    int32_t K;
+};
+
+struct GemmArgs {
+    GemmTerm t[2];
+    int32_t nterms;  // 1 or 2
+    int32_t concat;  // nterms == 2: 1 -> term i writes columns [i*N, (i+1)*N), 0 -> terms are summed
+    int64_t M;
+    int32_t N;  // columns per term
+    float* C;
+    int64_t ldc;
+    int64_t slab_stride;  // elements between split-K slabs
+    int32_t kchunk;       // K range per blockIdx.z slice (multiple of 32); 0 -> whole K
+    const float* bias;    // indexed by output column (global column incl. concat offset)
+    int32_t act;
+    int32_t accumulate;  // C += result (before act; only with act == identity)
+    int32_t tiles_m, tiles_n;  // tiles_n is per term
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
+    constexpr int BK = 32;
+    constexpr int KP = BK + 4;  // padded k stride for k-contiguous tiles (conflict-free ds_read_b128)
+    constexpr int PA = BM / 32;  // float4 loads per thread per stage
+    constexpr int PB = BN / 32;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AS_FLOATS = A_KC ? BM * KP : BK * BM;
+    constexpr int BS_FLOATS = B_KC ? BN * KP : BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[AS_FLOATS + BS_FLOATS];
+    float* As = smem;
+    float* Bs = smem + AS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- XCD-aware tile id: consecutive tile ids (same A row panel) stay on one XCD
+    const int nwg = gridDim.x;
+    int wgid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, local = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tiles_n_total = g.tiles_n * ((g.nterms == 2 && g.concat) ? 2 : 1);
+    const int tile_m = wgid / tiles_n_total;
+    int tile_n = wgid - tile_m * tiles_n_total;
+    int term0 = 0, term1 = g.nterms;
+    int col_off = 0;
+    if (g.nterms == 2 && g.concat) {
+        term0 = tile_n / g.tiles_n;
+        term1 = term0 + 1;
+        tile_n -= term0 * g.tiles_n;
+        col_off = term0 * g.N;
+    }
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int term = term0; term < term1; ++term) {
+        const GemmTerm T = g.t[term];
+        int k_begin = 0, k_end = T.K;
+        if (g.kchunk > 0) {
+            k_begin = min((int64_t)blockIdx.z * g.kchunk, (int64_t)T.K);
+            k_end = min(k_begin + g.kchunk, T.K);
+        }
+        if (k_begin >= k_end) continue;
+
+        // ---- per-thread source pointers that do not depend on k (k-contiguous operands)
+        const float* a_row[PA];
+        bool a_ok[PA];
+        if constexpr (A_KC) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int64_t r = m0 + p * 32 + (tid >> 3);
+                a_ok[p] = r < g.M;
+                const int64_t src = a_ok[p] ? (T.a_idx ? (int64_t)T.a_idx[r] : r) : 0;
+                a_row[p] = T.A + src * T.lda + (tid & 7) * 4;
+            }
+        }
+        const float* b_row[PB];
+        bool b_ok[PB];
+        if constexpr (B_KC) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int r = n0 + p * 32 + (tid >> 3);
+                b_ok[p] = r < g.N;
+                b_row[p] = T.B + (int64_t)(b_ok[p] ? r : 0) * T.ldb + (tid & 7) * 4;
+            }
+        }
+
+        f32x4 ra[PA], rb[PB];
+        auto load_tiles = [&](int k0) {
+            // ---------------- A
+            if constexpr (A_KC) {
+                const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (a_ok[p] && k < k_end) {
+                        v = *reinterpret_cast<const f32x4*>(a_row[p] + k0);
+                        if (k + 3 >= k_end) {
+                            if (k + 1 >= k_end) v.y = 0.f;
+                            if (k + 2 >= k_end) v.z = 0.f;
+                            if (k + 3 >= k_end) v.w = 0.f;
+                        }
+                    }
+                    ra[p] = v;
+                }
+            } else {
+                constexpr int UPR = BM / 4;  // float4 units per k-row
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const int u = p * 256 + tid;
+                    const int kk = u / UPR;
+                    const int64_t r = m0 + (u - kk * UPR) * 4;
+                    const int k = k0 + kk;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (k < k_end && r < g.M) {
+                        const int64_t src = T.a_idx ? (int64_t)T.a_idx[k] : (int64_t)k;
+                        v = *reinterpret_cast<const f32x4*>(T.A + src * T.lda + r);
+                        if (r + 3 >= g.M) {
+                            if (r + 1 >= g.M) v.y = 0.f;
+                            if (r + 2 >= g.M) v.z = 0.f;
+                            if (r + 3 >= g.M) v.w = 0.f;
+                        }
+                    }
+                    ra[p] = v;
+                }
+            }
+            // ---------------- B
+            if constexpr (B_KC) {
+                const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+                for (int p = 0; p < PB; ++p) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (b_ok[p] && k < k_end) {
+                        v = *reinterpret_cast<const f32x4*>(b_row[p] + k0);
+                        if (k + 3 >= k_end) {
+                            if (k + 1 >= k_end) v.y = 0.f;
+                            if (k + 2 >= k_end) v.z = 0.f;
+                            if (k + 3 >= k_end) v.w = 0.f;
+                        }
+                    }
+                    rb[p] = v;
+                }
+            } else {
+                constexpr int UPR = BN / 4;
+#pragma unroll
+                for (int p = 0; p < PB; ++p) {
+                    const int u = p * 256 + tid;
+                    const int kk = u / UPR;
+                    const int r = n0 + (u - kk * UPR) * 4;
+                    const int k = k0 + kk;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (k < k_end && r < g.N) {
+                        v = *reinterpret_cast<const f32x4*>(T.B + (int64_t)k * T.ldb + r);
+                        if (r + 3 >= g.N) {
+                            if (r + 1 >= g.N) v.y = 0.f;
+                            if (r + 2 >= g.N) v.z = 0.f;
+                            if (r + 3 >= g.N) v.w = 0.f;
+                        }
+                    }
+                    rb[p] = v;
+                }
+            }
+        };
+        auto store_tiles = [&]() {
+            if constexpr (A_KC) {
+#pragma unroll
+                for (int p = 0; p < PA; ++p)
+                    *reinterpret_cast<f32x4*>(&As[(p * 32 + (tid >> 3)) * KP + (tid & 7) * 4]) = ra[p];
+            } else {
+                constexpr int UPR = BM / 4;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    const int u = p * 256 + tid;
+                    const int kk = u / UPR;
+                    *reinterpret_cast<f32x4*>(&As[kk * BM + (u - kk * UPR) * 4]) = ra[p];
+                }
+            }
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int p = 0; p < PB; ++p)
+                    *reinterpret_cast<f32x4*>(&Bs[(p * 32 + (tid >> 3)) * KP + (tid & 7) * 4]) = rb[p];
+            } else {
+                constexpr int UPR = BN / 4;
+#pragma unroll
+                for (int p = 0; p < PB; ++p) {
+                    const int u = p * 256 + tid;
+                    const int kk = u / UPR;
+                    *reinterpret_cast<f32x4*>(&Bs[kk * BN + (u - kk * UPR) * 4]) = rb[p];
+                }
+            }
+        };
+
+        load_tiles(k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            __syncthreads();  // everyone finished reading the previous stage
+            store_tiles();
+            __syncthreads();
+            if (k0 + BK < k_end) load_tiles(k0 + BK);  // in flight under the MFMAs below
+#pragma unroll
+            for (int gk = 0; gk < BK / 8; ++gk) {
+                float a[TM][4], b[TN][4];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int row = wm * (BM / 2) + tm * 32 + l31;
+                    if constexpr (A_KC) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&As[row * KP + gk * 8 + lh * 4]);
+                        a[tm][0] = v.x; a[tm][1] = v.y; a[tm][2] = v.z; a[tm][3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[tm][i] = As[(gk * 8 + lh * 4 + i) * BM + row];
+                    }
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = wn * (BN / 2) + tn * 32 + l31;
+                    if constexpr (B_KC) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[col * KP + gk * 8 + lh * 4]);
+                        b[tn][0] = v.x; b[tn][1] = v.y; b[tn][2] = v.z; b[tn][3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) b[tn][i] = Bs[(gk * 8 + lh * 4 + i) * BN + col];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i], acc[tm][tn], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // LDS is reused by the next term
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float* C = g.C + (g.kchunk > 0 ? (int64_t)blockIdx.z * g.slab_stride : 0);
+    const int n_total = g.N * ((g.nterms == 2 && g.concat) ? 2 : 1);
+    const int n_pad = (n_total + 3) & ~3;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * (BN / 2) + tn * 32 + l31;
+            const int gcol = col_off + col;
+            const bool col_ok = col < g.N;
+            const bool pad_col = !col_ok && (term1 == g.nterms) && gcol >= n_total && gcol < n_pad;
+            const float bv = (g.bias && col_ok) ? g.bias[gcol] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm * (BM / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row < g.M) {
+                    if (col_ok) {
+                        float v = acc[tm][tn][e] + bv;
+                        float* dst = C + row * g.ldc + gcol;
+                        if (g.accumulate) v += *dst;
+                        if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                        *dst = v;
+                    } else if (pad_col && g.kchunk == 0) {
+                        C[row * g.ldc + gcol] = 0.f;
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+template <int BM, int BN, bool A_KC, bool B_KC>
+static int launch_gemm(GemmArgs& g, int nz, hipStream_t st) {
+    g.tiles_m = (int)gs_ceil_div(g.M, BM);
+    g.tiles_n = (int)gs_ceil_div(g.N, BN);
+    const int64_t nblk = (int64_t)g.tiles_m * g.tiles_n * ((g.nterms == 2 && g.concat) ? 2 : 1);
+    GS_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm: bad grid (%lld tiles)", (long long)nblk);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, A_KC, B_KC>), dim3((unsigned)nblk, 1, (unsigned)nz), dim3(256), 0, st, g);
+    GS_LAUNCH_CHECK("gemm_f32_mfma_kernel");
+    return GS_OK;
+}
+
+template <bool A_KC, bool B_KC>
+static int dispatch_gemm(GemmArgs& g, int nz, hipStream_t st) {
+    // Large problems (>= 1024 128x128 tiles) use the 128x128 tile (2x2 MFMA tiles per wave, 4x the
+    // arithmetic intensity per LDS byte); everything else uses 64x64 to put >= 256 workgroups on the chip.
+    const int64_t big_tiles = gs_ceil_div(g.M, 128) * gs_ceil_div(g.N, 128) * ((g.nterms == 2 && g.concat) ? 2 : 1) * nz;
+    if (big_tiles >= 1024) return launch_gemm<128, 128, A_KC, B_KC>(g, nz, st);
+    return launch_gemm<64, 64, A_KC, B_KC>(g, nz, st);
+}
+
+static inline int rup4(int x) { return (x + 3) & ~3; }
+
+extern "C" int gs_gemm_f32(int transA, int transB, int64_t M, int32_t N, int64_t K, const float* A, int64_t lda,
+                           const int32_t* a_row_idx, const float* B, int64_t ldb, const float* bias, int act,
+                           float* C, int64_t ldc, void* stream) {
+    GS_CHECK_MAT(A, lda, "gs_gemm_f32 A");
+    GS_CHECK_MAT(B, ldb, "gs_gemm_f32 B");
+    GS_CHECK_MAT(C, ldc, "gs_gemm_f32 C");
+    GS_REQUIRE(M >= 0 && N > 0 && K > 0 && K < (1ll << 31), "gs_gemm_f32: bad sizes");
+    GS_REQUIRE(lda >= rup4(transA ? (int)M : (int)K) && ldb >= rup4(transB ? (int)K : N) && ldc >= rup4(N),
+               "gs_gemm_f32: leading dimensions must be >= round_up(width, 4)");
+    if (M == 0) return GS_OK;
+    GemmArgs g = {};
+    g.t[0] = GemmTerm{A, a_row_idx, B, lda, ldb, (int32_t)K};
+    g.nterms = 1;
+    g.M = M; g.N = N; g.C = C; g.ldc = ldc; g.bias = bias; g.act = act;
+    hipStream_t st = (hipStream_t)stream;
+    if (!transA && !transB) return dispatch_gemm<true, false>(g, 1, st);
+    if (transA && !transB) return dispatch_gemm<false, false>(g, 1, st);
+    if (!transA && transB) return dispatch_gemm<true, true>(g, 1, st);
+    return dispatch_gemm<false, true>(g, 1, st);
+}
+
+extern "C" int gs_sage_dense_fwd(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self,
+                                 const float* agg, int64_t ld_agg, const int32_t* agg_idx, int32_t d_agg, int64_t n,
+                                 const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
+                                 int32_t out_dim, int concat, int act, const float* bias, float* out, int64_t ldo,
+                                 void* stream) {
+    GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd agg");
+    GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_fwd W_neigh");
+    GS_CHECK_MAT(out, ldo, "gs_sage_dense_fwd out");
+    GS_REQUIRE(n >= 0 && d_agg > 0 && out_dim > 0, "gs_sage_dense_fwd: bad sizes");
+    GS_REQUIRE(ld_agg >= rup4(d_agg) && ldw_neigh >= rup4(out_dim), "gs_sage_dense_fwd: ld too small");
+    if (self) {
+        GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd self");
+        GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd W_self");
+        GS_REQUIRE(d_self > 0 && ld_self >= rup4(d_self) && ldw_self >= rup4(out_dim), "gs_sage_dense_fwd: self ld too small");
+        if (concat) GS_REQUIRE(out_dim % 4 == 0, "gs_sage_dense_fwd: concat needs out_dim %% 4 == 0 (got %d)", out_dim);
+    }
+    const int n_total = out_dim * ((self && concat) ? 2 : 1);
+    GS_REQUIRE(ldo >= rup4(n_total), "gs_sage_dense_fwd: ldo too small");
+    if (n == 0) return GS_OK;
+    GemmArgs g = {};
+    if (self) {
+        g.t[0] = GemmTerm{self, self_idx, W_self, ld_self, ldw_self, d_self};
+        g.t[1] = GemmTerm{agg, agg_idx, W_neigh, ld_agg, ldw_neigh, d_agg};
+        g.nterms = 2;
+        g.concat = concat ? 1 : 0;
+    } else {
+        g.t[0] = GemmTerm{agg, agg_idx, W_neigh, ld_agg, ldw_neigh, d_agg};
+        g.nterms = 1;
+    }
+    g.M = n; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
+    return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx, int32_t d, const float* dZ,
+                              int64_t ldz, int32_t col0, int32_t out_dim, int64_t n, int32_t n_slabs, float* slabs,
+                              int64_t ld_slab, void* stream) {
+    GS_CHECK_MAT(A, lda, "gs_dense_wgrad A");
+    GS_CHECK_MAT(dZ, ldz, "gs_dense_wgrad dZ");
+    GS_CHECK_MAT(slabs, ld_slab, "gs_dense_wgrad slabs");
+    GS_REQUIRE(d > 0 && out_dim > 0 && n > 0 && n < (1ll << 31) && n_slabs > 0 && n_slabs < 65536, "gs_dense_wgrad: bad sizes");
+    GS_REQUIRE(col0 >= 0 && col0 % 4 == 0, "gs_dense_wgrad: col0 must be a multiple of 4");
+    GS_REQUIRE(lda >= rup4(d) && ldz >= col0 + rup4(out_dim) && ld_slab >= rup4(out_dim), "gs_dense_wgrad: ld too small");
+    GemmArgs g = {};
+    g.t[0] = GemmTerm{A, a_idx, dZ + col0, lda, ldz, (int32_t)n};
+    g.nterms = 1;
+    g.M = d; g.N = out_dim; g.C = slabs; g.ldc = ld_slab;
+    g.slab_stride = (int64_t)d * ld_slab;
+    g.kchunk = (int32_t)(gs_ceil_div(gs_ceil_div(n, n_slabs), 32) * 32);
+    g.act = GS_ACT_IDENTITY;
+    return launch_gemm<64, 64, false, false>(g, n_slabs, (hipStream_t)stream);
+}
+
+extern "C" int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n, const float* W,
+                              int64_t ldw, int32_t d, float* dX, int64_t ldx, int accumulate, void* stream) {
+    GS_CHECK_MAT(dZ, ldz, "gs_dense_dgrad dZ");
+    GS_CHECK_MAT(W, ldw, "gs_dense_dgrad W");
+    GS_CHECK_MAT(dX, ldx, "gs_dense_dgrad dX");
+    GS_REQUIRE(d > 0 && out_dim > 0 && n >= 0, "gs_dense_dgrad: bad sizes");
+    GS_REQUIRE(col0 >= 0 && col0 % 4 == 0, "gs_dense_dgrad: col0 must be a multiple of 4");
+    GS_REQUIRE(ldz >= col0 + rup4(out_dim) && ldw >= rup4(out_dim) && ldx >= rup4(d), "gs_dense_dgrad: ld too small");
+    if (n == 0) return GS_OK;
+    GemmArgs g = {};
+    g.t[0] = GemmTerm{dZ + col0, nullptr, W, ldz, ldw, out_dim};
+    g.nterms = 1;
+    g.M = n; g.N = d; g.C = dX; g.ldc = ldx;
+    g.act = GS_ACT_IDENTITY;
+    g.accumulate = accumulate ? 1 : 0;
+    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------- elementwise helpers
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                      const float* __restrict__ Y, int64_t ldy, int64_t n,
+                                                      int32_t n_cols, int act, float* __restrict__ dZ, int64_t lddz) {
+    const int c4 = (n_cols + 3) / 4;
+    const int64_t total = n * (int64_t)c4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / c4;
+        const int col = (int)(t - r * c4) * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dY + r * lddy + col);
+        if (act == GS_ACT_RELU) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(Y + r * ldy + col);
+            g.x = y.x > 0.f ? g.x : 0.f;
+            g.y = y.y > 0.f ? g.y : 0.f;
+            g.z = y.z > 0.f ? g.z : 0.f;
+            g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        if (col + 3 >= n_cols) {
+            if (col + 1 >= n_cols) g.y = 0.f;
+            if (col + 2 >= n_cols) g.z = 0.f;
+            if (col + 3 >= n_cols) g.w = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dZ + r * lddz + col) = g;
+    }
+}
+
+extern "C" int gs_act_bwd(const float* dY, int64_t lddy, const float* Y, int64_t ldy, int64_t n, int32_t n_cols,
+                          int act, float* dZ, int64_t lddz, void* stream) {
+    GS_CHECK_MAT(dY, lddy, "gs_act_bwd dY");
+    GS_CHECK_MAT(dZ, lddz, "gs_act_bwd dZ");
+    if (act == GS_ACT_RELU) GS_CHECK_MAT(Y, ldy, "gs_act_bwd Y");
+    GS_REQUIRE(n >= 0 && n_cols > 0, "gs_act_bwd: bad sizes");
+    if (n == 0) return GS_OK;
+    const int64_t total = n * (int64_t)((n_cols + 3) / 4);
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dY, lddy, Y, ldy, n, n_cols, act,
+                       dZ, lddz);
+    GS_LAUNCH_CHECK("act_bwd_kernel");
+    return GS_OK;
+}

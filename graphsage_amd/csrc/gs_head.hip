@@ -1,0 +1,229 @@
+// K4 (segment max) and K5 (supervised head: l2-normalise, classification losses).  All small,
+// elementwise / row-reduction kernels: one wave per row for the reductions, float4 lanes elsewhere.
+#include "gs_common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------ segment max
+__global__ __launch_bounds__(256) void segment_max_fwd_kernel(const float* __restrict__ H, int64_t ldh, int64_t n,
+                                                              int32_t s, int32_t hidden, float* __restrict__ pooled,
+                                                              int64_t ldp, int32_t* __restrict__ argmax, int64_t lda) {
+    const int c4 = (hidden + 3) / 4;
+    const int64_t total = n * (int64_t)c4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / c4;
+        const int col = (int)(t - i * c4) * 4;
+        const float* base = H + i * s * ldh + col;
+        f32x4 best = *reinterpret_cast<const f32x4*>(base);
+        int ax = 0, ay = 0, az = 0, aw = 0;
+        for (int j = 1; j < s; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)j * ldh);
+            if (v.x > best.x) { best.x = v.x; ax = j; }
+            if (v.y > best.y) { best.y = v.y; ay = j; }
+            if (v.z > best.z) { best.z = v.z; az = j; }
+            if (v.w > best.w) { best.w = v.w; aw = j; }
+        }
+        if (col + 1 >= hidden) best.y = 0.f;
+        if (col + 2 >= hidden) best.z = 0.f;
+        if (col + 3 >= hidden) best.w = 0.f;
+        *reinterpret_cast<f32x4*>(pooled + i * ldp + col) = best;
+        int32_t* a = argmax + i * lda + col;
+        a[0] = ax;
+        if (col + 1 < hidden) a[1] = ay;
+        if (col + 2 < hidden) a[2] = az;
+        if (col + 3 < hidden) a[3] = aw;
+    }
+}
+
+extern "C" int gs_segment_max_fwd(const float* H, int64_t ldh, int64_t n, int32_t s, int32_t hidden, float* pooled,
+                                  int64_t ldp, int32_t* argmax, int64_t lda, void* stream) {
+    GS_CHECK_MAT(H, ldh, "gs_segment_max_fwd H");
+    GS_CHECK_MAT(pooled, ldp, "gs_segment_max_fwd pooled");
+    GS_REQUIRE(argmax && n >= 0 && s > 0 && hidden > 0 && lda >= hidden, "gs_segment_max_fwd: bad args");
+    if (n == 0) return GS_OK;
+    const int64_t total = n * (int64_t)((hidden + 3) / 4);
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(segment_max_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, H, ldh, n, s, hidden,
+                       pooled, ldp, argmax, lda);
+    GS_LAUNCH_CHECK("segment_max_fwd_kernel");
+    return GS_OK;
+}
+
+__global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __restrict__ d_pooled, int64_t ldd,
+                                                              const float* __restrict__ pooled, int64_t ldp,
+                                                              const int32_t* __restrict__ argmax, int64_t lda,
+                                                              int64_t rows, int32_t s, int32_t hidden,
+                                                              float* __restrict__ dH, int64_t ldh) {
+    const int c4 = (hidden + 3) / 4;
+    const int64_t total = rows * (int64_t)c4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / c4;
+        const int col = (int)(t - r * c4) * 4;
+        const int64_t i = r / s;
+        const int j = (int)(r - i * s);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (col + e < hidden) {
+                const bool hit = argmax[i * lda + col + e] == j && pooled[i * ldp + col + e] > 0.f;
+                g[e] = hit ? d_pooled[i * ldd + col + e] : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(dH + r * ldh + col) = g;
+    }
+}
+
+extern "C" int gs_segment_max_bwd(const float* d_pooled, int64_t ldd, const float* pooled, int64_t ldp,
+                                  const int32_t* argmax, int64_t lda, int64_t n, int32_t s, int32_t hidden, float* dH,
+                                  int64_t ldh, void* stream) {
+    GS_CHECK_MAT(dH, ldh, "gs_segment_max_bwd dH");
+    GS_REQUIRE(d_pooled && pooled && argmax && n >= 0 && s > 0 && hidden > 0, "gs_segment_max_bwd: bad args");
+    if (n == 0) return GS_OK;
+    const int64_t total = n * (int64_t)s * ((hidden + 3) / 4);
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 8192);
+    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_pooled, ldd, pooled, ldp,
+                       argmax, lda, n * (int64_t)s, s, hidden, dH, ldh);
+    GS_LAUNCH_CHECK("segment_max_bwd_kernel");
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------ l2 normalise
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int32_t d,
+                                                         float* __restrict__ y, int64_t ldy, float* __restrict__ inv_norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float v = x[r * ldx + c];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));  // tf.nn.l2_normalize epsilon
+    const int dp = (d + 3) & ~3;
+    for (int c = lane; c < dp; c += 64) y[r * ldy + c] = c < d ? x[r * ldx + c] * inv : 0.f;
+    if (lane == 0 && inv_norm) inv_norm[r] = inv;
+}
+
+extern "C" int gs_l2norm_fwd(const float* x, int64_t ldx, int64_t n, int32_t d, float* y, int64_t ldy, float* inv_norm,
+                             void* stream) {
+    GS_REQUIRE(x && y && n >= 0 && d > 0 && ldx >= d && ldy >= ((d + 3) & ~3), "gs_l2norm_fwd: bad args");
+    if (n == 0) return GS_OK;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)gs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, d,
+                       y, ldy, inv_norm);
+    GS_LAUNCH_CHECK("l2norm_fwd_kernel");
+    return GS_OK;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                         const float* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ inv_norm, int64_t n, int32_t d,
+                                                         float* __restrict__ dx, int64_t lddx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) dot += dy[r * lddy + c] * y[r * ldy + c];
+    dot = wave_sum(dot);
+    const float inv = inv_norm[r];
+    const bool clamped = inv >= 1.0e6f;  // sum(x^2) < 1e-12: y = x * 1e6, no normalisation term
+    const int dp = (d + 3) & ~3;
+    for (int c = lane; c < dp; c += 64) {
+        float g = 0.f;
+        if (c < d) {
+            const float dyv = dy[r * lddy + c];
+            g = clamped ? dyv * inv : inv * (dyv - y[r * ldy + c] * dot);
+        }
+        dx[r * lddx + c] = g;
+    }
+}
+
+extern "C" int gs_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* inv_norm, int64_t n,
+                             int32_t d, float* dx, int64_t lddx, void* stream) {
+    GS_REQUIRE(dy && y && inv_norm && dx && n >= 0 && d > 0 && lddx >= ((d + 3) & ~3), "gs_l2norm_bwd: bad args");
+    if (n == 0) return GS_OK;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)gs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y,
+                       ldy, inv_norm, n, d, dx, lddx);
+    GS_LAUNCH_CHECK("l2norm_bwd_kernel");
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------ classification loss
+__global__ __launch_bounds__(256) void class_loss_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                         const float* __restrict__ labels, int64_t ldlab, int64_t n,
+                                                         int32_t C, int sigmoid_loss, float* __restrict__ loss_rows,
+                                                         float* __restrict__ preds, int64_t ldp,
+                                                         float* __restrict__ dlogits, int64_t lddl) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float* x = logits + r * ldl;
+    const float* z = labels + r * ldlab;
+    const int Cp = (C + 3) & ~3;
+    if (sigmoid_loss) {
+        float acc = 0.f;
+        const float gscale = 1.0f / ((float)n * (float)C);
+        for (int c = lane; c < Cp; c += 64) {
+            float p = 0.f, g = 0.f;
+            if (c < C) {
+                const float xv = x[c], zv = z[c];
+                acc += fmaxf(xv, 0.f) - xv * zv + log1pf(expf(-fabsf(xv)));
+                p = 1.0f / (1.0f + expf(-xv));
+                g = (p - zv) * gscale;
+            }
+            if (preds) preds[r * ldp + c] = p;
+            if (dlogits) dlogits[r * lddl + c] = g;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) loss_rows[r] = acc / (float)C;
+    } else {
+        float m = -INFINITY;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+        m = wave_max(m);
+        float se = 0.f, zs = 0.f, zx = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float xv = x[c], zv = z[c];
+            se += expf(xv - m);
+            zs += zv;
+            zx += zv * xv;
+        }
+        se = wave_sum(se);
+        zs = wave_sum(zs);
+        zx = wave_sum(zx);
+        const float lse = m + logf(se);
+        const float inv_se = 1.0f / se;
+        const float gscale = 1.0f / (float)n;
+        for (int c = lane; c < Cp; c += 64) {
+            float p = 0.f, g = 0.f;
+            if (c < C) {
+                p = expf(x[c] - m) * inv_se;
+                g = (p * zs - z[c]) * gscale;
+            }
+            if (preds) preds[r * ldp + c] = p;
+            if (dlogits) dlogits[r * lddl + c] = g;
+        }
+        if (lane == 0) loss_rows[r] = zs * lse - zx;  // -sum_c z_c (x_c - lse)
+    }
+}
+
+extern "C" int gs_class_loss(const float* logits, int64_t ldl, const float* labels, int64_t ldlab, int64_t n, int32_t C,
+                             int sigmoid_loss, float* loss_rows, float* preds, int64_t ldp, float* dlogits, int64_t lddl,
+                             void* stream) {
+    GS_REQUIRE(logits && labels && loss_rows && n >= 0 && C > 0, "gs_class_loss: bad args");
+    const int Cp = (C + 3) & ~3;
+    GS_REQUIRE((!preds || ldp >= Cp) && (!dlogits || lddl >= Cp), "gs_class_loss: output ld must be >= round_up(C,4)");
+    if (n == 0) return GS_OK;
+    hipLaunchKernelGGL(class_loss_kernel, dim3((unsigned)gs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, logits, ldl,
+                       labels, ldlab, n, C, sigmoid_loss, loss_rows, preds, ldp, dlogits, lddl);
+    GS_LAUNCH_CHECK("class_loss_kernel");
+    return GS_OK;
+}

@@ -1,0 +1,137 @@
+// K6: gradient finalisation and the optimizer (supervised_models.py:95-99, :104-108).
+// Weight gradients arrive as split-K slabs from gs_dense_wgrad (deterministic fixed-order sums).
+#include "gs_common.h"
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int32_t n_slabs,
+                                                           int64_t slab_stride, int32_t rows, int32_t cols,
+                                                           int64_t ld_slab, float wd, const float* __restrict__ w,
+                                                           int64_t ldw, float* __restrict__ grad, int64_t ldg,
+                                                           int accumulate) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(t / cols);
+        const int c = (int)(t - (int64_t)r * cols);
+        const float* p = slabs + (int64_t)r * ld_slab + c;
+        float s = 0.f;
+        for (int z = 0; z < n_slabs; ++z) s += p[(int64_t)z * slab_stride];
+        if (w && wd != 0.f) s += wd * w[(int64_t)r * ldw + c];
+        float* dst = grad + (int64_t)r * ldg + c;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+extern "C" int gs_reduce_slabs(const float* slabs, int32_t n_slabs, int64_t slab_stride, int32_t rows, int32_t cols,
+                               int64_t ld_slab, float weight_decay, const float* w, int64_t ldw, float* grad,
+                               int64_t ldg, int accumulate, void* stream) {
+    GS_REQUIRE(slabs && grad && n_slabs > 0 && rows > 0 && cols > 0, "gs_reduce_slabs: bad args");
+    const int64_t total = (int64_t)rows * cols;
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, slab_stride,
+                       rows, cols, ld_slab, weight_decay, w, ldw, grad, ldg, accumulate);
+    GS_LAUNCH_CHECK("reduce_slabs_kernel");
+    return GS_OK;
+}
+
+// Column sums as slabs (bias gradient): grid (col tiles of 64, row slices).  Each of the 4 waves strides
+// the slice's rows with 8 independent loads in flight, partials are combined in fixed order.
+__global__ __launch_bounds__(256) void colsum_slabs_kernel(const float* __restrict__ Z, int64_t ldz, int64_t n,
+                                                           int32_t n_cols, int64_t rows_per_slab,
+                                                           float* __restrict__ slabs, int64_t ld_slab) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+    const int64_t r1 = min(n, r0 + rows_per_slab);
+    float s = 0.f;
+    if (col < n_cols) {
+        int64_t r = r0 + wave;
+        for (; r + 28 < r1; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Z[(r + 4 * u) * ldz + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < r1; r += 4) s += Z[r * ldz + col];
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < n_cols)
+        slabs[(int64_t)blockIdx.y * ld_slab + col] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+extern "C" int gs_colsum_slabs(const float* Z, int64_t ldz, int64_t n, int32_t n_cols, int32_t n_slabs, float* slabs,
+                               int64_t ld_slab, void* stream) {
+    GS_REQUIRE(Z && slabs && n > 0 && n_cols > 0 && n_slabs > 0 && n_slabs < 65536 && ld_slab >= n_cols,
+               "gs_colsum_slabs: bad args");
+    const int64_t rps = gs_ceil_div(n, n_slabs);
+    hipLaunchKernelGGL(colsum_slabs_kernel, dim3((unsigned)gs_ceil_div(n_cols, 64), (unsigned)n_slabs), dim3(256), 0,
+                       (hipStream_t)stream, Z, ldz, n, n_cols, rps, slabs, ld_slab);
+    GS_LAUNCH_CHECK("colsum_slabs_kernel");
+    return GS_OK;
+}
+
+// TF-1.x Adam with elementwise clip.  t is read from device memory so the launch is hipGraph-replayable.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t count, float lr,
+                                                   float b1, float b2, float eps, float clip, float gscale,
+                                                   const uint64_t* __restrict__ step_dev) {
+    const float t = (float)((step_dev ? *step_dev : 0ull) + 1ull);
+    const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = grad[i] * gscale;
+        if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+        const float mi = b1 * m[i] + (1.0f - b1) * g;
+        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+extern "C" int gs_adam_step(float* p, const float* grad, float* m, float* v, int64_t count, float lr, float beta1,
+                            float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
+                            void* stream) {
+    GS_REQUIRE(p && grad && m && v && count >= 0, "gs_adam_step: bad args");
+    if (count == 0) return GS_OK;
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(count, 256), 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, count, lr, beta1, beta2,
+                       eps, clip, grad_scale, step_dev);
+    GS_LAUNCH_CHECK("adam_kernel");
+    return GS_OK;
+}
+
+// Single-block fixed-order reductions (loss scalar, weight-decay term).
+template <bool SQUARE>
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t count, float scale,
+                                                   float* __restrict__ out, int accumulate) {
+    __shared__ float part[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < count; i += 1024) {
+        const float v = x[i];
+        s += SQUARE ? v * v : v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < 16; ++w) tot += part[w];
+        tot *= scale;
+        out[0] = accumulate ? out[0] + tot : tot;
+    }
+}
+
+extern "C" int gs_sum_scaled(const float* x, int64_t count, float scale, float* out, int accumulate, void* stream) {
+    GS_REQUIRE(x && out && count >= 0, "gs_sum_scaled: bad args");
+    hipLaunchKernelGGL(sum_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, count, scale, out, accumulate);
+    GS_LAUNCH_CHECK("sum_kernel");
+    return GS_OK;
+}
+extern "C" int gs_sumsq_scaled(const float* x, int64_t count, float scale, float* out, int accumulate, void* stream) {
+    GS_REQUIRE(x && out && count >= 0, "gs_sumsq_scaled: bad args");
+    hipLaunchKernelGGL(sum_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, count, scale, out, accumulate);
+    GS_LAUNCH_CHECK("sum_kernel_sq");
+    return GS_OK;
+}

@@ -1,0 +1,162 @@
+// Runtime plumbing of the C ABI: error string, device info, streams, hipGraph capture/replay, events,
+// device-side counters, and the host-side (multithreaded C++) edge-list -> CSR builder.
+#include "gs_common.h"
+#include <string.h>
+#include <thread>
+#include <vector>
+#include <algorithm>
+#include <atomic>
+
+static thread_local char g_err[512] = "";
+
+void gs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* gs_last_error(void) { return g_err; }
+extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
+
+extern "C" int gs_device_info(int* cu_count, int* xcd_count, char* arch_name_host, int arch_name_len) {
+    int dev = 0;
+    GS_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    GS_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (xcd_count) *xcd_count = 8;  // MI355X: 8 XCDs x 32 CUs (not queryable through hipDeviceProp_t)
+    if (arch_name_host && arch_name_len > 0) {
+        strncpy(arch_name_host, prop.gcnArchName, (size_t)arch_name_len - 1);
+        arch_name_host[arch_name_len - 1] = 0;
+    }
+    return GS_OK;
+}
+
+// ----------------------------------------------------------------------------- streams / graphs
+extern "C" int gs_stream_create(void** stream_out) {
+    GS_REQUIRE(stream_out, "gs_stream_create: null out");
+    hipStream_t s;
+    GS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = (void*)s;
+    return GS_OK;
+}
+extern "C" int gs_stream_destroy(void* stream) {
+    GS_HIP(hipStreamDestroy((hipStream_t)stream));
+    return GS_OK;
+}
+extern "C" int gs_stream_sync(void* stream) {
+    GS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return GS_OK;
+}
+extern "C" int gs_capture_begin(void* stream) {
+    GS_REQUIRE(stream, "gs_capture_begin: the legacy NULL stream cannot be captured");
+    GS_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return GS_OK;
+}
+extern "C" int gs_capture_end(void* stream, void** graph_exec_out) {
+    GS_REQUIRE(graph_exec_out, "gs_capture_end: null out");
+    hipGraph_t graph = nullptr;
+    GS_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        gs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return GS_EHIP;
+    }
+    *graph_exec_out = (void*)exec;
+    return GS_OK;
+}
+extern "C" int gs_graph_launch(void* graph_exec, void* stream) {
+    GS_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return GS_OK;
+}
+extern "C" int gs_graph_destroy(void* graph_exec) {
+    GS_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return GS_OK;
+}
+
+// ----------------------------------------------------------------------------- events
+extern "C" int gs_event_create(void** ev_out) {
+    GS_REQUIRE(ev_out, "gs_event_create: null out");
+    hipEvent_t e;
+    GS_HIP(hipEventCreate(&e));
+    *ev_out = (void*)e;
+    return GS_OK;
+}
+extern "C" int gs_event_record(void* ev, void* stream) {
+    GS_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return GS_OK;
+}
+extern "C" int gs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out_host) {
+    GS_REQUIRE(ms_out_host, "gs_event_elapsed_ms: null out");
+    GS_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+    GS_HIP(hipEventElapsedTime(ms_out_host, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return GS_OK;
+}
+extern "C" int gs_event_destroy(void* ev) {
+    GS_HIP(hipEventDestroy((hipEvent_t)ev));
+    return GS_OK;
+}
+
+// ----------------------------------------------------------------------------- device counters
+__global__ void advance_counter_kernel(uint64_t* c, uint64_t delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
+}
+extern "C" int gs_advance_counter(uint64_t* counter_dev, uint64_t delta, void* stream) {
+    GS_REQUIRE(counter_dev, "gs_advance_counter: null counter");
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter_dev, delta);
+    GS_LAUNCH_CHECK("advance_counter_kernel");
+    return GS_OK;
+}
+
+// ----------------------------------------------------------------------------- host CSR builder
+// Counting sort by source node; parallel histogram + parallel fill over node ranges.
+extern "C" int gs_build_csr_host(const int32_t* src, const int32_t* dst, const uint8_t* keep,
+                                 int64_t n_edges, int64_t n_nodes, int symmetrize,
+                                 int64_t* rowptr, int32_t* col, int64_t col_capacity, int64_t* nnz_out) {
+    GS_REQUIRE(src && dst && rowptr && col && nnz_out && n_nodes > 0 && n_edges >= 0, "gs_build_csr_host: bad args");
+    std::vector<int64_t> cnt((size_t)n_nodes + 1, 0);
+    for (int64_t e = 0; e < n_edges; ++e) {
+        if (keep && !keep[e]) continue;
+        int32_t s = src[e], d = dst[e];
+        if (s < 0 || s >= n_nodes || d < 0 || d >= n_nodes) {
+            gs_set_error("gs_build_csr_host: edge %lld endpoint out of range", (long long)e);
+            return GS_EINVAL;
+        }
+        cnt[(size_t)s + 1]++;
+        if (symmetrize && s != d) cnt[(size_t)d + 1]++;
+    }
+    rowptr[0] = 0;
+    for (int64_t i = 0; i < n_nodes; ++i) rowptr[i + 1] = rowptr[i] + cnt[(size_t)i + 1];
+    int64_t nnz = rowptr[n_nodes];
+    *nnz_out = nnz;
+    if (nnz > col_capacity) {
+        gs_set_error("gs_build_csr_host: col capacity %lld < nnz %lld", (long long)col_capacity, (long long)nnz);
+        return GS_EINVAL;
+    }
+    std::vector<int64_t> cursor(rowptr, rowptr + n_nodes);
+    for (int64_t e = 0; e < n_edges; ++e) {
+        if (keep && !keep[e]) continue;
+        int32_t s = src[e], d = dst[e];
+        col[cursor[(size_t)s]++] = d;
+        if (symmetrize && s != d) col[cursor[(size_t)d]++] = s;
+    }
+    // sort each adjacency list (parallel over node ranges) so the CSR is canonical
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    std::atomic<int64_t> next(0);
+    const int64_t chunk = 4096;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                int64_t b = next.fetch_add(chunk);
+                if (b >= n_nodes) break;
+                int64_t e = std::min(n_nodes, b + chunk);
+                for (int64_t i = b; i < e; ++i) std::sort(col + rowptr[i], col + rowptr[i + 1]);
+            }
+        });
+    for (auto& x : th) x.join();
+    return GS_OK;
+}

@@ -1,0 +1,137 @@
+// K1: neighbor sampling kernels (int32 index work, latency/HBM bound, bit-exact vs the oracle).
+//
+//  * sample_padded_kernel     exact reference semantics on the padded [N+1, max_deg] table
+//                             (neigh_samplers.py:24-29 on the table of minibatch.py:227-259)
+//  * sample_csr_kernel        MI355X-native: wavefront-local sampling over CSR.  One wave owns 64
+//                             consecutive output slots; the <= 65 distinct source rows those slots
+//                             belong to are loaded ONCE per wave (ids -> rowptr pair) by the low
+//                             lanes and redistributed to the slots with ds_bpermute (__shfl); each
+//                             lane then draws one neighbor with a counter-based xorshift-multiply
+//                             hash and the wave stores its 64 picks as one coalesced 256-byte line.
+#include "gs_common.h"
+
+__global__ __launch_bounds__(256) void sample_padded_kernel(const int32_t* __restrict__ adj, int32_t max_deg,
+                                                            const int32_t* __restrict__ ids, int64_t n,
+                                                            const int32_t* __restrict__ col_perm, int32_t s,
+                                                            int32_t* __restrict__ out) {
+    int64_t total = n * (int64_t)s;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = o / s;
+        int32_t j = (int32_t)(o - i * s);
+        out[o] = adj[(int64_t)ids[i] * max_deg + col_perm[j]];
+    }
+}
+
+extern "C" int gs_sample_padded(const int32_t* adj, int64_t n_adj_rows, int32_t max_deg, const int32_t* ids,
+                                int64_t n, const int32_t* col_perm, int32_t num_samples, int32_t* out,
+                                void* stream) {
+    GS_REQUIRE(adj && ids && col_perm && out, "gs_sample_padded: null pointer");
+    GS_REQUIRE(n >= 0 && n_adj_rows > 0 && max_deg > 0, "gs_sample_padded: bad sizes");
+    GS_REQUIRE(num_samples > 0 && num_samples <= max_deg,
+               "gs_sample_padded: num_samples=%d must be in [1, max_degree=%d] (tf.slice would fail)",
+               num_samples, max_deg);
+    if (n == 0) return GS_OK;
+    int64_t total = n * (int64_t)num_samples;
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(sample_padded_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, adj, max_deg, ids, n,
+                       col_perm, num_samples, out);
+    GS_LAUNCH_CHECK("sample_padded_kernel");
+    return GS_OK;
+}
+
+// splitmix64 finalizer: xorshift-multiply rounds.  Restated bit-for-bit in oracle/sampler_hash.py.
+__device__ __forceinline__ uint64_t gs_mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+__global__ __launch_bounds__(256) void sample_csr_kernel(const int64_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col, int64_t n_nodes,
+                                                         int32_t pad_id, const int32_t* __restrict__ ids, int64_t n,
+                                                         int32_t s, uint64_t seed, uint64_t step,
+                                                         const uint64_t* __restrict__ step_dev, uint32_t hop,
+                                                         int64_t global_row_offset, int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t total = n * (int64_t)s;
+    const int64_t n_waves = gs_ceil_div(total, 64);
+    const uint64_t st = step + (step_dev ? *step_dev : 0ull);
+    const uint64_t key = gs_mix64(seed ^ (st * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)hop << 56));
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < n_waves; w += (int64_t)gridDim.x * 4) {
+        const int64_t o0 = w * 64;
+        const int64_t i_first = o0 / s;
+        // ---- per-wave row table: lane l holds (begin, deg) of source row i_first + l
+        int64_t beg = 0;
+        int32_t deg = 0;
+        {
+            int64_t i = i_first + lane;
+            if (i < n) {
+                int32_t id = ids[i];
+                if (id >= 0 && (int64_t)id < n_nodes) {
+                    int64_t b = rowptr[id], e = rowptr[id + 1];
+                    beg = b;
+                    deg = (int32_t)(e - b);
+                }
+            }
+        }
+        // slot -> row redistribution through the LDS crossbar (ds_bpermute)
+        const int64_t o = o0 + lane;
+        const int64_t i = (o < total) ? o / s : i_first;
+        const int src_lane = (int)(i - i_first);  // < 64 whenever o < total and s >= 1 (<= 64 rows/wave)
+        // s == 1 gives exactly 64 rows per wave (lanes 0..63) -> still fits the wave.
+        const int32_t my_deg = __shfl(deg, src_lane, 64);
+        const uint32_t beg_lo = (uint32_t)__shfl((int)(uint32_t)beg, src_lane, 64);
+        const uint32_t beg_hi = (uint32_t)__shfl((int)(uint32_t)(beg >> 32), src_lane, 64);
+        const int64_t my_beg = (int64_t)(((uint64_t)beg_hi << 32) | beg_lo);
+        if (o < total) {
+            const uint32_t j = (uint32_t)(o - i * s);
+            int32_t pick = pad_id;
+            if (my_deg > 0) {
+                const uint64_t u = gs_mix64(key + (uint64_t)(global_row_offset + i) * 0xD1342543DE82EF95ull + j);
+                const uint32_t r = (uint32_t)(u >> 32);
+                const uint32_t k = (uint32_t)(((uint64_t)r * (uint64_t)(uint32_t)my_deg) >> 32);  // Lemire range map
+                pick = col[my_beg + k];
+            }
+            out[o] = pick;  // 64 lanes -> one 256-byte coalesced store
+        }
+    }
+}
+
+extern "C" int gs_sample_uniform_csr(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,
+                                     const int32_t* ids, int64_t n, int32_t num_samples, uint64_t seed,
+                                     uint64_t step, const uint64_t* step_dev, uint32_t hop,
+                                     int64_t global_row_offset, int32_t* out, void* stream) {
+    GS_REQUIRE(rowptr && col && ids && out, "gs_sample_uniform_csr: null pointer");
+    GS_REQUIRE(n >= 0 && n_nodes > 0 && num_samples > 0, "gs_sample_uniform_csr: bad sizes");
+    GS_REQUIRE(hop < 256, "gs_sample_uniform_csr: hop must be < 256");
+    if (n == 0) return GS_OK;
+    int64_t total = n * (int64_t)num_samples;
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(sample_csr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, n_nodes,
+                       pad_id, ids, n, num_samples, seed, step, step_dev, hop, global_row_offset, out);
+    GS_LAUNCH_CHECK("sample_csr_kernel");
+    return GS_OK;
+}
+
+__global__ __launch_bounds__(256) void select_batch_kernel(const int32_t* __restrict__ order, int64_t n_order,
+                                                           const uint64_t* __restrict__ cursor, int64_t n,
+                                                           int32_t* __restrict__ batch) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint64_t c = cursor ? *cursor : 0ull;
+        batch[i] = order[(int64_t)((c + (uint64_t)i) % (uint64_t)n_order)];
+    }
+}
+
+extern "C" int gs_select_batch(const int32_t* order, int64_t n_order, const uint64_t* cursor_dev, int64_t n,
+                               int32_t* batch, void* stream) {
+    GS_REQUIRE(order && batch && n_order > 0 && n >= 0, "gs_select_batch: bad args");
+    if (n == 0) return GS_OK;
+    hipLaunchKernelGGL(select_batch_kernel, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       order, n_order, cursor_dev, n, batch);
+    GS_LAUNCH_CHECK("select_batch_kernel");
+    return GS_OK;
+}

@@ -1,0 +1,299 @@
+"""Typed Python wrappers over the C ABI (one function per entry point of include/graphsage_amd.h).
+
+`Mat` is a row-major fp32 device matrix with a padded leading dimension (what every kernel expects:
+16-byte aligned base, ld % 4 == 0).  torch only owns the memory.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_IDENTITY, ACT_RELU, call, ptr  # noqa: F401
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Mat(object):
+    """fp32 [rows, d] matrix stored in a [rows, ld] buffer, ld % 4 == 0 (pad columns are zero)."""
+
+    __slots__ = ("buf", "d")
+
+    def __init__(self, buf, d):
+        assert buf.dim() == 2 and buf.dtype == torch.float32 and buf.stride(1) == 1
+        assert buf.stride(0) % 4 == 0 and buf.data_ptr() % 16 == 0 and d <= buf.shape[1]
+        self.buf = buf
+        self.d = d
+
+    @staticmethod
+    def zeros(rows, d, device, ld_multiple=4):
+        ld = round_up(max(d, 1), ld_multiple)
+        return Mat(torch.zeros((rows, ld), dtype=torch.float32, device=device), d)
+
+    @staticmethod
+    def from_numpy(a, device, ld_multiple=4):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.ndim == 1:
+            a = a[None, :]
+        m = Mat.zeros(a.shape[0], a.shape[1], device, ld_multiple)
+        m.buf[:, : a.shape[1]].copy_(torch.from_numpy(a))
+        return m
+
+    @property
+    def rows(self):
+        return self.buf.shape[0]
+
+    @property
+    def ld(self):
+        return self.buf.stride(0)
+
+    @property
+    def ptr(self):
+        return ptr(self.buf)
+
+    def view(self):
+        """Logical [rows, d] view (torch tensor)."""
+        return self.buf[:, : self.d]
+
+    def numpy(self):
+        return self.view().detach().cpu().numpy()
+
+    def rows_slice(self, r0, r1):
+        return Mat(self.buf[r0:r1], self.d)
+
+
+def current_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _s(stream):
+    return current_stream() if stream is None else stream
+
+
+# ------------------------------------------------------------------------------------------ K1
+def sample_padded(adj, ids, col_perm, num_samples, out=None, stream=None):
+    n = ids.numel()
+    if out is None:
+        out = torch.empty((n * num_samples,), dtype=torch.int32, device=ids.device)
+    call("gs_sample_padded", ptr(adj), adj.shape[0], adj.shape[1], ptr(ids), n, ptr(col_perm), num_samples,
+         ptr(out), _s(stream))
+    return out
+
+
+def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, step=0, step_dev=None, hop=0,
+                       global_row_offset=0, out=None, stream=None):
+    n = ids.numel()
+    if out is None:
+        out = torch.empty((n * num_samples,), dtype=torch.int32, device=ids.device)
+    call("gs_sample_uniform_csr", ptr(rowptr), ptr(col), n_nodes, pad_id, ptr(ids), n, num_samples,
+         seed & 0xFFFFFFFFFFFFFFFF, step, ptr(step_dev), hop, global_row_offset, ptr(out), _s(stream))
+    return out
+
+
+def select_batch(order, cursor_dev, n, out, stream=None):
+    call("gs_select_batch", ptr(order), order.numel(), ptr(cursor_dev), n, ptr(out), _s(stream))
+    return out
+
+
+def advance_counter(counter_dev, delta, stream=None):
+    call("gs_advance_counter", ptr(counter_dev), delta, _s(stream))
+
+
+# ------------------------------------------------------------------------------------------ K2
+def gather_rows(X, ids, out=None, stream=None):
+    n = ids.numel()
+    if out is None:
+        out = Mat.zeros(n, X.d, ids.device)
+    call("gs_gather_rows", X.ptr, X.ld, ptr(ids), n, X.d, out.ptr, out.ld, _s(stream))
+    return out
+
+
+def gather_mean_fwd(X, idx, n, s, out=None, self_src=None, self_idx=None, stream=None):
+    """idx: int32 [n*s] or None (contiguous groups).  self_src (Mat) switches to the GCN mean."""
+    if out is None:
+        out = Mat.zeros(n, X.d, X.buf.device)
+    call("gs_gather_mean_fwd", X.ptr, X.ld, ptr(idx), n, s, X.d,
+         self_src.ptr if self_src is not None else None, self_src.ld if self_src is not None else 0,
+         ptr(self_idx), out.ptr, out.ld, _s(stream))
+    return out
+
+
+def mean_bwd(d_mean, n, s, scale, d_neigh, mask_y=None, accumulate=False, stream=None):
+    call("gs_mean_bwd", d_mean.ptr, d_mean.ld, n, s, d_mean.d, scale,
+         mask_y.ptr if mask_y is not None else None, mask_y.ld if mask_y is not None else 0,
+         d_neigh.ptr, d_neigh.ld, 1 if accumulate else 0, _s(stream))
+    return d_neigh
+
+
+# ------------------------------------------------------------------------------------------ K3
+def sage_dense_fwd(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, out_dim, concat, act, bias, out,
+                   stream=None):
+    call("gs_sage_dense_fwd",
+         self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0, ptr(self_idx),
+         self_m.d if self_m is not None else 0,
+         agg.ptr, agg.ld, ptr(agg_idx), agg.d, n,
+         W_self.ptr if W_self is not None else None, W_self.ld if W_self is not None else 0,
+         W_neigh.ptr, W_neigh.ld, out_dim, 1 if concat else 0, act, ptr(bias), out.ptr, out.ld, _s(stream))
+    return out
+
+
+def dense_wgrad(A, a_idx, dZ, col0, out_dim, n, n_slabs, slabs, ld_slab, stream=None):
+    """slabs: flat fp32 tensor with room for n_slabs * A.d * ld_slab floats."""
+    call("gs_dense_wgrad", A.ptr, A.ld, ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, out_dim, n, n_slabs, ptr(slabs),
+         ld_slab, _s(stream))
+
+
+def dense_dgrad(dZ, col0, out_dim, n, W, dX, accumulate=False, stream=None):
+    call("gs_dense_dgrad", dZ.ptr, dZ.ld, col0, out_dim, n, W.ptr, W.ld, W.rows, dX.ptr, dX.ld,
+         1 if accumulate else 0, _s(stream))
+    return dX
+
+
+def act_bwd(dY, Y, n, n_cols, act, dZ, stream=None):
+    call("gs_act_bwd", dY.ptr, dY.ld, Y.ptr if Y is not None else None, Y.ld if Y is not None else 0, n, n_cols,
+         act, dZ.ptr, dZ.ld, _s(stream))
+    return dZ
+
+
+def colsum_slabs(Z, n, n_cols, n_slabs, slabs, ld_slab, stream=None):
+    call("gs_colsum_slabs", Z.ptr, Z.ld, n, n_cols, n_slabs, ptr(slabs), ld_slab, _s(stream))
+
+
+def gemm(transA, transB, M, N, K, A, B, C, a_row_idx=None, bias=None, act=ACT_IDENTITY, stream=None):
+    call("gs_gemm_f32", 1 if transA else 0, 1 if transB else 0, M, N, K, A.ptr, A.ld, ptr(a_row_idx), B.ptr, B.ld,
+         ptr(bias), act, C.ptr, C.ld, _s(stream))
+    return C
+
+
+# ------------------------------------------------------------------------------------------ K4
+def segment_max_fwd(H, n, s, pooled, argmax, stream=None):
+    call("gs_segment_max_fwd", H.ptr, H.ld, n, s, H.d, pooled.ptr, pooled.ld, ptr(argmax), argmax.stride(0),
+         _s(stream))
+
+
+def segment_max_bwd(d_pooled, pooled, argmax, n, s, dH, stream=None):
+    call("gs_segment_max_bwd", d_pooled.ptr, d_pooled.ld, pooled.ptr, pooled.ld, ptr(argmax), argmax.stride(0), n, s,
+         pooled.d, dH.ptr, dH.ld, _s(stream))
+
+
+# ------------------------------------------------------------------------------------------ K5
+def l2norm_fwd(x, n, y, inv_norm, stream=None):
+    call("gs_l2norm_fwd", x.ptr, x.ld, n, x.d, y.ptr, y.ld, ptr(inv_norm), _s(stream))
+
+
+def l2norm_bwd(dy, y, inv_norm, n, dx, stream=None):
+    call("gs_l2norm_bwd", dy.ptr, dy.ld, y.ptr, y.ld, ptr(inv_norm), n, y.d, dx.ptr, dx.ld, _s(stream))
+
+
+def class_loss(logits, labels, n, C, sigmoid_loss, loss_rows, preds=None, dlogits=None, stream=None):
+    call("gs_class_loss", logits.ptr, logits.ld, labels.ptr, labels.ld, n, C, 1 if sigmoid_loss else 0,
+         ptr(loss_rows), preds.ptr if preds is not None else None, preds.ld if preds is not None else 0,
+         dlogits.ptr if dlogits is not None else None, dlogits.ld if dlogits is not None else 0, _s(stream))
+
+
+# ------------------------------------------------------------------------------------------ K6
+def reduce_slabs(slabs, n_slabs, slab_stride, rows, cols, ld_slab, weight_decay, w_ptr, ldw, grad_ptr, ldg,
+                 accumulate=False, stream=None):
+    call("gs_reduce_slabs", ptr(slabs) if hasattr(slabs, "is_cuda") else slabs, n_slabs, slab_stride, rows, cols,
+         ld_slab, weight_decay, w_ptr, ldw, grad_ptr, ldg, 1 if accumulate else 0, _s(stream))
+
+
+def adam_step(p, grad, m, v, count, lr, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, clip=5.0, grad_scale=1.0,
+              stream=None):
+    call("gs_adam_step", ptr(p), ptr(grad), ptr(m), ptr(v), count, lr, beta1, beta2, eps, clip, grad_scale,
+         ptr(step_dev), _s(stream))
+
+
+def sum_scaled(x, count, scale, out, accumulate=False, stream=None):
+    call("gs_sum_scaled", ptr(x), count, scale, ptr(out), 1 if accumulate else 0, _s(stream))
+
+
+def sumsq_scaled(x, count, scale, out, accumulate=False, stream=None):
+    call("gs_sumsq_scaled", ptr(x), count, scale, ptr(out), 1 if accumulate else 0, _s(stream))
+
+
+# ------------------------------------------------------------------------------------------ graphs / events
+class Stream(object):
+    """A non-blocking HIP stream created by the library (capturable into a hipGraph)."""
+
+    def __init__(self):
+        import ctypes
+        h = ctypes.c_void_p()
+        call("gs_stream_create", ctypes.byref(h))
+        self.handle = h.value
+
+    def sync(self):
+        call("gs_stream_sync", self.handle)
+
+    def __del__(self):
+        try:
+            _lib.load().gs_stream_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Graph(object):
+    """hipGraph captured from the kernel chain enqueued between begin() and end()."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.exec_ = None
+
+    def begin(self):
+        call("gs_capture_begin", self.stream)
+
+    def end(self):
+        import ctypes
+        h = ctypes.c_void_p()
+        call("gs_capture_end", self.stream, ctypes.byref(h))
+        self.exec_ = h.value
+
+    def launch(self):
+        call("gs_graph_launch", self.exec_, self.stream)
+
+    def __del__(self):
+        try:
+            if self.exec_:
+                _lib.load().gs_graph_destroy(self.exec_)
+        except Exception:
+            pass
+
+
+class Event(object):
+    def __init__(self):
+        import ctypes
+        h = ctypes.c_void_p()
+        call("gs_event_create", ctypes.byref(h))
+        self.handle = h.value
+
+    def record(self, stream):
+        call("gs_event_record", self.handle, stream)
+
+    def elapsed_ms(self, stop):
+        import ctypes
+        ms = ctypes.c_float()
+        call("gs_event_elapsed_ms", self.handle, stop.handle, ctypes.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().gs_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def build_csr_host(src, dst, n_nodes, symmetrize=True, keep_mask=None):
+    """Host-side C++ CSR builder (gs_build_csr_host).  numpy in, numpy out."""
+    import ctypes
+    import numpy as np
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    if keep_mask is not None:
+        keep_mask = np.ascontiguousarray(keep_mask, dtype=np.uint8)
+    cap = int(src.size) * (2 if symmetrize else 1)
+    rowptr = np.zeros((n_nodes + 1,), dtype=np.int64)
+    col = np.zeros((max(cap, 1),), dtype=np.int32)
+    nnz = ctypes.c_int64()
+    call("gs_build_csr_host", _lib.host_ptr(src), _lib.host_ptr(dst), _lib.host_ptr(keep_mask), src.size, n_nodes,
+         1 if symmetrize else 0, _lib.host_ptr(rowptr), _lib.host_ptr(col), cap, ctypes.byref(nnz))
+    return rowptr, col[: nnz.value].copy()

@@ -1,0 +1,250 @@
+/*
+ * graphsage_amd.h -- C ABI of the MI355X (gfx950) GraphSAGE sample-and-aggregate engine.
+ *
+ * The reference (williamleif/GraphSAGE, 100 % Python on TensorFlow 1.x) has no FFI of its own;
+ * its hot path bottoms out in TF ops.  Each entry point below replaces the TF-op call sites of
+ * one reference operator (cited as graphsage/<file>:<line>, relative to the reference tree) and
+ * is what a ctypes binding of that operator binds.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - Every pointer is a DEVICE pointer owned by the caller unless the name ends in _host.
+ *   - Every function enqueues work on `stream` (a hipStream_t passed as void*; must not be the
+ *     legacy NULL stream if the caller wants to capture it into a hipGraph) and returns
+ *     immediately.  The library allocates no device memory; scratch is caller-supplied.
+ *   - Return value: 0 = ok, <0 = error (GS_E*); gs_last_error() gives a thread-local message.
+ *     No C++ exception crosses the boundary.
+ *   - Matrices are row-major fp32 with an explicit leading dimension `ld*` (elements).  Every
+ *     fp32 matrix base pointer must be 16-byte aligned and every ld a multiple of 4 floats;
+ *     the logical width d may be anything <= ld.  Columns [d, round_up(d,4)) of OUTPUT matrices
+ *     are written as zeros; further pad columns are left untouched.
+ *   - Index arrays are int32 (the reference feeds int32 placeholders, supervised_train.py:116);
+ *     CSR row pointers are int64.
+ */
+#ifndef GRAPHSAGE_AMD_H
+#define GRAPHSAGE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_OK 0
+#define GS_EINVAL (-1)  /* bad argument (null pointer, misaligned, bad size)  */
+#define GS_EHIP (-2)    /* a HIP runtime call failed                           */
+#define GS_ENOTSUP (-3) /* combination not supported by the gfx950 kernels     */
+
+#define GS_ACT_IDENTITY 0
+#define GS_ACT_RELU 1
+
+#define GS_ABI_VERSION 1
+
+const char* gs_last_error(void);
+int gs_abi_version(void);
+/* Fills CU count, XCD count (8 on MI355X), gcnArchName (>= 64 bytes) of the current device. */
+int gs_device_info(int* cu_count, int* xcd_count, char* arch_name_host, int arch_name_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  neighbor sampling      replaces UniformNeighborSampler._call, neigh_samplers.py:24-29
+ *                            (called at models.py:272, result flattened at models.py:273)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Exact reference semantics on the padded table of minibatch.py:227-259:
+ *   out[i, j] = adj[ids[i], col_perm[j]],  j < num_samples
+ * i.e. embedding_lookup (:26) + ONE column permutation shared by all rows (:27) + slice (:28).
+ * TF's random_shuffle stream is not reproducible, so the permutation is an input.
+ * adj is [n_adj_rows, max_deg] int32 (n_adj_rows = N+1, row N = all-pad).  Bit-exact. */
+int gs_sample_padded(const int32_t* adj, int64_t n_adj_rows, int32_t max_deg,
+                     const int32_t* ids, int64_t n,
+                     const int32_t* col_perm, int32_t num_samples,
+                     int32_t* out, void* stream);
+
+/* MI355X-native sampler over a CSR adjacency (rowptr int64 [n_nodes+1], col int32 [nnz]):
+ *   deg = rowptr[id+1]-rowptr[id];  out[i,j] = deg ? col[rowptr[id] + ((u(i,j) >> 32) * deg >> 32)] : pad_id
+ * u(i,j) is a counter-based xorshift-multiply hash of
+ *   (seed, step + *step_dev, hop, global_row_offset + i, j)
+ * so the draw for a given root row does not depend on how rows are sharded over GPUs.
+ * ids >= n_nodes (the pad id) yield pad_id (the all-pad row N of the reference table).
+ * Uniform WITH replacement over the true neighbor set: the per-slot marginal equals the
+ * reference's (padded row resampled once + distinct columns); see DESIGN.md "sampler semantics".
+ * step_dev may be NULL. */
+int gs_sample_uniform_csr(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,
+                          const int32_t* ids, int64_t n, int32_t num_samples,
+                          uint64_t seed, uint64_t step, const uint64_t* step_dev, uint32_t hop,
+                          int64_t global_row_offset, int32_t* out, void* stream);
+
+/* batch[i] = order[(*cursor_dev + i) % n_order] for i < n  (epoch order lives on the device so the
+ * whole training step can be one hipGraph).  Replaces the host slicing of minibatch.py:302-307. */
+int gs_select_batch(const int32_t* order, int64_t n_order, const uint64_t* cursor_dev,
+                    int64_t n, int32_t* batch, void* stream);
+
+/* *counter_dev += delta  (advances step / cursor inside a captured graph). */
+int gs_advance_counter(uint64_t* counter_dev, uint64_t delta, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  feature gather (+ segmented mean)
+ *     replaces tf.nn.embedding_lookup at models.py:299, the reshape at models.py:326-327 and
+ *     reduce_mean(axis=1) at aggregators.py:48 (Mean) / :106-107 (GCN)
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[i, :] = X[ids[i], :d] */
+int gs_gather_rows(const float* X, int64_t ldx, const int32_t* ids, int64_t n, int32_t d,
+                   float* out, int64_t ldo, void* stream);
+
+/* mean[i, :] = scale * ( sum_{j<s} X[idx[i*s+j], :d]  [+ S[self_idx ? self_idx[i] : i, :d]] )
+ *   idx == NULL       -> neighbor row is i*s+j (contiguous groups; hidden layers, models.py:327)
+ *   self_src == NULL  -> MeanAggregator, scale = 1/s          (aggregators.py:48)
+ *   self_src != NULL  -> GCNAggregator,  scale = 1/(s+1)      (aggregators.py:106-107)
+ * The [n*s, d] gathered tensor of models.py:299 is never materialised. */
+int gs_gather_mean_fwd(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
+                       const float* self_src, int64_t ld_self, const int32_t* self_idx,
+                       float* mean, int64_t ldm, void* stream);
+
+/* Backward of the segmented mean for hidden layers (gradient of aggregators.py:48 / :106-107):
+ *   g = d_mean[r / s, :] * scale;  if (mask_y) g *= (mask_y[r, :] > 0)   (fused relu grad of the
+ *   producing layer, aggregators.py:64);  d_neigh[r, :] (+)= g   for r < n*s. */
+int gs_mean_bwd(const float* d_mean, int64_t ldd, int64_t n, int32_t s, int32_t d, float scale,
+                const float* mask_y, int64_t ldy, float* d_neigh, int64_t ldn, int accumulate,
+                void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  dense contraction (fp32 MFMA, v_mfma_f32_32x32x2_f32)
+ *     replaces tf.matmul at aggregators.py:51,53 (Mean), :110 (GCN), :183-184 (MaxPool),
+ *     concat/add_n at :56-58, bias :61-62, act :64, and Dense._call layers.py:104-116
+ * ------------------------------------------------------------------------------------------- */
+
+/* out = act( [ self·W_self  ||  agg·W_neigh ] + bias )          concat != 0   (out is [n, 2*out_dim])
+ * out = act(   self·W_self  +   agg·W_neigh   + bias )          concat == 0   (out is [n, out_dim])
+ * self == NULL -> single term  out = act(agg·W_neigh + bias)  (GCN / Dense).
+ * self_idx != NULL gathers the self rows from `self` on the fly (self row i = self[self_idx[i]]),
+ * which is how layer 0 consumes X[samples[hop]] without materialising it.  Same for agg_idx. */
+int gs_sage_dense_fwd(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self,
+                      const float* agg, int64_t ld_agg, const int32_t* agg_idx, int32_t d_agg,
+                      int64_t n,
+                      const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
+                      int32_t out_dim, int concat, int act, const float* bias,
+                      float* out, int64_t ldo, void* stream);
+
+/* Weight gradient as split-K slabs (deterministic; no atomics):
+ *   slab[z][:, :] = sum_{r in slice z} A[a_idx? a_idx[r] : r, :d]^T · dZ[r, col0:col0+out_dim]
+ * for z < n_slabs (row slices of equal size).  slabs is [n_slabs, d, ld_slab].  The caller sums
+ * the slabs with gs_reduce_slabs.  Gradient of the tf.matmul call sites above w.r.t. the weights. */
+int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx, int32_t d,
+                   const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,
+                   int32_t n_slabs, float* slabs, int64_t ld_slab, void* stream);
+
+/* Input gradient:  dX[n, d] (+)= dZ[:, col0:col0+out_dim] · W[d, out_dim]^T */
+int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,
+                   const float* W, int64_t ldw, int32_t d, float* dX, int64_t ldx, int accumulate,
+                   void* stream);
+
+/* dZ = dY * (Y > 0) for relu (tf relu grad, aggregators.py:64), dY for identity.  In-place allowed. */
+int gs_act_bwd(const float* dY, int64_t lddy, const float* Y, int64_t ldy, int64_t n, int32_t n_cols,
+               int act, float* dZ, int64_t lddz, void* stream);
+/* Bias gradient as slabs: slabs[z][c] = sum_{r in row slice z} Z[r, c]; sum them with gs_reduce_slabs
+ * (rows = 1).  Deterministic.  slabs is [n_slabs, ld_slab]. */
+int gs_colsum_slabs(const float* Z, int64_t ldz, int64_t n, int32_t n_cols, int32_t n_slabs,
+                    float* slabs, int64_t ld_slab, void* stream);
+
+/* General fp32 GEMM on the same MFMA kernel family (used by the operators above; exported for tests):
+ *   C[M,N] = act( opA(A)·opB(B) + bias ),  opA = A^T if transA (A stored [K, M]), same for B.
+ * a_row_idx gathers the SOURCE rows of A (rows of A as stored). */
+int gs_gemm_f32(int transA, int transB, int64_t M, int32_t N, int64_t K,
+                const float* A, int64_t lda, const int32_t* a_row_idx,
+                const float* B, int64_t ldb,
+                const float* bias, int act, float* C, int64_t ldc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  pooling aggregators     replaces aggregators.py:176-181 (MaxPool) / :254-259 (MeanPool)
+ * ------------------------------------------------------------------------------------------- */
+
+/* H[n*s, hidden] = relu(X[idx] · W_mlp + b_mlp)  (Dense, layers.py:104-116) is produced by
+ * gs_sage_dense_fwd(self=NULL, agg=X, agg_idx=idx, ...).  This reduces it:
+ *   pooled[i, c] = max_j H[i*s+j, c];  argmax[i, c] = first j attaining it   (reduce_max, :181) */
+int gs_segment_max_fwd(const float* H, int64_t ldh, int64_t n, int32_t s, int32_t hidden,
+                       float* pooled, int64_t ldp, int32_t* argmax, int64_t lda, void* stream);
+
+/* dH[i*s+j, c] = (j == argmax[i,c] && pooled[i,c] > 0) ? d_pooled[i,c] : 0
+ * (reduce_max gradient followed by the relu gradient of the Dense; ties: see DESIGN.md). */
+int gs_segment_max_bwd(const float* d_pooled, int64_t ldd, const float* pooled, int64_t ldp,
+                       const int32_t* argmax, int64_t lda, int64_t n, int32_t s, int32_t hidden,
+                       float* dH, int64_t ldh, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  supervised head         replaces supervised_models.py:85 (l2_normalize), :111-118 (losses),
+ *                             :122-126 (predict)
+ * ------------------------------------------------------------------------------------------- */
+
+/* y = x * rsqrt(max(sum(x^2), 1e-12)) per row; inv_norm[n] saved for backward. */
+int gs_l2norm_fwd(const float* x, int64_t ldx, int64_t n, int32_t d, float* y, int64_t ldy,
+                  float* inv_norm, void* stream);
+int gs_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* inv_norm,
+                  int64_t n, int32_t d, float* dx, int64_t lddx, void* stream);
+
+/* Fused classification loss forward+backward on logits [n, C] with float labels [n, C]
+ * (one-hot or multi-hot, the reference's feed contract, minibatch.py:264-274):
+ *   sigmoid_loss == 0: softmax CE, loss_rows[r] = -sum_c z log p;  dlogits = (p*sum(z) - z)/n
+ *   sigmoid_loss != 0: loss_rows[r] = sum_c (max(x,0) - x z + log1p(exp(-|x|)))/C ;
+ *                      dlogits = (sigmoid(x) - z)/(n*C)
+ * preds = softmax(logits) or sigmoid(logits) (supervised_models.py:122-126).
+ * mean(loss_rows) is the classification loss of :112-118.  preds / dlogits may be NULL. */
+int gs_class_loss(const float* logits, int64_t ldl, const float* labels, int64_t ldlab,
+                  int64_t n, int32_t C, int sigmoid_loss,
+                  float* loss_rows, float* preds, int64_t ldp, float* dlogits, int64_t lddl,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6  optimizer               replaces supervised_models.py:95-99 (clip_by_value +-5, Adam) and the
+ *                             weight-decay terms :104-108
+ * ------------------------------------------------------------------------------------------- */
+
+/* grad[i] = sum_{z<n_slabs} slabs[z*slab_stride + i] + weight_decay * w[i],  i < count.
+ * Rows of the slab are [rows, ld_slab] and the destination is dense [rows, cols]. */
+int gs_reduce_slabs(const float* slabs, int32_t n_slabs, int64_t slab_stride, int32_t rows, int32_t cols,
+                    int64_t ld_slab, float weight_decay, const float* w, int64_t ldw,
+                    float* grad, int64_t ldg, int accumulate, void* stream);
+
+/* TF-1.x Adam on a flat buffer with elementwise clip (tf.clip_by_value, supervised_models.py:96):
+ *   g = clamp(grad*grad_scale, -clip, clip) (clip <= 0 disables);  t = *step_dev + 1
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+ *   p -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)          (epsilon OUTSIDE the sqrt) */
+int gs_adam_step(float* p, const float* grad, float* m, float* v, int64_t count,
+                 float lr, float beta1, float beta2, float eps, float clip, float grad_scale,
+                 const uint64_t* step_dev, void* stream);
+
+/* out[0] = scale * sum_{i<count} x[i]   (single block, deterministic order) */
+int gs_sum_scaled(const float* x, int64_t count, float scale, float* out, int accumulate, void* stream);
+/* out[0] (+)= scale * sum x[i]^2  -- weight_decay * tf.nn.l2_loss(var), supervised_models.py:106 */
+int gs_sumsq_scaled(const float* x, int64_t count, float scale, float* out, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * hipGraph helpers: the per-step kernel chain is captured once and replayed (no tracing compiler).
+ * ------------------------------------------------------------------------------------------- */
+int gs_stream_create(void** stream_out);
+int gs_stream_destroy(void* stream);
+int gs_stream_sync(void* stream);
+int gs_capture_begin(void* stream);
+int gs_capture_end(void* stream, void** graph_exec_out);
+int gs_graph_launch(void* graph_exec, void* stream);
+int gs_graph_destroy(void* graph_exec);
+/* hipEvent timing on `stream` (torch.cuda.Event only sees torch's current stream). */
+int gs_event_create(void** ev_out);
+int gs_event_record(void* ev, void* stream);
+int gs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out_host); /* synchronises ev_stop */
+int gs_event_destroy(void* ev);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-side graph ingestion (C++, multithreaded): edge list -> CSR.  Replaces the networkx loops of
+ * minibatch.py:227-259 for the CSR engine (N2 "next" row).  All pointers are HOST pointers.
+ * keep_mask_host (nullable, per edge) drops edges (train_removed / val-test endpoints).
+ * ------------------------------------------------------------------------------------------- */
+int gs_build_csr_host(const int32_t* src_host, const int32_t* dst_host, const uint8_t* keep_mask_host,
+                      int64_t n_edges, int64_t n_nodes, int symmetrize,
+                      int64_t* rowptr_out_host /* [n_nodes+1] */, int32_t* col_out_host /* cap */,
+                      int64_t col_capacity, int64_t* nnz_out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHSAGE_AMD_H */

@@ -1,0 +1,48 @@
+"""CPU restatement (numpy uint64) of the CSR sampler of graphsage_amd/csrc/gs_sample.hip.
+
+TEST INFRASTRUCTURE ONLY (see oracle/graphsage_oracle.py header).  The reference has no CSR
+sampler: its sampler is the padded-table one (neigh_samplers.py:24-29, restated in
+graphsage_oracle.uniform_neighbor_sampler).  This file pins the NEW sampler's integer stream so
+the HIP kernel can be checked bit-exactly, and so tests can check its distribution against the
+reference's per-slot marginal (uniform over the neighbor set; pad id for degree-0 rows,
+minibatch.py:228,238-239).
+"""
+import numpy as np
+
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_G = np.uint64(0x9E3779B97F4A7C15)
+_R = np.uint64(0xD1342543DE82EF95)
+
+
+def mix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z ^ (z >> np.uint64(30))
+        z = z * _M1
+        z = z ^ (z >> np.uint64(27))
+        z = z * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, step, hop, global_row_offset=0):
+    ids = np.asarray(ids, dtype=np.int64)
+    n = ids.shape[0]
+    with np.errstate(over="ignore"):
+        key = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (np.uint64(step) * _G) ^ (np.uint64(hop) << np.uint64(56)))
+        i = (np.arange(n, dtype=np.uint64) + np.uint64(global_row_offset))[:, None]
+        j = np.arange(num_samples, dtype=np.uint64)[None, :]
+        u = mix64(key + i * _R + j)
+    r = (u >> np.uint64(32)).astype(np.uint64)
+    valid = (ids >= 0) & (ids < n_nodes)
+    safe = np.where(valid, ids, 0)
+    beg = np.where(valid, rowptr[safe], 0).astype(np.int64)
+    deg = np.where(valid, rowptr[safe + 1] - rowptr[safe], 0).astype(np.int64)
+    k = ((r * deg[:, None].astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
+    pos = beg[:, None] + k
+    has = deg[:, None] > 0
+    pos = np.where(has, pos, 0)
+    picked = np.asarray(col)[pos] if len(col) else np.zeros_like(pos)
+    out = np.where(has, picked, pad_id).astype(np.int32)
+    return out

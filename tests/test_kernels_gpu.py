@@ -1,0 +1,380 @@
+"""-m gpu parity tests: every HIP kernel (called through the C ABI) vs the NumPy oracle.
+
+Tolerances: bit-exact for int32 index outputs; rtol/atol 1e-4 for fp32 (north_star tolerance;
+TF/Eigen summation order is unspecified, ours is fixed -- see DESIGN.md).
+"""
+import numpy as np
+import pytest
+import torch
+
+from graphsage_amd import ops
+from graphsage_amd.ops import Mat
+from oracle import graphsage_oracle as orc
+from oracle import sampler_hash
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def _i32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+# ----------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("n,s,max_deg", [(512, 10, 128), (5120, 25, 128), (7, 3, 5), (1, 128, 128), (100, 1, 4)])
+def test_sample_padded_bit_exact(dev, n, s, max_deg):
+    rng = np.random.default_rng(n * 131 + s)
+    N = 1000
+    adj = rng.integers(0, N + 1, size=(N + 1, max_deg)).astype(np.int32)
+    adj[N, :] = N
+    ids = rng.integers(0, N + 1, size=n).astype(np.int32)
+    perm = rng.permutation(max_deg).astype(np.int32)
+    want = orc.uniform_neighbor_sampler(adj, ids, s, perm)
+    got = ops.sample_padded(_i32(adj, dev), _i32(ids, dev), _i32(perm, dev), s)
+    _sync()
+    assert np.array_equal(got.cpu().numpy().reshape(n, s), want)
+
+
+def _rand_csr(rng, N, max_deg, frac_zero=0.2):
+    deg = rng.integers(1, max_deg + 1, size=N)
+    deg[rng.random(N) < frac_zero] = 0
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, N, size=int(rowptr[-1])).astype(np.int32)
+    return rowptr, col
+
+
+@pytest.mark.parametrize("n,s", [(512, 10), (5120, 25), (3, 1), (64, 1), (65, 1), (1000, 64), (37, 100), (13, 7)])
+def test_sample_csr_bit_exact(dev, n, s):
+    rng = np.random.default_rng(n * 7 + s)
+    N = 5000
+    rowptr, col = _rand_csr(rng, N, 300)
+    ids = rng.integers(0, N + 1, size=n).astype(np.int32)  # includes the pad id N
+    for hop, step, off in [(0, 0, 0), (1, 17, 12345)]:
+        want = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, s, 123, step, hop, off)
+        got = ops.sample_uniform_csr(torch.from_numpy(rowptr).to(dev), _i32(col, dev), N, N, _i32(ids, dev), s, 123,
+                                     step=step, hop=hop, global_row_offset=off)
+        _sync()
+        assert np.array_equal(got.cpu().numpy().reshape(n, s), want)
+
+
+def test_sample_csr_step_dev_and_sharding(dev):
+    """step read from device memory == step by value; a row's draw is independent of sharding."""
+    rng = np.random.default_rng(5)
+    N = 3000
+    rowptr, col = _rand_csr(rng, N, 50)
+    ids = rng.integers(0, N, size=512).astype(np.int32)
+    rp, cl, idd = torch.from_numpy(rowptr).to(dev), _i32(col, dev), _i32(ids, dev)
+    full = ops.sample_uniform_csr(rp, cl, N, N, idd, 10, 99, step=7, hop=1).cpu().numpy()
+    step_dev = torch.tensor([7], dtype=torch.int64, device=dev)
+    via_dev = ops.sample_uniform_csr(rp, cl, N, N, idd, 10, 99, step=0, step_dev=step_dev, hop=1).cpu().numpy()
+    assert np.array_equal(full, via_dev)
+    half = ops.sample_uniform_csr(rp, cl, N, N, idd[256:].contiguous(), 10, 99, step=7, hop=1,
+                                  global_row_offset=256).cpu().numpy()
+    assert np.array_equal(full[2560:], half)
+
+
+def test_sample_csr_properties(dev):
+    """every pick is a true neighbor, degree-0 rows give the pad id, marginal is ~uniform (chi^2)."""
+    rng = np.random.default_rng(11)
+    N = 200
+    rowptr, col = _rand_csr(rng, N, 20)
+    # make adjacency lists duplicate-free so the uniformity test is clean
+    for i in range(N):
+        d = rowptr[i + 1] - rowptr[i]
+        col[rowptr[i]:rowptr[i + 1]] = rng.choice(N, size=d, replace=False)
+    node = int(np.argmax(np.diff(rowptr)))
+    d = int(rowptr[node + 1] - rowptr[node])
+    n = 20000
+    ids = np.full(n, node, dtype=np.int32)
+    got = ops.sample_uniform_csr(torch.from_numpy(rowptr).to(dev), _i32(col, dev), N, N, _i32(ids, dev), 8, 2024)
+    got = got.cpu().numpy()
+    neigh = col[rowptr[node]:rowptr[node + 1]]
+    assert np.isin(got, neigh).all()
+    counts = np.array([(got == v).sum() for v in neigh], dtype=np.float64)
+    exp = got.size / d
+    chi2 = ((counts - exp) ** 2 / exp).sum()
+    assert chi2 < d + 6 * np.sqrt(2 * d), (chi2, d)  # mean d-1, sd sqrt(2(d-1)); 6 sigma
+    zero = int(np.where(np.diff(rowptr) == 0)[0][0])
+    got0 = ops.sample_uniform_csr(torch.from_numpy(rowptr).to(dev), _i32(col, dev), N, N,
+                                  _i32(np.array([zero, N]), dev), 5, 1).cpu().numpy()
+    assert (got0 == N).all()
+
+
+def test_select_batch_and_counter(dev):
+    order = _i32(np.arange(100)[::-1].copy(), dev)
+    cur = torch.tensor([90], dtype=torch.int64, device=dev)
+    out = torch.empty(20, dtype=torch.int32, device=dev)
+    ops.select_batch(order, cur, 20, out)
+    ops.advance_counter(cur, 20)
+    _sync()
+    want = np.arange(100)[::-1][(90 + np.arange(20)) % 100]
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert int(cur.item()) == 110
+
+
+# ----------------------------------------------------------------------------- K2
+@pytest.mark.parametrize("n,s,d,ldm", [(5120, 25, 602, 32), (512, 10, 602, 32), (37, 3, 50, 4), (9, 1, 7, 4),
+                                       (64, 70, 130, 4), (5, 8, 256, 4), (3, 130, 1024, 4)])
+def test_gather_mean_fwd(dev, n, s, d, ldm):
+    rng = np.random.default_rng(n + s + d)
+    N = 3000
+    X = rng.normal(size=(N + 1, d)).astype(np.float32)
+    X[N] = 0
+    idx = rng.integers(0, N + 1, size=n * s).astype(np.int32)
+    Xd = Mat.from_numpy(X, dev, ld_multiple=ldm)
+    out = ops.gather_mean_fwd(Xd, _i32(idx, dev), n, s)
+    _sync()
+    want = X[idx].reshape(n, s, d).mean(axis=1, dtype=np.float32)
+    np.testing.assert_allclose(out.numpy(), want, **TOL)
+    assert (out.buf[:, d:].cpu().numpy() == 0).all()
+    # GCN mean: (sum neigh + self) / (s + 1), self rows gathered by index
+    sidx = rng.integers(0, N, size=n).astype(np.int32)
+    out2 = ops.gather_mean_fwd(Xd, _i32(idx, dev), n, s, self_src=Xd, self_idx=_i32(sidx, dev))
+    _sync()
+    want2 = (X[idx].reshape(n, s, d).sum(axis=1, dtype=np.float32) + X[sidx]) / np.float32(s + 1)
+    np.testing.assert_allclose(out2.numpy(), want2, **TOL)
+
+
+def test_gather_mean_contiguous_and_rows(dev):
+    rng = np.random.default_rng(3)
+    H = rng.normal(size=(5120, 256)).astype(np.float32)
+    Hd = Mat.from_numpy(H, dev)
+    out = ops.gather_mean_fwd(Hd, None, 512, 10)
+    _sync()
+    np.testing.assert_allclose(out.numpy(), H.reshape(512, 10, 256).mean(axis=1), **TOL)
+    ids = rng.integers(0, 5120, size=777).astype(np.int32)
+    rows = ops.gather_rows(Hd, _i32(ids, dev))
+    _sync()
+    assert np.array_equal(rows.numpy(), H[ids])  # pure copy: bit exact
+
+
+def test_gather_mean_empty(dev):
+    Xd = Mat.zeros(10, 8, dev)
+    out = Mat.zeros(0, 8, dev)
+    ops.gather_mean_fwd(Xd, torch.empty(0, dtype=torch.int32, device=dev), 0, 5, out=out)
+    _sync()
+
+
+def test_mean_bwd(dev):
+    rng = np.random.default_rng(4)
+    n, s, d = 512, 10, 256
+    dm = rng.normal(size=(n, d)).astype(np.float32)
+    y = rng.normal(size=(n * s, d)).astype(np.float32)
+    dn = Mat.zeros(n * s, d, dev)
+    ops.mean_bwd(Mat.from_numpy(dm, dev), n, s, 1.0 / s, dn, mask_y=Mat.from_numpy(y, dev))
+    _sync()
+    want = np.repeat(dm / np.float32(s), s, axis=0) * (y > 0)
+    np.testing.assert_allclose(dn.numpy(), want, **TOL)
+    ops.mean_bwd(Mat.from_numpy(dm, dev), n, s, 1.0 / s, dn, accumulate=True)
+    _sync()
+    np.testing.assert_allclose(dn.numpy(), want + np.repeat(dm / np.float32(s), s, axis=0), **TOL)
+
+
+# ----------------------------------------------------------------------------- K3
+def _asym(rng, shape):
+    return rng.normal(size=shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 41, 602), (512, 256, 602), (33, 7, 5), (1300, 130, 70)])
+def test_gemm_all_layouts(dev, tA, tB, M, N, K):
+    rng = np.random.default_rng(M + N + K + tA * 2 + tB)
+    A = _asym(rng, (M, K))
+    B = _asym(rng, (K, N))
+    bias = _asym(rng, (N,))
+    Ad = Mat.from_numpy(A.T.copy() if tA else A, dev)
+    Bd = Mat.from_numpy(B.T.copy() if tB else B, dev)
+    C = Mat.zeros(M, N, dev)
+    C.buf.fill_(7.0)
+    ops.gemm(tA, tB, M, N, K, Ad, Bd, C, bias=torch.from_numpy(bias).to(dev), act=ops.ACT_RELU)
+    _sync()
+    want = np.maximum(A.astype(np.float64) @ B.astype(np.float64) + bias, 0)
+    np.testing.assert_allclose(C.numpy(), want, rtol=1e-4, atol=1e-4 * np.sqrt(K))
+    assert (C.buf[:, N:ops.round_up(N, 4)].cpu().numpy() == 0).all()
+
+
+def test_gemm_big_tile_and_gather(dev):
+    """128x128 tile path (>= 1024 tiles) with gathered A rows: the MaxPool MLP shape in miniature."""
+    rng = np.random.default_rng(8)
+    Nn, d, hid, rows = 4000, 602, 512, 128 * 260
+    X = _asym(rng, (Nn, d))
+    W = _asym(rng, (d, hid)) * 0.05
+    b = _asym(rng, (hid,))
+    idx = rng.integers(0, Nn, size=rows).astype(np.int32)
+    C = Mat.zeros(rows, hid, dev)
+    ops.gemm(0, 0, rows, hid, d, Mat.from_numpy(X, dev, 32), Mat.from_numpy(W, dev), C, a_row_idx=_i32(idx, dev),
+             bias=torch.from_numpy(b).to(dev), act=ops.ACT_RELU)
+    _sync()
+    sel = rng.choice(rows, size=512, replace=False)
+    want = np.maximum(X[idx[sel]].astype(np.float64) @ W.astype(np.float64) + b, 0)
+    np.testing.assert_allclose(C.numpy()[sel], want, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("concat", [True, False])
+@pytest.mark.parametrize("n,d,out", [(5120, 602, 128), (512, 256, 128), (77, 50, 12)])
+def test_sage_dense_fwd(dev, concat, n, d, out):
+    rng = np.random.default_rng(n + d)
+    Nn = 3000
+    X = _asym(rng, (Nn, d))
+    mean = _asym(rng, (n, d))
+    Ws, Wn = _asym(rng, (d, out)) * 0.1, _asym(rng, (d, out)) * 0.1
+    sidx = rng.integers(0, Nn, size=n).astype(np.int32)
+    o = Mat.zeros(n, out * (2 if concat else 1), dev)
+    ops.sage_dense_fwd(Mat.from_numpy(X, dev, 32), _i32(sidx, dev), Mat.from_numpy(mean, dev), None, n,
+                       Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev), out, concat, ops.ACT_RELU, None, o)
+    _sync()
+    want, _ = orc.mean_aggregator_fwd(X[sidx].astype(np.float64), mean[:, None, :].astype(np.float64),
+                                      Ws.astype(np.float64), Wn.astype(np.float64), concat, "relu")
+    np.testing.assert_allclose(o.numpy(), want, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("n,d,out,col0,slabs", [(5120, 602, 128, 128, 16), (512, 602, 128, 0, 2), (100, 50, 41, 0, 3),
+                                                 (31, 256, 128, 0, 1)])
+def test_dense_wgrad_slabs(dev, n, d, out, col0, slabs):
+    rng = np.random.default_rng(n + d + out)
+    Nn = 2000
+    X = _asym(rng, (Nn, d))
+    idx = rng.integers(0, Nn, size=n).astype(np.int32)
+    dZ = _asym(rng, (n, col0 + out))
+    ld_slab = ops.round_up(out, 4)
+    sl = torch.full((slabs * d * ld_slab,), 3.0, dtype=torch.float32, device=dev)
+    ops.dense_wgrad(Mat.from_numpy(X, dev, 32), _i32(idx, dev), Mat.from_numpy(dZ, dev), col0, out, n, slabs, sl, ld_slab)
+    w = np.ones((d, out), np.float32)
+    grad = torch.zeros((d, ld_slab), dtype=torch.float32, device=dev)
+    ops.reduce_slabs(sl, slabs, d * ld_slab, d, out, ld_slab, 0.5, Mat.from_numpy(w, dev).ptr, ld_slab, ops.ptr(grad), ld_slab)
+    _sync()
+    want = X[idx].astype(np.float64).T @ dZ[:, col0:].astype(np.float64) + 0.5
+    np.testing.assert_allclose(grad.cpu().numpy()[:, :out], want, rtol=1e-4, atol=1e-4 * np.sqrt(n))
+    assert (grad.cpu().numpy()[:, out:] == 0).all()
+
+
+def test_dense_dgrad(dev):
+    rng = np.random.default_rng(21)
+    n, d, out, col0 = 512, 256, 128, 128
+    dZ = _asym(rng, (n, col0 + out))
+    W = _asym(rng, (d, out))
+    dX = Mat.from_numpy(np.ones((n, d), np.float32), dev)
+    ops.dense_dgrad(Mat.from_numpy(dZ, dev), col0, out, n, Mat.from_numpy(W, dev), dX, accumulate=True)
+    _sync()
+    want = 1.0 + dZ[:, col0:].astype(np.float64) @ W.astype(np.float64).T
+    np.testing.assert_allclose(dX.numpy(), want, rtol=1e-4, atol=1e-3)
+    # head-shaped: [512, 41] x [256, 41]^T
+    dZ2, W2 = _asym(rng, (n, 41)), _asym(rng, (256, 41))
+    dX2 = Mat.zeros(n, 256, dev)
+    ops.dense_dgrad(Mat.from_numpy(dZ2, dev), 0, 41, n, Mat.from_numpy(W2, dev), dX2)
+    _sync()
+    np.testing.assert_allclose(dX2.numpy(), dZ2.astype(np.float64) @ W2.astype(np.float64).T, rtol=1e-4, atol=1e-3)
+
+
+def test_act_bwd_and_colsum(dev):
+    rng = np.random.default_rng(22)
+    n, c = 777, 41
+    dY, Y = _asym(rng, (n, c)), _asym(rng, (n, c))
+    dZ = Mat.zeros(n, c, dev)
+    ops.act_bwd(Mat.from_numpy(dY, dev), Mat.from_numpy(Y, dev), n, c, ops.ACT_RELU, dZ)
+    sl = torch.zeros((5 * 44,), dtype=torch.float32, device=dev)
+    ops.colsum_slabs(dZ, n, c, 5, sl, 44)
+    _sync()
+    want = dY * (Y > 0)
+    np.testing.assert_allclose(dZ.numpy(), want, **TOL)
+    np.testing.assert_allclose(sl.cpu().numpy().reshape(5, 44)[:, :c].sum(0), want.sum(0), rtol=1e-4, atol=1e-3)
+
+
+# ----------------------------------------------------------------------------- K4
+def test_segment_max(dev):
+    rng = np.random.default_rng(23)
+    n, s, hid = 300, 25, 512
+    H = np.maximum(_asym(rng, (n * s, hid)), 0)
+    pooled, arg = Mat.zeros(n, hid, dev), torch.zeros((n, hid), dtype=torch.int32, device=dev)
+    ops.segment_max_fwd(Mat.from_numpy(H, dev), n, s, pooled, arg)
+    _sync()
+    H3 = H.reshape(n, s, hid)
+    assert np.array_equal(pooled.numpy(), H3.max(axis=1))
+    assert np.array_equal(arg.cpu().numpy(), H3.argmax(axis=1))
+    dP = _asym(rng, (n, hid))
+    dH = Mat.zeros(n * s, hid, dev)
+    ops.segment_max_bwd(Mat.from_numpy(dP, dev), pooled, arg, n, s, dH)
+    _sync()
+    want = np.zeros_like(H3)
+    np.put_along_axis(want, H3.argmax(axis=1)[:, None, :], (dP * (H3.max(axis=1) > 0))[:, None, :], axis=1)
+    assert np.array_equal(dH.numpy(), want.reshape(n * s, hid))
+
+
+# ----------------------------------------------------------------------------- K5
+def test_l2norm_fwd_bwd(dev):
+    rng = np.random.default_rng(24)
+    n, d = 512, 256
+    x = _asym(rng, (n, d))
+    x[3] = 0  # clamped row (sum sq < 1e-12)
+    dy = _asym(rng, (n, d))
+    y, inv, dx = Mat.zeros(n, d, dev), torch.zeros(n, device=dev), Mat.zeros(n, d, dev)
+    ops.l2norm_fwd(Mat.from_numpy(x, dev), n, y, inv)
+    ops.l2norm_bwd(Mat.from_numpy(dy, dev), y, inv, n, dx)
+    _sync()
+    wy, cache = orc.l2_normalize_fwd(x.astype(np.float64))
+    np.testing.assert_allclose(y.numpy(), wy, **TOL)
+    np.testing.assert_allclose(dx.numpy()[4:], orc.l2_normalize_bwd(dy.astype(np.float64), cache)[4:], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("sig,C", [(False, 41), (True, 121), (False, 3), (True, 64)])
+def test_class_loss(dev, sig, C):
+    rng = np.random.default_rng(C)
+    n = 300
+    x = _asym(rng, (n, C)) * 3
+    z = (rng.random((n, C)) > 0.5).astype(np.float32) if sig else np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]
+    lr, pr, dl = torch.zeros(n, device=dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
+    ops.class_loss(Mat.from_numpy(x, dev), Mat.from_numpy(z, dev), n, C, sig, lr, pr, dl)
+    _sync()
+    loss, dlog = orc.classification_loss(x.astype(np.float64), z.astype(np.float64), sig)
+    np.testing.assert_allclose(lr.cpu().numpy().mean(), loss, rtol=1e-4)
+    np.testing.assert_allclose(dl.numpy(), dlog, rtol=1e-4, atol=1e-7)
+    wp = orc.sigmoid(x.astype(np.float64)) if sig else orc.softmax(x.astype(np.float64))
+    np.testing.assert_allclose(pr.numpy(), wp, **TOL)
+
+
+# ----------------------------------------------------------------------------- K6
+def test_adam_matches_tf_formula(dev):
+    rng = np.random.default_rng(25)
+    cnt = 230185
+    p = _asym(rng, (cnt,))
+    g = _asym(rng, (cnt,)) * 8  # exercises the +-5 clip
+    pd, m, v = torch.from_numpy(p.copy()).to(dev), torch.zeros(cnt, device=dev), torch.zeros(cnt, device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    po, mo, vo = p.copy(), np.zeros(cnt, np.float32), np.zeros(cnt, np.float32)
+    for t in range(1, 4):
+        ops.adam_step(pd, torch.from_numpy(g).to(dev), m, v, cnt, 0.01, step)
+        ops.advance_counter(step, 1)
+        orc.adam_tf_update(po, orc.clip_by_value(g), mo, vo, t, 0.01)
+    _sync()
+    np.testing.assert_allclose(pd.cpu().numpy(), po, rtol=1e-5, atol=1e-6)
+
+
+def test_sum_kernels(dev):
+    x = torch.arange(10000, dtype=torch.float32, device=dev) / 1000.0
+    out = torch.zeros(1, device=dev)
+    ops.sum_scaled(x, 10000, 0.5, out)
+    ops.sumsq_scaled(x, 10000, 2.0, out, accumulate=True)
+    _sync()
+    xn = x.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(out.item(), 0.5 * xn.sum() + 2.0 * (xn ** 2).sum(), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- graphs
+def test_graph_capture_replay(dev):
+    st = ops.Stream()
+    x = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    g = ops.Graph(st.handle)
+    g.begin()
+    ops.advance_counter(x, 3, stream=st.handle)
+    ops.advance_counter(x, 4, stream=st.handle)
+    g.end()
+    for _ in range(5):
+        g.launch()
+    st.sync()
+    assert int(x.item()) == 35
