@@ -105,6 +105,7 @@ static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, i
 extern "C" int gs_gather_mean_fwd(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
                                   const float* self_src, int64_t ld_self, const int32_t* self_idx, float* mean,
                                   int64_t ldm, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(X, ldx, "gs_gather_mean_fwd X");
     GS_CHECK_MAT(mean, ldm, "gs_gather_mean_fwd mean");
     GS_REQUIRE(n >= 0 && s > 0 && d > 0, "gs_gather_mean_fwd: bad sizes n=%lld s=%d d=%d", (long long)n, s, d);
@@ -123,6 +124,7 @@ extern "C" int gs_gather_mean_fwd(const float* X, int64_t ldx, const int32_t* id
 
 extern "C" int gs_gather_rows(const float* X, int64_t ldx, const int32_t* ids, int64_t n, int32_t d, float* out,
                               int64_t ldo, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(X, ldx, "gs_gather_rows X");
     GS_CHECK_MAT(out, ldo, "gs_gather_rows out");
     GS_REQUIRE(ids && n >= 0 && d > 0, "gs_gather_rows: bad args");
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(256) void mean_bwd_kernel(const float* __restrict__
 extern "C" int gs_mean_bwd(const float* d_mean, int64_t ldd, int64_t n, int32_t s, int32_t d, float scale,
                            const float* mask_y, int64_t ldy, float* d_neigh, int64_t ldn, int accumulate,
                            void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(d_mean, ldd, "gs_mean_bwd d_mean");
     GS_CHECK_MAT(d_neigh, ldn, "gs_mean_bwd d_neigh");
     if (mask_y) GS_CHECK_MAT(mask_y, ldy, "gs_mean_bwd mask_y");

@@ -328,6 +328,7 @@ static inline int rup4(int x) { return (x + 3) & ~3; }
 extern "C" int gs_gemm_f32(int transA, int transB, int64_t M, int32_t N, int64_t K, const float* A, int64_t lda,
                            const int32_t* a_row_idx, const float* B, int64_t ldb, const float* bias, int act,
                            float* C, int64_t ldc, void* stream) {
+    if (M == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(A, lda, "gs_gemm_f32 A");
     GS_CHECK_MAT(B, ldb, "gs_gemm_f32 B");
     GS_CHECK_MAT(C, ldc, "gs_gemm_f32 C");
@@ -351,6 +352,7 @@ extern "C" int gs_sage_dense_fwd(const float* self, int64_t ld_self, const int32
                                  const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
                                  int32_t out_dim, int concat, int act, const float* bias, float* out, int64_t ldo,
                                  void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd agg");
     GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_fwd W_neigh");
     GS_CHECK_MAT(out, ldo, "gs_sage_dense_fwd out");
@@ -400,6 +402,7 @@ extern "C" int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx,
 
 extern "C" int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n, const float* W,
                               int64_t ldw, int32_t d, float* dX, int64_t ldx, int accumulate, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(dZ, ldz, "gs_dense_dgrad dZ");
     GS_CHECK_MAT(W, ldw, "gs_dense_dgrad W");
     GS_CHECK_MAT(dX, ldx, "gs_dense_dgrad dX");
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 extern "C" int gs_act_bwd(const float* dY, int64_t lddy, const float* Y, int64_t ldy, int64_t n, int32_t n_cols,
                           int act, float* dZ, int64_t lddz, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(dY, lddy, "gs_act_bwd dY");
     GS_CHECK_MAT(dZ, lddz, "gs_act_bwd dZ");
     if (act == GS_ACT_RELU) GS_CHECK_MAT(Y, ldy, "gs_act_bwd Y");

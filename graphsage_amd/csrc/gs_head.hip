@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void segment_max_fwd_kernel(const float* __res
 
 extern "C" int gs_segment_max_fwd(const float* H, int64_t ldh, int64_t n, int32_t s, int32_t hidden, float* pooled,
                                   int64_t ldp, int32_t* argmax, int64_t lda, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(H, ldh, "gs_segment_max_fwd H");
     GS_CHECK_MAT(pooled, ldp, "gs_segment_max_fwd pooled");
     GS_REQUIRE(argmax && n >= 0 && s > 0 && hidden > 0 && lda >= hidden, "gs_segment_max_fwd: bad args");
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __res
 extern "C" int gs_segment_max_bwd(const float* d_pooled, int64_t ldd, const float* pooled, int64_t ldp,
                                   const int32_t* argmax, int64_t lda, int64_t n, int32_t s, int32_t hidden, float* dH,
                                   int64_t ldh, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(dH, ldh, "gs_segment_max_bwd dH");
     GS_REQUIRE(d_pooled && pooled && argmax && n >= 0 && s > 0 && hidden > 0, "gs_segment_max_bwd: bad args");
     if (n == 0) return GS_OK;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
 
 extern "C" int gs_l2norm_fwd(const float* x, int64_t ldx, int64_t n, int32_t d, float* y, int64_t ldy, float* inv_norm,
                              void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_REQUIRE(x && y && n >= 0 && d > 0 && ldx >= d && ldy >= ((d + 3) & ~3), "gs_l2norm_fwd: bad args");
     if (n == 0) return GS_OK;
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)gs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, d,
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 
 extern "C" int gs_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* inv_norm, int64_t n,
                              int32_t d, float* dx, int64_t lddx, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_REQUIRE(dy && y && inv_norm && dx && n >= 0 && d > 0 && lddx >= ((d + 3) & ~3), "gs_l2norm_bwd: bad args");
     if (n == 0) return GS_OK;
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)gs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y,
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(256) void class_loss_kernel(const float* __restrict
 extern "C" int gs_class_loss(const float* logits, int64_t ldl, const float* labels, int64_t ldlab, int64_t n, int32_t C,
                              int sigmoid_loss, float* loss_rows, float* preds, int64_t ldp, float* dlogits, int64_t lddl,
                              void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_REQUIRE(logits && labels && loss_rows && n >= 0 && C > 0, "gs_class_loss: bad args");
     const int Cp = (C + 3) & ~3;
     GS_REQUIRE((!preds || ldp >= Cp) && (!dlogits || lddl >= Cp), "gs_class_loss: output ld must be >= round_up(C,4)");

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void sample_padded_kernel(const int32_t* __res
 extern "C" int gs_sample_padded(const int32_t* adj, int64_t n_adj_rows, int32_t max_deg, const int32_t* ids,
                                 int64_t n, const int32_t* col_perm, int32_t num_samples, int32_t* out,
                                 void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_REQUIRE(adj && ids && col_perm && out, "gs_sample_padded: null pointer");
     GS_REQUIRE(n >= 0 && n_adj_rows > 0 && max_deg > 0, "gs_sample_padded: bad sizes");
     GS_REQUIRE(num_samples > 0 && num_samples <= max_deg,
@@ -104,6 +105,7 @@ extern "C" int gs_sample_uniform_csr(const int64_t* rowptr, const int32_t* col, 
                                      const int32_t* ids, int64_t n, int32_t num_samples, uint64_t seed,
                                      uint64_t step, const uint64_t* step_dev, uint32_t hop,
                                      int64_t global_row_offset, int32_t* out, void* stream) {
+    if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_REQUIRE(rowptr && col && ids && out, "gs_sample_uniform_csr: null pointer");
     GS_REQUIRE(n >= 0 && n_nodes > 0 && num_samples > 0, "gs_sample_uniform_csr: bad sizes");
     GS_REQUIRE(hop < 256, "gs_sample_uniform_csr: hop must be < 256");

@@ -1,0 +1,189 @@
+"""Execution context of the MI355X engine: the launch stream, persistent workspaces (so a whole
+step can be captured into a hipGraph and replayed), trainable variables in ONE flat fp32 buffer
+(one Adam launch, one RCCL all-reduce), and split-K gradient slab arenas.
+
+This replaces what the TF1 runtime provided to the reference: tf.Variable storage
+(supervised_models.py:60, aggregators.py:30-33), gradient accumulation of
+optimizer.compute_gradients (supervised_models.py:95) and apply_gradients (:99).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .ops import Mat, round_up
+
+MAX_SLABS = 48  # slab capacity per variable (split-K partial sums of one backward pass)
+
+
+class Variable(object):
+    """A trainable fp32 matrix [rows, cols] living in the engine's flat parameter buffer."""
+
+    def __init__(self, name, init, decay=False):
+        init = np.asarray(init, dtype=np.float32)
+        if init.ndim == 1:
+            init = init[None, :]
+        self.name = name
+        self.rows, self.cols = init.shape
+        self.ld = round_up(self.cols, 4)
+        self.init = init
+        self.decay = decay  # member of aggregator.vars / node_pred.vars -> weight-decayed (supervised_models.py:104-108)
+        self.offset = None  # float offset in the flat buffers
+        self.value = None   # Mat view into engine.params
+        self.grad = None    # Mat view into engine.grads
+        self.slabs = None   # flat tensor [MAX_SLABS * rows * ld]
+        self.n_slabs = 0    # slabs written so far in the current backward pass
+
+    @property
+    def size(self):
+        return self.rows * self.ld
+
+    def numpy(self):
+        return self.value.numpy()
+
+    def assign(self, a):
+        a = np.asarray(a, dtype=np.float32).reshape(self.rows, self.cols)
+        self.value.buf[:, : self.cols].copy_(torch.from_numpy(a))
+
+    def slab_ptr(self, k):
+        return self.slabs.data_ptr() + 4 * k * self.size
+
+
+class Engine(object):
+    def __init__(self, device=None, stream=None):
+        if not torch.cuda.is_available():
+            raise ops._lib.GraphsageAmdError("graphsage_amd needs a HIP device (no CPU fallback)")
+        ops._lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._stream_obj = ops.Stream() if stream is None else None
+        self.stream = self._stream_obj.handle if stream is None else stream
+        self.variables = []
+        self.params = self.grads = self.adam_m = self.adam_v = None
+        self._ws = {}
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # optimizer step counter t-1
+        self.sample_clock_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # sampler RNG step
+        self.finalized = False
+
+    # -------------------------------------------------------------------------------- variables
+    def add_variable(self, name, init, decay=False):
+        assert not self.finalized, "variables must be created before Engine.finalize()"
+        v = Variable(name, init, decay)
+        self.variables.append(v)
+        return v
+
+    def finalize(self):
+        """Lay all variables out in one flat buffer (16-byte aligned segments)."""
+        if self.finalized:
+            return
+        off = 0
+        for v in self.variables:
+            v.offset = off
+            off += v.size
+        total = max(off, 4)
+        self.n_param_floats = total
+        self.params = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.adam_m = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.adam_v = torch.zeros(total, dtype=torch.float32, device=self.device)
+        for v in self.variables:
+            v.value = Mat(self.params[v.offset: v.offset + v.size].view(v.rows, v.ld), v.cols)
+            v.grad = Mat(self.grads[v.offset: v.offset + v.size].view(v.rows, v.ld), v.cols)
+            v.value.buf[:, : v.cols].copy_(torch.from_numpy(v.init))
+            v.slabs = torch.zeros(MAX_SLABS * v.size, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize()
+        self.finalized = True
+
+    def n_trainable(self):
+        return sum(v.rows * v.cols for v in self.variables)
+
+    # -------------------------------------------------------------------------------- workspaces
+    def ws_mat(self, key, rows, d, ld_multiple=4):
+        """Persistent [rows, d] matrix keyed by (key, rows, d): same buffer every step."""
+        k = ("m", key, rows, d)
+        m = self._ws.get(k)
+        if m is None:
+            m = Mat.zeros(rows, d, self.device, ld_multiple)
+            self._ws[k] = m
+        return m
+
+    def ws_i32(self, key, n):
+        k = ("i", key, n)
+        t = self._ws.get(k)
+        if t is None:
+            t = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+            self._ws[k] = t
+        return t
+
+    def ws_f32(self, key, n):
+        k = ("f", key, n)
+        t = self._ws.get(k)
+        if t is None:
+            t = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+            self._ws[k] = t
+        return t
+
+    # -------------------------------------------------------------------------------- gradients
+    def begin_backward(self):
+        for v in self.variables:
+            v.n_slabs = 0
+
+    @staticmethod
+    def pick_slabs(n_rows):
+        """Split-K slices for a weight gradient over n_rows: ~320 rows per slice, at most 24."""
+        return int(min(24, max(1, (n_rows + 319) // 320)))
+
+    def wgrad(self, var, A, a_idx, dZ, col0, n):
+        """var.slabs += A[a_idx]^T · dZ[:, col0:col0+var.cols] as new split-K slabs."""
+        k = self.pick_slabs(n)
+        if var.n_slabs + k > MAX_SLABS:
+            raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
+        assert A.d == var.rows
+        ops.call("gs_dense_wgrad", A.ptr, A.ld, ops.ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, var.cols, n, k,
+                 var.slab_ptr(var.n_slabs), var.ld, self.stream)
+        var.n_slabs += k
+
+    def bgrad(self, var, dZ, n, n_cols):
+        """Bias gradient slabs: column sums of dZ[:, :n_cols]."""
+        k = int(min(16, max(1, (n + 255) // 256)))
+        if var.n_slabs + k > MAX_SLABS:
+            raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
+        assert var.rows == 1 and var.cols == n_cols
+        ops.call("gs_colsum_slabs", dZ.ptr, dZ.ld, n, n_cols, k, var.slab_ptr(var.n_slabs), var.ld, self.stream)
+        var.n_slabs += k
+
+    def finish_backward(self, weight_decay):
+        """grads = sum of slabs (+ weight_decay * w for decayed variables)."""
+        for v in self.variables:
+            if v.n_slabs == 0:
+                v.grad.buf.zero_()  # not on the captured stream; only hit for unused variables
+                continue
+            wd = float(weight_decay) if v.decay else 0.0
+            ops.call("gs_reduce_slabs", v.slabs.data_ptr(), v.n_slabs, v.size, v.rows, v.cols, v.ld, wd,
+                     v.value.ptr, v.ld, v.grad.ptr, v.ld, 0, self.stream)
+
+    def adam(self, lr, clip=5.0, grad_scale=1.0):
+        ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_param_floats, lr, self.step_dev,
+                      clip=clip, grad_scale=grad_scale, stream=self.stream)
+        ops.advance_counter(self.step_dev, 1, stream=self.stream)
+
+    def sync(self):
+        ops.call("gs_stream_sync", self.stream)
+
+
+_default_engine = None
+
+
+def get_engine():
+    """Process-wide default engine (the analogue of TF's default graph + session)."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine()
+    return _default_engine
+
+
+def set_engine(e):
+    global _default_engine
+    _default_engine = e
+
+
+def reset_engine():
+    set_engine(None)

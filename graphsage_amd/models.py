@@ -1,0 +1,212 @@
+"""SampleAndAggregate: the sample -> gather -> aggregate schedule of graphsage/models.py:187-330 on
+the gfx950 engine, keeping the reference's method names and argument meaning:
+
+    samples, support_sizes = model.sample(inputs, layer_infos, batch_size)
+    out, aggregators       = model.aggregate(samples, [features], dims, num_samples, support_sizes,
+                                             batch_size, aggregators, name, concat, model_size)
+
+TF built a static graph once and ran it with sess.run; here the same Python runs eagerly on the
+engine's HIP stream, is captured into a hipGraph on its second execution for a given batch size,
+and replayed afterwards.  `aggregate_backward` is the hand-written reverse schedule (TF:
+optimizer.compute_gradients, models.py:379).
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .aggregators import GCNAggregator, MaxPoolingAggregator, MeanAggregator, MeanPoolingAggregator
+from .engine import get_engine
+from .layers import Rows, identity, relu
+from .ops import Mat
+
+# SAGEInfo is a namedtuple that specifies the parameters of the recursive GraphSAGE layers
+# (graphsage/models.py:180-185)
+SAGEInfo = namedtuple("SAGEInfo",
+                      ['layer_name',     # name of the layer (to get feature embedding etc.)
+                       'neigh_sampler',  # callable neigh_sampler constructor
+                       'num_samples',
+                       'output_dim'])    # the output (i.e., hidden) dimension
+
+_AGGREGATORS = {
+    "mean": MeanAggregator,
+    "maxpool": MaxPoolingAggregator,
+    "meanpool": MeanPoolingAggregator,
+    "gcn": GCNAggregator,
+}
+
+
+def _aggregator_cls(aggregator_type):
+    """Dispatch of models.py:211-222 / supervised_models.py:34-45 ('seq' is out of scope)."""
+    if aggregator_type == "seq":
+        raise NotImplementedError("SeqAggregator (LSTM) is outside the MI355X hot-path scope")
+    if aggregator_type not in _AGGREGATORS:
+        raise Exception("Unknown aggregator: ", aggregator_type)
+    return _AGGREGATORS[aggregator_type]
+
+
+class Placeholder(object):
+    """Host-side feed slot standing in for tf.placeholder (supervised_train.py:112-120)."""
+
+    def __init__(self, name, default=None):
+        self.name = name
+        self.value = default
+
+    def __repr__(self):
+        return "<Placeholder %s>" % self.name
+
+
+def device_features(features, engine=None):
+    """Upload the [N+1, F] feature table (row N = zero pad row, supervised_train.py:133-135) with a
+    leading dimension of whole 128-byte lines (F=602 -> ld=608)."""
+    e = engine or get_engine()
+    if isinstance(features, Mat):
+        return features
+    return Mat.from_numpy(np.asarray(features, dtype=np.float32), e.device, ld_multiple=32)
+
+
+class SampleAndAggregate(object):
+    """Base implementation of GraphSAGE (graphsage/models.py:187-405); the supervised subclass is in
+    supervised_models.py.  The unsupervised objective (_build/_loss/_accuracy, :332-405) is a
+    "next" row."""
+
+    def __init__(self, placeholders, features, adj, degrees, layer_infos, concat=True, aggregator_type="mean",
+                 model_size="small", identity_dim=0, **kwargs):
+        allowed_kwargs = {'name', 'logging', 'model_size'}
+        for kwarg in kwargs.keys():
+            assert kwarg in allowed_kwargs, 'Invalid keyword argument: ' + kwarg
+        self.name = kwargs.get('name') or self.__class__.__name__.lower()
+        self.engine = get_engine()
+        self.aggregator_cls = _aggregator_cls(aggregator_type)
+        self.aggregator_type = aggregator_type
+        self.model_size = model_size
+        self.adj_info = adj
+        if identity_dim > 0:
+            raise NotImplementedError("identity_dim > 0 (trainable node embeddings) is a 'next' row (SURVEY §8f N4)")
+        if features is None:
+            raise Exception("Must have a positive value for identity feature dimension if no input features given.")
+        self.features = device_features(features, self.engine)
+        self.degrees = degrees
+        self.concat = concat
+        self.dims = [self.features.d + identity_dim]
+        self.dims.extend([layer_infos[i].output_dim for i in range(len(layer_infos))])
+        self.placeholders = placeholders
+        self.batch_size = placeholders.get("batch_size") if placeholders else None
+        self.layer_infos = layer_infos
+        self.aggregators = None
+        self._tape = None
+
+    # ------------------------------------------------------------------------------ sample (S2)
+    def sample(self, inputs, layer_infos, batch_size=None):
+        """Sample neighbors to be the supportive fields for multi-layer convolutions
+        (models.py:254-275).  `inputs`: int32 device vector of batch node ids."""
+        if batch_size is None:
+            batch_size = inputs.numel()
+        samples = [inputs]
+        support_size = 1
+        support_sizes = [support_size]
+        for k in range(len(layer_infos)):
+            t = len(layer_infos) - k - 1
+            sampler = layer_infos[t].neigh_sampler
+            # this rank's first global row at this hop (keeps draws independent of the DP sharding)
+            sampler.global_row_offset = getattr(self, "row_offset", 0) * support_size
+            support_size *= layer_infos[t].num_samples
+            node = sampler((samples[k], layer_infos[t].num_samples))
+            samples.append(node.reshape(support_size * batch_size))
+            support_sizes.append(support_size)
+        return samples, support_sizes
+
+    # ------------------------------------------------------------------------------ aggregate (A0/A1)
+    def make_aggregators(self, dims, num_samples, concat, model_size, name=None):
+        """Aggregator construction of models.py:303-315 (one per layer, last layer identity act)."""
+        aggregators = []
+        for layer in range(len(num_samples)):
+            dim_mult = 2 if concat and (layer != 0) else 1
+            if layer == len(num_samples) - 1:
+                aggregator = self.aggregator_cls(dim_mult * dims[layer], dims[layer + 1], act=identity,
+                                                 dropout=self.placeholders['dropout'], name=name, concat=concat,
+                                                 model_size=model_size)
+            else:
+                aggregator = self.aggregator_cls(dim_mult * dims[layer], dims[layer + 1],
+                                                 dropout=self.placeholders['dropout'], name=name, concat=concat,
+                                                 model_size=model_size)
+            aggregators.append(aggregator)
+        return aggregators
+
+    def aggregate(self, samples, input_features, dims, num_samples, support_sizes, batch_size=None,
+                  aggregators=None, name=None, concat=False, model_size="small"):
+        """At each layer, aggregate hidden representations of neighbors to compute the hidden
+        representations at next layer (models.py:278-330).  Returns (hidden[0], aggregators)."""
+        if batch_size is None:
+            batch_size = samples[0].numel()
+        features = input_features[0] if isinstance(input_features, (list, tuple)) else input_features
+        # hidden[h] = embedding_lookup(features, samples[h]) -- kept LAZY (models.py:299)
+        hidden = [Rows(features, node_samples, requires_grad=False) for node_samples in samples]
+        new_agg = aggregators is None
+        if new_agg:
+            aggregators = self.make_aggregators(dims, num_samples, concat, model_size, name)
+            self.engine.finalize()
+        tape = []
+        for layer in range(len(num_samples)):
+            aggregator = aggregators[layer]
+            next_hidden = []
+            # as layer increases, the number of support nodes needed decreases
+            for hop in range(len(num_samples) - layer):
+                dim_mult = 2 if concat and (layer != 0) else 1
+                neigh_dims = [batch_size * support_sizes[hop],
+                              num_samples[len(num_samples) - hop - 1],
+                              dim_mult * dims[layer]]
+                h = aggregator((hidden[hop], hidden[hop + 1].reshape(neigh_dims)))
+                tape.append((layer, hop, aggregator, hidden[hop], hidden[hop + 1], h))
+                next_hidden.append(Rows(h, None, requires_grad=True))
+            hidden = next_hidden
+        self._tape = tape
+        return hidden[0].src, aggregators
+
+    def aggregate_backward(self, d_out):
+        """Reverse schedule of `aggregate`.  d_out: Mat = dLoss/d(hidden[0] of the last layer).
+        No gradient flows into the feature table (models.py:238: trainable=False)."""
+        e = self.engine
+        tape = self._tape
+        # gradient slots of the hidden matrices produced by aggregator calls: id(Mat) -> [Mat, state]
+        # state: 'raw' = dLoss/d(output after act); 'masked' = already multiplied by the relu mask
+        slots = {id(tape[-1][5]): [d_out, 'raw']}
+        # how many consumers each produced hidden matrix has (to decide whether the relu mask can be fused)
+        consumers = {}
+        for (_, _, _, self_rows, neigh_rows, _) in tape:
+            for r in (self_rows, neigh_rows):
+                if r.requires_grad:
+                    consumers[id(r.src)] = consumers.get(id(r.src), 0) + 1
+        produced_relu = {id(h): (agg.act_code == ops.ACT_RELU) for (_, _, agg, _, _, h) in tape}
+        for (layer, hop, agg, self_rows, neigh_rows, h) in reversed(tape):
+            slot = slots.pop(id(h), None)
+            if slot is None:
+                # output never used downstream (cannot happen in the reference schedule)
+                agg._saved.pop()
+                continue
+            d_h, state = slot
+            fuse = (neigh_rows.requires_grad and consumers.get(id(neigh_rows.src), 0) == 1
+                    and produced_relu.get(id(neigh_rows.src), False))
+            d_self, d_neigh = agg.backward(d_h, pre_masked=(state == 'masked'),
+                                           neigh_mask=neigh_rows.src if fuse else None)
+            if d_self is not None:
+                self._accumulate(slots, self_rows.src, d_self, 'raw')
+            if d_neigh is not None:
+                self._accumulate(slots, neigh_rows.src, d_neigh, 'masked' if fuse else 'raw')
+
+    def _accumulate(self, slots, mat, grad, state):
+        key = id(mat)
+        if key not in slots:
+            slots[key] = [grad, state]
+            return
+        cur, cur_state = slots[key]
+        assert cur_state == 'raw' and state == 'raw', "fused relu masks are only used for single-consumer tensors"
+        # cur += grad  (K >= 3: a hidden tensor can be both a self and a neighbor input)
+        ops.mean_bwd(grad, grad.rows, 1, 1.0, cur, accumulate=True, stream=self.engine.stream)
+
+    def reset_tapes(self):
+        if self.aggregators:
+            for a in self.aggregators:
+                a.reset()
+        self._tape = None

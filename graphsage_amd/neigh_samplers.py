@@ -1,0 +1,101 @@
+"""Classes that are used to sample node neighborhoods -- call surface of graphsage/neigh_samplers.py.
+
+`UniformNeighborSampler(adj_info)((ids, num_samples))` returns int32 [len(ids), num_samples]
+(neigh_samplers.py:24-29).  `adj_info` is a mutable adjacency handle (the analogue of the
+`adj_info` tf.Variable that the driver re-assigns between train and test adjacency,
+supervised_train.py:147-148,260-261,280,285): the sampler holds a reference, not a copy.
+
+Two adjacency layouts:
+  * PaddedAdjacency  -- the reference's [N+1, max_degree] table (minibatch.py:227-259); sampling is
+    `adj[ids][:, perm[:num_samples]]` with ONE column permutation per call (exact reference
+    semantics; the permutation is drawn on the host or injected for parity tests).
+  * CSRAdjacency     -- MI355X-native: rowptr/col on the device, counter-based per-slot draws
+    (gs_sample_uniform_csr).  Default for training; hipGraph-replayable (no host RNG).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .layers import Layer
+
+
+class PaddedAdjacency(object):
+    def __init__(self, adj, device):
+        adj = np.ascontiguousarray(adj, dtype=np.int32)
+        self.table = torch.from_numpy(adj).to(device)
+        self.n_nodes = adj.shape[0] - 1
+        self.max_degree = adj.shape[1]
+
+
+class CSRAdjacency(object):
+    def __init__(self, rowptr, col, n_nodes, device):
+        self.rowptr = torch.from_numpy(np.ascontiguousarray(rowptr, dtype=np.int64)).to(device)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        if col.size == 0:
+            col = np.zeros((1,), dtype=np.int32)
+        self.col = torch.from_numpy(col).to(device)
+        self.n_nodes = int(n_nodes)
+
+
+class AdjInfo(object):
+    """Mutable handle: `assign()` swaps the adjacency every sampler sees (tf.assign(adj_info, ...))."""
+
+    def __init__(self, adjacency):
+        self.current = adjacency
+        self.version = 0
+
+    def assign(self, adjacency):
+        if adjacency is not self.current:
+            self.current = adjacency
+            self.version += 1
+
+    @property
+    def n_nodes(self):
+        return self.current.n_nodes
+
+
+class UniformNeighborSampler(Layer):
+    """Uniformly samples neighbors (graphsage/neigh_samplers.py:15-29)."""
+
+    def __init__(self, adj_info, seed=123, **kwargs):
+        super(UniformNeighborSampler, self).__init__(**kwargs)
+        if not isinstance(adj_info, AdjInfo):
+            adj_info = AdjInfo(adj_info)
+        self.adj_info = adj_info
+        self.seed = int(seed)
+        self._rng = np.random.RandomState(seed)
+        self._injected_perms = None
+        self._call_index = 0          # sampler calls so far in this step = the `hop` stream id
+        self.global_row_offset = 0    # first global row of this rank's slice (data-parallel invariance)
+
+    # -- step bookkeeping driven by the model -------------------------------------------------
+    def new_step(self):
+        self._call_index = 0
+
+    def inject_perms(self, perms):
+        """Parity tests: column permutations to use for the next calls (padded layout only)."""
+        self._injected_perms = list(perms) if perms is not None else None
+
+    def _call(self, inputs):
+        ids, num_samples = inputs
+        e = self.engine
+        adj = self.adj_info.current
+        n = ids.numel()
+        out = e.ws_i32((self.name, "out", self._call_index), n * num_samples)
+        if isinstance(adj, PaddedAdjacency):
+            if num_samples > adj.max_degree:
+                raise ops._lib.GraphsageAmdError("num_samples %d > max_degree %d" % (num_samples, adj.max_degree))
+            if self._injected_perms:
+                perm = np.asarray(self._injected_perms.pop(0))[:num_samples]
+            else:
+                perm = self._rng.permutation(adj.max_degree)[:num_samples]
+            perm_dev = e.ws_i32((self.name, "perm", self._call_index), num_samples)
+            perm_dev.copy_(torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int32)))
+            torch.cuda.current_stream().synchronize()
+            ops.sample_padded(adj.table, ids, perm_dev, num_samples, out=out, stream=e.stream)
+        else:
+            ops.sample_uniform_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, ids, num_samples, self.seed,
+                                   step=0, step_dev=e.sample_clock_dev, hop=self._call_index,
+                                   global_row_offset=self.global_row_offset, out=out, stream=e.stream)
+        self._call_index += 1
+        return out[: n * num_samples].view(n, num_samples)

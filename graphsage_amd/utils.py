@@ -1,0 +1,188 @@
+"""Graph containers, synthetic dataset generators and adjacency builders.
+
+Replaces the networkx/json loading of graphsage/utils.py:19-75 for this engine: the reference's
+datasets are not shipped (example_data/.MISSING_LARGE_BLOBS) and networkx<=1.11 is not installable,
+so inputs are synthetic graphs of the reference's shapes.  The adjacency semantics
+of minibatch.py:227-259 are reproduced exactly:
+  * train adjacency: only train nodes have rows; only edges whose both endpoints are train nodes
+    (`train_removed` is set when either endpoint is val/test, utils.py:55-60);
+  * test adjacency: all nodes, all edges;
+  * pad id = N; padded rows are down/up-sampled ONCE to max_degree.
+"""
+import json
+import os
+
+import numpy as np
+
+
+class GraphData(object):
+    """Undirected graph as an edge list plus node attributes (what load_data returns, in arrays)."""
+
+    def __init__(self, n_nodes, src, dst, feats, labels, val_mask, test_mask, multilabel=False):
+        self.n_nodes = int(n_nodes)
+        self.src = np.ascontiguousarray(src, dtype=np.int32)
+        self.dst = np.ascontiguousarray(dst, dtype=np.int32)
+        self.feats = feats                      # float32 [N, F] (no pad row yet)
+        self.labels = labels                    # int64 [N] class ids, or float32 [N, C] multi-hot
+        self.val_mask = np.asarray(val_mask, dtype=bool)
+        self.test_mask = np.asarray(test_mask, dtype=bool)
+        self.multilabel = multilabel
+        # utils.py:55-60: an edge is train_removed if either endpoint is a val or test node
+        nt = self.val_mask | self.test_mask
+        self.train_removed = nt[self.src] | nt[self.dst]
+
+    @property
+    def num_classes(self):
+        if self.multilabel:
+            return int(self.labels.shape[1])
+        return int(self.labels.max()) + 1
+
+    def label_matrix(self):
+        """[N+1, C] float32 one-hot / multi-hot rows (minibatch.py:217-225); row N (pad) is zeros."""
+        C = self.num_classes
+        out = np.zeros((self.n_nodes + 1, C), dtype=np.float32)
+        if self.multilabel:
+            out[: self.n_nodes] = self.labels
+        else:
+            out[np.arange(self.n_nodes), self.labels] = 1.0
+        return out
+
+    def padded_features(self):
+        """features = vstack([features, zeros(F)])  (supervised_train.py:133-135)."""
+        return np.vstack([self.feats, np.zeros((1, self.feats.shape[1]), dtype=np.float32)]).astype(np.float32)
+
+
+def standardize_on_train(feats, train_mask):
+    """StandardScaler fit on the train rows, applied to all rows (utils.py:62-68)."""
+    tr = feats[train_mask]
+    mean = tr.mean(axis=0)
+    std = tr.std(axis=0)
+    std[std == 0] = 1.0
+    return ((feats - mean) / std).astype(np.float32)
+
+
+def build_csr(n_nodes, src, dst, keep=None):
+    """Symmetric CSR (rowptr int64, col int32) from an undirected edge list, via the C++ builder."""
+    from . import ops
+    return ops.build_csr_host(src, dst, n_nodes, symmetrize=True, keep_mask=keep)
+
+
+def build_csr_numpy(n_nodes, src, dst, keep=None):
+    """Pure-NumPy CSR builder (host logic check for the C++ builder)."""
+    if keep is not None:
+        src, dst = src[keep], dst[keep]
+    loops = src == dst
+    s = np.concatenate([src, dst[~loops]]).astype(np.int64)
+    d = np.concatenate([dst, src[~loops]]).astype(np.int64)
+    order = np.lexsort((d, s))
+    s, d = s[order], d[order]
+    rowptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.add.at(rowptr, s + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return rowptr, d.astype(np.int32)
+
+
+def padded_from_csr(rowptr, col, n_nodes, max_degree, rng):
+    """The reference's padded table (minibatch.py:227-259) from a CSR, vectorised:
+    deg > max_degree -> sample max_degree WITHOUT replacement; 0 < deg < max_degree -> WITH
+    replacement; deg == 0 -> all pad (= n_nodes).  Returns (adj [N+1, max_degree] int32, deg)."""
+    deg = np.diff(rowptr)
+    adj = np.full((n_nodes + 1, max_degree), n_nodes, dtype=np.int32)
+    small = np.where((deg > 0) & (deg <= max_degree))[0]
+    if small.size:
+        pick = (rng.random_sample((small.size, max_degree)) * deg[small][:, None]).astype(np.int64)
+        exact = deg[small] == max_degree
+        if exact.any():
+            pick[exact] = np.arange(max_degree)[None, :]
+        adj[small] = col[rowptr[small][:, None] + pick]
+    big = np.where(deg > max_degree)[0]
+    for i in big:  # few rows in practice (only hubs)
+        adj[i] = rng.choice(col[rowptr[i]:rowptr[i + 1]], max_degree, replace=False)
+    return adj, deg.astype(np.int64)
+
+
+def synthetic_graph(n_nodes=2000, feat_dim=50, num_classes=7, avg_degree=10, seed=123, multilabel=False,
+                    p_in=0.8, val_frac=0.1, test_frac=0.2, feat_noise=1.0, power_law=True, dtype=np.float32):
+    """Planted-community graph with learnable labels (SURVEY.md §8d config 2/3 shape: power-law degrees,
+    labels = communities, features = community centroid + noise)."""
+    rng = np.random.RandomState(seed)
+    comm = rng.randint(0, num_classes, size=n_nodes)
+    if power_law:
+        w = (rng.pareto(2.0, size=n_nodes) + 1.0)
+        w = np.minimum(w, np.percentile(w, 99.9))
+    else:
+        w = np.ones(n_nodes)
+    n_edges = int(n_nodes * avg_degree / 2)
+    p = w / w.sum()
+    src = rng.choice(n_nodes, size=n_edges, p=p)
+    # destination: same community with prob p_in, else anywhere (degree-weighted)
+    dst = rng.choice(n_nodes, size=n_edges, p=p)
+    same = rng.random_sample(n_edges) < p_in
+    order = np.argsort(comm, kind="stable")
+    starts = np.searchsorted(comm[order], np.arange(num_classes))
+    ends = np.searchsorted(comm[order], np.arange(num_classes), side="right")
+    cs = comm[src]
+    span = np.maximum(ends[cs] - starts[cs], 1)
+    dst_same = order[starts[cs] + (rng.random_sample(n_edges) * span).astype(np.int64) % span]
+    dst = np.where(same, dst_same, dst)
+    keep = src != dst
+    src, dst = src[keep].astype(np.int32), dst[keep].astype(np.int32)
+    centroids = rng.normal(size=(num_classes, feat_dim)).astype(dtype)
+    feats = centroids[comm] * 0.5 + rng.normal(size=(n_nodes, feat_dim)).astype(dtype) * feat_noise
+    r = rng.random_sample(n_nodes)
+    val_mask = r < val_frac
+    test_mask = (r >= val_frac) & (r < val_frac + test_frac)
+    feats = standardize_on_train(feats.astype(np.float32), ~(val_mask | test_mask))
+    if multilabel:
+        proj = rng.normal(size=(num_classes, num_classes))
+        labels = ((np.eye(num_classes)[comm] @ proj + 0.3 * rng.normal(size=(n_nodes, num_classes))) > 0.3)
+        labels = labels.astype(np.float32)
+    else:
+        labels = comm.astype(np.int64)
+    return GraphData(n_nodes, src, dst, feats, labels, val_mask, test_mask, multilabel=multilabel)
+
+
+def reddit_shaped(avg_degree=50, seed=123, n_nodes=232965, feat_dim=602, num_classes=41):
+    """Synthetic graph with Reddit's shape: N=232,965, F=602, C=41 single-label, 66/10/24 split."""
+    return synthetic_graph(n_nodes=n_nodes, feat_dim=feat_dim, num_classes=num_classes, avg_degree=avg_degree,
+                           seed=seed, val_frac=0.10, test_frac=0.24)
+
+
+def load_data(prefix, normalize=True):
+    """Reader for the reference's on-disk format (utils.py:19-75): <prefix>-G.json (node-link),
+    -id_map.json, -class_map.json, -feats.npy.  Returns a GraphData (random-walk pairs are only
+    needed by the unsupervised driver)."""
+    G = json.load(open(prefix + "-G.json"))
+    id_map = json.load(open(prefix + "-id_map.json"))
+    class_map = json.load(open(prefix + "-class_map.json"))
+    n = len(id_map)
+    id_map = {str(k): int(v) for k, v in id_map.items()}
+    nodes = G["nodes"]
+    val_mask = np.zeros(n, dtype=bool)
+    test_mask = np.zeros(n, dtype=bool)
+    node_ids = []
+    for nd in nodes:
+        i = id_map[str(nd["id"])]
+        node_ids.append(nd["id"])
+        val_mask[i] = bool(nd.get("val", False))
+        test_mask[i] = bool(nd.get("test", False))
+    # networkx<=1.11 node-link JSON: "source"/"target" are positions in the "nodes" list
+    src = np.array([id_map[str(node_ids[l["source"]])] for l in G["links"]], dtype=np.int32)
+    dst = np.array([id_map[str(node_ids[l["target"]])] for l in G["links"]], dtype=np.int32)
+    if os.path.exists(prefix + "-feats.npy"):
+        feats = np.load(prefix + "-feats.npy").astype(np.float32)
+    else:
+        raise Exception("No features present.. identity features are not supported by this engine yet")
+    first = next(iter(class_map.values()))
+    multilabel = isinstance(first, list)
+    if multilabel:
+        labels = np.zeros((n, len(first)), dtype=np.float32)
+        for k, v in class_map.items():
+            labels[id_map[str(k)]] = v
+    else:
+        labels = np.zeros(n, dtype=np.int64)
+        for k, v in class_map.items():
+            labels[id_map[str(k)]] = int(v)
+    if normalize:
+        feats = standardize_on_train(feats, ~(val_mask | test_mask))
+    return GraphData(n, src, dst, feats, labels, val_mask, test_mask, multilabel=multilabel)

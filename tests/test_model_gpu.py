@@ -1,0 +1,187 @@
+"""-m gpu end-to-end parity: SupervisedGraphsage (HIP kernels through the C ABI) vs the NumPy oracle on
+IDENTICAL sampled neighbor sets (north_star: within 1e-4 fp32), for every aggregator of SURVEY §8a."""
+import numpy as np
+import pytest
+import torch
+
+from graphsage_amd import engine as eng
+from graphsage_amd import inits, ops
+from graphsage_amd.minibatch import NodeMinibatchIterator
+from graphsage_amd.models import Placeholder, SAGEInfo
+from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, PaddedAdjacency, UniformNeighborSampler
+from graphsage_amd.supervised_models import SupervisedGraphsage
+from graphsage_amd.utils import synthetic_graph
+from oracle import graphsage_oracle as orc
+from oracle import sampler_hash
+
+pytestmark = pytest.mark.gpu
+
+
+def placeholders():
+    return {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'),
+            'dropout': Placeholder('dropout', 0.), 'batch_size': Placeholder('batch_size')}
+
+
+def oracle_params(model, agg_type):
+    agg = []
+    for a in model.aggregators:
+        p = {k: v.numpy().copy() for k, v in a.vars.items()}
+        if agg_type in ("maxpool", "meanpool"):
+            p["mlp_weights"] = a.mlp_layers[0].vars['weights'].numpy().copy()
+            p["mlp_bias"] = a.mlp_layers[0].vars['bias'].numpy().reshape(-1).copy()
+        agg.append(p)
+    return {"agg": agg, "node_pred": {"weights": model.node_pred.vars['weights'].numpy().copy(),
+                                      "bias": model.node_pred.vars['bias'].numpy().reshape(-1).copy()}}
+
+
+def device_grads(model, agg_type):
+    agg = []
+    for a in model.aggregators:
+        g = {k: v.grad.numpy().copy() for k, v in a.vars.items()}
+        if agg_type in ("maxpool", "meanpool"):
+            g["mlp_weights"] = a.mlp_layers[0].vars['weights'].grad.numpy().copy()
+            g["mlp_bias"] = a.mlp_layers[0].vars['bias'].grad.numpy().reshape(-1).copy()
+        agg.append(g)
+    return {"agg": agg, "node_pred": {"weights": model.node_pred.vars['weights'].grad.numpy().copy(),
+                                      "bias": model.node_pred.vars['bias'].grad.numpy().reshape(-1).copy()}}
+
+
+def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, dim=16, max_degree=10, n_nodes=400):
+    eng.reset_engine()
+    inits.set_seed(7)
+    G = synthetic_graph(n_nodes=n_nodes, feat_dim=feat_dim, num_classes=7, avg_degree=6, seed=5, multilabel=sigmoid)
+    ph = placeholders()
+    it = NodeMinibatchIterator(G, None, ph, None, G.num_classes, batch_size=32, max_degree=max_degree)
+    e = eng.get_engine()
+    if csr:
+        adj_train = CSRAdjacency(it.train_csr[0], it.train_csr[1], G.n_nodes, e.device)
+    else:
+        adj_train = PaddedAdjacency(it.adj, e.device)
+    adj_info = AdjInfo(adj_train)
+    sampler = UniformNeighborSampler(adj_info)
+    ns = [5, 3, 2][:K]
+    od = (2 * dim if agg_type == "gcn" else dim)
+    layer_infos = [SAGEInfo("node", sampler, ns[i], od) for i in range(K)]
+    model = SupervisedGraphsage(G.num_classes, ph, G.padded_features(), adj_info, it.deg, layer_infos,
+                                concat=concat, aggregator_type=agg_type, sigmoid_loss=sigmoid,
+                                learning_rate=0.01, weight_decay=wd)
+    return G, it, ph, sampler, model, ns
+
+
+CASES = [("mean", True, False), ("mean", False, True), ("gcn", False, False), ("maxpool", True, False),
+         ("meanpool", True, True), ("mean", True, True)]
+
+
+@pytest.mark.parametrize("agg_type,concat,sigmoid", CASES)
+def test_train_step_matches_oracle(dev, agg_type, concat, sigmoid):
+    wd = 0.01
+    G, it, ph, sampler, model, ns = build(dev, agg_type, concat, sigmoid, wd=wd)
+    model.use_graphs = False
+    rng = np.random.RandomState(3)
+    batch = rng.choice(it.train_nodes, size=37, replace=False).astype(np.int32)   # ragged batch
+    batch[0] = G.n_nodes - 1 if (G.val_mask | G.test_mask)[G.n_nodes - 1] else batch[0]
+    perms = [rng.permutation(it.max_degree) for _ in ns]
+    labels = it.label_matrix[batch]
+    params = oracle_params(model, agg_type)
+    sampler.inject_perms(perms)
+    feed = {ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)}
+    loss, preds = model.train_step(feed)
+    # ---- oracle on the identical neighbor sets
+    samples, support = orc.sample(it.adj, batch, ns, perms)
+    for got, want in zip(model.samples1, samples):
+        assert np.array_equal(got.cpu().numpy(), want)          # S1/S2: bit exact
+    feats = G.padded_features()
+    res = orc.supervised_fwd_bwd(params, feats, samples, support, labels, model.dims, ns, len(batch), agg_type,
+                                 concat, sigmoid, weight_decay=wd)
+    np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(preds, res["preds"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(model.outputs1.numpy(), res["outputs1"], rtol=1e-4, atol=1e-4)
+    got = device_grads(model, agg_type)
+    for (name, g), (_, w) in zip(orc.flat_param_items(got, agg_type), orc.flat_param_items(res["grads"], agg_type)):
+        np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                   err_msg=name)
+    # ---- optimizer: clip +-5 and TF Adam, t = 1
+    after = oracle_params(model, agg_type)
+    for (name, p0), (_, g), (_, p1) in zip(orc.flat_param_items(params, agg_type),
+                                           orc.flat_param_items(res["grads"], agg_type),
+                                           orc.flat_param_items(after, agg_type)):
+        p = p0.copy()
+        orc.adam_tf_update(p, orc.clip_by_value(g).reshape(p.shape), np.zeros_like(p), np.zeros_like(p), 1, 0.01)
+        np.testing.assert_allclose(p1.reshape(p.shape), p, rtol=1e-4, atol=2e-5, err_msg=name)
+
+
+def test_three_layer_mean(dev):
+    """samples_3 != 0 (supervised_train.py:153-156): a hidden tensor is both a self and a neighbor input."""
+    G, it, ph, sampler, model, ns = build(dev, "mean", True, False, K=3)
+    model.use_graphs = False
+    rng = np.random.RandomState(4)
+    batch = rng.choice(it.train_nodes, size=16, replace=False).astype(np.int32)
+    perms = [rng.permutation(it.max_degree) for _ in ns]
+    labels = it.label_matrix[batch]
+    params = oracle_params(model, "mean")
+    sampler.inject_perms(perms)
+    loss, preds = model.train_step({ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)})
+    samples, support = orc.sample(it.adj, batch, ns, perms)
+    res = orc.supervised_fwd_bwd(params, G.padded_features(), samples, support, labels, model.dims, ns, len(batch),
+                                 "mean", True, False)
+    np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+    got = device_grads(model, "mean")
+    for (name, g), (_, w) in zip(orc.flat_param_items(got, "mean"), orc.flat_param_items(res["grads"], "mean")):
+        np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()), err_msg=name)
+
+
+def test_eval_swaps_adjacency(dev):
+    """tf.assign(adj_info, test_adj) semantics: the sampler follows the handle (supervised_train.py:280,285)."""
+    G, it, ph, sampler, model, ns = build(dev, "mean", True, False)
+    model.use_graphs = False
+    e = eng.get_engine()
+    val = it.val_nodes[:20].astype(np.int32)
+    labels = it.label_matrix[val]
+    feed = {ph['batch']: val, ph['labels']: labels, ph['batch_size']: len(val)}
+    perms = [np.arange(it.max_degree), np.arange(it.max_degree)]
+    sampler.inject_perms(perms)
+    model.eval_step(feed)
+    # under the TRAIN adjacency every val node row is all-pad (minibatch.py:232-233)
+    assert (model.samples1[1].cpu().numpy() == G.n_nodes).all()
+    model.adj_info.assign(PaddedAdjacency(it.test_adj, e.device))
+    sampler.inject_perms(perms)
+    loss, preds = model.eval_step(feed)
+    want, _ = orc.sample(it.test_adj, val, ns, perms)
+    assert np.array_equal(model.samples1[2].cpu().numpy(), want[2])
+    assert np.isfinite(loss) and preds.shape == (20, G.num_classes)
+
+
+def test_csr_training_graph_replay_equals_eager(dev):
+    """CSR sampler + hipGraph replay: three steps replayed == three steps eager (deterministic kernels)."""
+    outs = []
+    for use_graphs in (False, True):
+        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+        model.use_graphs = use_graphs
+        order = it.train_nodes[:96]
+        model.attach_device_epoch(order, it.label_matrix)
+        losses = [model.train_step_device(32, fetch=True)[0] for _ in range(3)]
+        # the sampled ids must be what the oracle hash predicts for (seed, step=2, hop)
+        want1 = sampler_hash.sample_uniform_csr(it.train_csr[0], it.train_csr[1], G.n_nodes, G.n_nodes,
+                                                order[64:96], ns[1], 123, 2, 0)
+        assert np.array_equal(model.samples1[1].cpu().numpy().reshape(32, ns[1]), want1)
+        outs.append((losses, eng.get_engine().params.cpu().numpy().copy()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][0][2] < outs[0][0][0] + 0.5  # training is not diverging
+
+
+def test_training_learns(dev):
+    """A few epochs on a planted-community graph reach a high val micro-F1 (the metric's quality half)."""
+    G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True, n_nodes=3000, dim=32)
+    e = eng.get_engine()
+    model.attach_device_epoch(it.train_nodes, it.label_matrix)
+    B = 128
+    for epoch in range(4):
+        model.set_epoch_order(np.random.RandomState(epoch).permutation(it.train_nodes))
+        for _ in range(len(it.train_nodes) // B):
+            model.train_step_device(B)
+    model.adj_info.assign(CSRAdjacency(it.test_csr[0], it.test_csr[1], G.n_nodes, e.device))
+    val = it.val_nodes.astype(np.int32)
+    loss, preds = model.eval_step({ph['batch']: val, ph['labels']: it.label_matrix[val], ph['batch_size']: len(val)})
+    f1 = orc.calc_f1_micro(it.label_matrix[val], preds, False)
+    assert f1 > 0.8, f1
