@@ -99,10 +99,20 @@ def check(rc, what):
         raise GraphsageAmdError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
+_DEBUG_SYNC = os.environ.get("GS_DEBUG_SYNC", "0") == "1"
+
+
 def call(name, *args):
     lib = load()
+    if _DEBUG_SYNC:
+        import sys
+        import torch
+        sys.stderr.write("[gs] %s %s\n" % (name, " ".join(str(a) for a in args)))
+        sys.stderr.flush()
     rc = getattr(lib, name)(*args)
     check(rc, name)
+    if _DEBUG_SYNC and not name.startswith(("gs_capture", "gs_graph", "gs_stream", "gs_event")):
+        torch.cuda.synchronize()
 
 
 def ptr(t):

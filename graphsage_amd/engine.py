@@ -102,6 +102,7 @@ class Engine(object):
         m = self._ws.get(k)
         if m is None:
             m = Mat.zeros(rows, d, self.device, ld_multiple)
+            torch.cuda.synchronize()  # the zero-fill ran on torch's stream; order it before ours
             self._ws[k] = m
         return m
 
@@ -110,6 +111,7 @@ class Engine(object):
         t = self._ws.get(k)
         if t is None:
             t = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize()
             self._ws[k] = t
         return t
 
@@ -118,6 +120,7 @@ class Engine(object):
         t = self._ws.get(k)
         if t is None:
             t = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+            torch.cuda.synchronize()
             self._ws[k] = t
         return t
 

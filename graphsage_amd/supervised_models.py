@@ -200,6 +200,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         torch.cuda.synchronize()
 
     def set_epoch_order(self, order):
+        self.engine.sync()  # steps still queued on the engine stream read the old order / cursor
         self._order.copy_(torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)))
         self._cursor.zero_()
         torch.cuda.synchronize()
