@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Headline benchmark: sampled-edges/sec of the full GraphSAGE-mean TRAINING step
+(sample -> gather+mean -> dense -> loss -> backward -> [all-reduce] -> clip+Adam) on a synthetic
+Reddit-shaped graph (N=232,965, F=602, C=41, fan-out 25x10, batch 512 per GPU) -- BASELINE.json configs[1].
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One JSON line on rank 0.  `value` = (edges all ranks sampled in K steps) / (max-over-ranks wall time),
+features/CSR/labels/epoch order resident in HBM before the timed region.  See DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from graphsage_amd import distributed as gsd  # noqa: E402
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_model(G, it, args, world, rank):
+    from graphsage_amd import engine as eng
+    from graphsage_amd.models import Placeholder, SAGEInfo
+    from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, UniformNeighborSampler
+    from graphsage_amd.supervised_models import SupervisedGraphsage
+    eng.reset_engine()
+    e = eng.get_engine()
+    ph = {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'), 'dropout': Placeholder('dropout', 0.),
+          'batch_size': Placeholder('batch_size')}
+    adj_info = AdjInfo(CSRAdjacency(it.train_csr[0], it.train_csr[1], G.n_nodes, e.device))
+    sampler = UniformNeighborSampler(adj_info, seed=123)
+    layer_infos = [SAGEInfo("node", sampler, args.samples_1, args.dim_1),
+                   SAGEInfo("node", sampler, args.samples_2, args.dim_2)]
+    model = SupervisedGraphsage(G.num_classes, ph, G.padded_features(), adj_info, it.deg, layer_infos,
+                                concat=True, aggregator_type="mean", sigmoid_loss=False,
+                                learning_rate=0.01, weight_decay=0.0, world_size=world, rank=rank)
+    model.row_offset = rank * args.batch_size
+    return e, model, ph
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch_size", type=int, default=512)
+    ap.add_argument("--samples_1", type=int, default=25)
+    ap.add_argument("--samples_2", type=int, default=10)
+    ap.add_argument("--dim_1", type=int, default=128)
+    ap.add_argument("--dim_2", type=int, default=128)
+    ap.add_argument("--nodes", type=int, default=232965)
+    ap.add_argument("--feat_dim", type=int, default=602)
+    ap.add_argument("--classes", type=int, default=41)
+    ap.add_argument("--avg_degree", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank, local_rank, world = gsd.init_from_env()
+    if world != args.gpus and world > 1:
+        log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+
+    from graphsage_amd import ops
+    from graphsage_amd.minibatch import NodeMinibatchIterator
+    from graphsage_amd.utils import reddit_shaped
+
+    t0 = time.time()
+    G = reddit_shaped(avg_degree=args.avg_degree, seed=123, n_nodes=args.nodes, feat_dim=args.feat_dim,
+                      num_classes=args.classes)
+    it = NodeMinibatchIterator(G, None, {}, None, G.num_classes, batch_size=args.batch_size, max_degree=128,
+                               build_padded=False)
+    e, model, ph = build_model(G, it, args, world, rank)
+    if rank == 0:
+        log("graph+model ready in %.1fs: N=%d edges=%d train=%d params=%d" %
+            (time.time() - t0, G.n_nodes, len(G.src), len(it.train_nodes), e.n_trainable()))
+
+    B, s1, s2, F = args.batch_size, args.samples_1, args.samples_2, args.feat_dim
+    epoch = np.random.RandomState(123).permutation(it.train_nodes)
+    order = gsd.shard_order(epoch, rank, world, B) if world > 1 else epoch
+    model.attach_device_epoch(order, it.label_matrix)
+    if world > 1:
+        model.grad_hook = gsd.GradAllReduce(e)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):     # first two executions are eager + capture
+        model.train_step_device(B)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        model.train_step_device(B)
+    e.sync()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=e.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        torch.distributed.barrier()
+    loss_after = model._fetch(B)[0]
+
+    edges_per_step = B * (s2 + s2 * s1)
+    value = edges_per_step * world * args.steps / dt
+
+    result = {
+        "metric": "sampled-edges/sec, Reddit-shaped supervised graphsage_mean fan-out %dx%d" % (s1, s2),
+        "value": value, "unit": "sampled-edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), supervised "
+                               "graphsage_mean, fan-out %dx%d, batch %d per GPU, dims %d/%d, full training step "
+                               "(sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay" %
+                               (args.nodes, F, args.classes, args.avg_degree, s1, s2, B, args.dim_1, args.dim_2,
+                                "+RCCL all-reduce" if world > 1 else ""),
+                   "global_batch": B * world, "parallelism": "dp%d" % world, "loss_after": loss_after},
+    }
+
+    if rank == 0:
+        # ---------------- roofline of the dominant kernel (K2 hop-2 gather+mean), HIP events on the engine stream
+        n2 = B * s2
+        idx2 = model.samples1[2]
+        mean2 = ops.Mat.zeros(n2, F, e.device)
+        torch.cuda.synchronize()
+        iters = max(20, min(args.steps, 200))
+        evs = [(ops.Event(), ops.Event()) for _ in range(iters)]
+        for a, b in evs:                     # interleave K2 launches with full steps: same cache state as training
+            model.train_step_device(B)
+            a.record(e.stream)
+            ops.gather_mean_fwd(model.features, idx2, n2, s1, out=mean2, stream=e.stream)
+            b.record(e.stream)
+        e.sync()
+        k2_us = float(np.mean([a.elapsed_ms(b) for a, b in evs])) * 1e3
+        alg_bytes = n2 * s1 * F * 4 + n2 * s1 * 4 + n2 * F * 4    # rows*F*4 + ids + mean write
+        achieved = alg_bytes / (k2_us * 1e-6) / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                              "frac": achieved / 8000.0, "traffic": None,
+                              "kernel": "gather_mean_kernel<8> (K2, hop-2: [%d x %d] rows of %d fp32)" % (n2, s1, F),
+                              "avg_launch_us": k2_us, "algorithmic_bytes_per_launch": alg_bytes}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle.cpu_baseline import time_cpu_baseline
+            from graphsage_amd.utils import padded_from_csr
+            tc = time.time()
+            adj, _ = padded_from_csr(it.train_csr[0], it.train_csr[1], G.n_nodes, 128, np.random.RandomState(123))
+            cb = time_cpu_baseline(G.padded_features(), adj, it.label_matrix, it.train_nodes, G.num_classes,
+                                   batch_size=B, num_samples=(s1, s2), dims=(F, args.dim_1, args.dim_2),
+                                   budget_s=args.cpu_budget_s)
+            cb.pop("s_per_step", None)
+            result["cpu_baseline"] = cb
+            log("cpu baseline took %.1fs" % (time.time() - tc))
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

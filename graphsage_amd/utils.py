@@ -48,17 +48,35 @@ class GraphData(object):
         return out
 
     def padded_features(self):
-        """features = vstack([features, zeros(F)])  (supervised_train.py:133-135)."""
-        return np.vstack([self.feats, np.zeros((1, self.feats.shape[1]), dtype=np.float32)]).astype(np.float32)
+        """features = vstack([features, zeros(F)])  (supervised_train.py:133-135); cached."""
+        if getattr(self, "_padded", None) is None:
+            self._padded = np.vstack([self.feats, np.zeros((1, self.feats.shape[1]), dtype=np.float32)])
+        return self._padded
 
 
-def standardize_on_train(feats, train_mask):
-    """StandardScaler fit on the train rows, applied to all rows (utils.py:62-68)."""
-    tr = feats[train_mask]
-    mean = tr.mean(axis=0)
-    std = tr.std(axis=0)
+def standardize_on_train(feats, train_mask, chunk=16384):
+    """StandardScaler fit on the train rows, applied to all rows (utils.py:62-68).  In place and
+    chunked: a 233K x 602 table is 561 MB and page-faulting temporaries dominate otherwise."""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    n, f = feats.shape
+    cnt = 0
+    s1 = np.zeros(f, dtype=np.float64)
+    s2 = np.zeros(f, dtype=np.float64)
+    for a in range(0, n, chunk):
+        blk = feats[a:a + chunk][train_mask[a:a + chunk]]
+        cnt += blk.shape[0]
+        s1 += blk.sum(axis=0, dtype=np.float64)
+        s2 += np.einsum("ij,ij->j", blk, blk, dtype=np.float64)
+    mean = s1 / max(cnt, 1)
+    var = np.maximum(s2 / max(cnt, 1) - mean * mean, 0.0)
+    std = np.sqrt(var)
     std[std == 0] = 1.0
-    return ((feats - mean) / std).astype(np.float32)
+    mean32, inv32 = mean.astype(np.float32), (1.0 / std).astype(np.float32)
+    for a in range(0, n, chunk):
+        blk = feats[a:a + chunk]
+        blk -= mean32
+        blk *= inv32
+    return feats
 
 
 def build_csr(n_nodes, src, dst, keep=None):
@@ -127,12 +145,18 @@ def synthetic_graph(n_nodes=2000, feat_dim=50, num_classes=7, avg_degree=10, see
     dst = np.where(same, dst_same, dst)
     keep = src != dst
     src, dst = src[keep].astype(np.int32), dst[keep].astype(np.int32)
-    centroids = rng.normal(size=(num_classes, feat_dim)).astype(dtype)
-    feats = centroids[comm] * 0.5 + rng.normal(size=(n_nodes, feat_dim)).astype(dtype) * feat_noise
+    centroids = rng.normal(size=(num_classes, feat_dim)).astype(np.float32)
+    # float32 generation in place (no float64 temporaries: 561 MB tables page-fault slowly)
+    g32 = np.random.default_rng(seed + 1)
+    feats = g32.standard_normal((n_nodes, feat_dim), dtype=np.float32)
+    if feat_noise != 1.0:
+        feats *= np.float32(feat_noise)
+    for a in range(0, n_nodes, 16384):
+        feats[a:a + 16384] += centroids[comm[a:a + 16384]] * np.float32(0.5)
     r = rng.random_sample(n_nodes)
     val_mask = r < val_frac
     test_mask = (r >= val_frac) & (r < val_frac + test_frac)
-    feats = standardize_on_train(feats.astype(np.float32), ~(val_mask | test_mask))
+    feats = standardize_on_train(feats, ~(val_mask | test_mask))
     if multilabel:
         proj = rng.normal(size=(num_classes, num_classes))
         labels = ((np.eye(num_classes)[comm] @ proj + 0.3 * rng.normal(size=(n_nodes, num_classes))) > 0.3)
