@@ -158,5 +158,15 @@ extern "C" int gs_build_csr_host(const int32_t* src, const int32_t* dst, const u
             }
         });
     for (auto& x : th) x.join();
+    // drop parallel edges (networkx.Graph, which the reference loads into, keeps one edge per node pair)
+    int64_t w = 0;
+    for (int64_t i = 0; i < n_nodes; ++i) {
+        const int64_t b = rowptr[i], e = rowptr[i + 1];
+        rowptr[i] = w;
+        for (int64_t k = b; k < e; ++k)
+            if (k == b || col[k] != col[k - 1]) col[w++] = col[k];
+    }
+    rowptr[n_nodes] = w;
+    *nnz_out = w;
     return GS_OK;
 }

@@ -94,6 +94,10 @@ def build_csr_numpy(n_nodes, src, dst, keep=None):
     d = np.concatenate([dst, src[~loops]]).astype(np.int64)
     order = np.lexsort((d, s))
     s, d = s[order], d[order]
+    if s.size:  # one edge per node pair, like networkx.Graph
+        first = np.ones(s.size, dtype=bool)
+        first[1:] = (s[1:] != s[:-1]) | (d[1:] != d[:-1])
+        s, d = s[first], d[first]
     rowptr = np.zeros(n_nodes + 1, dtype=np.int64)
     np.add.at(rowptr, s + 1, 1)
     rowptr = np.cumsum(rowptr)

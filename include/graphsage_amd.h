@@ -238,6 +238,7 @@ int gs_event_destroy(void* ev);
  * Host-side graph ingestion (C++, multithreaded): edge list -> CSR.  Replaces the networkx loops of
  * minibatch.py:227-259 for the CSR engine (N2 "next" row).  All pointers are HOST pointers.
  * keep_mask_host (nullable, per edge) drops edges (train_removed / val-test endpoints).
+ * Adjacency lists come out sorted and de-duplicated (networkx.Graph semantics: one edge per node pair).
  * ------------------------------------------------------------------------------------------- */
 int gs_build_csr_host(const int32_t* src_host, const int32_t* dst_host, const uint8_t* keep_mask_host,
                       int64_t n_edges, int64_t n_nodes, int symmetrize,

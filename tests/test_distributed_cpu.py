@@ -1,0 +1,67 @@
+"""World-size-2 gloo test of the data-parallel math (runs on CPU): summing the per-rank gradients with ONE
+all-reduce of the flat buffer and scaling by 1/world_size reproduces the single-process gradient of the
+concatenated global batch (oracle), which is what SupervisedGraphsage's grad_hook + Adam(grad_scale) rely on."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "GS_DIST_BACKEND": "gloo"})
+    import torch.distributed as dist
+    from graphsage_amd import distributed as gsd
+    from oracle import graphsage_oracle as orc
+    r, _, w = gsd.init_from_env()
+    assert (r, w) == (rank, world)
+    rng = np.random.default_rng(0)                       # same data on every rank (replicated graph)
+    N, F, C, B = 200, 12, 4, 8
+    feat = np.vstack([rng.normal(size=(N, F)), np.zeros((1, F))]).astype(np.float32)
+    neigh = [list(rng.choice(N, size=rng.integers(1, 9), replace=False)) for _ in range(N)]
+    adj, _ = orc.construct_adj(neigh, 8, rng)
+    dims, ns = [F, 8, 8], [3, 2]
+    params = orc.make_supervised_params("mean", dims, C, True, rng)
+    order = rng.permutation(N)
+    perms = [rng.permutation(8), rng.permutation(8)]
+    labels_all = np.eye(C, dtype=np.float32)[rng.integers(0, C, N)]
+
+    def grads_of(batch):
+        samples, ss = orc.sample(adj, batch, ns, perms)
+        res = orc.supervised_fwd_bwd(params, feat, samples, ss, labels_all[batch], dims, ns, len(batch), "mean", True, False)
+        return np.concatenate([g.reshape(-1) for _, g in orc.flat_param_items(res["grads"], "mean")])
+
+    mine = gsd.shard_order(order, rank, world, B)[:B]
+    flat = torch.from_numpy(grads_of(mine).copy())
+    gsd.allreduce_sum_(flat)                              # ONE collective on the flat buffer
+    flat /= world                                         # Adam's grad_scale
+    want = grads_of(order[: B * world])                   # single-process gradient of the global batch
+    q.put((rank, float(np.abs(flat.numpy() - want).max()), float(np.abs(want).max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_equals_global_batch_gradient():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, scale in res:
+        assert err < 1e-5 * max(1.0, scale), (rank, err, scale)

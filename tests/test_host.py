@@ -1,0 +1,116 @@
+"""CPU tests of the host-side logic: the C-ABI library loads and exports every declared symbol, the C++ CSR
+builder, adjacency semantics of the minibatch iterator, data-parallel sharding, the reference-format reader."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from graphsage_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "graphsage_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), "header declares %s but the library does not export it" % name
+    assert sorted(declared) == _lib.EXPORTED_SYMBOLS, set(declared) ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.gs_abi_version() == 1
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from graphsage_amd import _lib, ops
+    with pytest.raises(_lib.GraphsageAmdError):
+        ops.ptr(torch.zeros(4))
+    if not torch.cuda.is_available():
+        from graphsage_amd import engine
+        with pytest.raises(_lib.GraphsageAmdError):
+            engine.Engine()
+
+
+def test_error_reporting_through_c_abi():
+    from graphsage_amd import _lib
+    lib = _lib.load()
+    rc = lib.gs_reduce_slabs(None, 1, 0, 1, 1, 4, 0.0, None, 0, None, 0, 0, None)
+    assert rc == -1 and b"gs_reduce_slabs" in lib.gs_last_error()
+
+
+def test_cpp_csr_builder_matches_numpy():
+    from graphsage_amd.utils import build_csr, build_csr_numpy
+    rng = np.random.RandomState(0)
+    n = 500
+    src = rng.randint(0, n, size=4000).astype(np.int32)
+    dst = rng.randint(0, n, size=4000).astype(np.int32)
+    keep = rng.rand(4000) < 0.7
+    for k in (None, keep):
+        r1, c1 = build_csr(n, src, dst, k)
+        r2, c2 = build_csr_numpy(n, src, dst, k)
+        assert np.array_equal(r1, r2) and np.array_equal(c1, c2)
+    r, c = build_csr(3, np.array([0], np.int32), np.array([0], np.int32))
+    assert r.tolist() == [0, 1, 1, 1] and c.tolist() == [0]          # self loop stored once
+    r, c = build_csr(3, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert r.tolist() == [0, 0, 0, 0] and c.size == 0                 # empty graph
+
+
+def test_minibatch_iterator_reference_semantics():
+    from graphsage_amd.minibatch import NodeMinibatchIterator
+    from graphsage_amd.utils import synthetic_graph
+    G = synthetic_graph(n_nodes=600, feat_dim=8, num_classes=5, avg_degree=8, seed=1)
+    ph = {k: k for k in ("batch", "labels", "batch_size", "dropout")}
+    it = NodeMinibatchIterator(G, None, ph, None, G.num_classes, batch_size=64, max_degree=6)
+    N = G.n_nodes
+    no_train = G.val_mask | G.test_mask
+    assert it.adj.shape == (N + 1, 6) and (it.adj[N] == N).all()
+    assert (it.adj[:N][no_train] == N).all()                          # minibatch.py:232-233
+    rp, col = it.train_csr
+    for i in np.where(~no_train)[0][:100]:
+        nb = col[rp[i]:rp[i + 1]]
+        assert not no_train[nb].any()                                 # train_removed edges are filtered (:234-236)
+        assert it.deg[i] == len(nb)
+        row = it.adj[i]
+        assert (row == N).all() if len(nb) == 0 else set(row).issubset(set(nb))
+        if len(nb) > 6:
+            assert len(set(row)) == 6
+    rpt, colt = it.test_csr
+    assert rpt[-1] > rp[-1]                                           # test adjacency has all edges
+    assert set(it.train_nodes).isdisjoint(set(np.where(no_train)[0]))
+    assert (it.deg[it.train_nodes] > 0).all()                         # :214-215
+    it.shuffle()
+    seen = []
+    while not it.end():
+        fd, labels = it.next_minibatch_feed_dict()
+        assert labels.shape[1] == G.num_classes and fd["batch_size"] == len(fd["batch"])
+        seen.extend(fd["batch"].tolist())
+    assert sorted(seen) == sorted(it.train_nodes.tolist())            # ragged last batch included (:302-307)
+    fd, lab, done, subset = it.incremental_node_val_feed_dict(64, 0)
+    assert len(subset) == min(64, len(it.val_nodes))
+
+
+def test_shard_order_covers_global_batches():
+    from graphsage_amd.distributed import shard_order
+    order = np.arange(1000)
+    parts = [shard_order(order, r, 4, 32) for r in range(4)]
+    assert all(len(p) == len(parts[0]) for p in parts) and len(parts[0]) % 32 == 0
+    step0 = np.concatenate([p[:32] for p in parts])
+    assert np.array_equal(step0, order[:128])                         # global batch i = concat of rank batches
+
+
+def test_load_data_reference_format(tmp_path):
+    from graphsage_amd.utils import load_data
+    prefix = str(tmp_path / "toy")
+    nodes = [{"id": "n%d" % i, "val": i == 3, "test": i == 4} for i in range(5)]
+    links = [{"source": 0, "target": 1}, {"source": 1, "target": 2}, {"source": 2, "target": 3}, {"source": 3, "target": 4}]
+    json.dump({"directed": False, "graph": {}, "nodes": nodes, "links": links, "multigraph": False}, open(prefix + "-G.json", "w"))
+    json.dump({"n%d" % i: i for i in range(5)}, open(prefix + "-id_map.json", "w"))
+    json.dump({"n%d" % i: i % 2 for i in range(5)}, open(prefix + "-class_map.json", "w"))
+    np.save(prefix + "-feats.npy", np.arange(15, dtype=np.float32).reshape(5, 3))
+    G = load_data(prefix)
+    assert G.n_nodes == 5 and G.src.tolist() == [0, 1, 2, 3] and G.dst.tolist() == [1, 2, 3, 4]
+    assert G.train_removed.tolist() == [False, False, True, True]      # utils.py:55-60
+    assert abs(G.feats[:3].mean()) < 1e-6                              # scaler fit on train rows only (:62-68)
+    assert G.label_matrix().shape == (6, 2)

@@ -1,0 +1,162 @@
+"""CPU tests: the oracle against the hand-computed golden fixture, finite differences, the CPU-baseline
+port and the reference's documented semantics."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import graphsage_oracle as orc
+from oracle import sampler_hash
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_mean.npz")
+
+
+def test_golden_tiny_mean_exact():
+    g = np.load(GOLD)
+    ns = list(g["num_samples"])
+    samples, support = orc.sample(g["adj"], g["batch"], ns, [g["perm0"], g["perm1"]])
+    assert support == [1, 2, 4]
+    assert np.array_equal(samples[1], g["samples1"]) and np.array_equal(samples[2], g["samples2"])
+    params = [{"self_weights": g["W0_self"], "neigh_weights": g["W0_neigh"]},
+              {"self_weights": g["W1_self"], "neigh_weights": g["W1_neigh"]}]
+    out, tape = orc.aggregate_fwd(samples, g["feats"], list(g["dims"]), ns, support, len(g["batch"]), params, "mean", True)
+    assert np.array_equal(out, g["out"])                         # integer-valued: exact in fp32
+    assert np.array_equal(tape[0][0][3], g["l0_hop0"]) and np.array_equal(tape[0][1][3], g["l0_hop1"])
+
+
+def test_sampler_semantics():
+    rng = np.random.default_rng(0)
+    N, md = 50, 8
+    neigh = [list(rng.choice(N, size=rng.integers(0, 14), replace=False)) for _ in range(N)]
+    skip = rng.random(N) < 0.2
+    adj, deg = orc.construct_adj(neigh, md, rng, skip_mask=skip)
+    assert adj.shape == (N + 1, md) and (adj[N] == N).all()
+    for i in range(N):
+        if skip[i] or len(neigh[i]) == 0:
+            assert (adj[i] == N).all()                           # val/test rows and isolated rows stay all-pad
+        else:
+            assert set(adj[i]).issubset(set(neigh[i]))
+            if len(neigh[i]) >= md:
+                assert len(set(adj[i])) == md                    # down-sampled WITHOUT replacement
+    ids = np.array([0, 1, N, 3])
+    perm = rng.permutation(md)
+    out = orc.uniform_neighbor_sampler(adj, ids, 5, perm)
+    assert out.shape == (4, 5) and (out[2] == N).all()
+    assert np.array_equal(out, adj[ids][:, perm[:5]])            # ONE column permutation shared by all rows
+
+
+@pytest.mark.parametrize("agg,concat", [("mean", True), ("mean", False), ("gcn", False), ("maxpool", True), ("meanpool", True)])
+@pytest.mark.parametrize("sig", [False, True])
+def test_backward_finite_differences(agg, concat, sig):
+    rng = np.random.default_rng(1)
+    N, F, C, B = 40, 6, 5, 4
+    feat = np.vstack([rng.normal(size=(N, F)), np.zeros((1, F))])
+    neigh = [list(rng.choice(N, size=rng.integers(0, 8), replace=False)) for _ in range(N)]
+    adj, _ = orc.construct_adj(neigh, 8, rng)
+    ns, dims = [3, 2], [F, 4, 4]
+    params = orc.make_supervised_params(agg, dims, C, concat, rng, dtype=np.float64)
+    if agg in ("maxpool", "meanpool"):
+        for p in params["agg"]:
+            p["mlp_weights"] = p["mlp_weights"][:, :7].copy()
+            p["mlp_bias"] = rng.normal(size=7) * 0.1
+            p["neigh_weights"] = orc.glorot((7, p["neigh_weights"].shape[1]), rng, np.float64)
+    params["node_pred"]["bias"] = rng.normal(size=C) * 0.1
+    perms = [rng.permutation(8), rng.permutation(8)]
+    batch = rng.choice(N, B, replace=False)
+    samples, ss = orc.sample(adj, batch, ns, perms)
+    labels = (rng.random((B, C)) > 0.5).astype(np.float64) if sig else np.eye(C)[rng.integers(0, C, B)]
+    f = lambda: orc.supervised_fwd_bwd(params, feat, samples, ss, labels, dims, ns, B, agg, concat, sig, weight_decay=0.01)
+    r = f()
+    for (name, p), (_, g) in zip(orc.flat_param_items(params, agg), orc.flat_param_items(r["grads"], agg)):
+        for _ in range(5):
+            idx = tuple(rng.integers(0, s) for s in p.shape)
+            old = p[idx]
+            p[idx] = old + 1e-6; lp = f()["loss"]
+            p[idx] = old - 1e-6; lm = f()["loss"]
+            p[idx] = old
+            fd = (lp - lm) / 2e-6
+            assert abs(fd - g[idx]) <= 1e-6 + 1e-5 * (abs(fd) + abs(g[idx])), (name, idx, fd, g[idx])
+
+
+def test_reference_schedule_semantics():
+    """Appendix A: support sizes, concat order, identity act on the last layer, pad row in the mean."""
+    rng = np.random.default_rng(2)
+    N, F = 30, 5
+    feat = np.vstack([rng.normal(size=(N, F)), np.zeros((1, F))]).astype(np.float32)
+    adj = rng.integers(0, N + 1, size=(N + 1, 6)).astype(np.int32)
+    samples, ss = orc.sample(adj, np.arange(4), [3, 2], [np.arange(6), np.arange(6)])
+    assert ss == [1, 2, 6] and [len(s) for s in samples] == [4, 8, 24]   # samples_2 is the hop next to the batch
+    params = orc.make_aggregator_params("mean", [F, 4, 4], True, rng)
+    assert params[1]["self_weights"].shape == (8, 4)                     # dim_mult = 2 for layer != 0
+    out, tape = orc.aggregate_fwd(samples, feat, [F, 4, 4], [3, 2], ss, 4, params, "mean", True)
+    assert out.shape == (4, 8) and (out < 0).any()                       # identity act on the last layer
+    y0 = tape[0][0][3]
+    assert (y0 >= 0).all()                                               # relu on layer 0
+    self0, means0 = tape[0][0][0], tape[0][0][1]
+    np.testing.assert_allclose(y0[:, :4], np.maximum(self0 @ params[0]["self_weights"], 0), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(means0, feat[samples[1]].reshape(4, 2, F).mean(1), rtol=1e-6)  # divisor is always s
+
+
+def test_adam_matches_closed_form_first_step():
+    p = np.array([1.0, -2.0], dtype=np.float32)
+    g = np.array([0.5, -7.0], dtype=np.float32)
+    m, v = np.zeros(2, np.float32), np.zeros(2, np.float32)
+    orc.adam_tf_update(p, orc.clip_by_value(g), m, v, 1, 0.01)
+    # t=1: m=0.1g, v=0.001g^2, lr_t = lr*sqrt(0.001)/0.1 -> step = lr * g/|g| (up to eps)
+    np.testing.assert_allclose(p, [1.0 - 0.01, -2.0 + 0.01], rtol=1e-5)
+
+
+def test_f1_matches_sklearn():
+    from sklearn import metrics
+    rng = np.random.default_rng(3)
+    y = (rng.random((200, 9)) > 0.6).astype(np.float32)
+    p = rng.random((200, 9)).astype(np.float32)
+    want = metrics.f1_score(y, (p > 0.5).astype(int), average="micro")
+    assert abs(orc.calc_f1_micro(y, p, True) - want) < 1e-9
+    yo = np.eye(9)[rng.integers(0, 9, 200)]
+    want = metrics.f1_score(yo.argmax(1), p.argmax(1), average="micro")
+    assert abs(orc.calc_f1_micro(yo, p, False) - want) < 1e-9
+
+
+def test_cpu_baseline_port_matches_oracle():
+    from oracle.cpu_baseline import CpuSupervisedMean
+    rng = np.random.default_rng(0)
+    N, F, C = 300, 20, 5
+    feat = np.vstack([rng.normal(size=(N, F)), np.zeros((1, F))]).astype(np.float32)
+    neigh = [list(rng.choice(N, size=rng.integers(0, 12), replace=False)) for _ in range(N)]
+    adj, _ = orc.construct_adj(neigh, 8, rng)
+    dims, ns = [F, 8, 8], [4, 3]
+    m = CpuSupervisedMean(feat, adj, dims, C, ns, lr=0.01, weight_decay=0.01)
+    params = orc.make_supervised_params("mean", dims, C, True, rng)
+    m.set_params_from_oracle(params)
+    batch = rng.choice(N, 16, replace=False)
+    perms = [rng.permutation(8), rng.permutation(8)]
+    labels = np.eye(C, dtype=np.float32)[rng.integers(0, C, 16)]
+    samples, ss = orc.sample(adj, batch, ns, perms)
+    res = orc.supervised_fwd_bwd(params, feat, samples, ss, labels, dims, ns, 16, "mean", True, False, weight_decay=0.01)
+    loss, logits, grads = m.train_step(batch, labels, perms)
+    assert abs(loss - res["loss"]) < 1e-5
+    np.testing.assert_allclose(logits, res["node_preds"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(grads[0].numpy(), res["grads"]["agg"][0]["neigh_weights"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(grads[-2].numpy(), res["grads"]["node_pred"]["weights"], rtol=1e-4, atol=1e-6)
+
+
+def test_csr_sampler_hash_properties():
+    rng = np.random.default_rng(5)
+    N = 100
+    deg = rng.integers(0, 9, size=N)
+    rowptr = np.zeros(N + 1, dtype=np.int64); rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, N, size=int(rowptr[-1])).astype(np.int32)
+    ids = rng.integers(0, N + 1, size=64)
+    a = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, 7, 123, 3, 1)
+    b = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, 7, 123, 3, 1)
+    assert np.array_equal(a, b)                                           # counter-based: pure function
+    c = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, 7, 123, 4, 1)
+    assert not np.array_equal(a, c)                                       # different step -> different draws
+    half = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids[32:], 7, 123, 3, 1, global_row_offset=32)
+    assert np.array_equal(a[32:], half)                                   # sharding invariance
+    for i, node in enumerate(ids):
+        if node == N or deg[node] == 0:
+            assert (a[i] == N).all()
+        else:
+            assert np.isin(a[i], col[rowptr[node]:rowptr[node + 1]]).all()
