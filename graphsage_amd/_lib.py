@@ -59,7 +59,25 @@ _PROTOS = {
     "gs_event_elapsed_ms": [_P, _P, POINTER(c_float)],
     "gs_event_destroy": [_P],
     "gs_build_csr_host": [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int64, POINTER(c_int64)],
+    "gs_dense_wgrad_grouped": [_P, c_int32, _P],
+    "gs_sage_dense_dgrad": [_P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
+    "gs_flat_reduce_adam": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
+                            c_float, c_float, _P, _P],
+    "gs_advance_counters": [_P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
+    "gs_stage_batch": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
 }
+
+
+class WgradDesc(ctypes.Structure):
+    """struct gs_wgrad_desc (include/graphsage_amd.h)"""
+    _fields_ = [("A", c_void_p), ("a_idx", c_void_p), ("dZ", c_void_p), ("slabs", c_void_p),
+                ("lda", c_int64), ("ldz", c_int64), ("ld_slab", c_int64), ("n", c_int64),
+                ("d", c_int32), ("col0", c_int32), ("out_dim", c_int32), ("n_slabs", c_int32)]
+
+
+class VarDesc(ctypes.Structure):
+    """struct gs_var_desc (include/graphsage_amd.h)"""
+    _fields_ = [("offset", c_int64), ("size", c_int64), ("slabs", c_void_p), ("n_slabs", c_int32), ("decay", c_int32)]
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS.keys()) + ["gs_last_error", "gs_abi_version"])
 

@@ -4,14 +4,17 @@ graphsage/aggregators.py, executing on the gfx950 kernels.
     agg = MeanAggregator(input_dim, output_dim, act=..., dropout=..., name=..., concat=..., model_size=...)
     out = agg((self_vecs, neigh_vecs))        # models.py:326-327
 
-`self_vecs` is a `Rows` [n, d]; `neigh_vecs` is a `Rows` reshaped to [n, s, d] (both may be lazy
-row gathers of the feature table, so the [n*s, d] tensor of models.py:299 is never materialised).
-`.vars` holds exactly the variables the reference's weight-decay loop sees (supervised_models.py:104-106).
-Every aggregator also implements `backward(d_out, ...)`.
+`self_vecs` is a `Rows` [n, d]; `neigh_vecs` is a `Rows` reshaped to [n, s, d] (both may be lazy row gathers of
+the feature table, so the [n*s, d] tensor of models.py:299 is never materialised).  `.vars` holds exactly the
+variables the reference's weight-decay loop sees (supervised_models.py:104-106).
+
+MI355X-first addition: the reference calls the SAME aggregator once per hop of a layer (models.py:321-328);
+`call_hops(self_all, [neigh_0, neigh_1, ...])` runs all hops of a layer in one dense launch (the rows of all
+hops are contiguous), and `backward_hops` is its hand-written reverse.  `_call` is `call_hops` with one hop.
 """
 from . import ops
-from .layers import Dense, Layer, Rows, _act_code, _check_dropout, relu
 from .inits import glorot, zeros
+from .layers import Dense, Layer, Rows, _act_code, _check_dropout, relu
 from .ops import ACT_IDENTITY, ACT_RELU
 
 
@@ -20,8 +23,35 @@ def _scope(self_name, name):
     return self_name + ('/' + name if name is not None else '') + '_vars'
 
 
+def _contiguous(rows_list):
+    """If the Rows views are adjacent slices of one buffer, return the single Rows covering all of them."""
+    first = rows_list[0]
+    total = first.n
+    for prev, cur in zip(rows_list[:-1], rows_list[1:]):
+        if (prev.ids is None) != (cur.ids is None):
+            return None
+        if cur.ids is not None:
+            if cur.src is not prev.src or cur.ids.data_ptr() != prev.ids.data_ptr() + 4 * prev.n:
+                return None
+        else:
+            if cur.src.ld != prev.src.ld or cur.src.d != prev.src.d or \
+                    cur.src.buf.data_ptr() != prev.src.buf.data_ptr() + 4 * prev.n * prev.src.ld:
+                return None
+        total += cur.n
+    if len(rows_list) == 1:
+        return Rows(first.src, first.ids, first.n, first.requires_grad)
+    if first.ids is not None:
+        import torch
+        ids = torch.as_strided(first.ids, (total,), (1,))
+        return Rows(first.src, ids, total, first.requires_grad)
+    import torch
+    from .ops import Mat
+    buf = torch.as_strided(first.src.buf, (total, first.src.buf.shape[1]), first.src.buf.stride())
+    return Rows(Mat(buf, first.src.d), None, total, first.requires_grad)
+
+
 class _SageBase(Layer):
-    """Shared plumbing: saved-activation stack, activation backward."""
+    """Shared plumbing: saved-activation stack, activation backward, masked scatter of input gradients."""
 
     def _push(self, rec):
         self._saved.append(rec)
@@ -36,6 +66,30 @@ class _SageBase(Layer):
 
     def reset(self):
         del self._saved[:]
+
+    def _call(self, inputs):
+        self_vecs, neigh_vecs = inputs
+        return self.call_hops(self_vecs, [neigh_vecs])
+
+    def backward(self, d_out, pre_masked=False):
+        """Single-hop reverse of `_call`: returns raw (d_self [n, d], d_neigh [n*s, d]) when the inputs
+        require gradients, else (None, None)."""
+        self_all, neighs = self._saved[-1][0], self._saved[-1][1]
+        need = self_all.requires_grad or neighs[0].requires_grad
+        if not need:
+            self.backward_hops(d_out, pre_masked)
+            return None, None
+        n, s, d = neighs[0].shape3
+        d_prev = self.engine.ws_mat((self.name, "d_prev1"), n + n * s, self.input_dim)
+        self.backward_hops(d_out, pre_masked, d_prev=d_prev, prev_mask=None, prev_offsets=[0, n, n + n * s])
+        return d_prev.rows_slice(0, n), d_prev.rows_slice(n, n + n * s)
+
+    def _scatter_self(self, d_self_all, n_total, d_prev, prev_mask):
+        """d_prev[0:n_total] = mask * d_self_all  (self rows of hop h are rows h of the previous layer)."""
+        e = self.engine
+        act = ACT_RELU if prev_mask is not None else ACT_IDENTITY
+        ops.act_bwd(d_self_all, prev_mask.rows_slice(0, n_total) if prev_mask is not None else None, n_total,
+                    d_self_all.d, act, d_prev.rows_slice(0, n_total), stream=e.stream)
 
 
 class MeanAggregator(_SageBase):
@@ -62,51 +116,65 @@ class MeanAggregator(_SageBase):
         self.neigh_input_dim = neigh_input_dim
         self._saved = []
 
-    def _call(self, inputs):
-        self_vecs, neigh_vecs = inputs
+    def call_hops(self, self_all, neighs):
         _check_dropout(self.dropout)
         e = self.engine
-        n, s, d = neigh_vecs.shape3
+        n_total = self_all.n
+        d = neighs[0].shape3[2]
         k = len(self._saved)
-        # reduce_mean(neigh_vecs, axis=1)   (aggregators.py:48) fused with the row gather
-        means = e.ws_mat((self.name, "mean", k), n, d)
-        ops.gather_mean_fwd(neigh_vecs.src, neigh_vecs.ids, n, s, out=means, stream=e.stream)
-        # from_neighs / from_self matmuls + concat|add + bias + act   (:51-64) in one launch
+        # reduce_mean(neigh_vecs, axis=1)   (aggregators.py:48) fused with the row gather, one launch per hop
+        means = e.ws_mat((self.name, "mean", k), n_total, d)
+        r = 0
+        for nv in neighs:
+            n, s, _ = nv.shape3
+            ops.gather_mean_fwd(nv.src, nv.ids, n, s, out=means.rows_slice(r, r + n), stream=e.stream)
+            r += n
+        assert r == n_total
+        # from_neighs / from_self matmuls + concat|add + bias + act   (:51-64): ONE launch for all hops
         n_out = self.output_dim * (2 if self.concat else 1)
-        out = e.ws_mat((self.name, "out", k), n, n_out)
+        out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
-        ops.sage_dense_fwd(self_vecs.src, self_vecs.ids, means, None, n, self.vars['self_weights'].value,
+        ops.sage_dense_fwd(self_all.src, self_all.ids, means, None, n_total, self.vars['self_weights'].value,
                            self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
                            stream=e.stream)
-        self._push((self_vecs, neigh_vecs, means, out))
+        self._push((self_all, neighs, means, out))
         return out
 
-    def backward(self, d_out, pre_masked=False, neigh_mask=None):
-        """Returns (d_self, d_neigh): Mats or None when the corresponding input needs no gradient.
-        `neigh_mask` (the relu output that produced the neighbor rows) fuses that layer's relu
-        gradient into d_neigh."""
+    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None):
         e = self.engine
-        self_vecs, neigh_vecs, means, out = self._saved.pop()
-        n, s, d = neigh_vecs.shape3
+        self_all, neighs, means, out = self._saved.pop()
+        n_total = self_all.n
         k = len(self._saved)
         o = self.output_dim
         n_out = o * (2 if self.concat else 1)
-        dz = self._dz(d_out, out, n, n_out, pre_masked)
+        dz = self._dz(d_out, out, n_total, n_out, pre_masked)
         col_n = o if self.concat else 0
-        e.wgrad(self.vars['self_weights'], self_vecs.src, self_vecs.ids, dz, 0, n)
-        e.wgrad(self.vars['neigh_weights'], means, None, dz, col_n, n)
+        e.wgrad(self.vars['self_weights'], self_all.src, self_all.ids, dz, 0, n_total)
+        e.wgrad(self.vars['neigh_weights'], means, None, dz, col_n, n_total)
         if self.bias:
-            e.bgrad(self.vars['bias'], dz, n, n_out)
-        d_self = d_neigh = None
-        if self_vecs.requires_grad:
-            d_self = e.ws_mat((self.name, "d_self", k), n, self.input_dim)
-            ops.dense_dgrad(dz, 0, o, n, self.vars['self_weights'].value, d_self, stream=e.stream)
-        if neigh_vecs.requires_grad:
-            d_means = e.ws_mat((self.name, "d_means", k), n, d)
-            ops.dense_dgrad(dz, col_n, o, n, self.vars['neigh_weights'].value, d_means, stream=e.stream)
-            d_neigh = e.ws_mat((self.name, "d_neigh", k), n * s, d)
-            ops.mean_bwd(d_means, n, s, 1.0 / s, d_neigh, mask_y=neigh_mask, stream=e.stream)
-        return d_self, d_neigh
+            e.bgrad(self.vars['bias'], dz, n_total, n_out)
+        if d_prev is None:
+            return
+        d_in = self.input_dim
+        if self.neigh_input_dim == d_in and d_in % 4 == 0 and (not self.concat or o % 4 == 0):
+            t2 = e.ws_mat((self.name, "dgrad2", k), n_total, 2 * d_in)       # [d_self | d_means] in one launch
+            ops.sage_dense_dgrad(dz, n_total, o, self.concat, self.vars['self_weights'].value,
+                                 self.vars['neigh_weights'].value, d_in, t2, stream=e.stream)
+            d_self_all, d_means_all = t2.cols_slice(0, d_in), t2.cols_slice(d_in, 2 * d_in)
+        else:
+            d_self_all = e.ws_mat((self.name, "d_self", k), n_total, d_in)
+            ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value, d_self_all, stream=e.stream)
+            d_means_all = e.ws_mat((self.name, "d_means", k), n_total, self.neigh_input_dim)
+            ops.dense_dgrad(dz, col_n, o, n_total, self.vars['neigh_weights'].value, d_means_all, stream=e.stream)
+        self._scatter_self(d_self_all, n_total, d_prev, prev_mask)
+        r = 0
+        for h, nv in enumerate(neighs):
+            n, s, _ = nv.shape3
+            r0 = prev_offsets[h + 1]
+            ops.mean_bwd(d_means_all.rows_slice(r, r + n), n, s, 1.0 / s, d_prev.rows_slice(r0, r0 + n * s),
+                         mask_y=prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None,
+                         accumulate=(h + 1 < len(neighs)), stream=e.stream)
+            r += n
 
 
 class GCNAggregator(_SageBase):
@@ -132,43 +200,56 @@ class GCNAggregator(_SageBase):
         self.output_dim = output_dim
         self._saved = []
 
-    def _call(self, inputs):
-        self_vecs, neigh_vecs = inputs
+    def call_hops(self, self_all, neighs):
         _check_dropout(self.dropout)
         e = self.engine
-        n, s, d = neigh_vecs.shape3
+        n_total = self_all.n
+        d = neighs[0].shape3[2]
         k = len(self._saved)
         # mean over {neighbors} U {self}  (aggregators.py:106-107)
-        means = e.ws_mat((self.name, "mean", k), n, d)
-        ops.gather_mean_fwd(neigh_vecs.src, neigh_vecs.ids, n, s, out=means, self_src=self_vecs.src,
-                            self_idx=self_vecs.ids, stream=e.stream)
-        out = e.ws_mat((self.name, "out", k), n, self.output_dim)
+        means = e.ws_mat((self.name, "mean", k), n_total, d)
+        r = 0
+        for nv in neighs:
+            n, s, _ = nv.shape3
+            sv = self_all.slice(r, r + n)
+            ops.gather_mean_fwd(nv.src, nv.ids, n, s, out=means.rows_slice(r, r + n), self_src=sv.src,
+                                self_idx=sv.ids, stream=e.stream)
+            r += n
+        out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
-        ops.sage_dense_fwd(None, None, means, None, n, None, self.vars['weights'].value, self.output_dim, False,
+        ops.sage_dense_fwd(None, None, means, None, n_total, None, self.vars['weights'].value, self.output_dim, False,
                            self.act_code, b, out, stream=e.stream)
-        self._push((self_vecs, neigh_vecs, means, out))
+        self._push((self_all, neighs, means, out))
         return out
 
-    def backward(self, d_out, pre_masked=False, neigh_mask=None):
+    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None):
         e = self.engine
-        self_vecs, neigh_vecs, means, out = self._saved.pop()
-        n, s, d = neigh_vecs.shape3
+        self_all, neighs, means, out = self._saved.pop()
+        n_total = self_all.n
         k = len(self._saved)
-        dz = self._dz(d_out, out, n, self.output_dim, pre_masked)
-        e.wgrad(self.vars['weights'], means, None, dz, 0, n)
+        dz = self._dz(d_out, out, n_total, self.output_dim, pre_masked)
+        e.wgrad(self.vars['weights'], means, None, dz, 0, n_total)
         if self.bias:
-            e.bgrad(self.vars['bias'], dz, n, self.output_dim)
-        d_self = d_neigh = None
-        if self_vecs.requires_grad or neigh_vecs.requires_grad:
-            d_means = e.ws_mat((self.name, "d_means", k), n, d)
-            ops.dense_dgrad(dz, 0, self.output_dim, n, self.vars['weights'].value, d_means, stream=e.stream)
-            if self_vecs.requires_grad:
-                d_self = e.ws_mat((self.name, "d_self", k), n, d)
-                ops.mean_bwd(d_means, n, 1, 1.0 / (s + 1), d_self, stream=e.stream)
-            if neigh_vecs.requires_grad:
-                d_neigh = e.ws_mat((self.name, "d_neigh", k), n * s, d)
-                ops.mean_bwd(d_means, n, s, 1.0 / (s + 1), d_neigh, mask_y=neigh_mask, stream=e.stream)
-        return d_self, d_neigh
+            e.bgrad(self.vars['bias'], dz, n_total, self.output_dim)
+        if d_prev is None:
+            return
+        d = means.d
+        d_means = e.ws_mat((self.name, "d_means", k), n_total, d)
+        ops.dense_dgrad(dz, 0, self.output_dim, n_total, self.vars['weights'].value, d_means, stream=e.stream)
+        r = 0
+        for nv in neighs:           # self parts first: d_self = d_means / (s + 1)
+            n, s, _ = nv.shape3
+            ops.mean_bwd(d_means.rows_slice(r, r + n), n, 1, 1.0 / (s + 1), d_prev.rows_slice(r, r + n),
+                         mask_y=prev_mask.rows_slice(r, r + n) if prev_mask is not None else None, stream=e.stream)
+            r += n
+        r = 0
+        for h, nv in enumerate(neighs):
+            n, s, _ = nv.shape3
+            r0 = prev_offsets[h + 1]
+            ops.mean_bwd(d_means.rows_slice(r, r + n), n, s, 1.0 / (s + 1), d_prev.rows_slice(r0, r0 + n * s),
+                         mask_y=prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None,
+                         accumulate=(h + 1 < len(neighs)), stream=e.stream)
+            r += n
 
 
 class _PoolingAggregator(_SageBase):
@@ -209,77 +290,102 @@ class _PoolingAggregator(_SageBase):
         self.neigh_input_dim = neigh_input_dim
         self._saved = []
 
-    def reset(self):
-        del self._saved[:]
-        for l in self.mlp_layers:
-            del l._saved[:]
-
-    def _call(self, inputs):
-        self_vecs, neigh_vecs = inputs
+    def call_hops(self, self_all, neighs):
+        _check_dropout(self.dropout)
         e = self.engine
-        n, s, d = neigh_vecs.shape3
+        n_total = self_all.n
         k = len(self._saved)
-        # h_reshaped = Dense(reshape(neigh, [n*s, d]))   (aggregators.py:176-179)
-        h = Rows(neigh_vecs.src, neigh_vecs.ids, n * s, neigh_vecs.requires_grad)
-        for l in self.mlp_layers:
-            h = l(h)
-        H = h  # Mat [n*s, hidden]
-        pooled = e.ws_mat((self.name, "pooled", k), n, self.hidden_dim)
+        mlp = self.mlp_layers[0]
+        rows_total = sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)
+        # h_reshaped = Dense(reshape(neigh, [n*s, d]))   (aggregators.py:176-179): one GEMM over every neighbor row
+        H = e.ws_mat((self.name, "H", k), rows_total, self.hidden_dim)
+        flat = [Rows(nv.src, nv.ids, nv.shape3[0] * nv.shape3[1], nv.requires_grad) for nv in neighs]
+        x_all = _contiguous(flat)
+        pieces = [x_all] if x_all is not None else flat
+        r = 0
+        for x in pieces:
+            ops.sage_dense_fwd(None, None, x.src, x.ids, x.n, None, mlp.vars['weights'].value, self.hidden_dim, False,
+                               ACT_RELU, mlp.vars['bias'].value.buf, H.rows_slice(r, r + x.n), stream=e.stream)
+            r += x.n
+        pooled = e.ws_mat((self.name, "pooled", k), n_total, self.hidden_dim)
         argmax = None
         if self.POOL == "max":
-            argmax = e.ws_i32((self.name, "argmax", k), n * self.hidden_dim).view(n, self.hidden_dim)
-            ops.segment_max_fwd(H, n, s, pooled, argmax, stream=e.stream)                 # reduce_max (:181)
-        else:
-            ops.gather_mean_fwd(H, None, n, s, out=pooled, stream=e.stream)              # reduce_mean (:259)
+            argmax = e.ws_i32((self.name, "argmax", k), n_total * self.hidden_dim).view(n_total, self.hidden_dim)
+        r = hr = 0
+        for nv in neighs:
+            n, s, _ = nv.shape3
+            if self.POOL == "max":
+                ops.segment_max_fwd(H.rows_slice(hr, hr + n * s), n, s, pooled.rows_slice(r, r + n), argmax[r:r + n],
+                                    stream=e.stream)                                             # reduce_max (:181)
+            else:
+                ops.gather_mean_fwd(H.rows_slice(hr, hr + n * s), None, n, s, out=pooled.rows_slice(r, r + n),
+                                    stream=e.stream)                                             # reduce_mean (:259)
+            r += n
+            hr += n * s
         n_out = self.output_dim * (2 if self.concat else 1)
-        out = e.ws_mat((self.name, "out", k), n, n_out)
+        out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
-        ops.sage_dense_fwd(self_vecs.src, self_vecs.ids, pooled, None, n, self.vars['self_weights'].value,
+        ops.sage_dense_fwd(self_all.src, self_all.ids, pooled, None, n_total, self.vars['self_weights'].value,
                            self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
                            stream=e.stream)
-        self._push((self_vecs, neigh_vecs, H, pooled, argmax, out))
+        self._push((self_all, neighs, pieces, H, pooled, argmax, out))
         return out
 
-    def backward(self, d_out, pre_masked=False, neigh_mask=None):
+    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None):
         e = self.engine
-        self_vecs, neigh_vecs, H, pooled, argmax, out = self._saved.pop()
-        n, s, d = neigh_vecs.shape3
+        self_all, neighs, pieces, H, pooled, argmax, out = self._saved.pop()
+        n_total = self_all.n
         k = len(self._saved)
         o = self.output_dim
         n_out = o * (2 if self.concat else 1)
-        dz = self._dz(d_out, out, n, n_out, pre_masked)
-        col_n = o if self.concat else 0
-        e.wgrad(self.vars['self_weights'], self_vecs.src, self_vecs.ids, dz, 0, n)
-        e.wgrad(self.vars['neigh_weights'], pooled, None, dz, col_n, n)
-        if self.bias:
-            e.bgrad(self.vars['bias'], dz, n, n_out)
-        d_self = None
-        if self_vecs.requires_grad:
-            d_self = e.ws_mat((self.name, "d_self", k), n, self.input_dim)
-            ops.dense_dgrad(dz, 0, o, n, self.vars['self_weights'].value, d_self, stream=e.stream)
-        d_pooled = e.ws_mat((self.name, "d_pooled", k), n, self.hidden_dim)
-        ops.dense_dgrad(dz, col_n, o, n, self.vars['neigh_weights'].value, d_pooled, stream=e.stream)
-        dH = e.ws_mat((self.name, "dH", k), n * s, self.hidden_dim)
         mlp = self.mlp_layers[0]
-        x, _ = mlp._saved.pop()
+        dz = self._dz(d_out, out, n_total, n_out, pre_masked)
+        col_n = o if self.concat else 0
+        e.wgrad(self.vars['self_weights'], self_all.src, self_all.ids, dz, 0, n_total)
+        e.wgrad(self.vars['neigh_weights'], pooled, None, dz, col_n, n_total)
+        if self.bias:
+            e.bgrad(self.vars['bias'], dz, n_total, n_out)
+        d_pooled = e.ws_mat((self.name, "d_pooled", k), n_total, self.hidden_dim)
+        ops.dense_dgrad(dz, col_n, o, n_total, self.vars['neigh_weights'].value, d_pooled, stream=e.stream)
+        dH = e.ws_mat((self.name, "dH", k), H.rows, self.hidden_dim)
         if self.POOL == "max":
-            # reduce_max grad then the Dense's relu grad: only the arg-max row of each (group, column)
-            # receives gradient, and only where the pooled activation is > 0.
-            dpm = e.ws_mat((self.name, "d_pooled_masked", k), n, self.hidden_dim)
-            ops.act_bwd(d_pooled, pooled, n, self.hidden_dim, ACT_RELU, dpm, stream=e.stream)
-            ops.segment_max_bwd(dpm, pooled, argmax, n, s, dH, stream=e.stream)
-            e.bgrad(mlp.vars['bias'], dpm, n, self.hidden_dim)  # column sums of dH == column sums of dpm
-        else:
-            ops.mean_bwd(d_pooled, n, s, 1.0 / s, dH, mask_y=H, stream=e.stream)
-            e.bgrad(mlp.vars['bias'], dH, n * s, self.hidden_dim)
-        e.wgrad(mlp.vars['weights'], x.src, x.ids, dH, 0, n * s)
-        d_neigh = None
-        if neigh_vecs.requires_grad:
-            d_neigh = e.ws_mat((self.name, "d_neigh", k), n * s, d)
-            ops.dense_dgrad(dH, 0, self.hidden_dim, n * s, mlp.vars['weights'].value, d_neigh, stream=e.stream)
-            if neigh_mask is not None:
-                ops.act_bwd(d_neigh, neigh_mask, n * s, d, ACT_RELU, d_neigh, stream=e.stream)
-        return d_self, d_neigh
+            # reduce_max grad then the Dense's relu grad: only the arg-max row of each (group, column) receives
+            # gradient, and only where the pooled activation is > 0.
+            dpm = e.ws_mat((self.name, "d_pooled_masked", k), n_total, self.hidden_dim)
+            ops.act_bwd(d_pooled, pooled, n_total, self.hidden_dim, ACT_RELU, dpm, stream=e.stream)
+            e.bgrad(mlp.vars['bias'], dpm, n_total, self.hidden_dim)   # column sums of dH == column sums of dpm
+        r = hr = 0
+        for nv in neighs:
+            n, s, _ = nv.shape3
+            if self.POOL == "max":
+                ops.segment_max_bwd(dpm.rows_slice(r, r + n), pooled.rows_slice(r, r + n), argmax[r:r + n], n, s,
+                                    dH.rows_slice(hr, hr + n * s), stream=e.stream)
+            else:
+                ops.mean_bwd(d_pooled.rows_slice(r, r + n), n, s, 1.0 / s, dH.rows_slice(hr, hr + n * s),
+                             mask_y=H.rows_slice(hr, hr + n * s), stream=e.stream)
+            r += n
+            hr += n * s
+        if self.POOL != "max":
+            e.bgrad(mlp.vars['bias'], dH, H.rows, self.hidden_dim)
+        r = 0
+        for x in pieces:
+            e.wgrad(mlp.vars['weights'], x.src, x.ids, dH.rows_slice(r, r + x.n), 0, x.n)
+            r += x.n
+        if d_prev is None:
+            return
+        d_self_all = e.ws_mat((self.name, "d_self", k), n_total, self.input_dim)
+        ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value, d_self_all, stream=e.stream)
+        self._scatter_self(d_self_all, n_total, d_prev, prev_mask)
+        d_neigh = e.ws_mat((self.name, "d_neigh", k), H.rows, self.neigh_input_dim)
+        ops.dense_dgrad(dH, 0, self.hidden_dim, H.rows, mlp.vars['weights'].value, d_neigh, stream=e.stream)
+        hr = 0
+        for h, nv in enumerate(neighs):
+            n, s, _ = nv.shape3
+            r0 = prev_offsets[h + 1]
+            ops.mean_bwd(d_neigh.rows_slice(hr, hr + n * s), n * s, 1, 1.0, d_prev.rows_slice(r0, r0 + n * s),
+                         mask_y=prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None,
+                         accumulate=(h + 1 < len(neighs)), stream=e.stream)
+            hr += n * s
 
 
 class MaxPoolingAggregator(_PoolingAggregator):

@@ -41,16 +41,27 @@ struct GemmArgs {
     int32_t tiles_m, tiles_n;  // tiles_n is per term
 };
 
+template <int BM, int BN, bool A_KC>
+struct GemmSmem {
+    static constexpr int KP = 36;
+    static constexpr int AS = A_KC ? BM * KP : 32 * BM;
+};
+
+// XCD-aware tile id: consecutive tile ids (same A row panel) stay on one XCD (block b runs on XCD b % 8)
+__device__ __forceinline__ int gs_xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, const int zslice, float* smem) {
     constexpr int BK = 32;
     constexpr int KP = BK + 4;  // padded k stride for k-contiguous tiles (conflict-free ds_read_b128)
     constexpr int PA = BM / 32;  // float4 loads per thread per stage
     constexpr int PB = BN / 32;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AS_FLOATS = A_KC ? BM * KP : BK * BM;
-    constexpr int BS_FLOATS = B_KC ? BN * KP : BK * BN;
-    __shared__ __attribute__((aligned(16))) float smem[AS_FLOATS + BS_FLOATS];
     float* As = smem;
     float* Bs = smem + AS_FLOATS;
 
@@ -60,15 +71,6 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // ---- XCD-aware tile id: consecutive tile ids (same A row panel) stay on one XCD
-    const int nwg = gridDim.x;
-    int wgid;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, local = bid >> 3;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    }
     const int tiles_n_total = g.tiles_n * ((g.nterms == 2 && g.concat) ? 2 : 1);
     const int tile_m = wgid / tiles_n_total;
     int tile_n = wgid - tile_m * tiles_n_total;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
         const GemmTerm T = g.t[term];
         int k_begin = 0, k_end = T.K;
         if (g.kchunk > 0) {
-            k_begin = min((int64_t)blockIdx.z * g.kchunk, (int64_t)T.K);
+            k_begin = min((int64_t)zslice * g.kchunk, (int64_t)T.K);
             k_end = min(k_begin + g.kchunk, T.K);
         }
         if (k_begin >= k_end) continue;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    float* C = g.C + (g.kchunk > 0 ? (int64_t)blockIdx.z * g.slab_stride : 0);
+    float* C = g.C + (g.kchunk > 0 ? (int64_t)zslice * g.slab_stride : 0);
     const int n_total = g.N * ((g.nterms == 2 && g.concat) ? 2 : 1);
     const int n_pad = (n_total + 3) & ~3;
 #pragma unroll
@@ -300,6 +302,35 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
                 }
             }
         }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
+    constexpr int AS_FLOATS = A_KC ? BM * 36 : 32 * BM;
+    constexpr int BS_FLOATS = B_KC ? BN * 36 : 32 * BN;
+    __shared__ __attribute__((aligned(16))) float smem[AS_FLOATS + BS_FLOATS];
+    gemm_tile<BM, BN, A_KC, B_KC>(g, gs_xcd_swizzle(blockIdx.x, gridDim.x), blockIdx.z, smem);
+}
+
+// Grouped weight-gradient launch: every dW = A^T·dZ of one backward pass (all layers, all variables, the bias
+// gradients as ones^T·dZ) in ONE kernel.  blockIdx.x -> (problem, split-K slice, tile) through a prefix table.
+#define GS_MAX_GROUP 12
+struct GroupedArgs {
+    GemmArgs p[GS_MAX_GROUP];
+    int32_t block_start[GS_MAX_GROUP + 1];
+    int32_t n;
+};
+
+__global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedArgs G) {
+    __shared__ __attribute__((aligned(16))) float smem[32 * 64 + 32 * 64];
+    const int bid = blockIdx.x;
+    int p = 0;
+    while (p + 1 < G.n && bid >= G.block_start[p + 1]) ++p;
+    const GemmArgs& g = G.p[p];
+    const int local = bid - G.block_start[p];
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int z = local / tiles;
+    gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -398,6 +429,65 @@ extern "C" int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx,
     g.kchunk = (int32_t)(gs_ceil_div(gs_ceil_div(n, n_slabs), 32) * 32);
     g.act = GS_ACT_IDENTITY;
     return launch_gemm<64, 64, false, false>(g, n_slabs, (hipStream_t)stream);
+}
+
+extern "C" int gs_sage_dense_dgrad(const float* dZ, int64_t ldz, int64_t n, int32_t out_dim, int fwd_concat,
+                                   const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
+                                   int32_t d_in, float* dX2, int64_t ldx, void* stream) {
+    if (n == 0) return GS_OK;
+    GS_CHECK_MAT(dZ, ldz, "gs_sage_dense_dgrad dZ");
+    GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_dgrad W_self");
+    GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_dgrad W_neigh");
+    GS_CHECK_MAT(dX2, ldx, "gs_sage_dense_dgrad dX2");
+    GS_REQUIRE(n > 0 && out_dim > 0 && d_in > 0 && d_in % 4 == 0, "gs_sage_dense_dgrad: d_in must be a positive multiple of 4");
+    GS_REQUIRE(!fwd_concat || out_dim % 4 == 0, "gs_sage_dense_dgrad: concat needs out_dim %% 4 == 0");
+    GS_REQUIRE(ldz >= (fwd_concat ? 2 : 1) * rup4(out_dim) && ldw_self >= rup4(out_dim) && ldw_neigh >= rup4(out_dim) &&
+               ldx >= 2 * d_in, "gs_sage_dense_dgrad: ld too small");
+    GemmArgs g = {};
+    g.t[0] = GemmTerm{dZ, nullptr, W_self, ldz, ldw_self, out_dim};
+    g.t[1] = GemmTerm{dZ + (fwd_concat ? out_dim : 0), nullptr, W_neigh, ldz, ldw_neigh, out_dim};
+    g.nterms = 2;
+    g.concat = 1;
+    g.M = n; g.N = d_in; g.C = dX2; g.ldc = ldx;
+    g.act = GS_ACT_IDENTITY;
+    return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, void* stream) {
+    GS_REQUIRE(descs_host && n_desc > 0, "gs_dense_wgrad_grouped: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n_desc; base += GS_MAX_GROUP) {
+        GroupedArgs G = {};
+        const int cnt = std::min(GS_MAX_GROUP, n_desc - base);
+        G.n = cnt;
+        int64_t blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const gs_wgrad_desc& q = descs_host[base + i];
+            GS_CHECK_MAT(q.A, q.lda, "gs_dense_wgrad_grouped A");
+            GS_CHECK_MAT(q.dZ, q.ldz, "gs_dense_wgrad_grouped dZ");
+            GS_CHECK_MAT(q.slabs, q.ld_slab, "gs_dense_wgrad_grouped slabs");
+            GS_REQUIRE(q.d > 0 && q.out_dim > 0 && q.n > 0 && q.n < (1ll << 31) && q.n_slabs > 0, "gs_dense_wgrad_grouped: bad sizes");
+            GS_REQUIRE(q.col0 >= 0 && q.col0 % 4 == 0, "gs_dense_wgrad_grouped: col0 must be a multiple of 4");
+            GS_REQUIRE(q.lda >= rup4(q.d) && q.ldz >= q.col0 + rup4(q.out_dim) && q.ld_slab >= rup4(q.out_dim),
+                       "gs_dense_wgrad_grouped: ld too small");
+            GemmArgs& g = G.p[i];
+            g.t[0] = GemmTerm{q.A, q.a_idx, q.dZ + q.col0, q.lda, q.ldz, (int32_t)q.n};
+            g.nterms = 1;
+            g.M = q.d; g.N = q.out_dim; g.C = q.slabs; g.ldc = q.ld_slab;
+            g.slab_stride = (int64_t)q.d * q.ld_slab;
+            g.kchunk = (int32_t)(gs_ceil_div(gs_ceil_div(q.n, q.n_slabs), 32) * 32);
+            g.act = GS_ACT_IDENTITY;
+            g.tiles_m = (int)gs_ceil_div(q.d, 64);
+            g.tiles_n = (int)gs_ceil_div(q.out_dim, 64);
+            G.block_start[i] = (int32_t)blocks;
+            blocks += (int64_t)g.tiles_m * g.tiles_n * q.n_slabs;
+        }
+        G.block_start[cnt] = (int32_t)blocks;
+        GS_REQUIRE(blocks > 0 && blocks < (1ll << 31), "gs_dense_wgrad_grouped: bad grid");
+        hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G);
+        GS_LAUNCH_CHECK("gemm_grouped_tn_kernel");
+    }
+    return GS_OK;
 }
 
 extern "C" int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n, const float* W,

@@ -135,3 +135,90 @@ extern "C" int gs_sumsq_scaled(const float* x, int64_t count, float scale, float
     GS_LAUNCH_CHECK("sum_kernel_sq");
     return GS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Flat gradient finalisation (+ optional fused clip/Adam): one launch over the whole parameter buffer.
+#define GS_MAX_VARS 24
+struct FlatVars {
+    int64_t offset[GS_MAX_VARS];
+    int64_t size[GS_MAX_VARS];
+    const float* slabs[GS_MAX_VARS];
+    int32_t n_slabs[GS_MAX_VARS];
+    int32_t decay[GS_MAX_VARS];
+    int32_t n;
+};
+
+__global__ __launch_bounds__(256) void flat_reduce_adam_kernel(const FlatVars V, float* __restrict__ params,
+                                                               float* __restrict__ grads, float* __restrict__ m,
+                                                               float* __restrict__ v, int64_t total4, float wd,
+                                                               int fuse_adam, float lr, float b1, float b2, float eps,
+                                                               float clip, float gscale,
+                                                               const uint64_t* __restrict__ step_dev) {
+    float lr_t = 0.f;
+    if (fuse_adam) {
+        const float t = (float)((step_dev ? *step_dev : 0ull) + 1ull);
+        lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    }
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = q * 4;  // every segment offset/size is a multiple of 4 floats
+        int k = 0;
+        while (k + 1 < V.n && i >= V.offset[k + 1]) ++k;
+        const int64_t rel = i - V.offset[k];
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (rel < V.size[k]) {
+            const float* sp = V.slabs[k] + rel;
+            const int ns = V.n_slabs[k];
+            for (int z = 0; z < ns; ++z) g += *reinterpret_cast<const f32x4*>(sp + (int64_t)z * V.size[k]);
+        }
+        f32x4 p = *reinterpret_cast<const f32x4*>(params + i);
+        if (V.decay[k] && wd != 0.f) g += p * wd;
+        *reinterpret_cast<f32x4*>(grads + i) = g;
+        if (fuse_adam) {
+            g *= gscale;
+            f32x4 mi = *reinterpret_cast<const f32x4*>(m + i);
+            f32x4 vi = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ge = g[e];
+                if (clip > 0.f) ge = fminf(fmaxf(ge, -clip), clip);
+                mi[e] = b1 * mi[e] + (1.0f - b1) * ge;
+                vi[e] = b2 * vi[e] + (1.0f - b2) * ge * ge;
+                p[e] -= lr_t * mi[e] / (sqrtf(vi[e]) + eps);
+            }
+            *reinterpret_cast<f32x4*>(m + i) = mi;
+            *reinterpret_cast<f32x4*>(v + i) = vi;
+            *reinterpret_cast<f32x4*>(params + i) = p;
+        }
+    }
+}
+
+extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
+                                   float* v, int64_t total, float weight_decay, int fuse_adam, float lr, float beta1,
+                                   float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
+                                   void* stream) {
+    GS_REQUIRE(vars_host && n_vars > 0 && n_vars <= GS_MAX_VARS, "gs_flat_reduce_adam: need 1..%d variables", GS_MAX_VARS);
+    GS_REQUIRE(params && grads && total > 0 && total % 4 == 0, "gs_flat_reduce_adam: bad flat buffer");
+    GS_REQUIRE(!fuse_adam || (m && v), "gs_flat_reduce_adam: Adam state missing");
+    FlatVars V = {};
+    V.n = n_vars;
+    int64_t expect = 0;
+    for (int i = 0; i < n_vars; ++i) {
+        GS_REQUIRE(vars_host[i].offset == expect && vars_host[i].size > 0 && vars_host[i].size % 4 == 0,
+                   "gs_flat_reduce_adam: variables must tile the flat buffer in order (var %d)", i);
+        GS_REQUIRE(vars_host[i].n_slabs == 0 || (vars_host[i].slabs && gs_aligned16(vars_host[i].slabs)),
+                   "gs_flat_reduce_adam: slabs of var %d missing/misaligned", i);
+        V.offset[i] = vars_host[i].offset;
+        V.size[i] = vars_host[i].size;
+        V.slabs[i] = vars_host[i].slabs;
+        V.n_slabs[i] = vars_host[i].n_slabs;
+        V.decay[i] = vars_host[i].decay;
+        expect += vars_host[i].size;
+    }
+    GS_REQUIRE(expect <= total, "gs_flat_reduce_adam: variables exceed the flat buffer");
+    const int64_t total4 = expect / 4;
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total4, 256), 1024);
+    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, V, params, grads, m, v,
+                       total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev);
+    GS_LAUNCH_CHECK("flat_reduce_adam_kernel");
+    return GS_OK;
+}

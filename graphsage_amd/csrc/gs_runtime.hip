@@ -111,6 +111,20 @@ extern "C" int gs_advance_counter(uint64_t* counter_dev, uint64_t delta, void* s
     return GS_OK;
 }
 
+__global__ void advance_counters_kernel(uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (c0) *c0 += d0;
+        if (c1) *c1 += d1;
+        if (c2) *c2 += d2;
+    }
+}
+extern "C" int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2,
+                                   void* stream) {
+    hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c0, d0, c1, d1, c2, d2);
+    GS_LAUNCH_CHECK("advance_counters_kernel");
+    return GS_OK;
+}
+
 // ----------------------------------------------------------------------------- host CSR builder
 // Counting sort by source node; parallel histogram + parallel fill over node ranges.
 extern "C" int gs_build_csr_host(const int32_t* src, const int32_t* dst, const uint8_t* keep,

@@ -137,3 +137,30 @@ extern "C" int gs_select_batch(const int32_t* order, int64_t n_order, const uint
     GS_LAUNCH_CHECK("select_batch_kernel");
     return GS_OK;
 }
+
+// batch selection + label-row gather in one launch: one wave per batch row.
+__global__ __launch_bounds__(256) void stage_batch_kernel(const int32_t* __restrict__ order, int64_t n_order,
+                                                          const uint64_t* __restrict__ cursor, int64_t n,
+                                                          int32_t* __restrict__ batch, const float* __restrict__ table,
+                                                          int64_t ldt, int32_t C, float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const uint64_t c = cursor ? *cursor : 0ull;
+    const int32_t id = order[(int64_t)((c + (uint64_t)i) % (uint64_t)n_order)];
+    if (lane == 0) batch[i] = id;
+    const int Cp = (C + 3) & ~3;
+    for (int k = lane; k < Cp; k += 64) out[i * ldo + k] = k < C ? table[(int64_t)id * ldt + k] : 0.f;
+}
+
+extern "C" int gs_stage_batch(const int32_t* order, int64_t n_order, const uint64_t* cursor_dev, int64_t n,
+                              int32_t* batch, const float* label_table, int64_t ld_table, int32_t C,
+                              float* labels_out, int64_t ld_out, void* stream) {
+    if (n == 0) return GS_OK;
+    GS_REQUIRE(order && batch && label_table && labels_out && n_order > 0 && C > 0, "gs_stage_batch: bad args");
+    GS_REQUIRE(ld_table >= C && ld_out >= ((C + 3) & ~3), "gs_stage_batch: ld too small");
+    hipLaunchKernelGGL(stage_batch_kernel, dim3((unsigned)gs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, order,
+                       n_order, cursor_dev, n, batch, label_table, ld_table, C, labels_out, ld_out);
+    GS_LAUNCH_CHECK("stage_batch_kernel");
+    return GS_OK;
+}

@@ -6,6 +6,8 @@ This replaces what the TF1 runtime provided to the reference: tf.Variable storag
 (supervised_models.py:60, aggregators.py:30-33), gradient accumulation of
 optimizer.compute_gradients (supervised_models.py:95) and apply_gradients (:99).
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -62,6 +64,7 @@ class Engine(object):
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # optimizer step counter t-1
         self.sample_clock_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # sampler RNG step
         self.finalized = False
+        self._pending = []
 
     # -------------------------------------------------------------------------------- variables
     def add_variable(self, name, init, decay=False):
@@ -128,45 +131,80 @@ class Engine(object):
     def begin_backward(self):
         for v in self.variables:
             v.n_slabs = 0
+        self._pending = []
 
     @staticmethod
-    def pick_slabs(n_rows):
-        """Split-K slices for a weight gradient over n_rows: ~320 rows per slice, at most 24."""
-        return int(min(24, max(1, (n_rows + 319) // 320)))
+    def pick_slabs(n_rows, tiles):
+        """Split-K slices for a weight gradient: enough (tile x slice) workgroups to cover the 256 CUs,
+        at least 64 reduction rows per slice, at most 24 slices."""
+        want = max(1, (256 + tiles - 1) // tiles)
+        return int(max(1, min(24, want, (n_rows + 63) // 64)))
+
+    def ones(self, n):
+        """[n, 1] matrix of ones: bias gradients are the grouped-GEMM problem ones^T · dZ."""
+        m = self._ws.get(("ones",))
+        if m is None or m.rows < n:
+            m = Mat(torch.ones((max(n, 1024), 4), dtype=torch.float32, device=self.device), 1)
+            torch.cuda.synchronize()
+            self._ws[("ones",)] = m
+        return m.rows_slice(0, n)
 
     def wgrad(self, var, A, a_idx, dZ, col0, n):
-        """var.slabs += A[a_idx]^T · dZ[:, col0:col0+var.cols] as new split-K slabs."""
-        k = self.pick_slabs(n)
+        """Queue var.slabs += A[a_idx]^T · dZ[:, col0:col0+var.cols] (split-K slabs); all queued problems of a
+        backward pass are issued as ONE grouped launch by launch_wgrads()."""
+        assert A.d == var.rows, (var.name, A.d, var.rows)
+        tiles = ((var.rows + 63) // 64) * ((var.cols + 63) // 64)
+        k = self.pick_slabs(n, tiles)
         if var.n_slabs + k > MAX_SLABS:
             raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
-        assert A.d == var.rows
-        ops.call("gs_dense_wgrad", A.ptr, A.ld, ops.ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, var.cols, n, k,
-                 var.slab_ptr(var.n_slabs), var.ld, self.stream)
+        d = ops._lib.WgradDesc()
+        d.A, d.a_idx, d.dZ = A.ptr, ops.ptr(a_idx), dZ.ptr
+        d.slabs = var.slab_ptr(var.n_slabs)
+        d.lda, d.ldz, d.ld_slab, d.n = A.ld, dZ.ld, var.ld, n
+        d.d, d.col0, d.out_dim, d.n_slabs = var.rows, col0, var.cols, k
+        self._pending.append(d)
         var.n_slabs += k
 
-    def bgrad(self, var, dZ, n, n_cols):
-        """Bias gradient slabs: column sums of dZ[:, :n_cols]."""
-        k = int(min(16, max(1, (n + 255) // 256)))
-        if var.n_slabs + k > MAX_SLABS:
-            raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
+    def bgrad(self, var, dZ, n, n_cols, col0=0):
+        """Bias gradient = column sums of dZ[:, col0:col0+n_cols] = ones^T · dZ (one more grouped problem)."""
         assert var.rows == 1 and var.cols == n_cols
-        ops.call("gs_colsum_slabs", dZ.ptr, dZ.ld, n, n_cols, k, var.slab_ptr(var.n_slabs), var.ld, self.stream)
-        var.n_slabs += k
+        self.wgrad(var, self.ones(n), None, dZ, col0, n)
 
-    def finish_backward(self, weight_decay):
-        """grads = sum of slabs (+ weight_decay * w for decayed variables)."""
-        for v in self.variables:
-            if v.n_slabs == 0:
-                v.grad.buf.zero_()  # not on the captured stream; only hit for unused variables
-                continue
-            wd = float(weight_decay) if v.decay else 0.0
-            ops.call("gs_reduce_slabs", v.slabs.data_ptr(), v.n_slabs, v.size, v.rows, v.cols, v.ld, wd,
-                     v.value.ptr, v.ld, v.grad.ptr, v.ld, 0, self.stream)
+    def launch_wgrads(self):
+        if not self._pending:
+            return
+        arr = (ops._lib.WgradDesc * len(self._pending))(*self._pending)
+        ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr), len(self._pending), self.stream)
+        self._pending = []
+
+    def _var_descs(self):
+        arr = (ops._lib.VarDesc * len(self.variables))()
+        for i, v in enumerate(self.variables):
+            arr[i].offset, arr[i].size = v.offset, v.size
+            arr[i].slabs = v.slabs.data_ptr()
+            arr[i].n_slabs, arr[i].decay = v.n_slabs, 1 if v.decay else 0
+        return arr
+
+    def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0):
+        """One grouped launch for every queued weight gradient, then ONE launch that sums the slabs into the
+        flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass."""
+        self.launch_wgrads()
+        arr = self._var_descs()
+        ops.call("gs_flat_reduce_adam", ctypes.addressof(arr), len(self.variables), ops.ptr(self.params),
+                 ops.ptr(self.grads), ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats,
+                 float(weight_decay), 1 if fuse_adam else 0, lr, 0.9, 0.999, 1e-8, clip, grad_scale,
+                 ops.ptr(self.step_dev), self.stream)
 
     def adam(self, lr, clip=5.0, grad_scale=1.0):
+        """Separate optimizer launch (data-parallel path: runs after the RCCL all-reduce of engine.grads)."""
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_param_floats, lr, self.step_dev,
                       clip=clip, grad_scale=grad_scale, stream=self.stream)
-        ops.advance_counter(self.step_dev, 1, stream=self.stream)
+
+    def advance(self, step=0, clock=0, cursor=None, cursor_delta=0):
+        """Advance the optimizer step / sampler clock / epoch cursor with ONE launch."""
+        ops.call("gs_advance_counters", ops.ptr(self.step_dev) if step else None, step,
+                 ops.ptr(self.sample_clock_dev) if clock else None, clock,
+                 ops.ptr(cursor) if (cursor is not None and cursor_delta) else None, cursor_delta, self.stream)
 
     def sync(self):
         ops.call("gs_stream_sync", self.stream)

@@ -68,6 +68,12 @@ class Rows(object):
     def d(self):
         return self.src.d
 
+    def slice(self, r0, r1):
+        """Rows [r0, r1) of this view."""
+        if self.ids is not None:
+            return Rows(self.src, self.ids[r0:r1], r1 - r0, self.requires_grad)
+        return Rows(self.src.rows_slice(r0, r1), None, r1 - r0, self.requires_grad)
+
     def reshape(self, dims):
         n, s, d = dims
         assert n * s == self.n and d == self.src.d, (dims, self.n, self.src.d)

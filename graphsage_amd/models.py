@@ -98,20 +98,41 @@ class SampleAndAggregate(object):
         self._tape = None
 
     # ------------------------------------------------------------------------------ sample (S2)
+    def ids_buffer(self, batch_size, layer_infos=None):
+        """One contiguous int32 buffer [batch | hop-1 samples | hop-2 samples | ...] so that the rows of all hops
+        of a layer are adjacent (lets `aggregate` run every hop of a layer in one launch).  Returns
+        (buffer, offsets) with offsets[k] = start of samples[k]."""
+        layer_infos = layer_infos or self.layer_infos
+        sizes = [batch_size]
+        support = 1
+        for k in range(len(layer_infos)):
+            support *= layer_infos[len(layer_infos) - k - 1].num_samples
+            sizes.append(batch_size * support)
+        offsets = [0]
+        for sz in sizes:
+            offsets.append(offsets[-1] + sz)
+        buf = self.engine.ws_i32(("ids_all", tuple(sizes)), offsets[-1])
+        return buf, offsets
+
     def sample(self, inputs, layer_infos, batch_size=None):
         """Sample neighbors to be the supportive fields for multi-layer convolutions
-        (models.py:254-275).  `inputs`: int32 device vector of batch node ids."""
+        (models.py:254-275).  `inputs`: int32 device vector of batch node ids.  When `inputs` is the head of
+        the model's contiguous id buffer, the sampled hops are written right behind it."""
         if batch_size is None:
             batch_size = inputs.numel()
         samples = [inputs]
         support_size = 1
         support_sizes = [support_size]
+        buf, offsets = self.ids_buffer(batch_size, layer_infos)
+        contiguous = inputs.data_ptr() == buf.data_ptr() and inputs.numel() == batch_size
         for k in range(len(layer_infos)):
             t = len(layer_infos) - k - 1
             sampler = layer_infos[t].neigh_sampler
             # this rank's first global row at this hop (keeps draws independent of the DP sharding)
             sampler.global_row_offset = getattr(self, "row_offset", 0) * support_size
             support_size *= layer_infos[t].num_samples
+            if contiguous:
+                sampler.next_out = buf[offsets[k + 1]: offsets[k + 2]]
             node = sampler((samples[k], layer_infos[t].num_samples))
             samples.append(node.reshape(support_size * batch_size))
             support_sizes.append(support_size)
@@ -137,7 +158,11 @@ class SampleAndAggregate(object):
     def aggregate(self, samples, input_features, dims, num_samples, support_sizes, batch_size=None,
                   aggregators=None, name=None, concat=False, model_size="small"):
         """At each layer, aggregate hidden representations of neighbors to compute the hidden
-        representations at next layer (models.py:278-330).  Returns (hidden[0], aggregators)."""
+        representations at next layer (models.py:278-330).  Returns (hidden[0], aggregators).
+
+        The reference calls the layer's aggregator once per hop (:321-328); here all hops of a layer go through
+        ONE batched call (their rows are contiguous), which is numerically the same computation."""
+        from .aggregators import _contiguous
         if batch_size is None:
             batch_size = samples[0].numel()
         features = input_features[0] if isinstance(input_features, (list, tuple)) else input_features
@@ -148,19 +173,28 @@ class SampleAndAggregate(object):
             aggregators = self.make_aggregators(dims, num_samples, concat, model_size, name)
             self.engine.finalize()
         tape = []
-        for layer in range(len(num_samples)):
+        K = len(num_samples)
+        for layer in range(K):
             aggregator = aggregators[layer]
-            next_hidden = []
-            # as layer increases, the number of support nodes needed decreases
-            for hop in range(len(num_samples) - layer):
-                dim_mult = 2 if concat and (layer != 0) else 1
-                neigh_dims = [batch_size * support_sizes[hop],
-                              num_samples[len(num_samples) - hop - 1],
-                              dim_mult * dims[layer]]
-                h = aggregator((hidden[hop], hidden[hop + 1].reshape(neigh_dims)))
-                tape.append((layer, hop, aggregator, hidden[hop], hidden[hop + 1], h))
-                next_hidden.append(Rows(h, None, requires_grad=True))
-            hidden = next_hidden
+            n_hops = K - layer
+            dim_mult = 2 if concat and (layer != 0) else 1
+            neighs = []
+            for hop in range(n_hops):
+                neigh_dims = [batch_size * support_sizes[hop], num_samples[K - hop - 1], dim_mult * dims[layer]]
+                neighs.append(hidden[hop + 1].reshape(neigh_dims))
+            self_all = _contiguous(hidden[:n_hops])
+            rows = [hidden[h].n for h in range(n_hops + 1)]
+            offsets = [0]
+            for r in rows:
+                offsets.append(offsets[-1] + r)
+            if self_all is not None:
+                h_all = aggregator.call_hops(self_all, neighs)               # every hop of the layer, one launch
+                outs = [h_all.rows_slice(offsets[h], offsets[h + 1]) for h in range(n_hops)]
+                tape.append(("batched", aggregator, rows, offsets, h_all))
+            else:                                                           # non-adjacent inputs: hop by hop (:326)
+                outs = [aggregator((hidden[hop], neighs[hop])) for hop in range(n_hops)]
+                tape.append(("per_hop", aggregator, rows, offsets, outs))
+            hidden = [Rows(o, None, requires_grad=True) for o in outs]
         self._tape = tape
         return hidden[0].src, aggregators
 
@@ -169,41 +203,21 @@ class SampleAndAggregate(object):
         No gradient flows into the feature table (models.py:238: trainable=False)."""
         e = self.engine
         tape = self._tape
-        # gradient slots of the hidden matrices produced by aggregator calls: id(Mat) -> [Mat, state]
-        # state: 'raw' = dLoss/d(output after act); 'masked' = already multiplied by the relu mask
-        slots = {id(tape[-1][5]): [d_out, 'raw']}
-        # how many consumers each produced hidden matrix has (to decide whether the relu mask can be fused)
-        consumers = {}
-        for (_, _, _, self_rows, neigh_rows, _) in tape:
-            for r in (self_rows, neigh_rows):
-                if r.requires_grad:
-                    consumers[id(r.src)] = consumers.get(id(r.src), 0) + 1
-        produced_relu = {id(h): (agg.act_code == ops.ACT_RELU) for (_, _, agg, _, _, h) in tape}
-        for (layer, hop, agg, self_rows, neigh_rows, h) in reversed(tape):
-            slot = slots.pop(id(h), None)
-            if slot is None:
-                # output never used downstream (cannot happen in the reference schedule)
-                agg._saved.pop()
-                continue
-            d_h, state = slot
-            fuse = (neigh_rows.requires_grad and consumers.get(id(neigh_rows.src), 0) == 1
-                    and produced_relu.get(id(neigh_rows.src), False))
-            d_self, d_neigh = agg.backward(d_h, pre_masked=(state == 'masked'),
-                                           neigh_mask=neigh_rows.src if fuse else None)
-            if d_self is not None:
-                self._accumulate(slots, self_rows.src, d_self, 'raw')
-            if d_neigh is not None:
-                self._accumulate(slots, neigh_rows.src, d_neigh, 'masked' if fuse else 'raw')
-
-    def _accumulate(self, slots, mat, grad, state):
-        key = id(mat)
-        if key not in slots:
-            slots[key] = [grad, state]
-            return
-        cur, cur_state = slots[key]
-        assert cur_state == 'raw' and state == 'raw', "fused relu masks are only used for single-consumer tensors"
-        # cur += grad  (K >= 3: a hidden tensor can be both a self and a neighbor input)
-        ops.mean_bwd(grad, grad.rows, 1, 1.0, cur, accumulate=True, stream=self.engine.stream)
+        d_cur, pre_masked = d_out, False
+        for layer in range(len(tape) - 1, -1, -1):
+            mode, agg, rows, offsets, outs = tape[layer]
+            if mode != "batched":
+                raise NotImplementedError("backward through non-contiguous hop inputs (use the model's id buffer)")
+            if layer == 0:
+                agg.backward_hops(d_cur, pre_masked)                         # features need no gradient
+                break
+            prev_mode, prev_agg, prev_rows, prev_offsets, prev_out = tape[layer - 1]
+            d_prev = e.ws_mat((self.name, "d_hidden", layer - 1), prev_out.rows, prev_out.d)
+            # the previous layer is never the last one, so its activation is relu (models.py:307-314): its
+            # relu gradient is fused into the scatter of this layer's input gradients
+            mask = prev_out if prev_agg.act_code == ops.ACT_RELU else None
+            agg.backward_hops(d_cur, pre_masked, d_prev=d_prev, prev_mask=mask, prev_offsets=prev_offsets)
+            d_cur, pre_masked = d_prev, mask is not None
 
     def reset_tapes(self):
         if self.aggregators:

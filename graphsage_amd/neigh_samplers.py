@@ -66,6 +66,7 @@ class UniformNeighborSampler(Layer):
         self._rng = np.random.RandomState(seed)
         self._injected_perms = None
         self._call_index = 0          # sampler calls so far in this step = the `hop` stream id
+        self.next_out = None          # optional destination of the next call (the model's contiguous id buffer)
         self.global_row_offset = 0    # first global row of this rank's slice (data-parallel invariance)
 
     # -- step bookkeeping driven by the model -------------------------------------------------
@@ -81,7 +82,10 @@ class UniformNeighborSampler(Layer):
         e = self.engine
         adj = self.adj_info.current
         n = ids.numel()
-        out = e.ws_i32((self.name, "out", self._call_index), n * num_samples)
+        out = self.next_out if self.next_out is not None else e.ws_i32((self.name, "out", self._call_index),
+                                                                        n * num_samples)
+        self.next_out = None
+        assert out.numel() >= n * num_samples
         if isinstance(adj, PaddedAdjacency):
             if num_samples > adj.max_degree:
                 raise ops._lib.GraphsageAmdError("num_samples %d > max_degree %d" % (num_samples, adj.max_degree))

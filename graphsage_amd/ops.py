@@ -61,6 +61,11 @@ class Mat(object):
     def rows_slice(self, r0, r1):
         return Mat(self.buf[r0:r1], self.d)
 
+    def cols_slice(self, c0, c1):
+        """Columns [c0, c1) as a matrix with the same leading dimension (c0 % 4 == 0)."""
+        assert c0 % 4 == 0 and c1 <= self.buf.shape[1]
+        return Mat(self.buf[:, c0:c1], c1 - c0)
+
 
 def current_stream():
     return torch.cuda.current_stream().cuda_stream
@@ -141,6 +146,17 @@ def dense_wgrad(A, a_idx, dZ, col0, out_dim, n, n_slabs, slabs, ld_slab, stream=
     """slabs: flat fp32 tensor with room for n_slabs * A.d * ld_slab floats."""
     call("gs_dense_wgrad", A.ptr, A.ld, ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, out_dim, n, n_slabs, ptr(slabs),
          ld_slab, _s(stream))
+
+
+def sage_dense_dgrad(dZ, n, out_dim, fwd_concat, W_self, W_neigh, d_in, dX2, stream=None):
+    call("gs_sage_dense_dgrad", dZ.ptr, dZ.ld, n, out_dim, 1 if fwd_concat else 0, W_self.ptr, W_self.ld,
+         W_neigh.ptr, W_neigh.ld, d_in, dX2.ptr, dX2.ld, _s(stream))
+    return dX2
+
+
+def stage_batch(order, cursor_dev, n, batch, label_table, labels_out, stream=None):
+    call("gs_stage_batch", ptr(order), order.numel(), ptr(cursor_dev), n, ptr(batch), label_table.ptr, label_table.ld,
+         label_table.d, labels_out.ptr, labels_out.ld, _s(stream))
 
 
 def dense_dgrad(dZ, col0, out_dim, n, W, dX, accumulate=False, stream=None):

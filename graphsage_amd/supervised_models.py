@@ -91,23 +91,24 @@ class SupervisedGraphsage(SampleAndAggregate):
                 if v.decay:
                     ops.call("gs_sumsq_scaled", v.value.ptr, v.size, 0.5 * self.weight_decay,
                              self.loss_dev.data_ptr(), 1, e.stream)
-        ops.advance_counter(e.sample_clock_dev, 1, stream=e.stream)
 
-    def _backward(self, n):
-        """Reverse of _forward; leaves summed gradients in engine.grads (compute_gradients, :95)."""
+    def _backward(self, n, fuse_adam):
+        """Reverse of _forward.  Every weight gradient of the pass is ONE grouped launch; the slab reduction
+        (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
         e.begin_backward()
         d_outputs1 = self.node_pred.backward(self._dlogits, need_input_grad=True)
         d_out = e.ws_mat("d_agg_out", n, self.agg_out.d)
         ops.l2norm_bwd(d_outputs1, self.outputs1, self._inv_norm, n, d_out, stream=e.stream)
         self.aggregate_backward(d_out)
-        e.finish_backward(self.weight_decay)
+        e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0)
 
     def _optimize(self):
-        """clip_by_value(+-5) + Adam  (:96-99).  Under data parallelism the local gradient is that of the
-        local batch mean; the hook sums over ranks and grad_scale divides by world_size."""
+        """Data-parallel path: clip_by_value(+-5) + Adam (:96-99) after the RCCL all-reduce.  The local gradient
+        is that of the local batch mean; the hook sums over ranks and grad_scale divides by world_size."""
         e = self.engine
         e.adam(self.learning_rate, clip=5.0, grad_scale=1.0 / self.world_size)
+        e.advance(step=1)
 
     # ------------------------------------------------------------------------------ feeds
     def _stage_feed(self, feed_dict):
@@ -121,7 +122,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         drop = feed_dict.get(ph['dropout'], 0.0)
         if float(drop) != 0.0:
             raise NotImplementedError("dropout > 0 is not implemented in the gfx950 kernels yet")
-        batch_dev = e.ws_i32("batch", n)
+        batch_dev = self.ids_buffer(n)[0][:n]     # head of the contiguous id buffer (see models.sample)
         batch_dev.copy_(torch.from_numpy(batch))
         labels = np.ascontiguousarray(np.asarray(feed_dict[ph['labels']]), dtype=np.float32)
         labels_dev = e.ws_mat("labels", n, self.num_classes)
@@ -163,21 +164,26 @@ class SupervisedGraphsage(SampleAndAggregate):
 
     def eval_step(self, feed_dict, fetch=True):
         batch_dev, labels_dev, n = self._stage_feed(feed_dict)
-        self._run(("eval", n, self._adj_version()), lambda: self._forward(batch_dev, labels_dev, n))
+        e = self.engine
+        self._run(("eval", n, self._adj_version()), lambda: (self._forward(batch_dev, labels_dev, n), e.advance(clock=1)))
         return self._fetch(n) if fetch else None
 
-    def _train_on_device(self, batch_dev, labels_dev, n, fetch=True):
+    def _train_on_device(self, batch_dev, labels_dev, n, fetch=True, prologue=None, cursor=None, key="train"):
         e = self.engine
+        fused = self.grad_hook is None
 
         def fwd_bwd():
+            if prologue is not None:
+                prologue()
             self._forward(batch_dev, labels_dev, n)
-            self._backward(n)
+            self._backward(n, fuse_adam=fused)
+            e.advance(step=1 if fused else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
 
-        if self.grad_hook is None:
-            self._run(("train", n, self._adj_version()), lambda: (fwd_bwd(), self._optimize()))
+        if fused:
+            self._run((key, n, self._adj_version()), fwd_bwd)     # the whole step: one hipGraph
         else:
-            self._run(("train_fb", n, self._adj_version()), fwd_bwd)
-            self.grad_hook(self)              # RCCL all-reduce of engine.grads (not captured)
+            self._run((key + "_fb", n, self._adj_version()), fwd_bwd)
+            self.grad_hook(self)              # RCCL all-reduce of engine.grads (ordered by stream events)
             self._run(("opt",), self._optimize)
         return self._fetch(n) if fetch else None
 
@@ -208,23 +214,13 @@ class SupervisedGraphsage(SampleAndAggregate):
     def train_step_device(self, n, fetch=False):
         """One training step on the next n ids of the device-resident epoch order."""
         e = self.engine
-        batch_dev = e.ws_i32("batch", n)
+        batch_dev = self.ids_buffer(n)[0][:n]
         labels_dev = e.ws_mat("labels", n, self.num_classes)
 
-        def step():
-            ops.select_batch(self._order, self._cursor, n, batch_dev, stream=e.stream)
-            ops.advance_counter(self._cursor, n, stream=e.stream)
-            ops.gather_rows(self.label_table, batch_dev, out=labels_dev, stream=e.stream)
-            self._forward(batch_dev, labels_dev, n)
-            self._backward(n)
+        def stage():   # batch selection + label gather: one launch (minibatch.py:264-274, 302-307 on the device)
+            ops.stage_batch(self._order, self._cursor, n, batch_dev, self.label_table, labels_dev, stream=e.stream)
 
-        if self.grad_hook is None:
-            self._run(("dtrain", n, self._adj_version()), lambda: (step(), self._optimize()))
-        else:
-            self._run(("dtrain_fb", n, self._adj_version()), step)
-            self.grad_hook(self)
-            self._run(("opt",), self._optimize)
-        return self._fetch(n) if fetch else None
+        return self._train_on_device(batch_dev, labels_dev, n, fetch, prologue=stage, cursor=self._cursor, key="dtrain")
 
     def predict(self):
         """sigmoid / softmax of the logits (supervised_models.py:122-126); filled by the last step."""

@@ -134,6 +134,27 @@ int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx, int32_t d,
                    const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,
                    int32_t n_slabs, float* slabs, int64_t ld_slab, void* stream);
 
+/* Both input gradients of a SAGE dense layer in ONE launch (two-term NT GEMM, concatenated output):
+ *   dX2[:, 0:d_in]       = dZ_self  · W_self^T      dZ_self  = dZ[:, 0:out_dim]
+ *   dX2[:, d_in:2*d_in]  = dZ_neigh · W_neigh^T     dZ_neigh = dZ[:, out_dim:2*out_dim] if fwd_concat else dZ_self
+ * d_in % 4 == 0 and (if fwd_concat) out_dim % 4 == 0.  Gradient of aggregators.py:51,53. */
+int gs_sage_dense_dgrad(const float* dZ, int64_t ldz, int64_t n, int32_t out_dim, int fwd_concat,
+                        const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
+                        int32_t d_in, float* dX2, int64_t ldx, void* stream);
+
+/* All weight gradients of one backward pass in ONE launch (grouped split-K GEMM).  Each descriptor is one
+ * gs_dense_wgrad problem; a bias gradient is the problem A = ones[n, 1] (d = 1).  descs_host is a HOST array
+ * that is consumed at call time (kernel arguments are copied), so it may be freed right after the call. */
+typedef struct gs_wgrad_desc {
+    const float* A;        /* [rows, lda] source of the reduction (row-gathered through a_idx if non-null) */
+    const int32_t* a_idx;
+    const float* dZ;       /* [n, ldz] */
+    float* slabs;          /* [n_slabs, d, ld_slab] */
+    int64_t lda, ldz, ld_slab, n;
+    int32_t d, col0, out_dim, n_slabs;
+} gs_wgrad_desc;
+int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, void* stream);
+
 /* Input gradient:  dX[n, d] (+)= dZ[:, col0:col0+out_dim] · W[d, out_dim]^T */
 int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,
                    const float* W, int64_t ldw, int32_t d, float* dX, int64_t ldx, int accumulate,
@@ -212,6 +233,28 @@ int gs_reduce_slabs(const float* slabs, int32_t n_slabs, int64_t slab_stride, in
 int gs_adam_step(float* p, const float* grad, float* m, float* v, int64_t count,
                  float lr, float beta1, float beta2, float eps, float clip, float grad_scale,
                  const uint64_t* step_dev, void* stream);
+
+/* Gradient finalisation over the whole flat parameter buffer in ONE launch:
+ *   grads[i] = sum_{z < n_slabs(var)} slabs_var[z*size_var + (i - offset_var)] + (decay_var ? weight_decay*params[i] : 0)
+ * and, when fuse_adam != 0, the clip + Adam update of gs_adam_step on the same element (single-GPU step).
+ * vars_host: HOST array of per-variable descriptors (consumed at call time). */
+typedef struct gs_var_desc {
+    int64_t offset, size;  /* segment of the flat buffers, in floats (size includes ld padding) */
+    const float* slabs;
+    int32_t n_slabs, decay;
+} gs_var_desc;
+int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
+                        int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,
+                        float eps, float clip, float grad_scale, const uint64_t* step_dev, void* stream);
+
+/* Up to three device counters advanced by one launch (cursor / sampler clock / optimizer step). */
+int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);
+
+/* batch[i] = order[(*cursor + i) % n_order];  labels_out[i, :C] = label_table[batch[i], :C]   (one launch;
+ * replaces minibatch.py:264-274 + 302-307 for the device-resident epoch). */
+int gs_stage_batch(const int32_t* order, int64_t n_order, const uint64_t* cursor_dev, int64_t n, int32_t* batch,
+                   const float* label_table, int64_t ld_table, int32_t C, float* labels_out, int64_t ld_out,
+                   void* stream);
 
 /* out[0] = scale * sum_{i<count} x[i]   (single block, deterministic order) */
 int gs_sum_scaled(const float* x, int64_t count, float scale, float* out, int accumulate, void* stream);

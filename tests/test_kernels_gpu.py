@@ -378,3 +378,80 @@ def test_graph_capture_replay(dev):
         g.launch()
     st.sync()
     assert int(x.item()) == 35
+
+
+# ----------------------------------------------------------------------------- grouped / fused launches
+def test_grouped_wgrad_and_flat_reduce_adam(dev):
+    """All weight gradients in one launch (+ bias gradient as ones^T dZ), then slab reduce + clip + Adam in one."""
+    import ctypes
+    from graphsage_amd import _lib
+    rng = np.random.default_rng(31)
+    Nn, d, out, n = 1500, 602, 128, 700
+    X = _asym(rng, (Nn, d))
+    idx = rng.integers(0, Nn, size=n).astype(np.int32)
+    mean = _asym(rng, (n, d))
+    dZ = _asym(rng, (n, 2 * out))
+    Xd, Md, dZd, idxd = Mat.from_numpy(X, dev, 32), Mat.from_numpy(mean, dev), Mat.from_numpy(dZ, dev), _i32(idx, dev)
+    ones = Mat(torch.ones((n, 4), device=dev), 1)
+    # flat layout: W_self [d,out] | W_neigh [d,out] | bias [1, 2*out]
+    sizes = [d * out, d * out, 2 * out]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    nsl = [3, 5, 2]
+    slabs = [torch.zeros(nsl[i] * sizes[i], device=dev) for i in range(3)]
+    descs = (_lib.WgradDesc * 3)()
+    for i, (A, aidx, col0, dd, od) in enumerate([(Xd, idxd, 0, d, out), (Md, None, out, d, out), (ones, None, 0, 1, 2 * out)]):
+        descs[i].A, descs[i].a_idx, descs[i].dZ, descs[i].slabs = A.ptr, ops.ptr(aidx), dZd.ptr, slabs[i].data_ptr()
+        descs[i].lda, descs[i].ldz, descs[i].ld_slab, descs[i].n = A.ld, dZd.ld, od, n
+        descs[i].d, descs[i].col0, descs[i].out_dim, descs[i].n_slabs = dd, col0, od, nsl[i]
+    ops.call("gs_dense_wgrad_grouped", ctypes.addressof(descs), 3, ops.current_stream())
+    total = int(offs[-1])
+    p0 = _asym(rng, (total,))
+    params, grads = torch.from_numpy(p0.copy()).to(dev), torch.zeros(total, device=dev)
+    m, v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    vd = (_lib.VarDesc * 3)()
+    for i in range(3):
+        vd[i].offset, vd[i].size, vd[i].slabs, vd[i].n_slabs, vd[i].decay = int(offs[i]), sizes[i], slabs[i].data_ptr(), nsl[i], int(i < 2)
+    wd = 0.01
+    ops.call("gs_flat_reduce_adam", ctypes.addressof(vd), 3, ops.ptr(params), ops.ptr(grads), ops.ptr(m), ops.ptr(v), total,
+             wd, 1, 0.01, 0.9, 0.999, 1e-8, 5.0, 1.0, ops.ptr(step), ops.current_stream())
+    _sync()
+    want = np.concatenate([(X[idx].astype(np.float64).T @ dZ[:, :out]).reshape(-1) + wd * p0[:sizes[0]],
+                           (mean.astype(np.float64).T @ dZ[:, out:]).reshape(-1) + wd * p0[offs[1]:offs[2]],
+                           dZ.astype(np.float64).sum(0)])
+    np.testing.assert_allclose(grads.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.sqrt(n))
+    pw = p0.copy()
+    orc.adam_tf_update(pw, orc.clip_by_value(want.astype(np.float32)), np.zeros(total, np.float32), np.zeros(total, np.float32), 1, 0.01)
+    np.testing.assert_allclose(params.cpu().numpy(), pw, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("concat", [True, False])
+def test_sage_dense_dgrad_two_outputs(dev, concat):
+    rng = np.random.default_rng(32)
+    n, d_in, o = 5632, 256, 128
+    dZ = _asym(rng, (n, o * (2 if concat else 1)))
+    Ws, Wn = _asym(rng, (d_in, o)), _asym(rng, (d_in, o))
+    t2 = Mat.zeros(n, 2 * d_in, dev)
+    ops.sage_dense_dgrad(Mat.from_numpy(dZ, dev), n, o, concat, Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev), d_in, t2)
+    _sync()
+    zs, zn = (dZ[:, :o], dZ[:, o:]) if concat else (dZ, dZ)
+    np.testing.assert_allclose(t2.cols_slice(0, d_in).numpy(), zs.astype(np.float64) @ Ws.T.astype(np.float64), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(t2.cols_slice(d_in, 2 * d_in).numpy(), zn.astype(np.float64) @ Wn.T.astype(np.float64), rtol=1e-4, atol=1e-3)
+
+
+def test_stage_batch_and_counters(dev):
+    rng = np.random.default_rng(33)
+    N, C, n = 500, 41, 64
+    table = _asym(rng, (N + 1, C))
+    order = rng.permutation(N)[:200].astype(np.int32)
+    cur = torch.tensor([190], dtype=torch.int64, device=dev)
+    c2 = torch.tensor([5], dtype=torch.int64, device=dev)
+    batch = torch.zeros(n, dtype=torch.int32, device=dev)
+    lab = Mat.zeros(n, C, dev)
+    ops.stage_batch(_i32(order, dev), cur, n, batch, Mat.from_numpy(table, dev), lab)
+    ops.call("gs_advance_counters", ops.ptr(cur), n, None, 0, ops.ptr(c2), 7, ops.current_stream())
+    _sync()
+    want = order[(190 + np.arange(n)) % 200]
+    assert np.array_equal(batch.cpu().numpy(), want)
+    assert np.array_equal(lab.numpy(), table[want])
+    assert int(cur.item()) == 254 and int(c2.item()) == 12
