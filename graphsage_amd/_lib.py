@@ -64,6 +64,10 @@ _PROTOS = {
     "gs_flat_reduce_adam": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_float, _P, _P],
     "gs_advance_counters": [_P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
+    "gs_head_fwd_bwd": [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int64, c_int32, c_int, _P, c_int64, _P,
+                        c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P],
+    "gs_sample_fanout_csr": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_int64, c_uint64, c_uint64, _P, c_uint32,
+                             c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
     "gs_stage_batch": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
 }
 

@@ -62,8 +62,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
     constexpr int PB = BN / 32;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AS_FLOATS = A_KC ? BM * KP : BK * BM;
-    float* As = smem;
-    float* Bs = smem + AS_FLOATS;
+    constexpr int BS_FLOATS = B_KC ? BN * KP : BK * BN;
+    constexpr int STAGE_FLOATS = AS_FLOATS + BS_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -125,8 +125,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
             }
         }
 
-        f32x4 ra[PA], rb[PB];
-        auto load_tiles = [&](int k0) {
+        f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+        auto load_tiles = [&](int k0, f32x4 (&ra)[PA], f32x4 (&rb)[PB]) {
             // ---------------- A
             if constexpr (A_KC) {
                 const int k = k0 + (tid & 7) * 4;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
                 }
             }
         };
-        auto store_tiles = [&]() {
+        auto store_tiles = [&](const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], float* As, float* Bs) {
             if constexpr (A_KC) {
 #pragma unroll
                 for (int p = 0; p < PA; ++p)
@@ -230,12 +230,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
             }
         };
 
-        load_tiles(k_begin);
-        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-            __syncthreads();  // everyone finished reading the previous stage
-            store_tiles();
-            __syncthreads();
-            if (k0 + BK < k_end) load_tiles(k0 + BK);  // in flight under the MFMAs below
+        auto compute = [&](const float* As, const float* Bs) {
 #pragma unroll
             for (int gk = 0; gk < BK / 8; ++gk) {
                 float a[TM][4], b[TN][4];
@@ -269,6 +264,28 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
                         for (int tn = 0; tn < TN; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i], acc[tm][tn], 0, 0, 0);
             }
+        };
+
+        // Software pipeline: two LDS stages, two register stages.  The global loads of tile t+2 are issued
+        // while tile t is consumed, so each load has two MFMA stages to land; one barrier per stage.  A stage
+        // buffer is rewritten only after the barrier of the following stage, which every wave passes after it
+        // finished reading that buffer.
+        float* As0 = smem;
+        float* Bs0 = smem + AS_FLOATS;
+        float* As1 = smem + STAGE_FLOATS;
+        float* Bs1 = smem + STAGE_FLOATS + AS_FLOATS;
+        load_tiles(k_begin, ra0, rb0);
+        if (k_begin + BK < k_end) load_tiles(k_begin + BK, ra1, rb1);
+        for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+            store_tiles(ra0, rb0, As0, Bs0);
+            __syncthreads();
+            if (k0 + 2 * BK < k_end) load_tiles(k0 + 2 * BK, ra0, rb0);
+            compute(As0, Bs0);
+            if (k0 + BK >= k_end) break;
+            store_tiles(ra1, rb1, As1, Bs1);
+            __syncthreads();
+            if (k0 + 3 * BK < k_end) load_tiles(k0 + 3 * BK, ra1, rb1);
+            compute(As1, Bs1);
         }
         __syncthreads();  // LDS is reused by the next term
     }
@@ -308,7 +325,7 @@ template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     constexpr int AS_FLOATS = A_KC ? BM * 36 : 32 * BM;
     constexpr int BS_FLOATS = B_KC ? BN * 36 : 32 * BN;
-    __shared__ __attribute__((aligned(16))) float smem[AS_FLOATS + BS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (AS_FLOATS + BS_FLOATS)];
     gemm_tile<BM, BN, A_KC, B_KC>(g, gs_xcd_swizzle(blockIdx.x, gridDim.x), blockIdx.z, smem);
 }
 
@@ -322,7 +339,7 @@ struct GroupedArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedArgs G) {
-    __shared__ __attribute__((aligned(16))) float smem[32 * 64 + 32 * 64];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (32 * 64 + 32 * 64)];
     const int bid = blockIdx.x;
     int p = 0;
     while (p + 1 < G.n && bid >= G.block_start[p + 1]) ++p;

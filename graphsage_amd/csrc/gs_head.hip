@@ -232,3 +232,186 @@ extern "C" int gs_class_loss(const float* logits, int64_t ldl, const float* labe
     GS_LAUNCH_CHECK("class_loss_kernel");
     return GS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Fused supervised head, forward AND backward in one launch (supervised_models.py:85-126 + their gradients):
+//   y = l2_normalize(x);  logits = y·W + b;  loss/preds/dlogits;  d_y = dlogits·W^T;  d_x = l2norm_bwd(d_y)
+// One wave per row; W [d, C] is staged once per block in LDS with an ODD row stride so that both access
+// patterns are bank-conflict free: lanes over c at fixed k (logits) and lanes over k at fixed c (d_y).
+__global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int32_t d,
+                                                           const float* __restrict__ W, int64_t ldw,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ labels, int64_t ldlab, int32_t C,
+                                                           int sigmoid_loss, int rows_per_wave,
+                                                           float* __restrict__ y_out, int64_t ldy,
+                                                           float* __restrict__ logits_out, int64_t ldlo,
+                                                           float* __restrict__ preds, int64_t ldp,
+                                                           float* __restrict__ dlogits, int64_t lddl,
+                                                           float* __restrict__ loss_rows, float* __restrict__ dx,
+                                                           int64_t lddx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Cs = ((C + 3) & ~3) | 1;  // odd LDS stride
+    float* Ws = lds;                    // [d][Cs]
+    float* ybuf = lds + (size_t)d * Cs; // [4 waves][d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int t = tid; t < d * C; t += 256) {
+        const int k = t / C, c = t - k * C;
+        Ws[k * Cs + c] = W[(int64_t)k * ldw + c];
+    }
+    __syncthreads();
+    float* yw = ybuf + wave * d;
+    const int Cp = (C + 3) & ~3;
+    const int dp = (d + 3) & ~3;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int64_t r = row0 + rr;
+        if (r >= n) break;  // wave-uniform
+        // ---- l2 normalise
+        float ss = 0.f;
+        for (int k = lane; k < d; k += 64) {
+            const float v = x[r * ldx + k];
+            yw[k] = v;
+            ss += v * v;
+        }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        const bool clamped = ss < 1e-12f;
+        for (int k = lane; k < dp; k += 64) {
+            const float v = k < d ? yw[k] * inv : 0.f;
+            if (k < d) yw[k] = v;
+            y_out[r * ldy + k] = v;
+        }
+        // ---- logits + loss + dlogits (lanes over classes, 64 at a time)
+        float loss_acc = 0.f;
+        // pass 1 (softmax only): max and sum need all classes -> keep logits in registers for up to 4 chunks
+        float lg[4];
+        const int nchunk = (C + 63) / 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lg[q] = -INFINITY;
+            if (q < nchunk) {
+                const int c = q * 64 + lane;
+                if (c < C) {
+                    float acc = bias ? bias[c] : 0.f;
+                    for (int k = 0; k < d; ++k) acc += yw[k] * Ws[k * Cs + c];
+                    lg[q] = acc;
+                }
+            }
+        }
+        float m = -INFINITY, se = 0.f, zs = 0.f, zx = 0.f;
+        if (!sigmoid_loss) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = fmaxf(m, lg[q]);
+            m = wave_max(m);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 64 + lane;
+                if (q < nchunk && c < C) {
+                    const float zv = labels[r * ldlab + c];
+                    se += expf(lg[q] - m);
+                    zs += zv;
+                    zx += zv * lg[q];
+                }
+            }
+            se = wave_sum(se);
+            zs = wave_sum(zs);
+            zx = wave_sum(zx);
+        }
+        const float inv_se = sigmoid_loss ? 0.f : 1.0f / se;
+        const float gscale = sigmoid_loss ? 1.0f / ((float)n * (float)C) : 1.0f / (float)n;
+        float dl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dl[q] = 0.f;
+            const int c = q * 64 + lane;
+            if (q < nchunk && c < Cp) {
+                float p = 0.f, g = 0.f, lo = 0.f;
+                if (c < C) {
+                    const float xv = lg[q], zv = labels[r * ldlab + c];
+                    lo = xv;
+                    if (sigmoid_loss) {
+                        loss_acc += fmaxf(xv, 0.f) - xv * zv + log1pf(expf(-fabsf(xv)));
+                        p = 1.0f / (1.0f + expf(-xv));
+                        g = (p - zv) * gscale;
+                    } else {
+                        p = expf(xv - m) * inv_se;
+                        g = (p * zs - zv) * gscale;
+                    }
+                }
+                dl[q] = g;
+                if (logits_out) logits_out[r * ldlo + c] = lo;
+                if (preds) preds[r * ldp + c] = p;
+                dlogits[r * lddl + c] = g;
+            }
+        }
+        if (sigmoid_loss) {
+            loss_acc = wave_sum(loss_acc);
+            if (lane == 0) loss_rows[r] = loss_acc / (float)C;
+        } else if (lane == 0) {
+            loss_rows[r] = zs * (m + logf(se)) - zx;
+        }
+        // ---- d_y = dlogits · W^T (lanes over k) and the l2-normalise backward
+        if (dx) {
+            float dot = 0.f;
+            float dyk[16];  // d <= 1024
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                dyk[j] = 0.f;
+                if (j * 64 < d) {  // wave-uniform: the cross-lane broadcasts below run with all lanes active
+                    const int k = j * 64 + lane;
+                    const int kc = min(k, d - 1);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q < nchunk) {
+                            const int cmax = min(64, C - q * 64);
+                            const int dbits = __float_as_int(dl[q]);
+                            for (int cc = 0; cc < cmax; ++cc)
+                                acc += __int_as_float(__builtin_amdgcn_readlane(dbits, cc)) * Ws[kc * Cs + q * 64 + cc];
+                        }
+                    }
+                    if (k < d) {
+                        dyk[j] = acc;
+                        dot += acc * yw[k];
+                    }
+                }
+            }
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = j * 64 + lane;
+                if (j * 64 < dp && k < dp) {
+                    float g = 0.f;
+                    if (k < d) g = clamped ? dyk[j] * inv : inv * (dyk[j] - yw[k] * dot);
+                    dx[r * lddx + k] = g;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int gs_head_fwd_bwd(const float* x, int64_t ldx, int64_t n, int32_t d, const float* W, int64_t ldw,
+                               const float* bias, const float* labels, int64_t ldlab, int32_t C, int sigmoid_loss,
+                               float* y, int64_t ldy, float* logits, int64_t ldlo, float* preds, int64_t ldp,
+                               float* dlogits, int64_t lddl, float* loss_rows, float* dx, int64_t lddx, void* stream) {
+    if (n == 0) return GS_OK;
+    GS_REQUIRE(x && W && labels && y && dlogits && loss_rows && d > 0 && C > 0, "gs_head_fwd_bwd: bad args");
+    const int Cp = (C + 3) & ~3, dp = (d + 3) & ~3;
+    GS_REQUIRE(d <= 1024 && C <= 256, "gs_head_fwd_bwd: supports d <= 1024 and C <= 256 (got %d, %d)", d, C);
+    GS_REQUIRE(ldy >= dp && lddl >= Cp && (!preds || ldp >= Cp) && (!logits || ldlo >= Cp) && (!dx || lddx >= dp) &&
+               ldw >= C && ldx >= d && ldlab >= C, "gs_head_fwd_bwd: ld too small");
+    const size_t lds_bytes = ((size_t)d * (Cp | 1) + 4 * (size_t)d) * sizeof(float);
+    GS_REQUIRE(lds_bytes <= 160 * 1024, "gs_head_fwd_bwd: W does not fit LDS (%zu bytes)", lds_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GS_HIP(hipFuncSetAttribute((const void*)head_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int rows_per_wave = n >= 4096 ? 4 : 1;
+    const int64_t blocks = gs_ceil_div(n, 4 * rows_per_wave);
+    hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, (hipStream_t)stream, x, ldx, n, d, W,
+                       ldw, bias, labels, ldlab, C, sigmoid_loss, rows_per_wave, y, ldy, logits, ldlo, preds, ldp, dlogits,
+                       lddl, loss_rows, dx, lddx);
+    GS_LAUNCH_CHECK("head_fwd_bwd_kernel");
+    return GS_OK;
+}

@@ -125,6 +125,29 @@ class SampleAndAggregate(object):
         support_sizes = [support_size]
         buf, offsets = self.ids_buffer(batch_size, layer_infos)
         contiguous = inputs.data_ptr() == buf.data_ptr() and inputs.numel() == batch_size
+        K = len(layer_infos)
+        sampler0 = layer_infos[0].neigh_sampler
+        from .neigh_samplers import CSRAdjacency
+        fused = (contiguous and K <= 3 and all(li.neigh_sampler is sampler0 for li in layer_infos)
+                 and isinstance(sampler0.adj_info.current, CSRAdjacency) and getattr(self, "fuse_sampler", True))
+        stage = getattr(self, "_pending_stage", None)
+        self._pending_stage = None
+        if fused:
+            # every hop (and, on the device-epoch path, batch + label staging) in ONE launch with an LDS fan-out buffer
+            fans = [layer_infos[K - k - 1].num_samples for k in range(K)]
+            per_root = 1
+            for f in fans[:-1]:
+                per_root *= f
+            if per_root <= 8192:
+                sampler0.fanout(buf, offsets, fans, batch_size, root_offset=getattr(self, "row_offset", 0), stage=stage)
+                for k in range(K):
+                    support_size *= fans[k]
+                    samples.append(buf[offsets[k + 1]: offsets[k + 2]])
+                    support_sizes.append(support_size)
+                return samples, support_sizes
+        if stage is not None:
+            order, cursor, table, labels_out = stage
+            ops.stage_batch(order, cursor, batch_size, inputs, table, labels_out, stream=self.engine.stream)
         for k in range(len(layer_infos)):
             t = len(layer_infos) - k - 1
             sampler = layer_infos[t].neigh_sampler

@@ -103,3 +103,19 @@ class UniformNeighborSampler(Layer):
                                    global_row_offset=self.global_row_offset, out=out, stream=e.stream)
         self._call_index += 1
         return out[: n * num_samples].view(n, num_samples)
+
+    def fanout(self, ids_all, offsets, fans, batch_size, root_offset=0, stage=None):
+        """All hops of a mini-batch in ONE launch (gs_sample_fanout_csr): `fans[h]` is the fan-out of the h-th
+        sampler call.  `stage` = (order, cursor_dev, label_table, labels_out) additionally selects the batch from
+        the device-resident epoch order and gathers its label rows in the same launch.  CSR adjacency only."""
+        e = self.engine
+        adj = self.adj_info.current
+        assert isinstance(adj, CSRAdjacency)
+        order = cursor = table = labels_out = None
+        if stage is not None:
+            order, cursor, table, labels_out = stage
+        ops.sample_fanout_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all, batch_size,
+                              self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,
+                              order=order, cursor_dev=cursor, label_table=table, labels_out=labels_out,
+                              stream=e.stream)
+        self._call_index += len(fans)

@@ -95,6 +95,20 @@ def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, ste
     return out
 
 
+def sample_fanout_csr(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, step_dev=None, hop0=0,
+                      root_offset=0, order=None, cursor_dev=None, label_table=None, labels_out=None, stream=None):
+    """Fused multi-hop sampler (+ optional batch/label staging); see gs_sample_fanout_csr."""
+    import ctypes
+    fan = (ctypes.c_int32 * len(fans))(*fans)
+    off = (ctypes.c_int64 * len(offsets))(*offsets)
+    call("gs_sample_fanout_csr", ptr(rowptr), ptr(col), n_nodes, pad_id, len(fans), ctypes.addressof(fan),
+         ctypes.addressof(off), ptr(ids_all), B, seed & 0xFFFFFFFFFFFFFFFF, 0, ptr(step_dev), hop0, root_offset,
+         ptr(order), order.numel() if order is not None else 0, ptr(cursor_dev),
+         label_table.ptr if label_table is not None else None, label_table.ld if label_table is not None else 0,
+         label_table.d if label_table is not None else 0, labels_out.ptr if labels_out is not None else None,
+         labels_out.ld if labels_out is not None else 0, _s(stream))
+
+
 def select_batch(order, cursor_dev, n, out, stream=None):
     call("gs_select_batch", ptr(order), order.numel(), ptr(cursor_dev), n, ptr(out), _s(stream))
     return out
@@ -205,6 +219,14 @@ def class_loss(logits, labels, n, C, sigmoid_loss, loss_rows, preds=None, dlogit
     call("gs_class_loss", logits.ptr, logits.ld, labels.ptr, labels.ld, n, C, 1 if sigmoid_loss else 0,
          ptr(loss_rows), preds.ptr if preds is not None else None, preds.ld if preds is not None else 0,
          dlogits.ptr if dlogits is not None else None, dlogits.ld if dlogits is not None else 0, _s(stream))
+
+
+def head_fwd_bwd(x, n, W, bias, labels, C, sigmoid_loss, y, logits, preds, dlogits, loss_rows, dx, stream=None):
+    call("gs_head_fwd_bwd", x.ptr, x.ld, n, x.d, W.ptr, W.ld, ptr(bias), labels.ptr, labels.ld, C,
+         1 if sigmoid_loss else 0, y.ptr, y.ld, logits.ptr if logits is not None else None,
+         logits.ld if logits is not None else 0, preds.ptr if preds is not None else None,
+         preds.ld if preds is not None else 0, dlogits.ptr, dlogits.ld, ptr(loss_rows),
+         dx.ptr if dx is not None else None, dx.ld if dx is not None else 0, _s(stream))
 
 
 # ------------------------------------------------------------------------------------------ K6

@@ -62,7 +62,12 @@ class SupervisedGraphsage(SampleAndAggregate):
                 seen.append(li.neigh_sampler)
         return seen
 
-    def _forward(self, batch, labels, n):
+    def _fused_head_ok(self, d):
+        C = self.num_classes
+        return (getattr(self, "fuse_head", True) and d <= 1024 and C <= 256
+                and (d * (((C + 3) & ~3) | 1) + 4 * d) * 4 <= 160 * 1024)
+
+    def _forward(self, batch, labels, n, train=False):
         """sample -> aggregate -> l2_normalize -> node_pred -> loss/preds  (supervised_models.py:79-92,102-126)."""
         e = self.engine
         self.reset_tapes()
@@ -73,17 +78,26 @@ class SupervisedGraphsage(SampleAndAggregate):
         out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n,
                                 aggregators=self.aggregators, concat=self.concat, model_size=self.model_size)
         self.samples1 = samples1
-        d_out = out.d
         self.agg_out = out
-        self.outputs1 = e.ws_mat("outputs1", n, d_out)
-        self._inv_norm = e.ws_f32("inv_norm", n)
-        ops.l2norm_fwd(out, n, self.outputs1, self._inv_norm, stream=e.stream)                      # :85
-        self.node_preds = self.node_pred(Rows(self.outputs1, None, requires_grad=True))             # :88-92
+        C = self.num_classes
+        self.outputs1 = e.ws_mat("outputs1", n, out.d)
         self._loss_rows = e.ws_f32("loss_rows", n)
-        self.preds = e.ws_mat("preds", n, self.num_classes)
-        self._dlogits = e.ws_mat("dlogits", n, self.num_classes)
-        ops.class_loss(self.node_preds, labels, n, self.num_classes, self.sigmoid_loss, self._loss_rows, self.preds,
-                       self._dlogits, stream=e.stream)                                               # :111-126
+        self.preds = e.ws_mat("preds", n, C)
+        self._dlogits = e.ws_mat("dlogits", n, C)
+        self._head_fused = self._fused_head_ok(out.d)
+        if self._head_fused:
+            # l2_normalize (:85) + Dense head (:88-92) + loss/preds (:111-126) + their gradients: ONE launch
+            self.node_preds = e.ws_mat("node_preds", n, C)
+            self._d_agg_out = e.ws_mat("d_agg_out", n, out.d) if train else None
+            ops.head_fwd_bwd(out, n, self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels,
+                             C, self.sigmoid_loss, self.outputs1, self.node_preds, self.preds, self._dlogits,
+                             self._loss_rows, self._d_agg_out, stream=e.stream)
+        else:
+            self._inv_norm = e.ws_f32("inv_norm", n)
+            ops.l2norm_fwd(out, n, self.outputs1, self._inv_norm, stream=e.stream)                      # :85
+            self.node_preds = self.node_pred(Rows(self.outputs1, None, requires_grad=True))             # :88-92
+            ops.class_loss(self.node_preds, labels, n, C, self.sigmoid_loss, self._loss_rows, self.preds,
+                           self._dlogits, stream=e.stream)                                               # :111-126
         # loss = weight decay terms (:104-108) + mean classification loss
         ops.sum_scaled(self._loss_rows, n, 1.0 / n, self.loss_dev, stream=e.stream)
         if self.weight_decay != 0.0:
@@ -97,9 +111,14 @@ class SupervisedGraphsage(SampleAndAggregate):
         (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
         e.begin_backward()
-        d_outputs1 = self.node_pred.backward(self._dlogits, need_input_grad=True)
-        d_out = e.ws_mat("d_agg_out", n, self.agg_out.d)
-        ops.l2norm_bwd(d_outputs1, self.outputs1, self._inv_norm, n, d_out, stream=e.stream)
+        if self._head_fused:
+            e.wgrad(self.node_pred.vars['weights'], self.outputs1, None, self._dlogits, 0, n)
+            e.bgrad(self.node_pred.vars['bias'], self._dlogits, n, self.num_classes)
+            d_out = self._d_agg_out
+        else:
+            d_outputs1 = self.node_pred.backward(self._dlogits, need_input_grad=True)
+            d_out = e.ws_mat("d_agg_out", n, self.agg_out.d)
+            ops.l2norm_bwd(d_outputs1, self.outputs1, self._inv_norm, n, d_out, stream=e.stream)
         self.aggregate_backward(d_out)
         e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0)
 
@@ -175,7 +194,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         def fwd_bwd():
             if prologue is not None:
                 prologue()
-            self._forward(batch_dev, labels_dev, n)
+            self._forward(batch_dev, labels_dev, n, train=True)
             self._backward(n, fuse_adam=fused)
             e.advance(step=1 if fused else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
 
@@ -217,8 +236,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         batch_dev = self.ids_buffer(n)[0][:n]
         labels_dev = e.ws_mat("labels", n, self.num_classes)
 
-        def stage():   # batch selection + label gather: one launch (minibatch.py:264-274, 302-307 on the device)
-            ops.stage_batch(self._order, self._cursor, n, batch_dev, self.label_table, labels_dev, stream=e.stream)
+        def stage():   # batch selection + label gather (minibatch.py:264-274, 302-307) ride along with the sampler launch
+            self._pending_stage = (self._order, self._cursor, self.label_table, labels_dev)
 
         return self._train_on_device(batch_dev, labels_dev, n, fetch, prologue=stage, cursor=self._cursor, key="dtrain")
 

@@ -74,6 +74,21 @@ int gs_sample_uniform_csr(const int64_t* rowptr, const int32_t* col, int64_t n_n
                           uint64_t seed, uint64_t step, const uint64_t* step_dev, uint32_t hop,
                           int64_t global_row_offset, int32_t* out, void* stream);
 
+/* Fused multi-hop fan-out (replaces the K calls of models.py:268-274 with ONE launch): one workgroup per root,
+ * hop h kept in an LDS fan-out buffer for hop h+1, all hops written to the contiguous buffer
+ *   ids_all = [roots (B) | hop 1 (B*fan[0]) | hop 2 (B*fan[0]*fan[1]) | ...]   at offsets_host[0..n_hops].
+ * fan_host[h] is the fan-out of the h-th sampler call (= layer_infos[K-1-h].num_samples).  Draws are bit-identical
+ * to n_hops calls of gs_sample_uniform_csr with hop = hop0 + h and global_row_offset = root_offset*support[h].
+ * If order != NULL the roots are first staged as ids_all[i] = order[(*cursor_dev + i) % n_order] and, if
+ * label_table != NULL, labels_out[i] = label_table[root_i] (minibatch.py:264-274, 302-307 on the device). */
+int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,
+                         int32_t n_hops, const int32_t* fan_host, const int64_t* offsets_host,
+                         int32_t* ids_all, int64_t B, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+                         uint32_t hop0, int64_t root_offset,
+                         const int32_t* order, int64_t n_order, const uint64_t* cursor_dev,
+                         const float* label_table, int64_t ld_table, int32_t C, float* labels_out, int64_t ld_out,
+                         void* stream);
+
 /* batch[i] = order[(*cursor_dev + i) % n_order] for i < n  (epoch order lives on the device so the
  * whole training step can be one hipGraph).  Replaces the host slicing of minibatch.py:302-307. */
 int gs_select_batch(const int32_t* order, int64_t n_order, const uint64_t* cursor_dev,
@@ -214,6 +229,14 @@ int gs_class_loss(const float* logits, int64_t ldl, const float* labels, int64_t
                   int64_t n, int32_t C, int sigmoid_loss,
                   float* loss_rows, float* preds, int64_t ldp, float* dlogits, int64_t lddl,
                   void* stream);
+
+/* Fused head, forward AND backward in one launch (one wave per row, W staged in LDS):
+ *   y = l2_normalize(x) (:85);  logits = y·W + b (:88-92);  loss_rows / preds / dlogits as gs_class_loss;
+ *   dx = l2norm_bwd(dlogits·W^T)   (dx may be NULL for evaluation).  d <= 1024, C <= 256, W must fit LDS. */
+int gs_head_fwd_bwd(const float* x, int64_t ldx, int64_t n, int32_t d, const float* W, int64_t ldw,
+                    const float* bias, const float* labels, int64_t ldlab, int32_t C, int sigmoid_loss,
+                    float* y, int64_t ldy, float* logits, int64_t ldlo, float* preds, int64_t ldp,
+                    float* dlogits, int64_t lddl, float* loss_rows, float* dx, int64_t lddx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  optimizer               replaces supervised_models.py:95-99 (clip_by_value +-5, Adam) and the

@@ -455,3 +455,64 @@ def test_stage_batch_and_counters(dev):
     assert np.array_equal(batch.cpu().numpy(), want)
     assert np.array_equal(lab.numpy(), table[want])
     assert int(cur.item()) == 254 and int(c2.item()) == 12
+
+
+@pytest.mark.parametrize("fans,B", [([10, 25], 512), ([3, 2, 4], 37), ([7], 100), ([64, 2], 5)])
+def test_fused_fanout_sampler_bit_exact(dev, fans, B):
+    """ONE launch == hop-by-hop gs_sample_uniform_csr == the oracle hash; plus batch/label staging."""
+    rng = np.random.default_rng(sum(fans) + B)
+    N, C = 4000, 41
+    rowptr, col = _rand_csr(rng, N, 60)
+    order = rng.permutation(N).astype(np.int32)
+    table = _asym(rng, (N + 1, C))
+    sizes = [B]
+    for f in fans:
+        sizes.append(sizes[-1] * f)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ids_all = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device=dev)
+    cur = torch.tensor([N - 20], dtype=torch.int64, device=dev)   # wraps around the epoch order
+    clock = torch.tensor([5], dtype=torch.int64, device=dev)
+    lab = Mat.zeros(B, C, dev)
+    rp, cl = torch.from_numpy(rowptr).to(dev), _i32(col, dev)
+    ops.sample_fanout_csr(rp, cl, N, N, fans, offs.tolist(), ids_all, B, 123, step_dev=clock, hop0=1, root_offset=1000,
+                          order=_i32(order, dev), cursor_dev=cur, label_table=Mat.from_numpy(table, dev), labels_out=lab)
+    _sync()
+    got = ids_all.cpu().numpy()
+    roots = order[(N - 20 + np.arange(B)) % N]
+    assert np.array_equal(got[:B], roots)
+    assert np.array_equal(lab.numpy(), table[roots])
+    prev, support = roots, 1
+    for h, f in enumerate(fans):
+        want = sampler_hash.sample_uniform_csr(rowptr, col, N, N, prev, f, 123, 5, 1 + h, global_row_offset=1000 * support)
+        seg = got[offs[h + 1]:offs[h + 2]]
+        assert np.array_equal(seg.reshape(-1, f), want), "hop %d" % h
+        dev_hop = ops.sample_uniform_csr(rp, cl, N, N, _i32(prev, dev), f, 123, step=5, hop=1 + h,
+                                         global_row_offset=1000 * support).cpu().numpy()
+        assert np.array_equal(seg, dev_hop)
+        prev, support = want.reshape(-1), support * f
+
+
+@pytest.mark.parametrize("sig,C,d,n", [(False, 41, 256, 512), (True, 121, 256, 300), (False, 7, 50, 37), (True, 64, 64, 5000)])
+def test_fused_head_fwd_bwd(dev, sig, C, d, n):
+    rng = np.random.default_rng(C + d)
+    x = _asym(rng, (n, d))
+    x[min(3, n - 1)] = 0                                            # clamped row (sum sq < 1e-12)
+    W, b = _asym(rng, (d, C)) * 0.3, _asym(rng, (C,)) * 0.1
+    z = (rng.random((n, C)) > 0.5).astype(np.float32) if sig else np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]
+    y, lo, pr, dl = Mat.zeros(n, d, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
+    lr, dx = torch.zeros(n, device=dev), Mat.zeros(n, d, dev)
+    ops.head_fwd_bwd(Mat.from_numpy(x, dev), n, Mat.from_numpy(W, dev), torch.from_numpy(b).to(dev), Mat.from_numpy(z, dev),
+                     C, sig, y, lo, pr, dl, lr, dx)
+    _sync()
+    x64, W64 = x.astype(np.float64), W.astype(np.float64)
+    wy, cache = orc.l2_normalize_fwd(x64)
+    logits = wy @ W64 + b
+    loss, dlog = orc.classification_loss(logits, z.astype(np.float64), sig)
+    np.testing.assert_allclose(y.numpy(), wy, **TOL)
+    np.testing.assert_allclose(lo.numpy(), logits, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lr.cpu().numpy().mean(), loss, rtol=1e-4)
+    np.testing.assert_allclose(dl.numpy(), dlog, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(pr.numpy(), orc.sigmoid(logits) if sig else orc.softmax(logits), **TOL)
+    want_dx = orc.l2_normalize_bwd(dlog @ W64.T, cache)
+    keep = np.ones(n, bool); keep[min(3, n - 1)] = False
+    np.testing.assert_allclose(dx.numpy()[keep], want_dx[keep], rtol=1e-4, atol=1e-6)

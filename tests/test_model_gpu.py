@@ -46,7 +46,8 @@ def device_grads(model, agg_type):
                                       "bias": model.node_pred.vars['bias'].grad.numpy().reshape(-1).copy()}}
 
 
-def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, dim=16, max_degree=10, n_nodes=400):
+def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, dim=16, max_degree=10, n_nodes=400,
+          fuse=True):
     eng.reset_engine()
     inits.set_seed(7)
     G = synthetic_graph(n_nodes=n_nodes, feat_dim=feat_dim, num_classes=7, avg_degree=6, seed=5, multilabel=sigmoid)
@@ -65,6 +66,7 @@ def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, d
     model = SupervisedGraphsage(G.num_classes, ph, G.padded_features(), adj_info, it.deg, layer_infos,
                                 concat=concat, aggregator_type=agg_type, sigmoid_loss=sigmoid,
                                 learning_rate=0.01, weight_decay=wd)
+    model.fuse_head = model.fuse_sampler = fuse
     return G, it, ph, sampler, model, ns
 
 
@@ -72,10 +74,11 @@ CASES = [("mean", True, False), ("mean", False, True), ("gcn", False, False), ("
          ("meanpool", True, True), ("mean", True, True)]
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("agg_type,concat,sigmoid", CASES)
-def test_train_step_matches_oracle(dev, agg_type, concat, sigmoid):
+def test_train_step_matches_oracle(dev, agg_type, concat, sigmoid, fuse):
     wd = 0.01
-    G, it, ph, sampler, model, ns = build(dev, agg_type, concat, sigmoid, wd=wd)
+    G, it, ph, sampler, model, ns = build(dev, agg_type, concat, sigmoid, wd=wd, fuse=fuse)
     model.use_graphs = False
     rng = np.random.RandomState(3)
     batch = rng.choice(it.train_nodes, size=37, replace=False).astype(np.int32)   # ragged batch
@@ -154,8 +157,8 @@ def test_eval_swaps_adjacency(dev):
 def test_csr_training_graph_replay_equals_eager(dev):
     """CSR sampler + hipGraph replay: three steps replayed == three steps eager (deterministic kernels)."""
     outs = []
-    for use_graphs in (False, True):
-        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+    for use_graphs, fuse in ((False, True), (True, True), (False, False)):
+        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True, fuse=fuse)
         model.use_graphs = use_graphs
         order = it.train_nodes[:96]
         model.attach_device_epoch(order, it.label_matrix)
@@ -165,8 +168,11 @@ def test_csr_training_graph_replay_equals_eager(dev):
                                                 order[64:96], ns[1], 123, 2, 0)
         assert np.array_equal(model.samples1[1].cpu().numpy().reshape(32, ns[1]), want1)
         outs.append((losses, eng.get_engine().params.cpu().numpy().copy()))
-    assert outs[0][0] == outs[1][0]
+    assert outs[0][0] == outs[1][0]                       # eager == hipGraph replay, bitwise
     assert np.array_equal(outs[0][1], outs[1][1])
+    # fused sampler/head kernels vs the per-hop / unfused kernels: same maths, different summation order
+    np.testing.assert_allclose(outs[0][0], outs[2][0], rtol=1e-5)
+    np.testing.assert_allclose(outs[0][1], outs[2][1], rtol=1e-4, atol=1e-6)
     assert outs[0][0][2] < outs[0][0][0] + 0.5  # training is not diverging
 
 
