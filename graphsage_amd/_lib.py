@@ -68,6 +68,7 @@ _PROTOS = {
                         c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P],
     "gs_sample_fanout_csr": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_int64, c_uint64, c_uint64, _P, c_uint32,
                              c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
+    "gs_finalize_step": [_P, c_int64, c_float, _P, c_int, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_stage_batch": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
 }
 

@@ -252,14 +252,36 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Cs = ((C + 3) & ~3) | 1;  // odd LDS stride
     float* Ws = lds;                    // [d][Cs]
-    float* ybuf = lds + (size_t)d * Cs; // [4 waves][d]
+    float* ybuf = lds + (((size_t)d * Cs + 3) & ~(size_t)3); // [4 waves][round_up(d,4)], 16-byte aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int t = tid; t < d * C; t += 256) {
-        const int k = t / C, c = t - k * C;
-        Ws[k * Cs + c] = W[(int64_t)k * ldw + c];
+    {
+        const int c4n = (C + 3) >> 2;            // float4 per W row
+        const int total = d * c4n;
+        for (int t0 = tid; t0 < total; t0 += 256 * 4) {
+            f32x4 v[4];
+            int kk[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {        // 4 independent 16-byte loads in flight per thread
+                const int t = t0 + u * 256;
+                kk[u] = t / c4n;
+                cc[u] = (t - kk[u] * c4n) * 4;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t < total) v[u] = *reinterpret_cast<const f32x4*>(W + (int64_t)kk[u] * ldw + cc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + u * 256 < total) {
+                    float* dst = Ws + kk[u] * Cs + cc[u];   // odd stride -> scalar LDS stores
+                    dst[0] = v[u].x;
+                    if (cc[u] + 1 < C) dst[1] = v[u].y;
+                    if (cc[u] + 2 < C) dst[2] = v[u].z;
+                    if (cc[u] + 3 < C) dst[3] = v[u].w;
+                }
+            }
+        }
     }
     __syncthreads();
-    float* yw = ybuf + wave * d;
+    float* yw = ybuf + wave * ((d + 3) & ~3);
     const int Cp = (C + 3) & ~3;
     const int dp = (d + 3) & ~3;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
@@ -292,9 +314,17 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
             if (q < nchunk) {
                 const int c = q * 64 + lane;
                 if (c < C) {
-                    float acc = bias ? bias[c] : 0.f;
-                    for (int k = 0; k < d; ++k) acc += yw[k] * Ws[k * Cs + c];
-                    lg[q] = acc;
+                    float a0 = bias ? bias[c] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    int k = 0;
+                    for (; k + 4 <= d; k += 4) {
+                        const f32x4 yv = *reinterpret_cast<const f32x4*>(yw + k);   // broadcast read
+                        a0 += yv.x * Ws[(k + 0) * Cs + c];
+                        a1 += yv.y * Ws[(k + 1) * Cs + c];
+                        a2 += yv.z * Ws[(k + 2) * Cs + c];
+                        a3 += yv.w * Ws[(k + 3) * Cs + c];
+                    }
+                    for (; k < d; ++k) a0 += yw[k] * Ws[k * Cs + c];
+                    lg[q] = (a0 + a1) + (a2 + a3);
                 }
             }
         }
@@ -366,8 +396,14 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restri
                         if (q < nchunk) {
                             const int cmax = min(64, C - q * 64);
                             const int dbits = __float_as_int(dl[q]);
-                            for (int cc = 0; cc < cmax; ++cc)
+                            float acc1 = 0.f;
+                            int cc = 0;
+                            for (; cc + 2 <= cmax; cc += 2) {
                                 acc += __int_as_float(__builtin_amdgcn_readlane(dbits, cc)) * Ws[kc * Cs + q * 64 + cc];
+                                acc1 += __int_as_float(__builtin_amdgcn_readlane(dbits, cc + 1)) * Ws[kc * Cs + q * 64 + cc + 1];
+                            }
+                            if (cc < cmax) acc += __int_as_float(__builtin_amdgcn_readlane(dbits, cc)) * Ws[kc * Cs + q * 64 + cc];
+                            acc += acc1;
                         }
                     }
                     if (k < d) {
@@ -400,7 +436,7 @@ extern "C" int gs_head_fwd_bwd(const float* x, int64_t ldx, int64_t n, int32_t d
     GS_REQUIRE(d <= 1024 && C <= 256, "gs_head_fwd_bwd: supports d <= 1024 and C <= 256 (got %d, %d)", d, C);
     GS_REQUIRE(ldy >= dp && lddl >= Cp && (!preds || ldp >= Cp) && (!logits || ldlo >= Cp) && (!dx || lddx >= dp) &&
                ldw >= C && ldx >= d && ldlab >= C, "gs_head_fwd_bwd: ld too small");
-    const size_t lds_bytes = ((size_t)d * (Cp | 1) + 4 * (size_t)d) * sizeof(float);
+    const size_t lds_bytes = ((((size_t)d * (Cp | 1) + 3) & ~(size_t)3) + 4 * (size_t)dp) * sizeof(float);
     GS_REQUIRE(lds_bytes <= 160 * 1024, "gs_head_fwd_bwd: W does not fit LDS (%zu bytes)", lds_bytes);
     static bool attr_set = false;
     if (!attr_set) {

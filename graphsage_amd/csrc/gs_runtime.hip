@@ -125,6 +125,41 @@ extern "C" int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint
     return GS_OK;
 }
 
+// Step epilogue in ONE launch: loss_out[0] = scale * sum(loss_rows[0:n]) (+= if accumulate) in a fixed order, then
+// the device counters are advanced (cursor / sampler clock / optimizer step).
+__global__ __launch_bounds__(256) void finalize_step_kernel(const float* __restrict__ loss_rows, int64_t n, float scale,
+                                                            float* __restrict__ loss_out, int accumulate, uint64_t* c0,
+                                                            uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2,
+                                                            uint64_t d2) {
+    __shared__ float part[4];
+    if (loss_rows) {
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < n; i += 256) s += loss_rows[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+            loss_out[0] = accumulate ? loss_out[0] + tot : tot;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (c0) *c0 += d0;
+        if (c1) *c1 += d1;
+        if (c2) *c2 += d2;
+    }
+}
+extern "C" int gs_finalize_step(const float* loss_rows, int64_t n, float scale, float* loss_out, int accumulate,
+                                uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2,
+                                void* stream) {
+    GS_REQUIRE(!loss_rows || (loss_out && n >= 0), "gs_finalize_step: bad args");
+    hipLaunchKernelGGL(finalize_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, n, scale, loss_out,
+                       accumulate, c0, d0, c1, d1, c2, d2);
+    GS_LAUNCH_CHECK("finalize_step_kernel");
+    return GS_OK;
+}
+
 // ----------------------------------------------------------------------------- host CSR builder
 // Counting sort by source node; parallel histogram + parallel fill over node ranges.
 extern "C" int gs_build_csr_host(const int32_t* src, const int32_t* dst, const uint8_t* keep,

@@ -200,9 +200,12 @@ class Engine(object):
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_param_floats, lr, self.step_dev,
                       clip=clip, grad_scale=grad_scale, stream=self.stream)
 
-    def advance(self, step=0, clock=0, cursor=None, cursor_delta=0):
-        """Advance the optimizer step / sampler clock / epoch cursor with ONE launch."""
-        ops.call("gs_advance_counters", ops.ptr(self.step_dev) if step else None, step,
+    def advance(self, step=0, clock=0, cursor=None, cursor_delta=0, loss_rows=None, n=0, loss_out=None, accumulate=False):
+        """Step epilogue, ONE launch: (optionally) loss_out = mean(loss_rows) and advance the optimizer step /
+        sampler clock / epoch cursor."""
+        ops.call("gs_finalize_step", ops.ptr(loss_rows), n, (1.0 / n) if n else 0.0, ops.ptr(loss_out),
+                 1 if accumulate else 0,
+                 ops.ptr(self.step_dev) if step else None, step,
                  ops.ptr(self.sample_clock_dev) if clock else None, clock,
                  ops.ptr(cursor) if (cursor is not None and cursor_delta) else None, cursor_delta, self.stream)
 

@@ -98,13 +98,16 @@ class SupervisedGraphsage(SampleAndAggregate):
             self.node_preds = self.node_pred(Rows(self.outputs1, None, requires_grad=True))             # :88-92
             ops.class_loss(self.node_preds, labels, n, C, self.sigmoid_loss, self._loss_rows, self.preds,
                            self._dlogits, stream=e.stream)                                               # :111-126
-        # loss = weight decay terms (:104-108) + mean classification loss
-        ops.sum_scaled(self._loss_rows, n, 1.0 / n, self.loss_dev, stream=e.stream)
+        # loss = weight decay terms (:104-108) + mean classification loss (the mean is added by the step epilogue)
+        self._loss_accumulate = False
         if self.weight_decay != 0.0:
+            first = True
             for v in e.variables:
                 if v.decay:
                     ops.call("gs_sumsq_scaled", v.value.ptr, v.size, 0.5 * self.weight_decay,
-                             self.loss_dev.data_ptr(), 1, e.stream)
+                             self.loss_dev.data_ptr(), 0 if first else 1, e.stream)
+                    first = False
+            self._loss_accumulate = not first
 
     def _backward(self, n, fuse_adam):
         """Reverse of _forward.  Every weight gradient of the pass is ONE grouped launch; the slab reduction
@@ -121,6 +124,10 @@ class SupervisedGraphsage(SampleAndAggregate):
             ops.l2norm_bwd(d_outputs1, self.outputs1, self._inv_norm, n, d_out, stream=e.stream)
         self.aggregate_backward(d_out)
         e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0)
+
+    def _epilogue(self, n, **counters):
+        self.engine.advance(loss_rows=self._loss_rows, n=n, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
+                            **counters)
 
     def _optimize(self):
         """Data-parallel path: clip_by_value(+-5) + Adam (:96-99) after the RCCL all-reduce.  The local gradient
@@ -184,7 +191,7 @@ class SupervisedGraphsage(SampleAndAggregate):
     def eval_step(self, feed_dict, fetch=True):
         batch_dev, labels_dev, n = self._stage_feed(feed_dict)
         e = self.engine
-        self._run(("eval", n, self._adj_version()), lambda: (self._forward(batch_dev, labels_dev, n), e.advance(clock=1)))
+        self._run(("eval", n, self._adj_version()), lambda: (self._forward(batch_dev, labels_dev, n), self._epilogue(n, clock=1)))
         return self._fetch(n) if fetch else None
 
     def _train_on_device(self, batch_dev, labels_dev, n, fetch=True, prologue=None, cursor=None, key="train"):
@@ -196,7 +203,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                 prologue()
             self._forward(batch_dev, labels_dev, n, train=True)
             self._backward(n, fuse_adam=fused)
-            e.advance(step=1 if fused else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
+            self._epilogue(n, step=1 if fused else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
 
         if fused:
             self._run((key, n, self._adj_version()), fwd_bwd)     # the whole step: one hipGraph

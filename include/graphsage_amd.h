@@ -273,6 +273,11 @@ int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* par
 /* Up to three device counters advanced by one launch (cursor / sampler clock / optimizer step). */
 int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);
 
+/* Step epilogue in one launch: loss_out[0] (+)= scale * sum(loss_rows[0:n]) (skipped if loss_rows == NULL), then
+ * the (non-NULL) counters are advanced. */
+int gs_finalize_step(const float* loss_rows, int64_t n, float scale, float* loss_out, int accumulate,
+                     uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);
+
 /* batch[i] = order[(*cursor + i) % n_order];  labels_out[i, :C] = label_table[batch[i], :C]   (one launch;
  * replaces minibatch.py:264-274 + 302-307 for the device-resident epoch). */
 int gs_stage_batch(const int32_t* order, int64_t n_order, const uint64_t* cursor_dev, int64_t n, int32_t* batch,
