@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--avg_degree", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--steps-per-launch", dest="steps_per_launch", type=int, default=1,
+                    help="consecutive training steps replayed per hipGraph launch (single GPU)")
     args = ap.parse_args()
 
     rank, local_rank, world = gsd.init_from_env()
@@ -99,12 +101,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 3)):     # first two executions are eager + capture
-        model.train_step_device(B)
+    spl = args.steps_per_launch
+    # the first two executions of a graph key are eager + capture: warm both the k-step and the 1-step graphs
+    model.train_steps_device(B, max(args.warmup, 2 * spl + 4), steps_per_launch=spl)
     barrier()
     t0 = time.time()
-    for _ in range(args.steps):
-        model.train_step_device(B)
+    model.train_steps_device(B, args.steps, steps_per_launch=spl)
     e.sync()
     torch.cuda.synchronize()
     dt = time.time() - t0
@@ -125,7 +127,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), supervised "
                                "graphsage_mean, fan-out %dx%d, batch %d per GPU, dims %d/%d, full training step "
-                               "(sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay" %
+                               "(sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step gather co-scheduled with the "
+                               "layer-0 contraction (horizontal fusion)" %
                                (args.nodes, F, args.classes, args.avg_degree, s1, s2, B, args.dim_1, args.dim_2,
                                 "+RCCL all-reduce" if world > 1 else ""),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss_after": loss_after},

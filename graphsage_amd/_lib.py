@@ -56,6 +56,7 @@ _PROTOS = {
     "gs_graph_destroy": [_P],
     "gs_event_create": [POINTER(c_void_p)],
     "gs_event_record": [_P, _P],
+    "gs_stream_wait_event": [_P, _P],
     "gs_event_elapsed_ms": [_P, _P, POINTER(c_float)],
     "gs_event_destroy": [_P],
     "gs_build_csr_host": [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int64, POINTER(c_int64)],
@@ -69,6 +70,8 @@ _PROTOS = {
     "gs_sample_fanout_csr": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_int64, c_uint64, c_uint64, _P, c_uint32,
                              c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
     "gs_finalize_step": [_P, c_int64, c_float, _P, c_int, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
+    "gs_sage_dense_fwd_cogather": [_P, c_int64, _P, c_int32, _P, c_int64, _P, c_int32, c_int64, _P, c_int64, _P, c_int64,
+                                   c_int32, c_int, c_int, _P, _P, c_int64, _P, c_int32, _P],
     "gs_stage_batch": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
 }
 
@@ -78,6 +81,12 @@ class WgradDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("a_idx", c_void_p), ("dZ", c_void_p), ("slabs", c_void_p),
                 ("lda", c_int64), ("ldz", c_int64), ("ld_slab", c_int64), ("n", c_int64),
                 ("d", c_int32), ("col0", c_int32), ("out_dim", c_int32), ("n_slabs", c_int32)]
+
+
+class GatherDesc(ctypes.Structure):
+    """struct gs_gather_desc (include/graphsage_amd.h)"""
+    _fields_ = [("X", c_void_p), ("idx", c_void_p), ("self_src", c_void_p), ("self_idx", c_void_p), ("out", c_void_p),
+                ("ldx", c_int64), ("ld_self", c_int64), ("ldo", c_int64), ("n", c_int64), ("s", c_int32), ("d", c_int32)]
 
 
 class VarDesc(ctypes.Structure):

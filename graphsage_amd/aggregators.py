@@ -50,6 +50,13 @@ def _contiguous(rows_list):
     return Rows(Mat(buf, first.src.d), None, total, first.requires_grad)
 
 
+def _run_jobs(e, jobs):
+    """Issue gather+mean job descriptors as standalone launches (aggregators without a fused variant)."""
+    for j in jobs or ():
+        ops.call("gs_gather_mean_fwd", j.X, j.ldx, j.idx, j.n, j.s, j.d, j.self_src, j.ld_self, j.self_idx, j.out, j.ldo,
+                 e.stream)
+
+
 class _SageBase(Layer):
     """Shared plumbing: saved-activation stack, activation backward, masked scatter of input gradients."""
 
@@ -116,27 +123,55 @@ class MeanAggregator(_SageBase):
         self.neigh_input_dim = neigh_input_dim
         self._saved = []
 
-    def call_hops(self, self_all, neighs):
-        _check_dropout(self.dropout)
+    def prefetch(self, self_all, neighs, tag=0):
+        """The weight-free half of the call: reduce_mean(neigh_vecs, axis=1) (aggregators.py:48) fused with the row
+        gather, one launch per hop.  Because it needs no weights it can run ahead of time (next step's data chain)."""
         e = self.engine
         n_total = self_all.n
         d = neighs[0].shape3[2]
-        k = len(self._saved)
-        # reduce_mean(neigh_vecs, axis=1)   (aggregators.py:48) fused with the row gather, one launch per hop
-        means = e.ws_mat((self.name, "mean", k), n_total, d)
+        means = e.ws_mat((self.name, "mean", len(self._saved), tag), n_total, d)
         r = 0
         for nv in neighs:
             n, s, _ = nv.shape3
             ops.gather_mean_fwd(nv.src, nv.ids, n, s, out=means.rows_slice(r, r + n), stream=e.stream)
             r += n
         assert r == n_total
+        return means
+
+    def prefetch_jobs(self, self_all, neighs, tag=0):
+        """Like prefetch(), but only DESCRIBES the gather+mean launches (one per hop) so that they can be issued
+        inside another kernel's launch (horizontal fusion).  Returns (means, jobs)."""
+        e = self.engine
+        n_total = self_all.n
+        d = neighs[0].shape3[2]
+        means = e.ws_mat((self.name, "mean", len(self._saved), tag), n_total, d)
+        jobs, r = [], 0
+        for nv in neighs:
+            n, s, _ = nv.shape3
+            jobs.append(ops.gather_job(nv.src, nv.ids, n, s, means.rows_slice(r, r + n)))
+            r += n
+        return means, jobs
+
+    def call_hops(self, self_all, neighs, means=None, side_jobs=None):
+        _check_dropout(self.dropout)
+        e = self.engine
+        n_total = self_all.n
+        k = len(self._saved)
+        if means is None:
+            means = self.prefetch(self_all, neighs)
         # from_neighs / from_self matmuls + concat|add + bias + act   (:51-64): ONE launch for all hops
         n_out = self.output_dim * (2 if self.concat else 1)
         out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
-        ops.sage_dense_fwd(self_all.src, self_all.ids, means, None, n_total, self.vars['self_weights'].value,
-                           self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
-                           stream=e.stream)
+        if side_jobs:
+            # horizontally fused launch: these GEMM tiles + the NEXT step's gather-mean waves share the CUs
+            ops.sage_dense_fwd_cogather(self_all.src, self_all.ids, means, None, n_total,
+                                        self.vars['self_weights'].value, self.vars['neigh_weights'].value,
+                                        self.output_dim, self.concat, self.act_code, b, out, side_jobs, stream=e.stream)
+        else:
+            ops.sage_dense_fwd(self_all.src, self_all.ids, means, None, n_total, self.vars['self_weights'].value,
+                               self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
+                               stream=e.stream)
         self._push((self_all, neighs, means, out))
         return out
 
@@ -200,14 +235,24 @@ class GCNAggregator(_SageBase):
         self.output_dim = output_dim
         self._saved = []
 
-    def call_hops(self, self_all, neighs):
-        _check_dropout(self.dropout)
+    def prefetch_jobs(self, self_all, neighs, tag=0):
+        e = self.engine
+        d = neighs[0].shape3[2]
+        means = e.ws_mat((self.name, "mean", len(self._saved), tag), self_all.n, d)
+        jobs, r = [], 0
+        for nv in neighs:
+            n, s, _ = nv.shape3
+            sv = self_all.slice(r, r + n)
+            jobs.append(ops.gather_job(nv.src, nv.ids, n, s, means.rows_slice(r, r + n), self_src=sv.src, self_idx=sv.ids))
+            r += n
+        return means, jobs
+
+    def prefetch(self, self_all, neighs, tag=0):
+        """mean over {neighbors} U {self}  (aggregators.py:106-107); weight-free, so it can run ahead of time."""
         e = self.engine
         n_total = self_all.n
         d = neighs[0].shape3[2]
-        k = len(self._saved)
-        # mean over {neighbors} U {self}  (aggregators.py:106-107)
-        means = e.ws_mat((self.name, "mean", k), n_total, d)
+        means = e.ws_mat((self.name, "mean", len(self._saved), tag), n_total, d)
         r = 0
         for nv in neighs:
             n, s, _ = nv.shape3
@@ -215,6 +260,16 @@ class GCNAggregator(_SageBase):
             ops.gather_mean_fwd(nv.src, nv.ids, n, s, out=means.rows_slice(r, r + n), self_src=sv.src,
                                 self_idx=sv.ids, stream=e.stream)
             r += n
+        return means
+
+    def call_hops(self, self_all, neighs, means=None, side_jobs=None):
+        _check_dropout(self.dropout)
+        e = self.engine
+        _run_jobs(e, side_jobs)
+        n_total = self_all.n
+        k = len(self._saved)
+        if means is None:
+            means = self.prefetch(self_all, neighs)
         out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
         ops.sage_dense_fwd(None, None, means, None, n_total, None, self.vars['weights'].value, self.output_dim, False,
@@ -290,9 +345,16 @@ class _PoolingAggregator(_SageBase):
         self.neigh_input_dim = neigh_input_dim
         self._saved = []
 
-    def call_hops(self, self_all, neighs):
+    def prefetch(self, self_all, neighs, tag=0):
+        return None   # the pooling MLP needs the weights: nothing can run ahead
+
+    def prefetch_jobs(self, self_all, neighs, tag=0):
+        return None, []
+
+    def call_hops(self, self_all, neighs, means=None, side_jobs=None):
         _check_dropout(self.dropout)
         e = self.engine
+        _run_jobs(e, side_jobs)
         n_total = self_all.n
         k = len(self._saved)
         mlp = self.mlp_layers[0]

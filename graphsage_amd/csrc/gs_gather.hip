@@ -8,77 +8,15 @@
 // >= 32 waves per CU), the [n*s, d] gathered tensor of models.py:299 never exists.
 // Summation order is j = 0..s-1, fixed => results are deterministic run to run.
 #include "gs_common.h"
-
-__device__ __forceinline__ f32x4 gs_mask_tail(f32x4 v, int col, int d) {
-    // zero the elements at logical column >= d (only the last float4 of a row can be partial)
-    if (col + 3 >= d) {
-        if (col + 0 >= d) v.x = 0.f;
-        if (col + 1 >= d) v.y = 0.f;
-        if (col + 2 >= d) v.z = 0.f;
-        if (col + 3 >= d) v.w = 0.f;
-    }
-    return v;
-}
+#include "gs_gather_dev.h"
 
 template <int U>
-__global__ __launch_bounds__(256) void gather_mean_kernel(const float* __restrict__ X, int64_t ldx,
-                                                          const int32_t* __restrict__ idx, int64_t n, int32_t s,
-                                                          int32_t d, const float* __restrict__ S, int64_t lds_,
-                                                          const int32_t* __restrict__ sidx, float* __restrict__ out,
-                                                          int64_t ldo, float scale, int32_t chunks) {
+__global__ __launch_bounds__(256) void gather_mean_kernel(const GatherArgs a) {
     const int lane = threadIdx.x & 63;
-    const int64_t n_items = n * (int64_t)chunks;
+    const int64_t n_items = a.n * (int64_t)a.chunks;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_items) return;  // wave-uniform
-    const int64_t row = w / chunks;
-    const int c = (int)(w - row * chunks);
-    const int col = (c * 64 + lane) * 4;
-    const bool active = col < d;
-
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int jb = 0; jb < s; jb += 64) {
-        const int cnt = min(64, s - jb);  // uniform
-        int32_t my = 0;
-        if (lane < cnt) my = idx ? idx[row * s + jb + lane] : (int32_t)(row * s + jb + lane);
-        if (active) {
-            int j = 0;
-            for (; j + U <= cnt; j += U) {
-                f32x4 v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int32_t r = __builtin_amdgcn_readlane(my, j + u);
-                    v[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + col);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) acc += v[u];
-            }
-            if (j < cnt) {
-                // remainder batch: load everything (index clamped), select afterwards -- keeps the
-                // loads unconditional so they stay in flight together.
-                f32x4 v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int jj = min(j + u, cnt - 1);
-                    const int32_t r = __builtin_amdgcn_readlane(my, jj);
-                    v[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + col);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float m = (j + u < cnt) ? 1.f : 0.f;
-                    acc += v[u] * m;
-                }
-            }
-        }
-    }
-    if (active) {
-        if (S) {
-            const int64_t sr = sidx ? (int64_t)sidx[row] : row;
-            acc += *reinterpret_cast<const f32x4*>(S + sr * lds_ + col);
-        }
-        acc *= scale;
-        acc = gs_mask_tail(acc, col, d);
-        *reinterpret_cast<f32x4*>(out + row * ldo + col) = acc;
-    }
+    gather_mean_wave<U>(a, w, lane);
 }
 
 static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
@@ -89,15 +27,13 @@ static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, i
     const int64_t n_items = n * (int64_t)chunks;
     const int64_t blocks = gs_ceil_div(n_items, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gather: grid too large (%lld blocks)", (long long)blocks);
+    GatherArgs a = {X, ldx, idx, n, s, d, S, ld_self, sidx, out, ldo, scale, chunks};
     if (s >= 8)
-        hipLaunchKernelGGL(gather_mean_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, idx, n, s, d, S,
-                           ld_self, sidx, out, ldo, scale, chunks);
+        hipLaunchKernelGGL(gather_mean_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     else if (s >= 4)
-        hipLaunchKernelGGL(gather_mean_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, idx, n, s, d, S,
-                           ld_self, sidx, out, ldo, scale, chunks);
+        hipLaunchKernelGGL(gather_mean_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL(gather_mean_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, idx, n, s, d, S,
-                           ld_self, sidx, out, ldo, scale, chunks);
+        hipLaunchKernelGGL(gather_mean_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     GS_LAUNCH_CHECK("gather_mean_kernel");
     return GS_OK;
 }

@@ -16,6 +16,7 @@
 // SAGE "[self·W_self || mean·W_neigh]" (concat) or "self·W_self + mean·W_neigh" (add) in ONE kernel,
 // with bias + relu fused in the epilogue.  Split-K writes per-slice slabs (deterministic, no atomics).
 #include "gs_common.h"
+#include "gs_gather_dev.h"
 
 struct GemmTerm {
     const float* A;
@@ -350,6 +351,38 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedArgs 
     gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem);
 }
 
+// Horizontal fusion: ONE launch whose first `gemm_blocks` workgroups are the tiles of the (MFMA-bound) SAGE dense
+// contraction and whose remaining workgroups run gather+mean jobs (HBM-bound, e.g. the NEXT step's layer-0
+// neighbor means, which need no weights).  The dispatcher places the GEMM tiles first and back-fills every CU's
+// free wave slots with gather waves, so the two roofs overlap on the same CUs without any cross-stream
+// dependency (a fork/join hipGraph costs ~20 us of queue synchronisation per step on this platform).
+#define GS_MAX_COJOBS 4
+struct CoGather {
+    GatherArgs job[GS_MAX_COJOBS];
+    int64_t wave_start[GS_MAX_COJOBS + 1];  // prefix sums of work items (waves) per job
+    int32_t n;
+};
+
+__global__ __launch_bounds__(256) void sage_dense_cogather_kernel(const GemmArgs g, const int gemm_blocks, const CoGather J) {
+    constexpr int AS_FLOATS = 64 * 36;
+    constexpr int BS_FLOATS = 32 * 64;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (AS_FLOATS + BS_FLOATS)];
+    if ((int)blockIdx.x < gemm_blocks) {
+        gemm_tile<64, 64, true, false>(g, gs_xcd_swizzle(blockIdx.x, gemm_blocks), 0, smem);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x - gemm_blocks) * 4 + (threadIdx.x >> 6);
+    if (w >= J.wave_start[J.n]) return;  // wave-uniform
+    int k = 0;
+    while (k + 1 < J.n && w >= J.wave_start[k + 1]) ++k;
+    const GatherArgs& a = J.job[k];
+    if (a.s >= 8)
+        gather_mean_wave<8>(a, w - J.wave_start[k], lane);
+    else
+        gather_mean_wave<1>(a, w - J.wave_start[k], lane);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 template <int BM, int BN, bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs& g, int nz, hipStream_t st) {
@@ -427,6 +460,56 @@ extern "C" int gs_sage_dense_fwd(const float* self, int64_t ld_self, const int32
     }
     g.M = n; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
     return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self,
+                                          const float* agg, int64_t ld_agg, const int32_t* agg_idx, int32_t d_agg,
+                                          int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,
+                                          int64_t ldw_neigh, int32_t out_dim, int concat, int act, const float* bias,
+                                          float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs,
+                                          void* stream) {
+    GS_REQUIRE(n > 0 && self && agg && W_self && W_neigh && out, "gs_sage_dense_fwd_cogather: needs the two-term SAGE form");
+    GS_REQUIRE(n_jobs >= 0 && n_jobs <= GS_MAX_COJOBS && (n_jobs == 0 || jobs_host), "gs_sage_dense_fwd_cogather: 0..%d jobs", GS_MAX_COJOBS);
+    GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_cogather agg");
+    GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_cogather self");
+    GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd_cogather W_self");
+    GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_fwd_cogather W_neigh");
+    GS_CHECK_MAT(out, ldo, "gs_sage_dense_fwd_cogather out");
+    GS_REQUIRE(d_self > 0 && d_agg > 0 && out_dim > 0 && ld_self >= rup4(d_self) && ld_agg >= rup4(d_agg) &&
+               ldw_self >= rup4(out_dim) && ldw_neigh >= rup4(out_dim), "gs_sage_dense_fwd_cogather: ld too small");
+    if (concat) GS_REQUIRE(out_dim % 4 == 0, "gs_sage_dense_fwd_cogather: concat needs out_dim %% 4 == 0");
+    GS_REQUIRE(ldo >= rup4(out_dim * (concat ? 2 : 1)), "gs_sage_dense_fwd_cogather: ldo too small");
+    GemmArgs g = {};
+    g.t[0] = GemmTerm{self, self_idx, W_self, ld_self, ldw_self, d_self};
+    g.t[1] = GemmTerm{agg, agg_idx, W_neigh, ld_agg, ldw_neigh, d_agg};
+    g.nterms = 2;
+    g.concat = concat ? 1 : 0;
+    g.M = n; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
+    g.tiles_m = (int)gs_ceil_div(n, 64);
+    g.tiles_n = (int)gs_ceil_div(out_dim, 64);
+    const int64_t gemm_blocks = (int64_t)g.tiles_m * g.tiles_n * (concat ? 2 : 1);
+    CoGather J = {};
+    J.n = n_jobs;
+    int64_t waves = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const gs_gather_desc& q = jobs_host[i];
+        GS_CHECK_MAT(q.X, q.ldx, "gs_sage_dense_fwd_cogather job X");
+        GS_CHECK_MAT(q.out, q.ldo, "gs_sage_dense_fwd_cogather job out");
+        GS_REQUIRE(q.n > 0 && q.s > 0 && q.d > 0 && q.ldx >= rup4(q.d) && q.ldo >= rup4(q.d), "gs_sage_dense_fwd_cogather: bad job %d", i);
+        if (q.self_src) GS_CHECK_MAT(q.self_src, q.ld_self, "gs_sage_dense_fwd_cogather job self");
+        const int chunks = ((q.d + 3) / 4 + 63) / 64;
+        J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
+                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks};
+        J.wave_start[i] = waves;
+        waves += q.n * (int64_t)chunks;
+    }
+    J.wave_start[n_jobs] = waves;
+    const int64_t blocks = gemm_blocks + gs_ceil_div(waves, 4);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_sage_dense_fwd_cogather: grid too large");
+    hipLaunchKernelGGL(sage_dense_cogather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g,
+                       (int)gemm_blocks, J);
+    GS_LAUNCH_CHECK("sage_dense_cogather_kernel");
+    return GS_OK;
 }
 
 extern "C" int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx, int32_t d, const float* dZ,

@@ -89,6 +89,10 @@ extern "C" int gs_event_record(void* ev, void* stream) {
     GS_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
     return GS_OK;
 }
+extern "C" int gs_stream_wait_event(void* stream, void* ev) {
+    GS_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    return GS_OK;
+}
 extern "C" int gs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out_host) {
     GS_REQUIRE(ms_out_host, "gs_event_elapsed_ms: null out");
     GS_HIP(hipEventSynchronize((hipEvent_t)ev_stop));

@@ -65,6 +65,10 @@ class Engine(object):
         self.sample_clock_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # sampler RNG step
         self.finalized = False
         self._pending = []
+        # second stream for the data chain (sampling + gathers of the NEXT step overlap this step's compute)
+        self._stream2_obj = None
+        self.stream2 = None
+        self._ev_fork = self._ev_join = None
 
     # -------------------------------------------------------------------------------- variables
     def add_variable(self, name, init, decay=False):
@@ -208,6 +212,29 @@ class Engine(object):
                  ops.ptr(self.step_dev) if step else None, step,
                  ops.ptr(self.sample_clock_dev) if clock else None, clock,
                  ops.ptr(cursor) if (cursor is not None and cursor_delta) else None, cursor_delta, self.stream)
+
+    def ensure_stream2(self):
+        if self.stream2 is None:
+            self._stream2_obj = ops.Stream()
+            self.stream2 = self._stream2_obj.handle
+            self._ev_fork, self._ev_join = ops.Event(), ops.Event()
+        return self.stream2
+
+    def fork_join(self, main_fn, side_fn):
+        """Run side_fn on the second stream concurrently with main_fn on the engine stream (fork after what is
+        already queued, join before what comes next).  Works eagerly and inside a hipGraph capture."""
+        s2 = self.ensure_stream2()
+        s1 = self.stream
+        self._ev_fork.record(s1)
+        self._ev_fork.wait(s2)
+        self.stream = s2
+        try:
+            side_fn()
+        finally:
+            self.stream = s1
+        main_fn()
+        self._ev_join.record(s2)
+        self._ev_join.wait(s1)
 
     def sync(self):
         ops.call("gs_stream_sync", self.stream)

@@ -98,7 +98,7 @@ class SampleAndAggregate(object):
         self._tape = None
 
     # ------------------------------------------------------------------------------ sample (S2)
-    def ids_buffer(self, batch_size, layer_infos=None):
+    def ids_buffer(self, batch_size, layer_infos=None, parity=None):
         """One contiguous int32 buffer [batch | hop-1 samples | hop-2 samples | ...] so that the rows of all hops
         of a layer are adjacent (lets `aggregate` run every hop of a layer in one launch).  Returns
         (buffer, offsets) with offsets[k] = start of samples[k]."""
@@ -111,7 +111,9 @@ class SampleAndAggregate(object):
         offsets = [0]
         for sz in sizes:
             offsets.append(offsets[-1] + sz)
-        buf = self.engine.ws_i32(("ids_all", tuple(sizes)), offsets[-1])
+        if parity is None:
+            parity = getattr(self, "_parity", 0)
+        buf = self.engine.ws_i32(("ids_all", tuple(sizes), parity), offsets[-1])
         return buf, offsets
 
     def sample(self, inputs, layer_infos, batch_size=None):
@@ -178,13 +180,27 @@ class SampleAndAggregate(object):
             aggregators.append(aggregator)
         return aggregators
 
-    def aggregate(self, samples, input_features, dims, num_samples, support_sizes, batch_size=None,
-                  aggregators=None, name=None, concat=False, model_size="small"):
-        """At each layer, aggregate hidden representations of neighbors to compute the hidden
-        representations at next layer (models.py:278-330).  Returns (hidden[0], aggregators).
+    def layer_inputs(self, hidden, layer, batch_size, num_samples, support_sizes, dims, concat):
+        """(self_all, neighs, rows, offsets) of one layer: the contiguous self rows of all hops and the per-hop
+        neighbor views reshaped as models.py:323-327."""
+        from .aggregators import _contiguous
+        K = len(num_samples)
+        n_hops = K - layer
+        dim_mult = 2 if concat and (layer != 0) else 1
+        neighs = []
+        for hop in range(n_hops):
+            neigh_dims = [batch_size * support_sizes[hop], num_samples[K - hop - 1], dim_mult * dims[layer]]
+            neighs.append(hidden[hop + 1].reshape(neigh_dims))
+        self_all = _contiguous(hidden[:n_hops])
+        rows = [hidden[h].n for h in range(n_hops + 1)]
+        offsets = [0]
+        for r in rows:
+            offsets.append(offsets[-1] + r)
+        return self_all, neighs, rows, offsets
 
-        The reference calls the layer's aggregator once per hop (:321-328); here all hops of a layer go through
-        ONE batched call (their rows are contiguous), which is numerically the same computation."""
+    def aggregate(self, samples, input_features, dims, num_samples, support_sizes, batch_size=None,
+                  aggregators=None, name=None, concat=False, model_size="small", layer0_means=None,
+                  layer0_side_jobs=None):
         from .aggregators import _contiguous
         if batch_size is None:
             batch_size = samples[0].numel()
@@ -200,18 +216,12 @@ class SampleAndAggregate(object):
         for layer in range(K):
             aggregator = aggregators[layer]
             n_hops = K - layer
-            dim_mult = 2 if concat and (layer != 0) else 1
-            neighs = []
-            for hop in range(n_hops):
-                neigh_dims = [batch_size * support_sizes[hop], num_samples[K - hop - 1], dim_mult * dims[layer]]
-                neighs.append(hidden[hop + 1].reshape(neigh_dims))
-            self_all = _contiguous(hidden[:n_hops])
-            rows = [hidden[h].n for h in range(n_hops + 1)]
-            offsets = [0]
-            for r in rows:
-                offsets.append(offsets[-1] + r)
+            self_all, neighs, rows, offsets = self.layer_inputs(hidden, layer, batch_size, num_samples, support_sizes,
+                                                               dims, concat)
             if self_all is not None:
-                h_all = aggregator.call_hops(self_all, neighs)               # every hop of the layer, one launch
+                means = layer0_means if layer == 0 else None
+                jobs = layer0_side_jobs if layer == 0 else None
+                h_all = aggregator.call_hops(self_all, neighs, means=means, side_jobs=jobs)   # all hops, one launch
                 outs = [h_all.rows_slice(offsets[h], offsets[h + 1]) for h in range(n_hops)]
                 tape.append(("batched", aggregator, rows, offsets, h_all))
             else:                                                           # non-adjacent inputs: hop by hop (:326)

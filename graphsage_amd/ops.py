@@ -156,6 +156,27 @@ def sage_dense_fwd(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, out_dim, 
     return out
 
 
+def gather_job(X, idx, n, s, out, self_src=None, self_idx=None):
+    """Descriptor of one gather+mean job for sage_dense_fwd_cogather (same arguments as gather_mean_fwd)."""
+    j = _lib.GatherDesc()
+    j.X, j.idx, j.out = X.ptr, ptr(idx), out.ptr
+    j.self_src = self_src.ptr if self_src is not None else None
+    j.self_idx = ptr(self_idx)
+    j.ldx, j.ld_self, j.ldo, j.n, j.s, j.d = X.ld, (self_src.ld if self_src is not None else 0), out.ld, n, s, X.d
+    return j
+
+
+def sage_dense_fwd_cogather(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, out_dim, concat, act, bias, out,
+                            jobs, stream=None):
+    """gs_sage_dense_fwd + the gather jobs in ONE horizontally fused launch."""
+    import ctypes
+    arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_dense_fwd_cogather", self_m.ptr, self_m.ld, ptr(self_idx), self_m.d, agg.ptr, agg.ld, ptr(agg_idx),
+         agg.d, n, W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld, out_dim, 1 if concat else 0, act, ptr(bias),
+         out.ptr, out.ld, ctypes.addressof(arr), len(jobs), _s(stream))
+    return out
+
+
 def dense_wgrad(A, a_idx, dZ, col0, out_dim, n, n_slabs, slabs, ld_slab, stream=None):
     """slabs: flat fp32 tensor with room for n_slabs * A.d * ld_slab floats."""
     call("gs_dense_wgrad", A.ptr, A.ld, ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, out_dim, n, n_slabs, ptr(slabs),
@@ -306,6 +327,10 @@ class Event(object):
 
     def record(self, stream):
         call("gs_event_record", self.handle, stream)
+
+    def wait(self, stream):
+        """Make `stream` wait for this event (fork/join; a graph edge while capturing)."""
+        call("gs_stream_wait_event", stream, self.handle)
 
     def elapsed_ms(self, stop):
         import ctypes

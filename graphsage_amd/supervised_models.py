@@ -41,6 +41,10 @@ class SupervisedGraphsage(SampleAndAggregate):
         self._warm = set()
         self.use_graphs = True
         self.grad_hook = None     # called between backward and the optimizer (RCCL all-reduce for DP)
+        self.pipeline = True      # overlap the next step's data chain with this step's compute (device epoch)
+        self._primed = None
+        self._prefetched = {}
+        self._pending_stage = None
         self.build()
 
     # ------------------------------------------------------------------------------ build (:78-100)
@@ -67,16 +71,38 @@ class SupervisedGraphsage(SampleAndAggregate):
         return (getattr(self, "fuse_head", True) and d <= 1024 and C <= 256
                 and (d * (((C + 3) & ~3) | 1) + 4 * d) * 4 <= 160 * 1024)
 
-    def _forward(self, batch, labels, n, train=False):
+    def _sample_phase(self, batch, n, parity, stage=None):
+        """Batch/label staging + neighbor sampling into the parity-keyed id buffer (weight-free)."""
+        self._parity = parity
+        for s in self._samplers():
+            s.new_step()
+        self._pending_stage = stage
+        return self.sample(batch, self.layer_infos, n)
+
+    def _layer0_inputs(self, samples, support_sizes, n):
+        hidden = [Rows(self.features, sm, requires_grad=False) for sm in samples]
+        self_all, neighs, _, _ = self.layer_inputs(hidden, 0, n, self.num_samples, support_sizes, self.dims, self.concat)
+        return self_all, neighs
+
+    def _data_phase(self, batch, n, parity, stage=None):
+        """The weight-free half of a step: batch/label staging, neighbor sampling and the layer-0 gather+mean.
+        Writes only parity-keyed buffers, so it can run ahead of (or concurrently with) the previous step's compute."""
+        samples, support_sizes = self._sample_phase(batch, n, parity, stage)
+        self_all, neighs = self._layer0_inputs(samples, support_sizes, n)
+        means0 = self.aggregators[0].prefetch(self_all, neighs, tag=parity) if self_all is not None else None
+        return samples, support_sizes, means0
+
+    def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None):
         """sample -> aggregate -> l2_normalize -> node_pred -> loss/preds  (supervised_models.py:79-92,102-126)."""
         e = self.engine
         self.reset_tapes()
         del self.node_pred._saved[:]
-        for s in self._samplers():
-            s.new_step()
-        samples1, support_sizes1 = self.sample(batch, self.layer_infos, n)
+        if prefetched is None:
+            prefetched = self._data_phase(batch, n, getattr(self, "_parity", 0), stage=getattr(self, "_pending_stage", None))
+        samples1, support_sizes1, means0 = prefetched
         out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n,
-                                aggregators=self.aggregators, concat=self.concat, model_size=self.model_size)
+                                aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
+                                layer0_means=means0, layer0_side_jobs=side_jobs)
         self.samples1 = samples1
         self.agg_out = out
         C = self.num_classes
@@ -141,6 +167,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         """Copy the host feed (batch ids + label matrix) into persistent device buffers."""
         e = self.engine
         ph = self.placeholders
+        self._parity = 0
+        self._pending_stage = None
         batch = np.ascontiguousarray(np.asarray(feed_dict[ph['batch']]), dtype=np.int32)
         n = int(batch.shape[0])
         bs = feed_dict.get(ph['batch_size'], n)
@@ -151,7 +179,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         batch_dev = self.ids_buffer(n)[0][:n]     # head of the contiguous id buffer (see models.sample)
         batch_dev.copy_(torch.from_numpy(batch))
         labels = np.ascontiguousarray(np.asarray(feed_dict[ph['labels']]), dtype=np.float32)
-        labels_dev = e.ws_mat("labels", n, self.num_classes)
+        labels_dev = e.ws_mat(("labels", 0), n, self.num_classes)
         labels_dev.buf[:, : self.num_classes].copy_(torch.from_numpy(labels.reshape(n, self.num_classes)))
         torch.cuda.current_stream().synchronize()
         return batch_dev, labels_dev, n
@@ -229,24 +257,127 @@ class SupervisedGraphsage(SampleAndAggregate):
         if not isinstance(label_table, Mat):
             label_table = Mat.from_numpy(np.asarray(label_table, dtype=np.float32), e.device)
         self.label_table = label_table
+        self._primed = None
         torch.cuda.synchronize()
 
     def set_epoch_order(self, order):
         self.engine.sync()  # steps still queued on the engine stream read the old order / cursor
         self._order.copy_(torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)))
         self._cursor.zero_()
+        if self._primed is not None:
+            # a prefetched-but-unused batch of the old order is dropped: give its sampler-clock tick back so the
+            # pipelined schedule draws exactly the samples of the sequential one
+            self.engine.sample_clock_dev -= 1
+        self._primed = None
         torch.cuda.synchronize()
 
     def train_step_device(self, n, fetch=False):
-        """One training step on the next n ids of the device-resident epoch order."""
+        """One training step on the next n ids of the device-resident epoch order.
+
+        Pipelined (default): the data chain of step t+1 (batch/label staging + fan-out sampling + layer-0
+        gather-means; HBM-bound, needs no weights) runs on a second HIP stream concurrently with the compute chain
+        of step t (MFMA-bound), as the two branches of ONE fork/join hipGraph.  Buffers alternate by parity; the
+        batches, samples and updates are exactly those of the sequential schedule."""
         e = self.engine
-        batch_dev = self.ids_buffer(n)[0][:n]
-        labels_dev = e.ws_mat("labels", n, self.num_classes)
+        if not getattr(self, "pipeline", True):
+            self._parity = 0
+            batch_dev = self.ids_buffer(n)[0][:n]
+            labels_dev = e.ws_mat(("labels", 0), n, self.num_classes)
 
-        def stage():   # batch selection + label gather (minibatch.py:264-274, 302-307) ride along with the sampler launch
-            self._pending_stage = (self._order, self._cursor, self.label_table, labels_dev)
+            def stage():   # batch selection + label gather ride along with the fused sampler launch
+                self._pending_stage = (self._order, self._cursor, self.label_table, labels_dev)
 
-        return self._train_on_device(batch_dev, labels_dev, n, fetch, prologue=stage, cursor=self._cursor, key="dtrain")
+            return self._train_on_device(batch_dev, labels_dev, n, fetch, prologue=stage, cursor=self._cursor,
+                                         key="dtrain")
+        fused = self.grad_hook is None
+        data = self._data_fn(n)
+        if self._primed != n:                       # fill the pipeline: data chain of the first step
+            self._prefetched = {}
+            self._pipe_parity = 0
+            data(0)
+            e.sync()
+            self._primed = n
+        self._pipelined_steps(n, 1, data, fused)
+        return self._fetch(n) if fetch else None
+
+    def _data_fn(self, n):
+        e = self.engine
+
+        def data(parity):
+            batch_dev = self.ids_buffer(n, parity=parity)[0][:n]
+            labels_dev = e.ws_mat(("labels", parity), n, self.num_classes)
+            pre = self._data_phase(batch_dev, n, parity, stage=(self._order, self._cursor, self.label_table, labels_dev))
+            e.advance(clock=1, cursor=self._cursor, cursor_delta=n)
+            self._prefetched[parity] = (batch_dev, labels_dev, pre)
+        return data
+
+    def _pipelined_steps(self, n, k, data, fused):
+        """k consecutive pipelined steps as ONE hipGraph launch (k even, or 1).
+
+        pipeline == "fused" (default): single stream.  Step t first samples step t+1 (one small launch), then its
+        layer-0 dense launch carries step t+1's gather+mean waves along (horizontal fusion), so the HBM-bound
+        gather overlaps the MFMA-bound contraction without any cross-stream dependency.
+        pipeline == "streams": the whole data chain of step t+1 runs on a second stream (fork/join graph)."""
+        e = self.engine
+        p0 = self._pipe_parity
+        mode = "streams" if self.pipeline == "streams" else "fused"
+
+        def compute(p, side_jobs=None):
+            batch_dev, labels_dev, pre = self._prefetched[p]
+            self._parity = p
+            self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=side_jobs)
+            self._backward(n, fuse_adam=fused)
+
+        def body():
+            p = p0
+            for _ in range(k):
+                if mode == "streams":
+                    def main(p=p):
+                        compute(p)
+                        self._epilogue(n, step=1 if fused else 0)
+                    e.fork_join(main, lambda p=p: data(1 - p))
+                else:
+                    q = 1 - p
+                    batch_q = self.ids_buffer(n, parity=q)[0][:n]
+                    labels_q = e.ws_mat(("labels", q), n, self.num_classes)
+                    samples, support = self._sample_phase(batch_q, n, q, stage=(self._order, self._cursor,
+                                                                                self.label_table, labels_q))
+                    self_all, neighs = self._layer0_inputs(samples, support, n)
+                    means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
+                    self._prefetched[q] = (batch_q, labels_q, (samples, support, means_q))
+                    compute(p, side_jobs=jobs)
+                    self._epilogue(n, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=n)
+                p = 1 - p
+
+        key = ("ptrain" if fused else "ptrain_fb", mode, n, k, p0, self._adj_version())
+        self._run(key, body)
+        if not fused:
+            assert k == 1
+            self.grad_hook(self)              # RCCL all-reduce of engine.grads (ordered by stream events)
+            self._run(("opt",), self._optimize)
+        if k % 2 == 1:
+            self._pipe_parity = 1 - p0
+
+    def train_steps_device(self, n, steps, steps_per_launch=8):
+        """`steps` training steps on the device-resident epoch; on a single GPU `steps_per_launch` consecutive steps
+        are replayed per hipGraph launch (amortises the launch gap; the schedule and results are unchanged)."""
+        fused = self.grad_hook is None
+        k = steps_per_launch - (steps_per_launch % 2)
+        if not (getattr(self, "pipeline", True) and fused and self.use_graphs and k >= 2):
+            for _ in range(steps):
+                self.train_step_device(n)
+            return
+        done = 0
+        if self._primed != n and steps > 0:
+            self.train_step_device(n)             # fills the pipeline
+            done = 1
+        data = self._data_fn(n)
+        while steps - done >= k:
+            self._pipelined_steps(n, k, data, fused)
+            done += k
+        while done < steps:
+            self.train_step_device(n)
+            done += 1
 
     def predict(self):
         """sigmoid / softmax of the logits (supervised_models.py:122-126); filled by the last step."""

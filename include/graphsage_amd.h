@@ -141,6 +141,27 @@ int gs_sage_dense_fwd(const float* self, int64_t ld_self, const int32_t* self_id
                       int32_t out_dim, int concat, int act, const float* bias,
                       float* out, int64_t ldo, void* stream);
 
+/* Horizontally fused launch: gs_sage_dense_fwd (two-term form) PLUS up to 4 independent gs_gather_mean_fwd jobs in
+ * the SAME kernel launch -- the GEMM tiles are the first workgroups, the gather waves back-fill the CUs.  Used to
+ * overlap the MFMA-bound layer-0 contraction of step t with the HBM-bound neighbor gather of step t+1 (which needs
+ * no weights) without cross-stream synchronisation.  Results are identical to the separate calls. */
+typedef struct gs_gather_desc {
+    const float* X;            /* [*, ldx] table                                         */
+    const int32_t* idx;        /* [n*s] (NULL -> contiguous groups)                       */
+    const float* self_src;     /* GCN: self rows (NULL -> MeanAggregator scale 1/s)       */
+    const int32_t* self_idx;
+    float* out;                /* [n, ldo]                                                */
+    int64_t ldx, ld_self, ldo, n;
+    int32_t s, d;
+} gs_gather_desc;
+int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self,
+                               const float* agg, int64_t ld_agg, const int32_t* agg_idx, int32_t d_agg,
+                               int64_t n,
+                               const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
+                               int32_t out_dim, int concat, int act, const float* bias,
+                               float* out, int64_t ldo,
+                               const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
+
 /* Weight gradient as split-K slabs (deterministic; no atomics):
  *   slab[z][:, :] = sum_{r in slice z} A[a_idx? a_idx[r] : r, :d]^T · dZ[r, col0:col0+out_dim]
  * for z < n_slabs (row slices of equal size).  slabs is [n_slabs, d, ld_slab].  The caller sums
@@ -302,6 +323,8 @@ int gs_graph_destroy(void* graph_exec);
 /* hipEvent timing on `stream` (torch.cuda.Event only sees torch's current stream). */
 int gs_event_create(void** ev_out);
 int gs_event_record(void* ev, void* stream);
+/* Makes `stream` wait for `ev` (fork/join of a second stream; inside a capture this becomes a graph edge). */
+int gs_stream_wait_event(void* stream, void* ev);
 int gs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out_host); /* synchronises ev_stop */
 int gs_event_destroy(void* ev);
 

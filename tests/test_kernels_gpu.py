@@ -516,3 +516,28 @@ def test_fused_head_fwd_bwd(dev, sig, C, d, n):
     want_dx = orc.l2_normalize_bwd(dlog @ W64.T, cache)
     keep = np.ones(n, bool); keep[min(3, n - 1)] = False
     np.testing.assert_allclose(dx.numpy()[keep], want_dx[keep], rtol=1e-4, atol=1e-6)
+
+
+def test_sage_dense_cogather_equals_separate_calls(dev):
+    """Horizontally fused launch (GEMM tiles + gather waves) == the two separate launches, bitwise."""
+    rng = np.random.default_rng(41)
+    Nn, d, out, n = 3000, 602, 128, 1000
+    X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
+    mean = _asym(rng, (n, d))
+    Ws, Wn = _asym(rng, (d, out)) * 0.1, _asym(rng, (d, out)) * 0.1
+    sidx = rng.integers(0, Nn, size=n).astype(np.int32)
+    idx_a = rng.integers(0, Nn + 1, size=700 * 25).astype(np.int32)
+    idx_b = rng.integers(0, Nn + 1, size=90 * 10).astype(np.int32)
+    Xd, Md, Wsd, Wnd = Mat.from_numpy(X, dev, 32), Mat.from_numpy(mean, dev), Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
+    ia, ib, si = _i32(idx_a, dev), _i32(idx_b, dev), _i32(sidx, dev)
+    o1, o2 = Mat.zeros(n, 2 * out, dev), Mat.zeros(n, 2 * out, dev)
+    ma1, mb1, ma2, mb2 = Mat.zeros(700, d, dev), Mat.zeros(90, d, dev), Mat.zeros(700, d, dev), Mat.zeros(90, d, dev)
+    ops.sage_dense_fwd(Xd, si, Md, None, n, Wsd, Wnd, out, True, ops.ACT_RELU, None, o1)
+    ops.gather_mean_fwd(Xd, ia, 700, 25, out=ma1)
+    ops.gather_mean_fwd(Xd, ib, 90, 10, out=mb1)
+    jobs = [ops.gather_job(Xd, ia, 700, 25, ma2), ops.gather_job(Xd, ib, 90, 10, mb2)]
+    ops.sage_dense_fwd_cogather(Xd, si, Md, None, n, Wsd, Wnd, out, True, ops.ACT_RELU, None, o2, jobs)
+    _sync()
+    assert np.array_equal(o1.numpy(), o2.numpy())
+    assert np.array_equal(ma1.numpy(), ma2.numpy()) and np.array_equal(mb1.numpy(), mb2.numpy())
+    np.testing.assert_allclose(ma2.numpy(), X[idx_a].reshape(700, 25, d).mean(1), **TOL)

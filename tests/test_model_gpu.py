@@ -157,9 +157,12 @@ def test_eval_swaps_adjacency(dev):
 def test_csr_training_graph_replay_equals_eager(dev):
     """CSR sampler + hipGraph replay: three steps replayed == three steps eager (deterministic kernels)."""
     outs = []
-    for use_graphs, fuse in ((False, True), (True, True), (False, False)):
+    # (hipGraph?, fused kernels?, cross-step pipeline?)
+    for use_graphs, fuse, pipe in ((False, True, False), (True, True, True), (False, False, False), (True, True, False),
+                                   (False, True, True), (True, True, "streams"), (False, True, "streams")):
         G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True, fuse=fuse)
         model.use_graphs = use_graphs
+        model.pipeline = pipe
         order = it.train_nodes[:96]
         model.attach_device_epoch(order, it.label_matrix)
         losses = [model.train_step_device(32, fetch=True)[0] for _ in range(3)]
@@ -168,8 +171,26 @@ def test_csr_training_graph_replay_equals_eager(dev):
                                                 order[64:96], ns[1], 123, 2, 0)
         assert np.array_equal(model.samples1[1].cpu().numpy().reshape(32, ns[1]), want1)
         outs.append((losses, eng.get_engine().params.cpu().numpy().copy()))
-    assert outs[0][0] == outs[1][0]                       # eager == hipGraph replay, bitwise
-    assert np.array_equal(outs[0][1], outs[1][1])
+    # several steps per graph launch: same schedule, same bits
+    G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+    model.attach_device_epoch(it.train_nodes[:96], it.label_matrix)
+    for _ in range(3):                                    # eager, capture, replay of the 2-step graph (+ priming step)
+        model.set_epoch_order(it.train_nodes[:96])
+        model.train_steps_device(32, 3, steps_per_launch=2)
+    eng.get_engine().sync()
+    multi = eng.get_engine().params.cpu().numpy().copy()
+    G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+    model.use_graphs = model.pipeline = False
+    model.attach_device_epoch(it.train_nodes[:96], it.label_matrix)
+    for _ in range(3):
+        model.set_epoch_order(it.train_nodes[:96])
+        for _ in range(3):
+            model.train_step_device(32)
+    eng.get_engine().sync()
+    assert np.array_equal(multi, eng.get_engine().params.cpu().numpy())
+    for other in (1, 3, 4, 5, 6):     # eager == hipGraph replay == fused / two-stream pipelines, bitwise
+        assert outs[0][0] == outs[other][0]
+        assert np.array_equal(outs[0][1], outs[other][1])
     # fused sampler/head kernels vs the per-hop / unfused kernels: same maths, different summation order
     np.testing.assert_allclose(outs[0][0], outs[2][0], rtol=1e-5)
     np.testing.assert_allclose(outs[0][1], outs[2][1], rtol=1e-4, atol=1e-6)
