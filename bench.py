@@ -151,8 +151,14 @@ def main():
         k2_us = float(np.mean([a.elapsed_ms(b) for a, b in evs])) * 1e3
         alg_bytes = n2 * s1 * F * 4 + n2 * s1 * 4 + n2 * F * 4    # rows*F*4 + ids + mean write
         achieved = alg_bytes / (k2_us * 1e-6) / 1e9
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_k2_pmc.json")
+        if os.path.exists(pmc) and (B, s1, s2, F) == (512, 25, 10, 602):
+            with open(pmc) as fpm:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+                traffic = json.load(fpm)["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01_k2_pmc.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE x1.974, calibrated)"
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                              "frac": achieved / 8000.0, "traffic": None,
+                              "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gather_mean_kernel<8> (K2, hop-2: [%d x %d] rows of %d fp32)" % (n2, s1, F),
                               "avg_launch_us": k2_us, "algorithmic_bytes_per_launch": alg_bytes}
         if not args.no_cpu_baseline and world == 1:
