@@ -86,6 +86,36 @@ def main():
     slabs = torch.zeros(nsl * F * D, device=dev)
     us = timeit(lambda: ops.dense_wgrad(X, idx1, h1, 0, D, n2, nsl, slabs, D, stream=s), s, args.iters)
     rec("K6 dense_wgrad L0 hop1 [602x128 <- 5120] x16 slabs", us, flops=2 * n2 * F * D)
+    nb = n2 + B
+    idsb = torch.randint(0, N, (nb,), generator=g, dtype=torch.int32).to(dev)
+    hb = Mat(torch.randn((nb, 2 * D), generator=g).to(dev), 2 * D)
+    for nsl in (13, 26, 32, 44):
+        slabs = torch.zeros(nsl * F * D, device=dev)
+        us = timeit(lambda: ops.dense_wgrad(X, idsb, hb, 0, D, nb, nsl, slabs, D, stream=s), s, args.iters)
+        rec("K6 dense_wgrad L0 all hops [602x128 <- 5632] x%d slabs tile=%s" % (nsl, os.environ.get("GS_WGRAD_TILE", "6464")), us,
+            flops=2 * nb * F * D)
+    # layer-1 sized contractions (tiny M)
+    h0 = Mat(torch.randn((B, 2 * D), generator=g).to(dev), 2 * D)
+    m1 = Mat(torch.randn((B, 2 * D), generator=g).to(dev), 2 * D)
+    W1s = Mat(torch.randn((2 * D, D), generator=g).to(dev) * 0.05, D)
+    W1n = Mat(torch.randn((2 * D, D), generator=g).to(dev) * 0.05, D)
+    o1 = Mat.zeros(B, 2 * D, dev)
+    us = timeit(lambda: ops.sage_dense_fwd(h0, None, m1, None, B, W1s, W1n, D, True, ops.ACT_IDENTITY, None, o1, stream=s), s, args.iters)
+    rec("K3 sage_dense_fwd L1 [512x256x128 x2]", us, flops=2 * 2 * B * 2 * D * D)
+    t2 = Mat.zeros(B, 4 * D, dev)
+    us = timeit(lambda: ops.sage_dense_dgrad(o1, B, D, True, W1s, W1n, 2 * D, t2, stream=s), s, args.iters)
+    rec("K6 sage_dense_dgrad L1 [512x128 -> 2x 512x256]", us, flops=2 * 2 * B * 2 * D * D)
+    # fused head
+    C = 41
+    Wh = Mat.zeros(2 * D, C, dev)
+    Wh.buf[:, :C] = torch.randn((2 * D, C), generator=g).to(dev) * 0.05
+    bh = torch.zeros(C, device=dev)
+    lab = Mat.zeros(B, C, dev)
+    lab.buf[:, :C] = torch.nn.functional.one_hot(torch.randint(0, C, (B,), generator=g), C).float().to(dev)
+    y, lo, pr, dl = Mat.zeros(B, 2 * D, dev), Mat.zeros(B, C, dev), Mat.zeros(B, C, dev), Mat.zeros(B, C, dev)
+    lr_, dx = torch.zeros(B, device=dev), Mat.zeros(B, 2 * D, dev)
+    us = timeit(lambda: ops.head_fwd_bwd(o1, B, Wh, bh, lab, C, False, y, lo, pr, dl, lr_, dx, stream=s), s, args.iters)
+    rec("K5 head_fwd_bwd [512x256x41]", us)
     # K4 MaxPool MLP GEMM [128000, 602] x [602, 512] with gathered rows
     Wm = Mat(torch.randn((F, 512), generator=g).to(dev) * 0.05, 512)
     H = Mat.zeros(n2 * s1, 512, dev)

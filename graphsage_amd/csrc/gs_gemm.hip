@@ -17,6 +17,7 @@
 // with bias + relu fused in the epilogue.  Split-K writes per-slice slabs (deterministic, no atomics).
 #include "gs_common.h"
 #include "gs_gather_dev.h"
+#include <stdlib.h>
 
 struct GemmTerm {
     const float* A;
@@ -41,6 +42,8 @@ struct GemmArgs {
     int32_t accumulate;  // C += result (before act; only with act == identity)
     int32_t tiles_m, tiles_n;  // tiles_n is per term
 };
+
+#define GS_IDXCAP 1024  // gather indices cached in LDS per k-chunk (row-gathered TN operand)
 
 template <int BM, int BN, bool A_KC>
 struct GemmSmem {
@@ -102,6 +105,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
             k_end = min(k_begin + g.kchunk, T.K);
         }
         if (k_begin >= k_end) continue;
+        int32_t* idx_lds = reinterpret_cast<int32_t*>(smem + 2 * STAGE_FLOATS);
+        int idx_base = k_begin;
 
         // ---- per-thread source pointers that do not depend on k (k-contiguous operands)
         const float* a_row[PA];
@@ -154,7 +159,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
                     const int k = k0 + kk;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (k < k_end && r < g.M) {
-                        const int64_t src = T.a_idx ? (int64_t)T.a_idx[k] : (int64_t)k;
+                        const int64_t src = T.a_idx ? (int64_t)idx_lds[k - idx_base] : (int64_t)k;
                         v = *reinterpret_cast<const f32x4*>(T.A + src * T.lda + r);
                         if (r + 3 >= g.M) {
                             if (r + 1 >= g.M) v.y = 0.f;
@@ -275,18 +280,32 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
         float* Bs0 = smem + AS_FLOATS;
         float* As1 = smem + STAGE_FLOATS;
         float* Bs1 = smem + STAGE_FLOATS + AS_FLOATS;
-        load_tiles(k_begin, ra0, rb0);
-        if (k_begin + BK < k_end) load_tiles(k_begin + BK, ra1, rb1);
-        for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
-            store_tiles(ra0, rb0, As0, Bs0);
-            __syncthreads();
-            if (k0 + 2 * BK < k_end) load_tiles(k0 + 2 * BK, ra0, rb0);
-            compute(As0, Bs0);
-            if (k0 + BK >= k_end) break;
-            store_tiles(ra1, rb1, As1, Bs1);
-            __syncthreads();
-            if (k0 + 3 * BK < k_end) load_tiles(k0 + 3 * BK, ra1, rb1);
-            compute(As1, Bs1);
+        const bool cache_idx = !A_KC && T.a_idx != nullptr;
+        const int k_end_all = k_end;
+        for (int kc = k_begin; kc < k_end_all; kc += (cache_idx ? GS_IDXCAP : (1 << 30))) {
+            // row-gathered reduction operand: the gather indices of this k-chunk go to LDS once, so each stage
+            // has ONE global latency (the row) instead of two dependent ones (index, then row)
+            k_end = cache_idx ? min(kc + GS_IDXCAP, k_end_all) : k_end_all;
+            if (cache_idx) {
+                __syncthreads();
+                idx_base = kc;
+                for (int t = tid; t < k_end - kc; t += 256) idx_lds[t] = T.a_idx[kc + t];
+                __syncthreads();
+            }
+            load_tiles(kc, ra0, rb0);
+            if (kc + BK < k_end) load_tiles(kc + BK, ra1, rb1);
+            for (int k0 = kc; k0 < k_end; k0 += 2 * BK) {
+                store_tiles(ra0, rb0, As0, Bs0);
+                __syncthreads();
+                if (k0 + 2 * BK < k_end) load_tiles(k0 + 2 * BK, ra0, rb0);
+                compute(As0, Bs0);
+                if (k0 + BK >= k_end) break;
+                store_tiles(ra1, rb1, As1, Bs1);
+                __syncthreads();
+                if (k0 + 3 * BK < k_end) load_tiles(k0 + 3 * BK, ra1, rb1);
+                compute(As1, Bs1);
+            }
+            if (!cache_idx) break;
         }
         __syncthreads();  // LDS is reused by the next term
     }
@@ -326,7 +345,7 @@ template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
     constexpr int AS_FLOATS = A_KC ? BM * 36 : 32 * BM;
     constexpr int BS_FLOATS = B_KC ? BN * 36 : 32 * BN;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (AS_FLOATS + BS_FLOATS)];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (AS_FLOATS + BS_FLOATS) + (A_KC ? 0 : GS_IDXCAP)];
     gemm_tile<BM, BN, A_KC, B_KC>(g, gs_xcd_swizzle(blockIdx.x, gridDim.x), blockIdx.z, smem);
 }
 
@@ -340,7 +359,7 @@ struct GroupedArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedArgs G) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (32 * 64 + 32 * 64)];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (32 * 64 + 32 * 64) + GS_IDXCAP];
     const int bid = blockIdx.x;
     int p = 0;
     while (p + 1 < G.n && bid >= G.block_start[p + 1]) ++p;
@@ -349,6 +368,179 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedArgs 
     const int tiles = g.tiles_m * g.tiles_n;
     const int z = local / tiles;
     gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem);
+}
+
+// Small-M contraction (M <= 2048: the layer-1 / head-sized GEMMs, which are pure latency with 64x64 tiles because
+// only a few dozen workgroups exist).  One 32x32 output tile per workgroup; the 4 waves split K four ways (wave w
+// owns k-stages w, w+4, ...) and stage their operand slices in WAVE-PRIVATE LDS regions, so the K loop has no
+// barriers at all; the four partial tiles are summed in fixed order through LDS at the end.  A is k-contiguous
+// (NN and NT forms); the summation order differs from the 64x64 kernel only in the final 4-way combine.
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmArgs g) {
+    constexpr int BK = 32, KP = 36;
+    constexpr int A_FLOATS = 32 * KP;
+    constexpr int B_FLOATS = B_KC ? 32 * KP : BK * 32;
+    constexpr int WAVE_FLOATS = A_FLOATS + B_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[4 * WAVE_FLOATS > 4 * 32 * 33 ? 4 * WAVE_FLOATS : 4 * 32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* As = smem + wave * WAVE_FLOATS;
+    float* Bs = As + A_FLOATS;
+
+    const int tiles_n_total = g.tiles_n * ((g.nterms == 2 && g.concat) ? 2 : 1);
+    const int wgid = blockIdx.x;
+    const int tile_m = wgid / tiles_n_total;
+    int tile_n = wgid - tile_m * tiles_n_total;
+    int term0 = 0, term1 = g.nterms, col_off = 0;
+    if (g.nterms == 2 && g.concat) {
+        term0 = tile_n / g.tiles_n;
+        term1 = term0 + 1;
+        tile_n -= term0 * g.tiles_n;
+        col_off = term0 * g.N;
+    }
+    const int64_t m0 = (int64_t)tile_m * 32;
+    const int n0 = tile_n * 32;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    for (int term = term0; term < term1; ++term) {
+        const GemmTerm T = g.t[term];
+        const int K = T.K;
+        // per-lane source rows: lane -> (row = p*8 + lane/8, k-quad = lane%8) for p < 4
+        const float* a_row[4];
+        bool a_ok[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t r = m0 + p * 8 + (lane >> 3);
+            a_ok[p] = r < g.M;
+            const int64_t src = a_ok[p] ? (T.a_idx ? (int64_t)T.a_idx[r] : r) : 0;
+            a_row[p] = T.A + src * T.lda + (lane & 7) * 4;
+        }
+        auto load = [&](int k0, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
+            const int k = k0 + (lane & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_ok[p] && k < K) {
+                    v = *reinterpret_cast<const f32x4*>(a_row[p] + k0);
+                    if (k + 3 >= K) {
+                        if (k + 1 >= K) v.y = 0.f;
+                        if (k + 2 >= K) v.z = 0.f;
+                        if (k + 3 >= K) v.w = 0.f;
+                    }
+                }
+                ra[p] = v;
+            }
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int r = n0 + p * 8 + (lane >> 3);
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (r < g.N && k < K) {
+                        v = *reinterpret_cast<const f32x4*>(T.B + (int64_t)r * T.ldb + k);
+                        if (k + 3 >= K) {
+                            if (k + 1 >= K) v.y = 0.f;
+                            if (k + 2 >= K) v.z = 0.f;
+                            if (k + 3 >= K) v.w = 0.f;
+                        }
+                    }
+                    rb[p] = v;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int kk = k0 + p * 8 + (lane >> 3);
+                    const int r = n0 + (lane & 7) * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (kk < K && r < g.N) {
+                        v = *reinterpret_cast<const f32x4*>(T.B + (int64_t)kk * T.ldb + r);
+                        if (r + 3 >= g.N) {
+                            if (r + 1 >= g.N) v.y = 0.f;
+                            if (r + 2 >= g.N) v.z = 0.f;
+                            if (r + 3 >= g.N) v.w = 0.f;
+                        }
+                    }
+                    rb[p] = v;
+                }
+            }
+        };
+        auto store = [&](const f32x4 (&ra)[4], const f32x4 (&rb)[4]) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<f32x4*>(&As[(p * 8 + (lane >> 3)) * KP + (lane & 7) * 4]) = ra[p];
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    *reinterpret_cast<f32x4*>(&Bs[(p * 8 + (lane >> 3)) * KP + (lane & 7) * 4]) = rb[p];
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    *reinterpret_cast<f32x4*>(&Bs[(p * 8 + (lane >> 3)) * 32 + (lane & 7) * 4]) = rb[p];
+            }
+        };
+        f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+        const int kstride = 4 * BK;                      // this wave's stages: k0 = wave*32, +128, ...
+        int k0 = wave * BK;
+        if (k0 < K) load(k0, ra0, rb0);
+        if (k0 + kstride < K) load(k0 + kstride, ra1, rb1);
+        int which = 0;
+        for (; k0 < K; k0 += kstride) {
+            if (which == 0) store(ra0, rb0); else store(ra1, rb1);
+            if (k0 + 2 * kstride < K) {
+                if (which == 0) load(k0 + 2 * kstride, ra0, rb0); else load(k0 + 2 * kstride, ra1, rb1);
+            }
+            which ^= 1;
+#pragma unroll
+            for (int gk = 0; gk < BK / 8; ++gk) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(&As[l31 * KP + gk * 8 + lh * 4]);
+                float b[4];
+                if constexpr (B_KC) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(&Bs[l31 * KP + gk * 8 + lh * 4]);
+                    b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b[i] = Bs[(gk * 8 + lh * 4 + i) * 32 + l31];
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[3], acc, 0, 0, 0);
+            }
+        }
+    }
+    // ---- combine the four K-partials (fixed order 0,1,2,3) and run the epilogue with coalesced float4 stores
+    __syncthreads();
+    float* part = smem;  // [4][32][33]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        part[wave * (32 * 33) + row * 33 + l31] = acc[e];
+    }
+    __syncthreads();
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    const int64_t grow = m0 + row;
+    const int n_total = g.N * ((g.nterms == 2 && g.concat) ? 2 : 1);
+    const int n_pad = (n_total + 3) & ~3;
+    if (grow < g.M) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = n0 + c4 + i;
+            const int gcol = col_off + col;
+            const float* pp = part + row * 33 + c4 + i;
+            float v = ((pp[0] + pp[32 * 33]) + pp[2 * 32 * 33]) + pp[3 * 32 * 33];
+            if (col < g.N) {
+                if (g.bias) v += g.bias[gcol];
+                float* dst = g.C + grow * g.ldc + gcol;
+                if (g.accumulate) v += *dst;
+                if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                *dst = v;
+            } else if (term1 == g.nterms && gcol >= n_total && gcol < n_pad) {
+                g.C[grow * g.ldc + gcol] = 0.f;
+            }
+        }
+    }
 }
 
 // Horizontal fusion: ONE launch whose first `gemm_blocks` workgroups are the tiles of the (MFMA-bound) SAGE dense
@@ -395,8 +587,24 @@ static int launch_gemm(GemmArgs& g, int nz, hipStream_t st) {
     return GS_OK;
 }
 
+template <bool B_KC>
+static int launch_gemm_small(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (int)gs_ceil_div(g.M, 32);
+    g.tiles_n = (int)gs_ceil_div(g.N, 32);
+    const int64_t nblk = (int64_t)g.tiles_m * g.tiles_n * ((g.nterms == 2 && g.concat) ? 2 : 1);
+    GS_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm_small: bad grid");
+    hipLaunchKernelGGL((gemm_small_kernel<B_KC>), dim3((unsigned)nblk), dim3(256), 0, st, g);
+    GS_LAUNCH_CHECK("gemm_small_kernel");
+    return GS_OK;
+}
+
 template <bool A_KC, bool B_KC>
 static int dispatch_gemm(GemmArgs& g, int nz, hipStream_t st) {
+    if constexpr (A_KC) {
+        // few rows: 64x64 tiles would give a few dozen latency-bound workgroups -> K-split 32x32 variant
+        static const bool no_small = getenv("GS_NO_SMALL_GEMM") != nullptr;
+        if (!no_small && nz == 1 && g.kchunk == 0 && g.M <= 2048) return launch_gemm_small<B_KC>(g, st);
+    }
     // Large problems (>= 1024 128x128 tiles) use the 128x128 tile (2x2 MFMA tiles per wave, 4x the
     // arithmetic intensity per LDS byte); everything else uses 64x64 to put >= 256 workgroups on the chip.
     const int64_t big_tiles = gs_ceil_div(g.M, 128) * gs_ceil_div(g.N, 128) * ((g.nterms == 2 && g.concat) ? 2 : 1) * nz;
@@ -485,6 +693,16 @@ extern "C" int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, co
     g.nterms = 2;
     g.concat = concat ? 1 : 0;
     g.M = n; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
+    if (n <= 2048) {
+        // small contraction: nothing worth overlapping with -> issue the gather jobs and the (K-split) GEMM as the
+        // separate launches would, so results stay identical to the unfused calls
+        for (int i = 0; i < n_jobs; ++i) {
+            const gs_gather_desc& q = jobs_host[i];
+            int rc = gs_gather_mean_fwd(q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo, stream);
+            if (rc != GS_OK) return rc;
+        }
+        return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
+    }
     g.tiles_m = (int)gs_ceil_div(n, 64);
     g.tiles_n = (int)gs_ceil_div(out_dim, 64);
     const int64_t gemm_blocks = (int64_t)g.tiles_m * g.tiles_n * (concat ? 2 : 1);
@@ -528,6 +746,10 @@ extern "C" int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx,
     g.slab_stride = (int64_t)d * ld_slab;
     g.kchunk = (int32_t)(gs_ceil_div(gs_ceil_div(n, n_slabs), 32) * 32);
     g.act = GS_ACT_IDENTITY;
+    // experiment hook (benchmarks/micro.py): GS_WGRAD_TILE=12864 | 128128 selects a larger split-K tile
+    static const char* tile_env = getenv("GS_WGRAD_TILE");
+    if (tile_env && atoi(tile_env) == 12864) return launch_gemm<128, 64, false, false>(g, n_slabs, (hipStream_t)stream);
+    if (tile_env && atoi(tile_env) == 128128) return launch_gemm<128, 128, false, false>(g, n_slabs, (hipStream_t)stream);
     return launch_gemm<64, 64, false, false>(g, n_slabs, (hipStream_t)stream);
 }
 

@@ -139,10 +139,11 @@ class Engine(object):
 
     @staticmethod
     def pick_slabs(n_rows, tiles):
-        """Split-K slices for a weight gradient: enough (tile x slice) workgroups to cover the 256 CUs,
-        at least 64 reduction rows per slice, at most 24 slices."""
-        want = max(1, (256 + tiles - 1) // tiles)
-        return int(max(1, min(24, want, (n_rows + 63) // 64)))
+        """Split-K slices for a weight gradient.  The kernel is latency-bound per workgroup (one global round trip
+        per 32-row stage), so the goal is many short workgroups: ~768 (tile x slice) workgroups per problem, at
+        least 64 reduction rows per slice, at most 32 slices."""
+        want = max(1, (768 + tiles - 1) // tiles)
+        return int(max(1, min(32, want, (n_rows + 63) // 64)))
 
     def ones(self, n):
         """[n, 1] matrix of ones: bias gradients are the grouped-GEMM problem ones^T · dZ."""

@@ -68,8 +68,8 @@ class SupervisedGraphsage(SampleAndAggregate):
 
     def _fused_head_ok(self, d):
         C = self.num_classes
-        return (getattr(self, "fuse_head", True) and d <= 1024 and C <= 256
-                and (d * (((C + 3) & ~3) | 1) + 4 * d) * 4 <= 160 * 1024)
+        return (getattr(self, "fuse_head", True) and d in (64, 128, 256, 512) and C <= 128
+                and (d * (((C + 3) & ~3) | 1) + 4 + 4 * d) * 4 <= 160 * 1024)
 
     def _sample_phase(self, batch, n, parity, stage=None):
         """Batch/label staging + neighbor sampling into the parity-keyed id buffer (weight-free)."""

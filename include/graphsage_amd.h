@@ -253,7 +253,8 @@ int gs_class_loss(const float* logits, int64_t ldl, const float* labels, int64_t
 
 /* Fused head, forward AND backward in one launch (one wave per row, W staged in LDS):
  *   y = l2_normalize(x) (:85);  logits = y·W + b (:88-92);  loss_rows / preds / dlogits as gs_class_loss;
- *   dx = l2norm_bwd(dlogits·W^T)   (dx may be NULL for evaluation).  d <= 1024, C <= 256, W must fit LDS. */
+ *   dx = l2norm_bwd(dlogits·W^T)   (dx may be NULL for evaluation).  Supports d in {64,128,256,512}, C <= 128 and
+ *   W fitting LDS; returns GS_ENOTSUP otherwise (callers then use the unfused kernels above). */
 int gs_head_fwd_bwd(const float* x, int64_t ldx, int64_t n, int32_t d, const float* W, int64_t ldw,
                     const float* bias, const float* labels, int64_t ldlab, int32_t C, int sigmoid_loss,
                     float* y, int64_t ldy, float* logits, int64_t ldlo, float* preds, int64_t ldp,

@@ -492,7 +492,8 @@ def test_fused_fanout_sampler_bit_exact(dev, fans, B):
         prev, support = want.reshape(-1), support * f
 
 
-@pytest.mark.parametrize("sig,C,d,n", [(False, 41, 256, 512), (True, 121, 256, 300), (False, 7, 50, 37), (True, 64, 64, 5000)])
+@pytest.mark.parametrize("sig,C,d,n", [(False, 41, 256, 512), (True, 121, 256, 300), (False, 7, 64, 37), (True, 64, 64, 5000),
+                                       (False, 3, 128, 9), (True, 100, 256, 70), (False, 60, 512, 33)])
 def test_fused_head_fwd_bwd(dev, sig, C, d, n):
     rng = np.random.default_rng(C + d)
     x = _asym(rng, (n, d))
@@ -521,7 +522,7 @@ def test_fused_head_fwd_bwd(dev, sig, C, d, n):
 def test_sage_dense_cogather_equals_separate_calls(dev):
     """Horizontally fused launch (GEMM tiles + gather waves) == the two separate launches, bitwise."""
     rng = np.random.default_rng(41)
-    Nn, d, out, n = 3000, 602, 128, 1000
+    Nn, d, out, n = 3000, 602, 128, 2500   # > 2048 rows: the fused 64x64 path (smaller n falls back to separate launches)
     X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
     mean = _asym(rng, (n, d))
     Ws, Wn = _asym(rng, (d, out)) * 0.1, _asym(rng, (d, out)) * 0.1

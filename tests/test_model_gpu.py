@@ -46,7 +46,7 @@ def device_grads(model, agg_type):
                                       "bias": model.node_pred.vars['bias'].grad.numpy().reshape(-1).copy()}}
 
 
-def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, dim=16, max_degree=10, n_nodes=400,
+def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, dim=32, max_degree=10, n_nodes=400,
           fuse=True):
     eng.reset_engine()
     inits.set_seed(7)
