@@ -49,6 +49,9 @@ def build_model(G, it, args, world, rank):
 
 
 def main():
+    if os.environ.get("GS_FAULT_DUMP_S"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["GS_FAULT_DUMP_S"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -134,8 +137,9 @@ def main():
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss_after": loss_after},
     }
 
-    if rank == 0:
-        # ---------------- roofline of the dominant kernel (K2 hop-2 gather+mean), HIP events on the engine stream
+    # ---------------- roofline of the dominant kernel (K2 hop-2 gather+mean), HIP events on the engine stream.
+    # Every rank runs the region (the interleaved training steps all-reduce under N>1); rank 0 reports.
+    if True:
         n2 = B * s2
         idx2 = model.samples1[2]
         mean2 = ops.Mat.zeros(n2, F, e.device)
@@ -161,7 +165,7 @@ def main():
                               "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gather_mean_kernel<8> (K2, hop-2: [%d x %d] rows of %d fp32)" % (n2, s1, F),
                               "avg_launch_us": k2_us, "algorithmic_bytes_per_launch": alg_bytes}
-        if not args.no_cpu_baseline and world == 1:
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
             from oracle.cpu_baseline import time_cpu_baseline
             from graphsage_amd.utils import padded_from_csr
             tc = time.time()
@@ -172,7 +176,8 @@ def main():
             cb.pop("s_per_step", None)
             result["cpu_baseline"] = cb
             log("cpu baseline took %.1fs" % (time.time() - tc))
-        print(json.dumps(result), flush=True)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
