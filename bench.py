@@ -39,10 +39,12 @@ def build_model(G, it, args, world, rank):
           'batch_size': Placeholder('batch_size')}
     adj_info = AdjInfo(CSRAdjacency(it.train_csr[0], it.train_csr[1], G.n_nodes, e.device))
     sampler = UniformNeighborSampler(adj_info, seed=123)
-    layer_infos = [SAGEInfo("node", sampler, args.samples_1, args.dim_1),
-                   SAGEInfo("node", sampler, args.samples_2, args.dim_2)]
+    agg = {"graphsage_mean": "mean", "gcn": "gcn", "graphsage_maxpool": "maxpool", "graphsage_meanpool": "meanpool"}[args.model]
+    mult = 2 if agg == "gcn" else 1          # supervised_train.py:175-176
+    layer_infos = [SAGEInfo("node", sampler, args.samples_1, mult * args.dim_1),
+                   SAGEInfo("node", sampler, args.samples_2, mult * args.dim_2)]
     model = SupervisedGraphsage(G.num_classes, ph, G.padded_features(), adj_info, it.deg, layer_infos,
-                                concat=True, aggregator_type="mean", sigmoid_loss=False,
+                                concat=(agg != "gcn"), aggregator_type=agg, sigmoid_loss=False,
                                 learning_rate=0.01, weight_decay=0.0, world_size=world, rank=rank)
     model.row_offset = rank * args.batch_size
     return e, model, ph
@@ -65,6 +67,8 @@ def main():
     ap.add_argument("--feat_dim", type=int, default=602)
     ap.add_argument("--classes", type=int, default=41)
     ap.add_argument("--avg_degree", type=int, default=50)
+    ap.add_argument("--model", default="graphsage_mean",
+                    help="graphsage_mean (headline, BASELINE configs[1]) | graphsage_maxpool (configs[2]) | gcn | graphsage_meanpool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--steps-per-launch", dest="steps_per_launch", type=int, default=1,
@@ -123,17 +127,17 @@ def main():
     edges_per_step = B * (s2 + s2 * s1)
     value = edges_per_step * world * args.steps / dt
 
+    workload = ("Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), supervised %s, fan-out %dx%d, batch %d "
+                "per GPU, dims %d/%d, full training step (sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step "
+                "gather co-scheduled with the layer-0 contraction (horizontal fusion)" %
+                (args.nodes, F, args.classes, args.avg_degree, args.model, s1, s2, B, args.dim_1, args.dim_2,
+                 "+RCCL all-reduce" if world > 1 else ""))
     result = {
-        "metric": "sampled-edges/sec, Reddit-shaped supervised graphsage_mean fan-out %dx%d" % (s1, s2),
+        "metric": "sampled-edges/sec, Reddit-shaped supervised %s fan-out %dx%d" % (args.model, s1, s2),
         "value": value, "unit": "sampled-edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), supervised "
-                               "graphsage_mean, fan-out %dx%d, batch %d per GPU, dims %d/%d, full training step "
-                               "(sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step gather co-scheduled with the "
-                               "layer-0 contraction (horizontal fusion)" %
-                               (args.nodes, F, args.classes, args.avg_degree, s1, s2, B, args.dim_1, args.dim_2,
-                                "+RCCL all-reduce" if world > 1 else ""),
+        "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss_after": loss_after},
     }
 
@@ -165,7 +169,7 @@ def main():
                               "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gather_mean_kernel<8> (K2, hop-2: [%d x %d] rows of %d fp32)" % (n2, s1, F),
                               "avg_launch_us": k2_us, "algorithmic_bytes_per_launch": alg_bytes}
-        if rank == 0 and not args.no_cpu_baseline and world == 1:
+        if rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "graphsage_mean":
             from oracle.cpu_baseline import time_cpu_baseline
             from graphsage_amd.utils import padded_from_csr
             tc = time.time()

@@ -38,6 +38,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         self.row_offset = 0
         self.label_table = None   # optional device-resident [N+1, C] label matrix (device fast path)
         self._graphs = {}
+        self._graph_outputs = {}
         self._warm = set()
         self.use_graphs = True
         self.grad_hook = None     # called between backward and the optimizer (RCCL all-reduce for DP)
@@ -184,11 +185,18 @@ class SupervisedGraphsage(SampleAndAggregate):
         torch.cuda.current_stream().synchronize()
         return batch_dev, labels_dev, n
 
+    _OUT_ATTRS = ("preds", "samples1", "outputs1", "node_preds", "agg_out", "_loss_rows", "_dlogits", "_loss_accumulate",
+                  "_head_fused", "_d_agg_out", "_tape")
+
     def _run(self, key, fn):
-        """Eager on first use, captured into a hipGraph on the second, replayed afterwards."""
+        """Eager on first use, captured into a hipGraph on the second, replayed afterwards.  The Python attributes
+        that name a step's output buffers are snapshotted per key and restored on replay (the Python of `fn` does
+        not run again, and other step shapes -- e.g. a validation batch -- may have re-pointed them meanwhile)."""
         e = self.engine
         g = self._graphs.get(key)
         if g is not None:
+            for name, val in self._graph_outputs[key].items():
+                setattr(self, name, val)
             g.launch()
             return
         if not self.use_graphs or key not in self._warm or self._needs_host_rng():
@@ -202,6 +210,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         finally:
             g.end()
         self._graphs[key] = g
+        self._graph_outputs[key] = {name: getattr(self, name) for name in self._OUT_ATTRS if hasattr(self, name)}
         g.launch()
 
     def _needs_host_rng(self):
