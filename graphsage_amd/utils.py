@@ -124,7 +124,8 @@ def padded_from_csr(rowptr, col, n_nodes, max_degree, rng):
 
 
 def synthetic_graph(n_nodes=2000, feat_dim=50, num_classes=7, avg_degree=10, seed=123, multilabel=False,
-                    p_in=0.8, val_frac=0.1, test_frac=0.2, feat_noise=1.0, power_law=True, dtype=np.float32):
+                    p_in=0.8, val_frac=0.1, test_frac=0.2, feat_noise=1.0, power_law=True, dtype=np.float32,
+                    feat_signal=0.5):
     """Planted-community graph with learnable labels (SURVEY.md §8d config 2/3 shape: power-law degrees,
     labels = communities, features = community centroid + noise)."""
     rng = np.random.RandomState(seed)
@@ -156,7 +157,7 @@ def synthetic_graph(n_nodes=2000, feat_dim=50, num_classes=7, avg_degree=10, see
     if feat_noise != 1.0:
         feats *= np.float32(feat_noise)
     for a in range(0, n_nodes, 16384):
-        feats[a:a + 16384] += centroids[comm[a:a + 16384]] * np.float32(0.5)
+        feats[a:a + 16384] += centroids[comm[a:a + 16384]] * np.float32(feat_signal)
     r = rng.random_sample(n_nodes)
     val_mask = r < val_frac
     test_mask = (r >= val_frac) & (r < val_frac + test_frac)
@@ -170,10 +171,10 @@ def synthetic_graph(n_nodes=2000, feat_dim=50, num_classes=7, avg_degree=10, see
     return GraphData(n_nodes, src, dst, feats, labels, val_mask, test_mask, multilabel=multilabel)
 
 
-def reddit_shaped(avg_degree=50, seed=123, n_nodes=232965, feat_dim=602, num_classes=41):
+def reddit_shaped(avg_degree=50, seed=123, n_nodes=232965, feat_dim=602, num_classes=41, feat_signal=0.5):
     """Synthetic graph with Reddit's shape: N=232,965, F=602, C=41 single-label, 66/10/24 split."""
     return synthetic_graph(n_nodes=n_nodes, feat_dim=feat_dim, num_classes=num_classes, avg_degree=avg_degree,
-                           seed=seed, val_frac=0.10, test_frac=0.24)
+                           seed=seed, val_frac=0.10, test_frac=0.24, feat_signal=feat_signal)
 
 
 def load_data(prefix, normalize=True):
