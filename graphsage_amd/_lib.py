@@ -72,6 +72,9 @@ _PROTOS = {
     "gs_finalize_step": [_P, c_int64, c_float, _P, c_int, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_sage_dense_fwd_cogather": [_P, c_int64, _P, c_int32, _P, c_int64, _P, c_int32, c_int64, _P, c_int64, _P, c_int64,
                                    c_int32, c_int, c_int, _P, _P, c_int64, _P, c_int32, _P],
+    "gs_unsup_stage": [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_uint64, _P, _P, _P],
+    "gs_linkpred_fwd_bwd": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, _P, _P, c_int64, _P, c_int64,
+                            _P, POINTER(c_int32), _P],
     "gs_stage_batch": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
 }
 

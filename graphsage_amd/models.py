@@ -67,12 +67,19 @@ def device_features(features, engine=None):
 
 
 class SampleAndAggregate(object):
-    """Base implementation of GraphSAGE (graphsage/models.py:187-405); the supervised subclass is in
-    supervised_models.py.  The unsupervised objective (_build/_loss/_accuracy, :332-405) is a
-    "next" row."""
+    """Base implementation of unsupervised GraphSAGE (graphsage/models.py:187-405): three sample+aggregate passes
+    (batch1, batch2, 20 degree^0.75 negatives) sharing the aggregators, l2-normalise, skip-gram cross-entropy
+    (prediction.py:102-110), loss/batch_size, clip +-5, Adam, MRR.  Here the three passes are ONE pass over the
+    concatenated roots [batch1 | batch2 | negatives] (rows are independent and the aggregators are shared, so it is
+    the same computation).  `FLAGS.learning_rate / weight_decay / neg_sample_size` are explicit keyword arguments.
+
+        loss, ranks, aff_all, mrr, outputs1 = model.train_step(feed_dict)   # unsupervised_train.py:273-274
+        loss, ranks, mrr = model.eval_step(feed_dict)                        # :69-71
+    The supervised subclass is in supervised_models.py."""
 
     def __init__(self, placeholders, features, adj, degrees, layer_infos, concat=True, aggregator_type="mean",
-                 model_size="small", identity_dim=0, **kwargs):
+                 model_size="small", identity_dim=0, learning_rate=0.00001, weight_decay=0.0, neg_sample_size=20,
+                 world_size=1, rank=0, _defer_build=False, **kwargs):
         allowed_kwargs = {'name', 'logging', 'model_size'}
         for kwarg in kwargs.keys():
             assert kwarg in allowed_kwargs, 'Invalid keyword argument: ' + kwarg
@@ -96,6 +103,232 @@ class SampleAndAggregate(object):
         self.layer_infos = layer_infos
         self.aggregators = None
         self._tape = None
+        self.learning_rate = float(learning_rate)
+        self.weight_decay = float(weight_decay)
+        self.neg_sample_size = int(neg_sample_size)
+        self.world_size, self.rank = int(world_size), int(rank)
+        self.row_offset = 0
+        self._graphs, self._graph_outputs, self._warm = {}, {}, set()
+        self.use_graphs = True
+        self.grad_hook = None
+        self.pipeline = True
+        self._primed = None
+        self._prefetched = {}
+        self._pending_stage = None
+        if not _defer_build:
+            self.inputs1 = placeholders["batch1"]
+            self.inputs2 = placeholders["batch2"]
+            self.build()
+
+    # ------------------------------------------------------------------------------ unsupervised build (:332-391)
+    def build(self):
+        e = self.engine
+        self.num_samples = [layer_info.num_samples for layer_info in self.layer_infos]
+        self.aggregators = self.make_aggregators(self.dims, self.num_samples, self.concat, self.model_size)
+        from .prediction import BipartiteEdgePredLayer
+        dim_mult = 2 if self.concat else 1
+        self.link_pred_layer = BipartiteEdgePredLayer(dim_mult * self.dims[-1], dim_mult * self.dims[-1], self.placeholders,
+                                                      act="sigmoid", bilinear_weights=False, name='edge_predict')
+        e.finalize()
+        self.loss_dev = torch.zeros(1, dtype=torch.float32, device=e.device)
+        self.mrr_dev = torch.zeros(1, dtype=torch.float32, device=e.device)
+        # fixed unigram distribution ~ degree^0.75 of tf.nn.fixed_unigram_candidate_sampler (:336-343) as a uint32 CDF
+        w = np.power(np.asarray(self.degrees, dtype=np.float64), 0.75)
+        if w.sum() <= 0:
+            w = np.ones_like(w)
+        c = np.cumsum(w) / w.sum()
+        cdf = np.minimum(np.floor(c * 4294967296.0), 4294967295.0).astype(np.uint32)
+        cdf[-1] = np.uint32(4294967295)
+        self._neg_cdf = torch.from_numpy(cdf.view(np.int32).copy()).to(e.device)   # raw bits; the kernel reads uint32
+        self._n_cdf = int(cdf.shape[0])
+        self.neg_seed = 123
+        torch.cuda.synchronize()
+
+    _OUT_ATTRS = ("samples1", "outputs_all", "outputs1", "agg_out", "_loss_rows", "_rr_rows", "aff_all", "_dY",
+                  "_loss_accumulate", "_tape", "_inv_norm")
+
+    def _roots(self, B, parity=None):
+        """[batch1 (B) | batch2 (B) | negatives] = the head of the contiguous id buffer."""
+        n_roots = 2 * B + self.neg_sample_size
+        return self.ids_buffer(n_roots, parity=parity)[0][:n_roots], n_roots
+
+    def _stage_negatives(self, roots, B, pairs=None, cursor=None):
+        e = self.engine
+        ops.call("gs_unsup_stage", ops.ptr(pairs), pairs.shape[0] if pairs is not None else 0, ops.ptr(cursor), B,
+                 ops.ptr(self._neg_cdf), self._n_cdf, self.neg_sample_size, self.neg_seed, ops.ptr(e.sample_clock_dev),
+                 ops.ptr(roots), e.stream)
+
+    def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None):
+        """_build (:347-370) + _loss (:385-391) + _accuracy (:393-405) and, when training, the gradient of the
+        link-prediction head w.r.t. the normalised embeddings."""
+        e = self.engine
+        self.reset_tapes()
+        if prefetched is None:
+            prefetched = self._data_phase(roots, n_roots, getattr(self, "_parity", 0))
+        samples1, support_sizes1, means0 = prefetched
+        out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n_roots,
+                                aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
+                                layer0_means=means0, layer0_side_jobs=side_jobs)
+        self.samples1 = samples1
+        self.agg_out = out
+        d = out.d
+        self.outputs_all = e.ws_mat("outputs_all", n_roots, d)
+        self._inv_norm = e.ws_f32("inv_norm", n_roots)
+        ops.l2norm_fwd(out, n_roots, self.outputs_all, self._inv_norm, stream=e.stream)            # :368-370
+        self.outputs1 = self.outputs_all.rows_slice(0, B)
+        self._loss_rows = e.ws_f32("loss_rows", B)
+        self._rr_rows = e.ws_f32("rr_rows", B)
+        self.aff_all = e.ws_mat("aff_all", B, self.neg_sample_size + 1)
+        self._dY = e.ws_mat("d_outputs_all", n_roots, d)
+        self.link_pred_layer.loss_and_grads(self.outputs_all, B, self.neg_sample_size, 1.0 / B, self._loss_rows,
+                                            self._rr_rows, self.aff_all, self._dY)
+        # loss = (sum_vars wd*l2_loss + xent) / batch_size  (:386-390, :378); the xent mean is added by the epilogue
+        self._loss_accumulate = False
+        if self.weight_decay != 0.0:
+            first = True
+            for a in self.aggregators:
+                for v in a.vars.values():
+                    ops.call("gs_sumsq_scaled", v.value.ptr, v.size, 0.5 * self.weight_decay / B, self.loss_dev.data_ptr(),
+                             0 if first else 1, e.stream)
+                    first = False
+            self._loss_accumulate = not first
+        ops.sum_scaled(self._rr_rows, B, 1.0 / B, self.mrr_dev, stream=e.stream)                    # mrr (:404)
+
+    def _backward_unsup(self, B, n_roots, fuse_adam):
+        e = self.engine
+        e.begin_backward()
+        d_out = e.ws_mat("d_agg_out", n_roots, self.agg_out.d)
+        ops.l2norm_bwd(self._dY, self.outputs_all, self._inv_norm, n_roots, d_out, stream=e.stream)
+        self.aggregate_backward(d_out)
+        # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
+        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0)
+
+    def _epilogue_unsup(self, B, **counters):
+        self.engine.advance(loss_rows=self._loss_rows, n=B, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
+                            **counters)
+
+    def _optimize(self):
+        e = self.engine
+        e.adam(self.learning_rate, clip=5.0, grad_scale=1.0 / self.world_size)
+        e.advance(step=1)
+
+    def _stage_feed_unsup(self, feed_dict):
+        e = self.engine
+        ph = self.placeholders
+        self._parity = 0
+        self._pending_stage = None
+        b1 = np.ascontiguousarray(np.asarray(feed_dict[ph['batch1']]), dtype=np.int32)
+        b2 = np.ascontiguousarray(np.asarray(feed_dict[ph['batch2']]), dtype=np.int32)
+        B = int(b1.shape[0])
+        assert b2.shape[0] == B and int(feed_dict.get(ph['batch_size'], B)) == B
+        if float(feed_dict.get(ph['dropout'], 0.0)) != 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented in the gfx950 kernels yet")
+        roots, n_roots = self._roots(B, parity=0)
+        roots[:B].copy_(torch.from_numpy(b1))
+        roots[B:2 * B].copy_(torch.from_numpy(b2))
+        torch.cuda.current_stream().synchronize()
+        return roots, B, n_roots
+
+    def _fetch_unsup(self, B, with_outputs=True):
+        self.engine.sync()
+        loss = float(self.loss_dev.item())
+        mrr = float(self.mrr_dev.item())
+        aff = self.aff_all.numpy()
+        ranks = (aff[:, :-1] >= aff[:, -1:]).sum(axis=1)
+        outs = self.outputs1.numpy() if with_outputs else None
+        return loss, ranks, aff, mrr, outs
+
+    def train_step(self, feed_dict, fetch=True):
+        """sess.run([merged, opt_op, loss, ranks, aff_all, mrr, outputs1], feed_dict)  (unsupervised_train.py:273-274)."""
+        e = self.engine
+        roots, B, n_roots = self._stage_feed_unsup(feed_dict)
+        fused = self.grad_hook is None
+
+        def fwd_bwd():
+            self._stage_negatives(roots, B)
+            self._forward_unsup(roots, B, n_roots, True)
+            self._backward_unsup(B, n_roots, fuse_adam=fused)
+            self._epilogue_unsup(B, step=1 if fused else 0, clock=1)
+
+        self._run(("utrain" if fused else "utrain_fb", B, self._adj_version()), fwd_bwd)
+        if not fused:
+            self.grad_hook(self)
+            self._run(("opt",), self._optimize)
+        return self._fetch_unsup(B) if fetch else None
+
+    def eval_step(self, feed_dict):
+        """sess.run([loss, ranks, mrr], feed_dict)  (unsupervised_train.py:69-71); also used for the (n, n) embedding
+        pairs of save_val_embeddings (:94-117) -- `.outputs1` holds the embeddings of batch1."""
+        roots, B, n_roots = self._stage_feed_unsup(feed_dict)
+
+        def fwd():
+            self._stage_negatives(roots, B)
+            self._forward_unsup(roots, B, n_roots, False)
+            self._epilogue_unsup(B, clock=1)
+
+        self._run(("ueval", B, self._adj_version()), fwd)
+        loss, ranks, aff, mrr, outs = self._fetch_unsup(B)
+        return loss, ranks, mrr, outs
+
+    # ---- device-resident epoch: edge pairs live in HBM; steady state is one hipGraph replay per step with the next
+    #      step's sampling + gather co-scheduled with this step's layer-0 contraction (see supervised_models.py)
+    def attach_device_pairs(self, pairs):
+        e = self.engine
+        self._pairs = torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)).to(e.device)
+        self._cursor = torch.zeros(1, dtype=torch.int64, device=e.device)
+        self._primed = None
+        torch.cuda.synchronize()
+
+    def set_epoch_pairs(self, pairs):
+        self.engine.sync()
+        self._pairs.copy_(torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)))
+        self._cursor.zero_()
+        if self._primed is not None:
+            self.engine.sample_clock_dev -= 1
+        self._primed = None
+        torch.cuda.synchronize()
+
+    def train_step_device(self, B, fetch=False):
+        e = self.engine
+        fused = self.grad_hook is None
+
+        def sample_next(parity):
+            roots, n_roots = self._roots(B, parity=parity)
+            self._parity = parity
+            self._stage_negatives(roots, B, pairs=self._pairs, cursor=self._cursor)
+            samples, support = self._sample_phase(roots, n_roots, parity)
+            return roots, n_roots, samples, support
+
+        if self._primed != B:
+            self._prefetched = {}
+            self._pipe_parity = 0
+            roots, n_roots, samples, support = sample_next(0)
+            self_all, neighs = self._layer0_inputs(samples, support, n_roots)
+            means0 = self.aggregators[0].prefetch(self_all, neighs, tag=0) if self_all is not None else None
+            e.advance(clock=1, cursor=self._cursor, cursor_delta=B)
+            self._prefetched[0] = (roots, n_roots, (samples, support, means0))
+            e.sync()
+            self._primed = B
+        p = self._pipe_parity
+
+        def body():
+            q = 1 - p
+            roots_q, n_roots_q, samples, support = sample_next(q)
+            self_all, neighs = self._layer0_inputs(samples, support, n_roots_q)
+            means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
+            self._prefetched[q] = (roots_q, n_roots_q, (samples, support, means_q))
+            roots, n_roots, pre = self._prefetched[p]
+            self._parity = p
+            self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=jobs)
+            self._backward_unsup(B, n_roots, fuse_adam=fused)
+            self._epilogue_unsup(B, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=B)
+
+        self._run(("updtrain" if fused else "updtrain_fb", B, p, self._adj_version()), body)
+        if not fused:
+            self.grad_hook(self)
+            self._run(("opt",), self._optimize)
+        self._pipe_parity = 1 - p
+        return self._fetch_unsup(B) if fetch else None
 
     # ------------------------------------------------------------------------------ sample (S2)
     def ids_buffer(self, batch_size, layer_infos=None, parity=None):
@@ -251,6 +484,67 @@ class SampleAndAggregate(object):
             mask = prev_out if prev_agg.act_code == ops.ACT_RELU else None
             agg.backward_hops(d_cur, pre_masked, d_prev=d_prev, prev_mask=mask, prev_offsets=prev_offsets)
             d_cur, pre_masked = d_prev, mask is not None
+
+    # ------------------------------------------------------------------------------ step machinery (shared)
+    def _samplers(self):
+        seen = []
+        for li in self.layer_infos:
+            if li.neigh_sampler not in seen:
+                seen.append(li.neigh_sampler)
+        return seen
+
+    def _sample_phase(self, batch, n, parity, stage=None):
+        """Batch/label staging + neighbor sampling into the parity-keyed id buffer (weight-free)."""
+        self._parity = parity
+        for s in self._samplers():
+            s.new_step()
+        self._pending_stage = stage
+        return self.sample(batch, self.layer_infos, n)
+
+    def _layer0_inputs(self, samples, support_sizes, n):
+        hidden = [Rows(self.features, sm, requires_grad=False) for sm in samples]
+        self_all, neighs, _, _ = self.layer_inputs(hidden, 0, n, self.num_samples, support_sizes, self.dims, self.concat)
+        return self_all, neighs
+
+    def _data_phase(self, batch, n, parity, stage=None):
+        """The weight-free half of a step: batch/label staging, neighbor sampling and the layer-0 gather+mean.
+        Writes only parity-keyed buffers, so it can run ahead of (or concurrently with) the previous step's compute."""
+        samples, support_sizes = self._sample_phase(batch, n, parity, stage)
+        self_all, neighs = self._layer0_inputs(samples, support_sizes, n)
+        means0 = self.aggregators[0].prefetch(self_all, neighs, tag=parity) if self_all is not None else None
+        return samples, support_sizes, means0
+
+    def _run(self, key, fn):
+        """Eager on first use, captured into a hipGraph on the second, replayed afterwards.  The Python attributes
+        that name a step's output buffers are snapshotted per key and restored on replay (the Python of `fn` does
+        not run again, and other step shapes -- e.g. a validation batch -- may have re-pointed them meanwhile)."""
+        e = self.engine
+        g = self._graphs.get(key)
+        if g is not None:
+            for name, val in self._graph_outputs[key].items():
+                setattr(self, name, val)
+            g.launch()
+            return
+        if not self.use_graphs or key not in self._warm or self._needs_host_rng():
+            fn()
+            self._warm.add(key)
+            return
+        g = ops.Graph(e.stream)
+        g.begin()
+        try:
+            fn()
+        finally:
+            g.end()
+        self._graphs[key] = g
+        self._graph_outputs[key] = {name: getattr(self, name) for name in self._OUT_ATTRS if hasattr(self, name)}
+        g.launch()
+
+    def _needs_host_rng(self):
+        from .neigh_samplers import PaddedAdjacency
+        return any(isinstance(s.adj_info.current, PaddedAdjacency) for s in self._samplers())
+
+    def _adj_version(self):
+        return tuple(id(s.adj_info.current) for s in self._samplers())
 
     def reset_tapes(self):
         if self.aggregators:

@@ -27,26 +27,17 @@ class SupervisedGraphsage(SampleAndAggregate):
                  learning_rate=0.01, weight_decay=0.0, world_size=1, rank=0, **kwargs):
         super(SupervisedGraphsage, self).__init__(placeholders, features, adj, degrees, layer_infos, concat=concat,
                                                   aggregator_type=aggregator_type, model_size=model_size,
-                                                  identity_dim=identity_dim, **kwargs)
+                                                  identity_dim=identity_dim, learning_rate=learning_rate,
+                                                  weight_decay=weight_decay, world_size=world_size, rank=rank,
+                                                  _defer_build=True, **kwargs)
         self.inputs1 = placeholders["batch"]
         self.num_classes = num_classes
         self.sigmoid_loss = sigmoid_loss
-        self.learning_rate = float(learning_rate)
-        self.weight_decay = float(weight_decay)
-        self.world_size = int(world_size)
-        self.rank = int(rank)
-        self.row_offset = 0
         self.label_table = None   # optional device-resident [N+1, C] label matrix (device fast path)
-        self._graphs = {}
-        self._graph_outputs = {}
-        self._warm = set()
-        self.use_graphs = True
-        self.grad_hook = None     # called between backward and the optimizer (RCCL all-reduce for DP)
-        self.pipeline = True      # overlap the next step's data chain with this step's compute (device epoch)
-        self._primed = None
-        self._prefetched = {}
-        self._pending_stage = None
         self.build()
+
+    _OUT_ATTRS = ("preds", "samples1", "outputs1", "node_preds", "agg_out", "_loss_rows", "_dlogits", "_loss_accumulate",
+                  "_head_fused", "_d_agg_out", "_tape")
 
     # ------------------------------------------------------------------------------ build (:78-100)
     def build(self):
@@ -60,38 +51,10 @@ class SupervisedGraphsage(SampleAndAggregate):
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=e.device)
 
     # ------------------------------------------------------------------------------ one step
-    def _samplers(self):
-        seen = []
-        for li in self.layer_infos:
-            if li.neigh_sampler not in seen:
-                seen.append(li.neigh_sampler)
-        return seen
-
     def _fused_head_ok(self, d):
         C = self.num_classes
         return (getattr(self, "fuse_head", True) and d in (64, 128, 256, 512) and C <= 128
                 and (d * (((C + 3) & ~3) | 1) + 4 + 4 * d) * 4 <= 160 * 1024)
-
-    def _sample_phase(self, batch, n, parity, stage=None):
-        """Batch/label staging + neighbor sampling into the parity-keyed id buffer (weight-free)."""
-        self._parity = parity
-        for s in self._samplers():
-            s.new_step()
-        self._pending_stage = stage
-        return self.sample(batch, self.layer_infos, n)
-
-    def _layer0_inputs(self, samples, support_sizes, n):
-        hidden = [Rows(self.features, sm, requires_grad=False) for sm in samples]
-        self_all, neighs, _, _ = self.layer_inputs(hidden, 0, n, self.num_samples, support_sizes, self.dims, self.concat)
-        return self_all, neighs
-
-    def _data_phase(self, batch, n, parity, stage=None):
-        """The weight-free half of a step: batch/label staging, neighbor sampling and the layer-0 gather+mean.
-        Writes only parity-keyed buffers, so it can run ahead of (or concurrently with) the previous step's compute."""
-        samples, support_sizes = self._sample_phase(batch, n, parity, stage)
-        self_all, neighs = self._layer0_inputs(samples, support_sizes, n)
-        means0 = self.aggregators[0].prefetch(self_all, neighs, tag=parity) if self_all is not None else None
-        return samples, support_sizes, means0
 
     def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None):
         """sample -> aggregate -> l2_normalize -> node_pred -> loss/preds  (supervised_models.py:79-92,102-126)."""
@@ -184,41 +147,6 @@ class SupervisedGraphsage(SampleAndAggregate):
         labels_dev.buf[:, : self.num_classes].copy_(torch.from_numpy(labels.reshape(n, self.num_classes)))
         torch.cuda.current_stream().synchronize()
         return batch_dev, labels_dev, n
-
-    _OUT_ATTRS = ("preds", "samples1", "outputs1", "node_preds", "agg_out", "_loss_rows", "_dlogits", "_loss_accumulate",
-                  "_head_fused", "_d_agg_out", "_tape")
-
-    def _run(self, key, fn):
-        """Eager on first use, captured into a hipGraph on the second, replayed afterwards.  The Python attributes
-        that name a step's output buffers are snapshotted per key and restored on replay (the Python of `fn` does
-        not run again, and other step shapes -- e.g. a validation batch -- may have re-pointed them meanwhile)."""
-        e = self.engine
-        g = self._graphs.get(key)
-        if g is not None:
-            for name, val in self._graph_outputs[key].items():
-                setattr(self, name, val)
-            g.launch()
-            return
-        if not self.use_graphs or key not in self._warm or self._needs_host_rng():
-            fn()
-            self._warm.add(key)
-            return
-        g = ops.Graph(e.stream)
-        g.begin()
-        try:
-            fn()
-        finally:
-            g.end()
-        self._graphs[key] = g
-        self._graph_outputs[key] = {name: getattr(self, name) for name in self._OUT_ATTRS if hasattr(self, name)}
-        g.launch()
-
-    def _needs_host_rng(self):
-        from .neigh_samplers import PaddedAdjacency
-        return any(isinstance(s.adj_info.current, PaddedAdjacency) for s in self._samplers())
-
-    def _adj_version(self):
-        return tuple(id(s.adj_info.current) for s in self._samplers())
 
     # ------------------------------------------------------------------------------ public steps
     def train_step(self, feed_dict, fetch=True):

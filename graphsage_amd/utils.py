@@ -215,3 +215,36 @@ def load_data(prefix, normalize=True):
     if normalize:
         feats = standardize_on_train(feats, ~(val_mask | test_mask))
     return GraphData(n, src, dst, feats, labels, val_mask, test_mask, multilabel=multilabel)
+
+
+WALK_LEN = 5      # utils.py:16
+N_WALKS = 50      # utils.py:17
+
+
+def run_random_walks(rowptr, col, nodes, num_walks=N_WALKS, walk_len=WALK_LEN, seed=123, max_pairs=None):
+    """Co-occurrence pairs from uniform random walks (utils.py:77-92), vectorised over all walks:
+    for each start node and each of num_walks walks, walk walk_len steps and emit (start, current) whenever the
+    current node differs from the start.  Runs on the TRAIN subgraph CSR (the reference takes G.subgraph(train
+    nodes), :101-103).  Returns int32 [n_pairs, 2]."""
+    rng = np.random.RandomState(seed)
+    nodes = np.asarray(nodes, dtype=np.int64)
+    deg = np.diff(rowptr)
+    nodes = nodes[deg[nodes] > 0]                       # :80-81
+    if max_pairs is not None:
+        per_node = max(1, (walk_len - 1) * num_walks)
+        keep = max(1, min(len(nodes), int(np.ceil(max_pairs / per_node))))
+        nodes = rng.choice(nodes, size=keep, replace=False)
+    start = np.repeat(nodes, num_walks)
+    cur = start.copy()
+    out = []
+    for j in range(walk_len):
+        if j > 0:
+            m = cur != start                            # self co-occurrences are useless (:87-88)
+            out.append(np.stack([start[m], cur[m]], axis=1))
+        d = deg[cur]
+        nxt = col[rowptr[cur] + (rng.random_sample(cur.shape[0]) * d).astype(np.int64)]
+        cur = np.where(d > 0, nxt, cur)
+    pairs = np.concatenate(out, axis=0).astype(np.int32) if out else np.zeros((0, 2), np.int32)
+    if max_pairs is not None and len(pairs) > max_pairs:
+        pairs = pairs[rng.permutation(len(pairs))[:max_pairs]]
+    return pairs

@@ -261,6 +261,31 @@ int gs_head_fwd_bwd(const float* x, int64_t ldx, int64_t n, int32_t d, const flo
                     float* dlogits, int64_t lddl, float* loss_rows, float* dx, int64_t lddx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N3  unsupervised objective   replaces models.py:336-343 (negative sampler), minibatch.py:113-132 (pair batches),
+ *                              prediction.py:68-110 (BipartiteEdgePredLayer xent loss), models.py:393-405 (MRR)
+ * ------------------------------------------------------------------------------------------- */
+
+/* ids_out = [batch1 (B) | batch2 (B) | negatives (n_neg)]:
+ *   pairs != NULL: batch1[i], batch2[i] = pairs[(*cursor_dev + i) % n_pairs]   (int32 [n_pairs, 2])
+ *   cdf   != NULL: negatives drawn from the fixed unigram distribution ~ degree^0.75 with replacement
+ *                  (tf.nn.fixed_unigram_candidate_sampler, unique=False): cdf is uint32 [n_nodes],
+ *                  cdf[i] = floor(2^32 * P(node <= i)); draw = first i with cdf[i] > hash32(seed, *clock_dev, slot). */
+int gs_unsup_stage(const int32_t* pairs, int64_t n_pairs, const uint64_t* cursor_dev, int64_t B,
+                   const uint32_t* cdf, int64_t n_nodes, int32_t n_neg, uint64_t seed, const uint64_t* clock_dev,
+                   int32_t* ids_out, void* stream);
+
+/* Skip-gram cross-entropy head on the l2-normalised embeddings Y = [outputs1 (B) | outputs2 (B) | neg_outputs (n_neg)]:
+ *   loss_rows[i] = xent(1, <o1_i,o2_i>) + neg_weight * sum_j xent(0, <o1_i,neg_j>)         (prediction.py:102-110)
+ *   rr_rows[i]   = 1 / (1 + #{j : <o1_i,neg_j> >= <o1_i,o2_i>})                            (models.py:399-404)
+ *   aff_all[i]   = [neg_aff_i (n_neg) | aff_i]  (optional, models.py:400)
+ *   dY rows [0,2B) = scale * dLoss/dY;  the negatives' gradient arrives as ceil(B/4) slabs [n_neg, d] in neg_slabs
+ *   (sum them with gs_reduce_slabs into dY rows [2B, 2B+n_neg)).  scale = 1/batch_size (models.py:378).
+ * d in {64,128,256,512}; 5*n_neg*d*4 bytes must fit LDS. */
+int gs_linkpred_fwd_bwd(const float* Y, int64_t ldy, int64_t B, int32_t d, int32_t n_neg, float neg_weight, float scale,
+                        float* loss_rows, float* rr_rows, float* aff_all, int64_t ld_aff,
+                        float* dY, int64_t lddy, float* neg_slabs, int32_t* n_slabs_out_host, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K6  optimizer               replaces supervised_models.py:95-99 (clip_by_value +-5, Adam) and the
  *                             weight-decay terms :104-108
  * ------------------------------------------------------------------------------------------- */

@@ -500,3 +500,64 @@ def calc_f1_micro(y_true, y_pred, sigmoid_loss):
     t = (y_true > 0.5).astype(np.int64)
     tp = float((p & t).sum()); fp = float((p & (1 - t)).sum()); fn = float(((1 - p) & t).sum())
     return 0.0 if tp == 0 else 2 * tp / (2 * tp + fp + fn)
+
+
+# --------------------------------------------------------------------------
+# N3  unsupervised objective            models.py:332-405, prediction.py:68-110
+# --------------------------------------------------------------------------
+
+def _softplus(x):
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def linkpred_fwd_bwd(o1, o2, neg, neg_sample_weights=1.0):
+    """BipartiteEdgePredLayer._xent_loss (prediction.py:102-110) with bilinear_weights=False:
+    aff = sum(o1*o2, axis=1) (:79); neg_aff = o1 @ neg.T (:91); loss = sum(xent(1, aff)) + w*sum(xent(0, neg_aff)).
+    MRR per models.py:393-405: aff_all = [neg_aff | aff]; the rank of the true pair (0-based, ties broken towards
+    the negatives as tf.nn.top_k does: lower index first) is #{j: neg_aff_j >= aff}; mrr = mean(1/(rank+1)).
+    Returns dict(loss (summed, NOT yet divided by batch_size), mrr, ranks, aff_all, d_o1, d_o2, d_neg)."""
+    aff = (o1 * o2).sum(axis=1, dtype=o1.dtype)
+    neg_aff = o1 @ neg.T
+    loss = _softplus(-aff).sum(dtype=o1.dtype) + neg_sample_weights * _softplus(neg_aff).sum(dtype=o1.dtype)
+    ranks = (neg_aff >= aff[:, None]).sum(axis=1)
+    mrr = (1.0 / (ranks + 1)).mean()
+    d_aff = sigmoid(aff) - 1.0
+    d_neg_aff = neg_sample_weights * sigmoid(neg_aff)
+    d_o1 = d_aff[:, None] * o2 + d_neg_aff @ neg
+    d_o2 = d_aff[:, None] * o1
+    d_neg = d_neg_aff.T @ o1
+    return {"loss": loss, "mrr": mrr, "ranks": ranks, "aff_all": np.concatenate([neg_aff, aff[:, None]], axis=1),
+            "d_o1": d_o1, "d_o2": d_o2, "d_neg": d_neg}
+
+
+def unsupervised_fwd_bwd(params_agg, features, samples, support_sizes, dims, num_samples, batch_size, n_neg,
+                         aggregator_type="mean", concat=True, weight_decay=0.0, neg_sample_weights=1.0, want_grads=True):
+    """SampleAndAggregate._build/_loss/build (models.py:332-391) on INJECTED samples whose roots are
+    [batch1 (B) | batch2 (B) | neg_samples (n_neg)]: the three aggregate() passes of :350-360 share the aggregators,
+    and rows are independent, so one pass over the concatenated roots is the same computation.
+    loss = (sum wd*l2_loss(aggregator vars) + xent) / batch_size   (:386-390, :378)."""
+    n_roots = 2 * batch_size + n_neg
+    out, tape = aggregate_fwd(samples, features, dims, num_samples, support_sizes, n_roots, params_agg,
+                              aggregator_type, concat)
+    out_n, ncache = l2_normalize_fwd(out)                                  # :368-370
+    B = batch_size
+    lp = linkpred_fwd_bwd(out_n[:B], out_n[B:2 * B], out_n[2 * B:], neg_sample_weights)
+    dt = features.dtype
+    wd = np.asarray(weight_decay, dtype=dt)
+    reg = np.asarray(0, dtype=dt)
+    for p in params_agg:
+        for k in _decayed_keys(aggregator_type):
+            reg = reg + wd * (p[k] * p[k]).sum(dtype=dt) / 2
+    loss = (reg + lp["loss"]) / np.asarray(B, dtype=dt)
+    res = {"loss": loss, "mrr": lp["mrr"], "ranks": lp["ranks"], "aff_all": lp["aff_all"], "outputs1": out_n[:B],
+           "outputs_all": out_n}
+    if not want_grads:
+        return res
+    d_out_n = np.concatenate([lp["d_o1"], lp["d_o2"], lp["d_neg"]], axis=0) / np.asarray(B, dtype=dt)
+    d_out = l2_normalize_bwd(d_out_n, ncache)
+    g_agg = aggregate_bwd(d_out, tape, params_agg, num_samples, aggregator_type, concat)
+    for li, p in enumerate(params_agg):
+        for k in _decayed_keys(aggregator_type):
+            g_agg[li][k] = g_agg[li][k] + wd * p[k] / np.asarray(B, dtype=dt)
+    res["grads"] = g_agg
+    return res

@@ -46,3 +46,22 @@ def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, ste
     picked = np.asarray(col)[pos] if len(col) else np.zeros_like(pos)
     out = np.where(has, picked, pad_id).astype(np.int32)
     return out
+
+
+def unigram_cdf_u32(degrees, distortion=0.75):
+    """Fixed-point CDF of tf.nn.fixed_unigram_candidate_sampler(unigrams=degrees, distortion=0.75)
+    (models.py:336-343): cdf[i] = floor(2^32 * P(node <= i)), last entry forced to 2^32-1."""
+    w = np.power(np.asarray(degrees, dtype=np.float64), distortion)
+    c = np.cumsum(w) / w.sum()
+    cdf = np.minimum(np.floor(c * 4294967296.0), 4294967295.0).astype(np.uint32)
+    cdf[-1] = np.uint32(4294967295)
+    return cdf
+
+
+def sample_unigram(cdf, n_neg, seed, clock):
+    """Restatement of the negative draw of gs_unsup_stage: slot t -> first index whose cdf exceeds a 32-bit hash."""
+    with np.errstate(over="ignore"):
+        key = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (np.uint64(clock) * _G) ^ (np.uint64(0xFF) << np.uint64(56)))
+        r = (mix64(key + np.arange(n_neg, dtype=np.uint64)) >> np.uint64(32)).astype(np.uint64)
+    idx = np.searchsorted(cdf.astype(np.uint64), r, side="right")
+    return np.minimum(idx, len(cdf) - 1).astype(np.int32)
