@@ -39,6 +39,15 @@ def build_model(G, it, args, world, rank):
           'batch_size': Placeholder('batch_size')}
     adj_info = AdjInfo(CSRAdjacency(it.train_csr[0], it.train_csr[1], G.n_nodes, e.device))
     sampler = UniformNeighborSampler(adj_info, seed=123)
+    if args.unsupervised:
+        from graphsage_amd.models import SampleAndAggregate
+        ph = {'batch1': Placeholder('batch1'), 'batch2': Placeholder('batch2'), 'neg_samples': Placeholder('neg'),
+              'dropout': Placeholder('dropout', 0.), 'batch_size': Placeholder('batch_size')}
+        layer_infos = [SAGEInfo("node", sampler, args.samples_1, args.dim_1), SAGEInfo("node", sampler, args.samples_2, args.dim_2)]
+        model = SampleAndAggregate(ph, G.padded_features(), adj_info, it.deg, layer_infos, concat=True, aggregator_type="mean",
+                                   learning_rate=0.00001, weight_decay=0.0, neg_sample_size=20, world_size=world, rank=rank)
+        model.row_offset = rank * (2 * args.batch_size + 20)
+        return e, model, ph
     agg = {"graphsage_mean": "mean", "gcn": "gcn", "graphsage_maxpool": "maxpool", "graphsage_meanpool": "meanpool"}[args.model]
     mult = 2 if agg == "gcn" else 1          # supervised_train.py:175-176
     layer_infos = [SAGEInfo("node", sampler, args.samples_1, mult * args.dim_1),
@@ -69,9 +78,11 @@ def main():
     ap.add_argument("--avg_degree", type=int, default=50)
     ap.add_argument("--model", default="graphsage_mean",
                     help="graphsage_mean (headline, BASELINE configs[1]) | graphsage_maxpool (configs[2]) | gcn | graphsage_meanpool")
+    ap.add_argument("--unsupervised", action="store_true",
+                    help="BASELINE configs[3]: unsupervised graphsage_mean on random-walk pairs (20 negatives, xent, MRR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
-    ap.add_argument("--steps-per-launch", dest="steps_per_launch", type=int, default=1,
+    ap.add_argument("--steps-per-launch", dest="steps_per_launch", type=int, default=8,
                     help="consecutive training steps replayed per hipGraph launch (single GPU)")
     args = ap.parse_args()
 
@@ -97,9 +108,19 @@ def main():
             (time.time() - t0, G.n_nodes, len(G.src), len(it.train_nodes), e.n_trainable()))
 
     B, s1, s2, F = args.batch_size, args.samples_1, args.samples_2, args.feat_dim
-    epoch = np.random.RandomState(123).permutation(it.train_nodes)
-    order = gsd.shard_order(epoch, rank, world, B) if world > 1 else epoch
-    model.attach_device_epoch(order, it.label_matrix)
+    if args.unsupervised:
+        from graphsage_amd.utils import run_random_walks
+        pairs = run_random_walks(it.train_csr[0], it.train_csr[1], it.train_nodes, max_pairs=2000000, seed=123)
+        pairs = np.random.RandomState(123).permutation(pairs)
+        if world > 1:
+            n_steps = len(pairs) // (B * world)
+            pairs = pairs[: n_steps * B * world].reshape(n_steps, world, B, 2)[:, rank].reshape(-1, 2)
+        model.attach_device_pairs(pairs)
+        args.model = "unsupervised graphsage_mean"
+    else:
+        epoch = np.random.RandomState(123).permutation(it.train_nodes)
+        order = gsd.shard_order(epoch, rank, world, B) if world > 1 else epoch
+        model.attach_device_epoch(order, it.label_matrix)
     if world > 1:
         model.grad_hook = gsd.GradAllReduce(e)
 
@@ -109,11 +130,15 @@ def main():
         torch.cuda.synchronize()
 
     spl = args.steps_per_launch
+
+    def run_steps(k):
+        model.train_steps_device(B, k, steps_per_launch=spl)
+
     # the first two executions of a graph key are eager + capture: warm both the k-step and the 1-step graphs
-    model.train_steps_device(B, max(args.warmup, 2 * spl + 4), steps_per_launch=spl)
+    run_steps(max(args.warmup, 2 * spl + 6))
     barrier()
     t0 = time.time()
-    model.train_steps_device(B, args.steps, steps_per_launch=spl)
+    run_steps(args.steps)
     e.sync()
     torch.cuda.synchronize()
     dt = time.time() - t0
@@ -122,9 +147,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
         torch.distributed.barrier()
-    loss_after = model._fetch(B)[0]
+    loss_after = model._fetch_unsup(B)[0] if args.unsupervised else model._fetch(B)[0]
 
-    edges_per_step = B * (s2 + s2 * s1)
+    edges_per_step = ((2 * B + 20) if args.unsupervised else B) * (s2 + s2 * s1)
     value = edges_per_step * world * args.steps / dt
 
     workload = ("Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), supervised %s, fan-out %dx%d, batch %d "
@@ -144,14 +169,14 @@ def main():
     # ---------------- roofline of the dominant kernel (K2 hop-2 gather+mean), HIP events on the engine stream.
     # Every rank runs the region (the interleaved training steps all-reduce under N>1); rank 0 reports.
     if True:
-        n2 = B * s2
+        n2 = ((2 * B + 20) if args.unsupervised else B) * s2
         idx2 = model.samples1[2]
         mean2 = ops.Mat.zeros(n2, F, e.device)
         torch.cuda.synchronize()
         iters = max(20, min(args.steps, 200))
         evs = [(ops.Event(), ops.Event()) for _ in range(iters)]
         for a, b in evs:                     # interleave K2 launches with full steps: same cache state as training
-            model.train_step_device(B)
+            run_steps(1)
             a.record(e.stream)
             ops.gather_mean_fwd(model.features, idx2, n2, s1, out=mean2, stream=e.stream)
             b.record(e.stream)
@@ -161,7 +186,7 @@ def main():
         achieved = alg_bytes / (k2_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_k2_pmc.json")
-        if os.path.exists(pmc) and (B, s1, s2, F) == (512, 25, 10, 602):
+        if os.path.exists(pmc) and (B, s1, s2, F) == (512, 25, 10, 602) and not args.unsupervised:
             with open(pmc) as fpm:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
                 traffic = json.load(fpm)["traffic_bytes_per_launch"]
             traffic_src = "profiles/r01_k2_pmc.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE x1.974, calibrated)"

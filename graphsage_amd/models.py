@@ -289,6 +289,28 @@ class SampleAndAggregate(object):
         torch.cuda.synchronize()
 
     def train_step_device(self, B, fetch=False):
+        self._pipelined_steps_unsup(B, 1)
+        return self._fetch_unsup(B) if fetch else None
+
+    def train_steps_device(self, B, steps, steps_per_launch=8):
+        """`steps` steps on the device-resident pairs; on one GPU `steps_per_launch` consecutive steps are replayed per
+        hipGraph launch (keeps the GPU fed when the host is slow or shared)."""
+        k = steps_per_launch - (steps_per_launch % 2)
+        if not (self.grad_hook is None and self.use_graphs and k >= 2):
+            for _ in range(steps):
+                self._pipelined_steps_unsup(B, 1)
+            return
+        done = 0
+        while done < steps:
+            # k-step graphs always start at buffer parity 0 (one captured graph); single steps realign the parity
+            if self._primed == B and self._pipe_parity == 0 and steps - done >= k:
+                self._pipelined_steps_unsup(B, k)
+                done += k
+            else:
+                self._pipelined_steps_unsup(B, 1)
+                done += 1
+
+    def _pipelined_steps_unsup(self, B, k):
         e = self.engine
         fused = self.grad_hook is None
 
@@ -309,26 +331,30 @@ class SampleAndAggregate(object):
             self._prefetched[0] = (roots, n_roots, (samples, support, means0))
             e.sync()
             self._primed = B
-        p = self._pipe_parity
+        p0 = self._pipe_parity
 
         def body():
-            q = 1 - p
-            roots_q, n_roots_q, samples, support = sample_next(q)
-            self_all, neighs = self._layer0_inputs(samples, support, n_roots_q)
-            means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
-            self._prefetched[q] = (roots_q, n_roots_q, (samples, support, means_q))
-            roots, n_roots, pre = self._prefetched[p]
-            self._parity = p
-            self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=jobs)
-            self._backward_unsup(B, n_roots, fuse_adam=fused)
-            self._epilogue_unsup(B, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=B)
+            p = p0
+            for _ in range(k):
+                q = 1 - p
+                roots_q, n_roots_q, samples, support = sample_next(q)
+                self_all, neighs = self._layer0_inputs(samples, support, n_roots_q)
+                means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
+                self._prefetched[q] = (roots_q, n_roots_q, (samples, support, means_q))
+                roots, n_roots, pre = self._prefetched[p]
+                self._parity = p
+                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=jobs)
+                self._backward_unsup(B, n_roots, fuse_adam=fused)
+                self._epilogue_unsup(B, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=B)
+                p = q
 
-        self._run(("updtrain" if fused else "updtrain_fb", B, p, self._adj_version()), body)
+        self._run(("updtrain" if fused else "updtrain_fb", B, k, p0, self._adj_version()), body)
         if not fused:
+            assert k == 1
             self.grad_hook(self)
             self._run(("opt",), self._optimize)
-        self._pipe_parity = 1 - p
-        return self._fetch_unsup(B) if fetch else None
+        if k % 2 == 1:
+            self._pipe_parity = 1 - p0
 
     # ------------------------------------------------------------------------------ sample (S2)
     def ids_buffer(self, batch_size, layer_infos=None, parity=None):

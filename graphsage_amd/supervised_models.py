@@ -305,16 +305,15 @@ class SupervisedGraphsage(SampleAndAggregate):
                 self.train_step_device(n)
             return
         done = 0
-        if self._primed != n and steps > 0:
-            self.train_step_device(n)             # fills the pipeline
-            done = 1
         data = self._data_fn(n)
-        while steps - done >= k:
-            self._pipelined_steps(n, k, data, fused)
-            done += k
         while done < steps:
-            self.train_step_device(n)
-            done += 1
+            # k-step graphs always start at buffer parity 0 (one captured graph); single steps realign the parity
+            if self._primed == n and self._pipe_parity == 0 and steps - done >= k:
+                self._pipelined_steps(n, k, data, fused)
+                done += k
+            else:
+                self.train_step_device(n)
+                done += 1
 
     def predict(self):
         """sigmoid / softmax of the logits (supervised_models.py:122-126); filled by the last step."""
