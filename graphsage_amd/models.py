@@ -322,13 +322,12 @@ class SampleAndAggregate(object):
             return roots, n_roots, samples, support
 
         if self._primed != B:
-            self._prefetched = {}
             self._pipe_parity = 0
             roots, n_roots, samples, support = sample_next(0)
             self_all, neighs = self._layer0_inputs(samples, support, n_roots)
             means0 = self.aggregators[0].prefetch(self_all, neighs, tag=0) if self_all is not None else None
             e.advance(clock=1, cursor=self._cursor, cursor_delta=B)
-            self._prefetched[0] = (roots, n_roots, (samples, support, means0))
+            self._prefetched[(B, 0)] = (roots, n_roots, (samples, support, means0))
             e.sync()
             self._primed = B
         p0 = self._pipe_parity
@@ -340,8 +339,8 @@ class SampleAndAggregate(object):
                 roots_q, n_roots_q, samples, support = sample_next(q)
                 self_all, neighs = self._layer0_inputs(samples, support, n_roots_q)
                 means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
-                self._prefetched[q] = (roots_q, n_roots_q, (samples, support, means_q))
-                roots, n_roots, pre = self._prefetched[p]
+                self._prefetched[(B, q)] = (roots_q, n_roots_q, (samples, support, means_q))
+                roots, n_roots, pre = self._prefetched[(B, p)]
                 self._parity = p
                 self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=jobs)
                 self._backward_unsup(B, n_roots, fuse_adam=fused)

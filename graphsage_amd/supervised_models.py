@@ -229,7 +229,6 @@ class SupervisedGraphsage(SampleAndAggregate):
         fused = self.grad_hook is None
         data = self._data_fn(n)
         if self._primed != n:                       # fill the pipeline: data chain of the first step
-            self._prefetched = {}
             self._pipe_parity = 0
             data(0)
             e.sync()
@@ -245,7 +244,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             labels_dev = e.ws_mat(("labels", parity), n, self.num_classes)
             pre = self._data_phase(batch_dev, n, parity, stage=(self._order, self._cursor, self.label_table, labels_dev))
             e.advance(clock=1, cursor=self._cursor, cursor_delta=n)
-            self._prefetched[parity] = (batch_dev, labels_dev, pre)
+            self._prefetched[(n, parity)] = (batch_dev, labels_dev, pre)   # static views of persistent buffers
         return data
 
     def _pipelined_steps(self, n, k, data, fused):
@@ -260,7 +259,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         mode = "streams" if self.pipeline == "streams" else "fused"
 
         def compute(p, side_jobs=None):
-            batch_dev, labels_dev, pre = self._prefetched[p]
+            batch_dev, labels_dev, pre = self._prefetched[(n, p)]
             self._parity = p
             self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=side_jobs)
             self._backward(n, fuse_adam=fused)
@@ -281,7 +280,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                                                                                 self.label_table, labels_q))
                     self_all, neighs = self._layer0_inputs(samples, support, n)
                     means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
-                    self._prefetched[q] = (batch_q, labels_q, (samples, support, means_q))
+                    self._prefetched[(n, q)] = (batch_q, labels_q, (samples, support, means_q))
                     compute(p, side_jobs=jobs)
                     self._epilogue(n, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=n)
                 p = 1 - p
