@@ -75,6 +75,8 @@ _PROTOS = {
     "gs_unsup_stage": [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_uint64, _P, _P, _P],
     "gs_linkpred_fwd_bwd": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, _P, _P, c_int64, _P, c_int64,
                             _P, POINTER(c_int32), _P],
+    "gs_maxpool_sparse_wgrad": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, c_int32, c_int32, _P,
+                                c_int64, _P],
     "gs_stage_batch": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
 }
 

@@ -409,13 +409,27 @@ class _PoolingAggregator(_SageBase):
             e.bgrad(self.vars['bias'], dz, n_total, n_out)
         d_pooled = e.ws_mat((self.name, "d_pooled", k), n_total, self.hidden_dim)
         ops.dense_dgrad(dz, col_n, o, n_total, self.vars['neigh_weights'].value, d_pooled, stream=e.stream)
-        dH = e.ws_mat((self.name, "dH", k), H.rows, self.hidden_dim)
+        dpm = None
         if self.POOL == "max":
             # reduce_max grad then the Dense's relu grad: only the arg-max row of each (group, column) receives
             # gradient, and only where the pooled activation is > 0.
             dpm = e.ws_mat((self.name, "d_pooled_masked", k), n_total, self.hidden_dim)
             ops.act_bwd(d_pooled, pooled, n_total, self.hidden_dim, ACT_RELU, dpm, stream=e.stream)
             e.bgrad(mlp.vars['bias'], dpm, n_total, self.hidden_dim)   # column sums of dH == column sums of dpm
+        threads = min(512, (self.hidden_dim + 63) // 64 * 64)
+        sparse = (self.POOL == "max" and d_prev is None and all(nv.ids is not None for nv in neighs)
+                  and getattr(self, "sparse_wgrad", True)
+                  and 16 * max(nv.shape3[1] for nv in neighs) <= 4 * threads)
+        if sparse:
+            # layer 0: the gathered feature rows need no gradient, so dH = [n*s, hidden] is never materialised; the
+            # MLP weight gradient is accumulated straight from the arg-max rows (gs_maxpool_sparse_wgrad)
+            r = 0
+            for nv in neighs:
+                n, s, _ = nv.shape3
+                e.sparse_pool_wgrad(mlp.vars['weights'], nv.src, nv.ids, n, s, argmax[r:r + n], dpm.rows_slice(r, r + n))
+                r += n
+            return
+        dH = e.ws_mat((self.name, "dH", k), H.rows, self.hidden_dim)
         r = hr = 0
         for nv in neighs:
             n, s, _ = nv.shape3

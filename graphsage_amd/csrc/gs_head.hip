@@ -454,3 +454,128 @@ extern "C" int gs_head_fwd_bwd(const float* x, int64_t ldx, int64_t n, int32_t d
     if (cq == 1) GS_HEAD_CASE(8, 1); else GS_HEAD_CASE(8, 2);
 #undef GS_HEAD_CASE
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Sparse weight gradient of the MaxPool MLP at layer 0 (aggregators.py:176-181 backward).
+// reduce_max routes the gradient of each (group g, hidden column c) to ONE of the s neighbor rows, so
+//   dW_mlp[f, c] = sum_g v[g, c] * X[ids[g*s + argmax[g, c]], f],      v = d_pooled masked by (pooled > 0)
+// is ~s-times sparser than the dense X^T·dH the reference executes (TF materialises dH = [n*s, hidden]).
+// Workgroup = (CB = 128 columns) x (a slice of groups): the s feature rows of a group are staged in LDS once,
+// thread t owns feature f = t and 128 column accumulators; the arg-max row of column c is broadcast with
+// v_readlane (SGPR row base), so the inner loop is one ds_read_b32 + one v_fmac per (f, c).  dH never exists.
+// Slices write split-K slabs (same layout as gs_dense_wgrad) summed by the flat reduce.
+#define GS_SPW_FB 64  // features per block (lane = feature)
+#define GS_SPW_PF 4   // float4 of the next group's row segments prefetched per thread
+// Block (fb, slice): features [64 fb, 64 fb + 64) x ALL hidden columns; wave w owns columns [64 w, 64 w + 64).  Each
+// X row is therefore gathered once per launch (10 blocks read disjoint 256 B segments of it); only the small
+// arg-max / value rows are re-read per feature block.
+template <int GB>   // groups staged per barrier pair
+__global__ __launch_bounds__(512) void maxpool_sparse_wgrad_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                    const int32_t* __restrict__ ids, int64_t G, int32_t s,
+                                                                    int32_t d, const int32_t* __restrict__ argmax, int64_t lda,
+                                                                    const float* __restrict__ dpm, int64_t ldd,
+                                                                    int32_t hidden, int64_t groups_per_slice,
+                                                                    float* __restrict__ slabs, int64_t ld_slab) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [GB*s][64]
+    const int dpad = (d + 3) & ~3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x;
+    const int f0 = blockIdx.x * GS_SPW_FB;
+    const int c0 = blockIdx.z * 512 + wave * 64;
+    const int64_t g0 = (int64_t)blockIdx.y * groups_per_slice;
+    const int64_t g1 = min(G, g0 + groups_per_slice);
+    const int n4 = GB * s * (GS_SPW_FB / 4);                     // float4 per staged chunk
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+    // software pipeline: the next chunk's segments / arg-max / values load to registers while this chunk computes
+    f32x4 pf[GS_SPW_PF];
+    int a_nx[GB];
+    float v_nx[GB];
+    auto prefetch = [&](int64_t g) {
+        const int64_t rows = (min(g1, g + GB) - g) * s;          // sampled rows left in this slice
+#pragma unroll
+        for (int u = 0; u < GS_SPW_PF; ++u) {
+            const int t = tid + u * nthreads;
+            if (t < n4) {
+                const int r = t >> 4, q = t & 15;
+                pf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < rows && f0 + q * 4 < dpad) {
+                    const int64_t id = ids[g * s + r];
+                    pf[u] = *reinterpret_cast<const f32x4*>(X + id * ldx + f0 + q * 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < GB; ++b) {
+            a_nx[b] = 0; v_nx[b] = 0.f;                          // value 0 => a group past the slice end adds nothing
+            if (g + b < g1 && c0 + lane < hidden) {
+                a_nx[b] = argmax[(g + b) * lda + c0 + lane];
+                v_nx[b] = dpm[(g + b) * ldd + c0 + lane];
+            }
+        }
+    };
+    if (g0 < g1) prefetch(g0);
+    for (int64_t g = g0; g < g1; g += GB) {
+        __syncthreads();  // previous chunk's segments are no longer read
+#pragma unroll
+        for (int u = 0; u < GS_SPW_PF; ++u) {
+            const int t = tid + u * nthreads;
+            if (t < n4) *reinterpret_cast<f32x4*>(&xs[t * 4]) = pf[u];
+        }
+        int a_cur[GB], v_cur[GB];
+#pragma unroll
+        for (int b = 0; b < GB; ++b) { a_cur[b] = a_nx[b]; v_cur[b] = __float_as_int(v_nx[b]); }
+        __syncthreads();
+        if (g + GB < g1) prefetch(g + GB);
+#pragma unroll
+        for (int b = 0; b < GB; ++b) {
+            const float* xb = xs + b * s * GS_SPW_FB + lane;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                const int ra = __builtin_amdgcn_readlane(a_cur[b], c);
+                const float va = __int_as_float(__builtin_amdgcn_readlane(v_cur[b], c));
+                acc[c] += va * xb[ra * GS_SPW_FB];
+            }
+        }
+    }
+    const int f = f0 + lane;
+    if (f < d) {
+        float* dst = slabs + ((int64_t)blockIdx.y * d + f) * ld_slab + c0;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            if (c0 + c + 3 < hidden) {
+                *reinterpret_cast<f32x4*>(dst + c) = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + c + e < hidden) dst[c + e] = acc[c + e];
+            }
+        }
+    }
+}
+
+extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
+                                       int32_t d, const int32_t* argmax, int64_t lda, const float* d_pooled_masked,
+                                       int64_t ldd, int32_t hidden, int32_t n_slabs, float* slabs, int64_t ld_slab,
+                                       void* stream) {
+    if (n_groups == 0) return GS_OK;
+    GS_REQUIRE(X && ids && argmax && d_pooled_masked && slabs && s > 0 && d > 0 && hidden > 0 && n_slabs > 0,
+               "gs_maxpool_sparse_wgrad: bad args");
+    GS_REQUIRE(gs_aligned16(X) && ldx % 4 == 0 && ldx >= ((d + 3) & ~3) && gs_aligned16(slabs) && ld_slab % 4 == 0 &&
+               ld_slab >= ((hidden + 3) & ~3), "gs_maxpool_sparse_wgrad: alignment / ld");
+    const int threads = hidden >= 512 ? 512 : ((hidden + 63) / 64) * 64;
+    if (s * (GS_SPW_FB / 4) > GS_SPW_PF * threads) {
+        gs_set_error("gs_maxpool_sparse_wgrad: needs 16*s <= %d*min(512, round_up(hidden,64)) (hidden=%d, s=%d); use gs_dense_wgrad",
+                     GS_SPW_PF, hidden, s);
+        return GS_ENOTSUP;
+    }
+    const int64_t gps = gs_ceil_div(n_groups, n_slabs);
+    const dim3 grid((unsigned)gs_ceil_div(d, GS_SPW_FB), (unsigned)n_slabs, (unsigned)gs_ceil_div(hidden, 512));
+    // one group per barrier pair: staging 2 or 4 groups per pair measured slower (more VGPRs -> fewer resident blocks)
+    hipLaunchKernelGGL(maxpool_sparse_wgrad_kernel<1>, grid, dim3(threads), (size_t)s * GS_SPW_FB * sizeof(float),
+                       (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
+                       slabs, ld_slab);
+    GS_LAUNCH_CHECK("maxpool_sparse_wgrad_kernel");
+    return GS_OK;
+}

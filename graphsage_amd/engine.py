@@ -7,6 +7,7 @@ This replaces what the TF1 runtime provided to the reference: tf.Variable storag
 optimizer.compute_gradients (supervised_models.py:95) and apply_gradients (:99).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -14,7 +15,7 @@ import torch
 from . import ops
 from .ops import Mat, round_up
 
-MAX_SLABS = 48  # slab capacity per variable (split-K partial sums of one backward pass)
+MAX_SLABS = 64  # slab capacity per variable (split-K partial sums of one backward pass)
 
 
 class Variable(object):
@@ -158,10 +159,17 @@ class Engine(object):
         """Queue var.slabs += A[a_idx]^T · dZ[:, col0:col0+var.cols] (split-K slabs); all queued problems of a
         backward pass are issued as ONE grouped launch by launch_wgrads()."""
         assert A.d == var.rows, (var.name, A.d, var.rows)
-        tiles = ((var.rows + 63) // 64) * ((var.cols + 63) // 64)
+        big = n >= 16384 and var.rows >= 128 and var.cols >= 128   # throughput-bound: own launch with 128x128 tiles
+        t = 128 if big else 64
+        tiles = ((var.rows + t - 1) // t) * ((var.cols + t - 1) // t)
         k = self.pick_slabs(n, tiles)
         if var.n_slabs + k > MAX_SLABS:
             raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
+        if big:
+            ops.call("gs_dense_wgrad", A.ptr, A.ld, ops.ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, var.cols, n, k,
+                     var.slab_ptr(var.n_slabs), var.ld, self.stream)
+            var.n_slabs += k
+            return
         d = ops._lib.WgradDesc()
         d.A, d.a_idx, d.dZ = A.ptr, ops.ptr(a_idx), dZ.ptr
         d.slabs = var.slab_ptr(var.n_slabs)
@@ -174,6 +182,15 @@ class Engine(object):
         """Bias gradient = column sums of dZ[:, col0:col0+n_cols] = ones^T · dZ (one more grouped problem)."""
         assert var.rows == 1 and var.cols == n_cols
         self.wgrad(var, self.ones(n), None, dZ, col0, n)
+
+    def sparse_pool_wgrad(self, var, X, ids, n_groups, s, argmax, dpm):
+        """MaxPool MLP weight gradient from the arg-max rows only (gs_maxpool_sparse_wgrad): new slabs of `var`."""
+        k = int(max(1, min(48, (n_groups + 31) // 32, MAX_SLABS - var.n_slabs)))
+        if k < 1 or var.n_slabs + k > MAX_SLABS:
+            raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
+        ops.maxpool_sparse_wgrad(X, ids, n_groups, s, argmax, dpm, var.cols, k, var.slab_ptr(var.n_slabs), var.ld,
+                                 stream=self.stream)
+        var.n_slabs += k
 
     def launch_wgrads(self):
         if not self._pending:

@@ -227,6 +227,12 @@ def segment_max_bwd(d_pooled, pooled, argmax, n, s, dH, stream=None):
          pooled.d, dH.ptr, dH.ld, _s(stream))
 
 
+def maxpool_sparse_wgrad(X, ids, n, s, argmax, dpm, hidden, n_slabs, slabs_ptr, ld_slab, stream=None):
+    """dW slabs [n_slabs, X.d, ld_slab] of the max-pool MLP from the arg-max rows only (dH never materialised)."""
+    call("gs_maxpool_sparse_wgrad", X.ptr, X.ld, ptr(ids), n, s, X.d, ptr(argmax), argmax.stride(0), dpm.ptr, dpm.ld,
+         hidden, n_slabs, slabs_ptr, ld_slab, _s(stream))
+
+
 # ------------------------------------------------------------------------------------------ K5
 def l2norm_fwd(x, n, y, inv_norm, stream=None):
     call("gs_l2norm_fwd", x.ptr, x.ld, n, x.d, y.ptr, y.ld, ptr(inv_norm), _s(stream))

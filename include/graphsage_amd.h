@@ -228,6 +228,15 @@ int gs_segment_max_bwd(const float* d_pooled, int64_t ldd, const float* pooled, 
                        const int32_t* argmax, int64_t lda, int64_t n, int32_t s, int32_t hidden,
                        float* dH, int64_t ldh, void* stream);
 
+/* Sparse weight gradient of the MaxPool MLP when its input rows need no gradient (layer 0):
+ *   slab[z][f, c] = sum_{g in slice z} v[g, c] * X[ids[g*s + argmax[g, c]], f],   v = d_pooled_masked
+ * (d_pooled_masked = d_pooled * (pooled > 0), e.g. from gs_act_bwd).  Equals X[ids]^T · dH of the dense path
+ * (gs_segment_max_bwd + gs_dense_wgrad) without materialising dH = [n*s, hidden]; ~s times fewer flops.
+ * Needs 16*s <= 4*min(512, round_up(hidden,64)); returns GS_ENOTSUP otherwise.  slabs: [n_slabs, d, ld_slab]. */
+int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s, int32_t d,
+                            const int32_t* argmax, int64_t lda, const float* d_pooled_masked, int64_t ldd,
+                            int32_t hidden, int32_t n_slabs, float* slabs, int64_t ld_slab, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K5  supervised head         replaces supervised_models.py:85 (l2_normalize), :111-118 (losses),
  *                             :122-126 (predict)

@@ -305,6 +305,28 @@ def test_segment_max(dev):
     assert np.array_equal(dH.numpy(), want.reshape(n * s, hid))
 
 
+@pytest.mark.parametrize("n,s,d,hid,k", [(203, 25, 602, 512, 7), (37, 10, 50, 128, 5), (9, 3, 70, 100, 2),
+                                          (64, 16, 33, 64, 3), (21, 25, 40, 1100, 2)])
+def test_maxpool_sparse_wgrad(dev, n, s, d, hid, k):
+    """dW = X[ids]^T . dH with dH one-hot per (group, column) == the dense product, without ever forming dH."""
+    rng = np.random.default_rng(29)
+    N = 500
+    X = _asym(rng, (N, d))
+    ids = rng.integers(0, N, size=n * s).astype(np.int32)
+    arg = rng.integers(0, s, size=(n, hid)).astype(np.int32)
+    dpm = _asym(rng, (n, hid)) * (rng.random((n, hid)) > 0.4)
+    ld = (hid + 3) // 4 * 4
+    slabs = torch.full((k, d, ld), float("nan"), device=dev)
+    ops.maxpool_sparse_wgrad(Mat.from_numpy(X, dev), torch.from_numpy(ids).to(dev), n, s, torch.from_numpy(arg).to(dev),
+                             Mat.from_numpy(dpm.astype(np.float32), dev), hid, k, slabs.data_ptr(), ld)
+    _sync()
+    got = slabs.cpu().numpy()[:, :, :hid].astype(np.float64).sum(axis=0)
+    dH = np.zeros((n, s, hid))
+    np.put_along_axis(dH, arg[:, None, :].astype(np.int64), dpm[:, None, :].astype(np.float64), axis=1)
+    want = X[ids].astype(np.float64).T @ dH.reshape(n * s, hid)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
 # ----------------------------------------------------------------------------- K5
 def test_l2norm_fwd_bwd(dev):
     rng = np.random.default_rng(24)
