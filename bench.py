@@ -116,7 +116,7 @@ def main():
             n_steps = len(pairs) // (B * world)
             pairs = pairs[: n_steps * B * world].reshape(n_steps, world, B, 2)[:, rank].reshape(-1, 2)
         model.attach_device_pairs(pairs)
-        args.model = "unsupervised graphsage_mean"
+        args.model = "graphsage_mean"
     else:
         epoch = np.random.RandomState(123).permutation(it.train_nodes)
         order = gsd.shard_order(epoch, rank, world, B) if world > 1 else epoch
@@ -152,13 +152,14 @@ def main():
     edges_per_step = ((2 * B + 20) if args.unsupervised else B) * (s2 + s2 * s1)
     value = edges_per_step * world * args.steps / dt
 
-    workload = ("Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), supervised %s, fan-out %dx%d, batch %d "
+    mode = "unsupervised" if args.unsupervised else "supervised"
+    workload = ("Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), " + mode + " %s, fan-out %dx%d, batch %d "
                 "per GPU, dims %d/%d, full training step (sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step "
                 "gather co-scheduled with the layer-0 contraction (horizontal fusion)" %
                 (args.nodes, F, args.classes, args.avg_degree, args.model, s1, s2, B, args.dim_1, args.dim_2,
                  "+RCCL all-reduce" if world > 1 else ""))
     result = {
-        "metric": "sampled-edges/sec, Reddit-shaped supervised %s fan-out %dx%d" % (args.model, s1, s2),
+        "metric": "sampled-edges/sec, Reddit-shaped %s %s fan-out %dx%d" % (mode, args.model, s1, s2),
         "value": value, "unit": "sampled-edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
