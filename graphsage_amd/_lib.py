@@ -64,6 +64,8 @@ _PROTOS = {
     "gs_sage_dense_dgrad": [_P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
     "gs_flat_reduce_adam": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_float, _P, _P],
+    "gs_scatter_add_rows": [_P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P, c_int64, _P],
+    "gs_copy_cols": [_P, c_int64, _P, c_int64, c_int64, c_int32, _P],
     "gs_advance_counters": [_P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_head_fwd_bwd": [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int64, c_int32, c_int, _P, c_int64, _P,
                         c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P],
@@ -96,7 +98,8 @@ class GatherDesc(ctypes.Structure):
 
 class VarDesc(ctypes.Structure):
     """struct gs_var_desc (include/graphsage_amd.h)"""
-    _fields_ = [("offset", c_int64), ("size", c_int64), ("slabs", c_void_p), ("n_slabs", c_int32), ("decay", c_int32)]
+    _fields_ = [("offset", c_int64), ("size", c_int64), ("slabs", c_void_p), ("n_slabs", c_int32), ("decay", c_int32),
+                ("clear", c_int32), ("reserved_", c_int32)]
 
 EXPORTED_SYMBOLS = sorted(list(_PROTOS.keys()) + ["gs_last_error", "gs_abi_version"])
 

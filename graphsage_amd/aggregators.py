@@ -175,7 +175,7 @@ class MeanAggregator(_SageBase):
         self._push((self_all, neighs, means, out))
         return out
 
-    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None):
+    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
         self_all, neighs, means, out = self._saved.pop()
         n_total = self_all.n
@@ -188,6 +188,21 @@ class MeanAggregator(_SageBase):
         e.wgrad(self.vars['neigh_weights'], means, None, dz, col_n, n_total)
         if self.bias:
             e.bgrad(self.vars['bias'], dz, n_total, n_out)
+        if embed_sink is not None:
+            # layer 0 over a table whose leading c columns are trainable (identity features): only those columns of
+            # the input gradients are formed ([n, c] = dz . W[:c]^T) and scattered per sampled id, 1/s per neighbor
+            var, c = embed_sink
+            d_self_e = e.ws_mat((self.name, "d_self_e", k), n_total, c)
+            ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value.rows_slice(0, c), d_self_e, stream=e.stream)
+            d_means_e = e.ws_mat((self.name, "d_means_e", k), n_total, c)
+            ops.dense_dgrad(dz, col_n, o, n_total, self.vars['neigh_weights'].value.rows_slice(0, c), d_means_e,
+                            stream=e.stream)
+            e.scatter_grad(var, d_self_e, self_all.ids, n_total, 1, 1.0)
+            r = 0
+            for nv in neighs:
+                n, s, _ = nv.shape3
+                e.scatter_grad(var, d_means_e.rows_slice(r, r + n), nv.ids, n, s, 1.0 / s)
+                r += n
         if d_prev is None:
             return
         d_in = self.input_dim
@@ -277,7 +292,7 @@ class GCNAggregator(_SageBase):
         self._push((self_all, neighs, means, out))
         return out
 
-    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None):
+    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
         self_all, neighs, means, out = self._saved.pop()
         n_total = self_all.n
@@ -286,6 +301,18 @@ class GCNAggregator(_SageBase):
         e.wgrad(self.vars['weights'], means, None, dz, 0, n_total)
         if self.bias:
             e.bgrad(self.vars['bias'], dz, n_total, self.output_dim)
+        if embed_sink is not None:
+            var, c = embed_sink                    # see MeanAggregator.backward_hops; self counts as one more neighbor
+            d_means_e = e.ws_mat((self.name, "d_means_e", k), n_total, c)
+            ops.dense_dgrad(dz, 0, self.output_dim, n_total, self.vars['weights'].value.rows_slice(0, c), d_means_e,
+                            stream=e.stream)
+            r = 0
+            for nv in neighs:
+                n, s, _ = nv.shape3
+                dm = d_means_e.rows_slice(r, r + n)
+                e.scatter_grad(var, dm, self_all.slice(r, r + n).ids, n, 1, 1.0 / (s + 1))
+                e.scatter_grad(var, dm, nv.ids, n, s, 1.0 / (s + 1))
+                r += n
         if d_prev is None:
             return
         d = means.d
@@ -393,7 +420,7 @@ class _PoolingAggregator(_SageBase):
         self._push((self_all, neighs, pieces, H, pooled, argmax, out))
         return out
 
-    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None):
+    def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
         self_all, neighs, pieces, H, pooled, argmax, out = self._saved.pop()
         n_total = self_all.n
@@ -417,7 +444,7 @@ class _PoolingAggregator(_SageBase):
             ops.act_bwd(d_pooled, pooled, n_total, self.hidden_dim, ACT_RELU, dpm, stream=e.stream)
             e.bgrad(mlp.vars['bias'], dpm, n_total, self.hidden_dim)   # column sums of dH == column sums of dpm
         threads = min(512, (self.hidden_dim + 63) // 64 * 64)
-        sparse = (self.POOL == "max" and d_prev is None and all(nv.ids is not None for nv in neighs)
+        sparse = (self.POOL == "max" and d_prev is None and embed_sink is None and all(nv.ids is not None for nv in neighs)
                   and getattr(self, "sparse_wgrad", True)
                   and 16 * max(nv.shape3[1] for nv in neighs) <= 4 * threads)
         if sparse:
@@ -447,6 +474,19 @@ class _PoolingAggregator(_SageBase):
         for x in pieces:
             e.wgrad(mlp.vars['weights'], x.src, x.ids, dH.rows_slice(r, r + x.n), 0, x.n)
             r += x.n
+        if embed_sink is not None:
+            var, c = embed_sink                    # see MeanAggregator.backward_hops; every neighbor row has its own dH
+            d_self_e = e.ws_mat((self.name, "d_self_e", k), n_total, c)
+            ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value.rows_slice(0, c), d_self_e, stream=e.stream)
+            e.scatter_grad(var, d_self_e, self_all.ids, n_total, 1, 1.0)
+            d_neigh_e = e.ws_mat((self.name, "d_neigh_e", k), H.rows, c)
+            ops.dense_dgrad(dH, 0, self.hidden_dim, H.rows, mlp.vars['weights'].value.rows_slice(0, c), d_neigh_e,
+                            stream=e.stream)
+            hr = 0
+            for nv in neighs:
+                n, s, _ = nv.shape3
+                e.scatter_grad(var, d_neigh_e.rows_slice(hr, hr + n * s), nv.ids, n * s, 1, 1.0)
+                hr += n * s
         if d_prev is None:
             return
         d_self_all = e.ws_mat((self.name, "d_self", k), n_total, self.input_dim)

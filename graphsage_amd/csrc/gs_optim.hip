@@ -142,9 +142,10 @@ extern "C" int gs_sumsq_scaled(const float* x, int64_t count, float scale, float
 struct FlatVars {
     int64_t offset[GS_MAX_VARS];
     int64_t size[GS_MAX_VARS];
-    const float* slabs[GS_MAX_VARS];
+    float* slabs[GS_MAX_VARS];
     int32_t n_slabs[GS_MAX_VARS];
     int32_t decay[GS_MAX_VARS];
+    int32_t clear[GS_MAX_VARS];
     int32_t n;
 };
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
         const int64_t rel = i - V.offset[k];
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         if (rel < V.size[k]) {
-            const float* sp = V.slabs[k] + rel;
+            float* sp = V.slabs[k] + rel;
             const int ns = V.n_slabs[k];
             const int64_t sz = V.size[k];
             int z = 0;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
                 g += v0; g += v1; g += v2; g += v3;
             }
             for (; z < ns; ++z) g += *reinterpret_cast<const f32x4*>(sp + (int64_t)z * sz);
+            if (V.clear[k]) *reinterpret_cast<f32x4*>(sp) = f32x4{0.f, 0.f, 0.f, 0.f};   // atomic accumulator: consume
         }
         f32x4 p = *reinterpret_cast<const f32x4*>(params + i);
         if (V.decay[k] && wd != 0.f) g += p * wd;
@@ -221,6 +223,8 @@ extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars,
         V.slabs[i] = vars_host[i].slabs;
         V.n_slabs[i] = vars_host[i].n_slabs;
         V.decay[i] = vars_host[i].decay;
+        V.clear[i] = vars_host[i].clear;
+        GS_REQUIRE(!vars_host[i].clear || vars_host[i].n_slabs == 1, "gs_flat_reduce_adam: var %d: clear needs n_slabs == 1", i);
         expect += vars_host[i].size;
     }
     GS_REQUIRE(expect <= total, "gs_flat_reduce_adam: variables exceed the flat buffer");

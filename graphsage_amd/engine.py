@@ -21,7 +21,7 @@ MAX_SLABS = 64  # slab capacity per variable (split-K partial sums of one backwa
 class Variable(object):
     """A trainable fp32 matrix [rows, cols] living in the engine's flat parameter buffer."""
 
-    def __init__(self, name, init, decay=False):
+    def __init__(self, name, init, decay=False, scatter=False):
         init = np.asarray(init, dtype=np.float32)
         if init.ndim == 1:
             init = init[None, :]
@@ -30,6 +30,9 @@ class Variable(object):
         self.ld = round_up(self.cols, 4)
         self.init = init
         self.decay = decay  # member of aggregator.vars / node_pred.vars -> weight-decayed (supervised_models.py:104-108)
+        # scatter: the gradient arrives through atomic row scatters (a gathered embedding table), not as split-K
+        # slabs: ONE accumulator slab that the reduce kernel zeroes after reading it
+        self.scatter = scatter
         self.offset = None  # float offset in the flat buffers
         self.value = None   # Mat view into engine.params
         self.grad = None    # Mat view into engine.grads
@@ -66,15 +69,16 @@ class Engine(object):
         self.sample_clock_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # sampler RNG step
         self.finalized = False
         self._pending = []
+        self.post_update_hooks = []
         # second stream for the data chain (sampling + gathers of the NEXT step overlap this step's compute)
         self._stream2_obj = None
         self.stream2 = None
         self._ev_fork = self._ev_join = None
 
     # -------------------------------------------------------------------------------- variables
-    def add_variable(self, name, init, decay=False):
+    def add_variable(self, name, init, decay=False, scatter=False):
         assert not self.finalized, "variables must be created before Engine.finalize()"
-        v = Variable(name, init, decay)
+        v = Variable(name, init, decay, scatter)
         self.variables.append(v)
         return v
 
@@ -96,7 +100,8 @@ class Engine(object):
             v.value = Mat(self.params[v.offset: v.offset + v.size].view(v.rows, v.ld), v.cols)
             v.grad = Mat(self.grads[v.offset: v.offset + v.size].view(v.rows, v.ld), v.cols)
             v.value.buf[:, : v.cols].copy_(torch.from_numpy(v.init))
-            v.slabs = torch.zeros(MAX_SLABS * v.size, dtype=torch.float32, device=self.device)
+            v.slabs = torch.zeros((1 if v.scatter else MAX_SLABS) * v.size, dtype=torch.float32, device=self.device)
+            v.n_slabs = 1 if v.scatter else 0
         torch.cuda.synchronize()
         self.finalized = True
 
@@ -135,7 +140,7 @@ class Engine(object):
     # -------------------------------------------------------------------------------- gradients
     def begin_backward(self):
         for v in self.variables:
-            v.n_slabs = 0
+            v.n_slabs = 1 if v.scatter else 0
         self._pending = []
 
     @staticmethod
@@ -192,6 +197,12 @@ class Engine(object):
                                  stream=self.stream)
         var.n_slabs += k
 
+    def scatter_grad(self, var, d, ids, n, s, scale):
+        """var.grad[ids[i*s + j], :] += scale * d[i, :var.cols]: gradient of a row gather from a trainable table."""
+        assert var.scatter
+        ops.scatter_add_rows(d, n, s, var.cols, scale, ids, Mat(var.slabs.view(var.rows, var.ld), var.cols),
+                             stream=self.stream)
+
     def launch_wgrads(self):
         if not self._pending:
             return
@@ -205,6 +216,7 @@ class Engine(object):
             arr[i].offset, arr[i].size = v.offset, v.size
             arr[i].slabs = v.slabs.data_ptr()
             arr[i].n_slabs, arr[i].decay = v.n_slabs, 1 if v.decay else 0
+            arr[i].clear = 1 if v.scatter else 0
         return arr
 
     def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0):
@@ -216,11 +228,19 @@ class Engine(object):
                  ops.ptr(self.grads), ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats,
                  float(weight_decay), 1 if fuse_adam else 0, lr, 0.9, 0.999, 1e-8, clip, grad_scale,
                  ops.ptr(self.step_dev), self.stream)
+        if fuse_adam:
+            self._params_updated()
 
     def adam(self, lr, clip=5.0, grad_scale=1.0):
         """Separate optimizer launch (data-parallel path: runs after the RCCL all-reduce of engine.grads)."""
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_param_floats, lr, self.step_dev,
                       clip=clip, grad_scale=grad_scale, stream=self.stream)
+        self._params_updated()
+
+    def _params_updated(self):
+        """Launches that must follow every optimizer step (e.g. refreshing a materialised copy of a variable)."""
+        for hook in self.post_update_hooks:
+            hook()
 
     def advance(self, step=0, clock=0, cursor=None, cursor_delta=0, loss_rows=None, n=0, loss_out=None, accumulate=False):
         """Step epilogue, ONE launch: (optionally) loss_out = mean(loss_rows) and advance the optimizer step /

@@ -18,6 +18,7 @@ import torch
 from . import ops
 from .aggregators import GCNAggregator, MaxPoolingAggregator, MeanAggregator, MeanPoolingAggregator
 from .engine import get_engine
+from .inits import glorot
 from .layers import Rows, identity, relu
 from .ops import Mat
 
@@ -89,14 +90,11 @@ class SampleAndAggregate(object):
         self.aggregator_type = aggregator_type
         self.model_size = model_size
         self.adj_info = adj
-        if identity_dim > 0:
-            raise NotImplementedError("identity_dim > 0 (trainable node embeddings) is a 'next' row (SURVEY §8f N4)")
-        if features is None:
-            raise Exception("Must have a positive value for identity feature dimension if no input features given.")
-        self.features = device_features(features, self.engine)
+        self.identity_dim = int(identity_dim)
+        self._init_features(features, adj, self.identity_dim)
         self.degrees = degrees
         self.concat = concat
-        self.dims = [self.features.d + identity_dim]
+        self.dims = [self.features.d]        # == (0 if features is None else F) + identity_dim  (:244)
         self.dims.extend([layer_infos[i].output_dim for i in range(len(layer_infos))])
         self.placeholders = placeholders
         self.batch_size = placeholders.get("batch_size") if placeholders else None
@@ -111,7 +109,8 @@ class SampleAndAggregate(object):
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
         self.grad_hook = None
-        self.pipeline = True
+        if self.identity_dim == 0:
+            self.pipeline = True
         self._primed = None
         self._prefetched = {}
         self._pending_stage = None
@@ -119,6 +118,41 @@ class SampleAndAggregate(object):
             self.inputs1 = placeholders["batch1"]
             self.inputs2 = placeholders["batch2"]
             self.build()
+
+    # ------------------------------------------------------------------------------ identity features (:229-240)
+    def _init_features(self, features, adj, identity_dim):
+        """self.features = concat([node_embeddings, features], axis=1) (models.py:229-240).  The trainable
+        `node_embeddings` [N+1, identity_dim] (tf.get_variable default initializer = glorot_uniform) lives in the flat
+        parameter buffer; the concatenation is kept materialised as ONE table so that a sampled id still costs one
+        row fetch, and its leading columns are refreshed after every optimizer step (Engine.post_update_hooks)."""
+        e = self.engine
+        self.embeds = None
+        if identity_dim > 0:
+            n_rows = adj.n_nodes + 1                                   # adj.get_shape()[0]
+            self.embeds = e.add_variable("node_embeddings", glorot((n_rows, identity_dim)), decay=False, scatter=True)
+        if features is None:
+            if identity_dim == 0:
+                raise Exception("Must have a positive value for identity feature dimension if no input features given.")
+            self.features = Mat.zeros(n_rows, identity_dim, e.device, ld_multiple=32)
+        elif self.embeds is None:
+            self.features = device_features(features, e)
+        else:
+            fixed = np.asarray(features.numpy() if isinstance(features, Mat) else features, dtype=np.float32)
+            if fixed.shape[0] != n_rows:
+                raise ops._lib.GraphsageAmdError("features must have N+1 = %d rows (got %d)" % (n_rows, fixed.shape[0]))
+            self.features = Mat.zeros(n_rows, identity_dim + fixed.shape[1], e.device, ld_multiple=32)
+            self.features.buf[:, identity_dim: identity_dim + fixed.shape[1]].copy_(torch.from_numpy(fixed))
+            torch.cuda.synchronize()
+        if self.embeds is not None:
+            e.post_update_hooks.append(self._refresh_embeds)
+            # the prefetch pipeline gathers step t+1's rows before step t's update: not valid for a trainable table
+            self.pipeline = False
+
+    def _refresh_embeds(self):
+        ops.copy_cols(self.embeds.value, self.features, self.embeds.rows, self.identity_dim, stream=self.engine.stream)
+
+    def _embed_sink(self):
+        return (self.embeds, self.identity_dim) if self.embeds is not None else None
 
     # ------------------------------------------------------------------------------ unsupervised build (:332-391)
     def build(self):
@@ -130,6 +164,8 @@ class SampleAndAggregate(object):
         self.link_pred_layer = BipartiteEdgePredLayer(dim_mult * self.dims[-1], dim_mult * self.dims[-1], self.placeholders,
                                                       act="sigmoid", bilinear_weights=False, name='edge_predict')
         e.finalize()
+        if self.embeds is not None:
+            self._refresh_embeds()
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=e.device)
         self.mrr_dev = torch.zeros(1, dtype=torch.float32, device=e.device)
         # fixed unigram distribution ~ degree^0.75 of tf.nn.fixed_unigram_candidate_sampler (:336-343) as a uint32 CDF
@@ -274,6 +310,9 @@ class SampleAndAggregate(object):
     #      step's sampling + gather co-scheduled with this step's layer-0 contraction (see supervised_models.py)
     def attach_device_pairs(self, pairs):
         e = self.engine
+        if self.embeds is not None:
+            raise NotImplementedError("the prefetching device-epoch path reads next-step rows before this step's update; "
+                                      "with identity_dim > 0 use train_step(feed_dict)")
         self._pairs = torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)).to(e.device)
         self._cursor = torch.zeros(1, dtype=torch.int64, device=e.device)
         self._primed = None
@@ -491,7 +530,7 @@ class SampleAndAggregate(object):
 
     def aggregate_backward(self, d_out):
         """Reverse schedule of `aggregate`.  d_out: Mat = dLoss/d(hidden[0] of the last layer).
-        No gradient flows into the feature table (models.py:238: trainable=False)."""
+        No gradient flows into the fixed feature columns (models.py:238: trainable=False)."""
         e = self.engine
         tape = self._tape
         d_cur, pre_masked = d_out, False
@@ -500,7 +539,8 @@ class SampleAndAggregate(object):
             if mode != "batched":
                 raise NotImplementedError("backward through non-contiguous hop inputs (use the model's id buffer)")
             if layer == 0:
-                agg.backward_hops(d_cur, pre_masked)                         # features need no gradient
+                # the fixed features need no gradient; trainable identity columns get theirs scattered per id
+                agg.backward_hops(d_cur, pre_masked, embed_sink=self._embed_sink())
                 break
             prev_mode, prev_agg, prev_rows, prev_offsets, prev_out = tape[layer - 1]
             d_prev = e.ws_mat((self.name, "d_hidden", layer - 1), prev_out.rows, prev_out.d)

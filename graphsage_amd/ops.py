@@ -233,6 +233,15 @@ def maxpool_sparse_wgrad(X, ids, n, s, argmax, dpm, hidden, n_slabs, slabs_ptr, 
          hidden, n_slabs, slabs_ptr, ld_slab, _s(stream))
 
 
+def scatter_add_rows(d, n, s, cols, scale, ids, table, stream=None):
+    """table[ids[i*s + j], :cols] += scale * d[i, :cols]  (gradient of a row gather w.r.t. the gathered table)."""
+    call("gs_scatter_add_rows", d.ptr, d.ld, n, s, cols, scale, ptr(ids), table.ptr, table.ld, _s(stream))
+
+
+def copy_cols(src, dst, rows, cols, stream=None):
+    call("gs_copy_cols", src.ptr, src.ld, dst.ptr, dst.ld, rows, cols, _s(stream))
+
+
 # ------------------------------------------------------------------------------------------ K5
 def l2norm_fwd(x, n, y, inv_norm, stream=None):
     call("gs_l2norm_fwd", x.ptr, x.ld, n, x.d, y.ptr, y.ld, ptr(inv_norm), _s(stream))

@@ -48,6 +48,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         self.node_pred = Dense(dim_mult * self.dims[-1], self.num_classes, dropout=self.placeholders['dropout'],
                                act=identity)
         e.finalize()
+        if self.embeds is not None:
+            self._refresh_embeds()
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=e.device)
 
     # ------------------------------------------------------------------------------ one step

@@ -319,12 +319,25 @@ int gs_adam_step(float* p, const float* grad, float* m, float* v, int64_t count,
  * vars_host: HOST array of per-variable descriptors (consumed at call time). */
 typedef struct gs_var_desc {
     int64_t offset, size;  /* segment of the flat buffers, in floats (size includes ld padding) */
-    const float* slabs;
+    float* slabs;
     int32_t n_slabs, decay;
+    int32_t clear;         /* != 0: slab 0 is an atomically accumulated gradient (gs_scatter_add_rows); it is zeroed
+                              after being read so that the next backward pass starts from 0 (needs n_slabs == 1) */
+    int32_t reserved_;
 } gs_var_desc;
 int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
                         int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,
                         float eps, float clip, float grad_scale, const uint64_t* step_dev, void* stream);
+
+/* Trainable identity features ("node_embeddings", models.py:229-240 / supervised_models.py:49-60): gradient of the
+ * layer-0 row gathers w.r.t. the leading `cols` columns of the gathered table, accumulated with fp32 atomics
+ * (tf.gradients of embedding_lookup: IndexedSlices summed per id):
+ *   table[ids[i*s + j], c] += scale * d[i, c]      i < n, j < s, c < cols */
+int gs_scatter_add_rows(const float* d, int64_t ldd, int64_t n, int32_t s, int32_t cols, float scale,
+                        const int32_t* ids, float* table, int64_t ldt, void* stream);
+/* dst[r, 0:cols] = src[r, 0:cols]: refreshes the embedding columns of the combined feature table (the
+ * tf.concat([embeds, features], axis=1) of models.py:240, kept materialised) after an optimizer step. */
+int gs_copy_cols(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t cols, void* stream);
 
 /* Up to three device counters advanced by one launch (cursor / sampler clock / optimizer step). */
 int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);

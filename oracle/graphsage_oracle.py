@@ -325,9 +325,12 @@ def aggregate_fwd(samples, features, dims, num_samples, support_sizes, batch_siz
     return hidden[0], tape
 
 
-def aggregate_bwd(d_out, tape, params, num_samples, aggregator_type="mean", concat=True):
-    """Reverse of aggregate_fwd.  No gradient flows into `features` (non-trainable
-    Variable, models.py:238), so layer-0 input grads are dropped."""
+def aggregate_bwd(d_out, tape, params, num_samples, aggregator_type="mean", concat=True, input_grads=False):
+    """Reverse of aggregate_fwd.  No gradient flows into the fixed `features`
+    (non-trainable Variable, models.py:238), so layer-0 input grads are dropped --
+    unless input_grads=True (identity features, models.py:229-240: the leading
+    columns of the table are the trainable `node_embeddings`), in which case
+    (grads, [dL/d hidden[h] of layer 0 for every hop h]) is returned."""
     K = len(num_samples)
     grads = [None] * K
     d_hidden = [d_out]
@@ -343,13 +346,26 @@ def aggregate_bwd(d_out, tape, params, num_samples, aggregator_type="mean", conc
             else:
                 for k in g:
                     g_layer[k] += g[k]
-            if layer > 0:
+            if layer > 0 or input_grads:
                 dn = d_neigh.reshape(-1, d_neigh.shape[-1])
                 d_prev[hop] = d_self if d_prev[hop] is None else d_prev[hop] + d_self
                 d_prev[hop + 1] = dn if d_prev[hop + 1] is None else d_prev[hop + 1] + dn
         grads[layer] = g_layer
         d_hidden = d_prev
+    if input_grads:
+        return grads, d_hidden
     return grads
+
+
+def embedding_grad(d_hidden0, samples, n_rows, identity_dim):
+    """Gradient w.r.t. `node_embeddings` [N+1, identity_dim] of
+    features = concat([embeds, fixed], axis=1); hidden[h] = embedding_lookup(features, samples[h])
+    (models.py:240, :299): the first identity_dim columns of every hop's input
+    gradient, summed per looked-up id (IndexedSlices semantics)."""
+    g = np.zeros((n_rows, identity_dim), dtype=d_hidden0[0].dtype)
+    for dh, ids in zip(d_hidden0, samples):
+        np.add.at(g, np.asarray(ids, dtype=np.int64), dh[:, :identity_dim])
+    return g
 
 
 # --------------------------------------------------------------------------
@@ -416,10 +432,13 @@ def make_supervised_params(aggregator_type, dims, num_classes, concat, rng, mode
 
 def supervised_fwd_bwd(params, features, samples, support_sizes, labels, dims, num_samples, batch_size,
                        aggregator_type="mean", concat=True, sigmoid_loss=False, weight_decay=0.0,
-                       want_grads=True):
+                       want_grads=True, identity_dim=0):
     """SupervisedGraphsage.build/_loss/predict on INJECTED `samples`
     (supervised_models.py:78-126).  Returns dict with loss, preds, outputs1,
-    node_preds and (optionally) clipped-free raw grads."""
+    node_preds and (optionally) clipped-free raw grads.  With identity_dim > 0,
+    `features` is concat([node_embeddings, fixed features], axis=1)
+    (supervised_models.py:49-60) and grads["embeds"] is returned (no weight decay:
+    the embedding is in neither aggregator.vars nor node_pred.vars)."""
     out, tape = aggregate_fwd(samples, features, dims, num_samples, support_sizes, batch_size,
                               params["agg"], aggregator_type, concat)
     out_n, ncache = l2_normalize_fwd(out)                                 # :85
@@ -444,11 +463,19 @@ def supervised_fwd_bwd(params, features, samples, support_sizes, labels, dims, n
     gb = dlogits.sum(axis=0, dtype=dt) + wd * b
     d_out_n = dlogits @ W.T
     d_out = l2_normalize_bwd(d_out_n, ncache)
-    g_agg = aggregate_bwd(d_out, tape, params["agg"], num_samples, aggregator_type, concat)
+    g_emb = None
+    if identity_dim > 0:
+        g_agg, d_hidden0 = aggregate_bwd(d_out, tape, params["agg"], num_samples, aggregator_type, concat,
+                                         input_grads=True)
+        g_emb = embedding_grad(d_hidden0, samples, features.shape[0], identity_dim)
+    else:
+        g_agg = aggregate_bwd(d_out, tape, params["agg"], num_samples, aggregator_type, concat)
     for li, p in enumerate(params["agg"]):
         for k in _decayed_keys(aggregator_type):
             g_agg[li][k] = g_agg[li][k] + wd * p[k]
     res["grads"] = {"agg": g_agg, "node_pred": {"weights": gW, "bias": gb}}
+    if g_emb is not None:
+        res["grads"]["embeds"] = g_emb
     return res
 
 

@@ -47,7 +47,7 @@ def device_grads(model, agg_type):
 
 
 def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, dim=32, max_degree=10, n_nodes=400,
-          fuse=True):
+          fuse=True, identity_dim=0, use_features=True):
     eng.reset_engine()
     inits.set_seed(7)
     G = synthetic_graph(n_nodes=n_nodes, feat_dim=feat_dim, num_classes=7, avg_degree=6, seed=5, multilabel=sigmoid)
@@ -63,9 +63,9 @@ def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, d
     ns = [5, 3, 2][:K]
     od = (2 * dim if agg_type == "gcn" else dim)
     layer_infos = [SAGEInfo("node", sampler, ns[i], od) for i in range(K)]
-    model = SupervisedGraphsage(G.num_classes, ph, G.padded_features(), adj_info, it.deg, layer_infos,
-                                concat=concat, aggregator_type=agg_type, sigmoid_loss=sigmoid,
-                                learning_rate=0.01, weight_decay=wd)
+    model = SupervisedGraphsage(G.num_classes, ph, G.padded_features() if use_features else None, adj_info, it.deg,
+                                layer_infos, concat=concat, aggregator_type=agg_type, sigmoid_loss=sigmoid,
+                                learning_rate=0.01, weight_decay=wd, identity_dim=identity_dim)
     model.fuse_head = model.fuse_sampler = fuse
     return G, it, ph, sampler, model, ns
 
@@ -111,6 +111,68 @@ def test_train_step_matches_oracle(dev, agg_type, concat, sigmoid, fuse):
         p = p0.copy()
         orc.adam_tf_update(p, orc.clip_by_value(g).reshape(p.shape), np.zeros_like(p), np.zeros_like(p), 1, 0.01)
         np.testing.assert_allclose(p1.reshape(p.shape), p, rtol=1e-4, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("agg_type,concat,sigmoid,idim,use_features",
+                         [("mean", True, False, 6, True), ("gcn", False, False, 8, True), ("maxpool", True, True, 5, True),
+                          ("meanpool", True, False, 4, True), ("mean", True, False, 12, False)])
+def test_identity_features_match_oracle(dev, agg_type, concat, sigmoid, idim, use_features):
+    """identity_dim > 0 (supervised_models.py:49-60): trainable node_embeddings concatenated in front of the features;
+    gradient = per-id sum of the layer-0 input gradients, dense clip + Adam, no weight decay.  Two steps: the second
+    checks that the gathered table was refreshed and the gradient accumulator cleared."""
+    wd = 0.01
+    G, it, ph, sampler, model, ns = build(dev, agg_type, concat, sigmoid, wd=wd, identity_dim=idim,
+                                          use_features=use_features)
+    model.use_graphs = False
+    assert model.dims[0] == idim + (G.feats.shape[1] if use_features else 0)
+    rng = np.random.RandomState(4)
+    batch = rng.choice(it.train_nodes, size=29, replace=False).astype(np.int32)
+    labels = it.label_matrix[batch]
+    feed = {ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)}
+    emb_m = emb_v = None
+    for step in (1, 2):
+        perms = [rng.permutation(it.max_degree) for _ in ns]
+        sampler.inject_perms(perms)
+        params = oracle_params(model, agg_type)
+        emb0 = model.embeds.numpy().copy()
+        assert emb0.shape == (G.n_nodes + 1, idim)
+        np.testing.assert_array_equal(model.features.numpy()[:, :idim], emb0)   # materialised concat is current
+        feats = np.concatenate([emb0, G.padded_features()], axis=1) if use_features else emb0
+        loss, preds = model.train_step(feed)
+        samples, support = orc.sample(it.adj, batch, ns, perms)
+        res = orc.supervised_fwd_bwd(params, feats, samples, support, labels, model.dims, ns, len(batch), agg_type,
+                                     concat, sigmoid, weight_decay=wd, identity_dim=idim)
+        np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(preds, res["preds"], rtol=1e-4, atol=1e-4)
+        got = device_grads(model, agg_type)
+        for (name, g), (_, w) in zip(orc.flat_param_items(got, agg_type), orc.flat_param_items(res["grads"], agg_type)):
+            np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                       err_msg=name)
+        w = res["grads"]["embeds"]
+        assert np.count_nonzero(w) > 0
+        np.testing.assert_allclose(model.embeds.grad.numpy(), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()))
+        if emb_m is None:
+            emb_m, emb_v = np.zeros_like(emb0), np.zeros_like(emb0)
+        want = emb0.copy()
+        orc.adam_tf_update(want, orc.clip_by_value(w), emb_m, emb_v, step, 0.01)     # dense Adam: untouched rows move too
+        np.testing.assert_allclose(model.embeds.numpy(), want, rtol=1e-4, atol=2e-5)
+    assert float(model.embeds.slabs.abs().max().item()) == 0.0                       # accumulator consumed
+
+
+def test_identity_features_graph_replay(dev):
+    """The scatter + refresh launches are part of the captured step: replayed steps == eager steps (up to the
+    summation order of the fp32 atomics)."""
+    outs = []
+    for use_graphs in (False, True):
+        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True, identity_dim=8)
+        model.use_graphs = use_graphs
+        batch = np.random.RandomState(1).choice(it.train_nodes, size=32, replace=False).astype(np.int32)
+        feed = {ph['batch']: batch, ph['labels']: it.label_matrix[batch], ph['batch_size']: 32}
+        losses = [model.train_step(feed)[0] for _ in range(4)]
+        outs.append((losses, model.embeds.numpy().copy(), model.features.numpy()[:, :8].copy()))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(outs[1][1], outs[1][2])
 
 
 def test_three_layer_mean(dev):
