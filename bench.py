@@ -59,7 +59,19 @@ def build_model(G, it, args, world, rank):
     return e, model, ph
 
 
-def main():
+def describe(args, F, s1, s2, B, world):
+    """(metric, config.workload) strings of the JSON line."""
+    mode = "unsupervised" if args.unsupervised else "supervised"
+    fmt = ("Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), " + mode + " %s, fan-out %dx%d, batch %d "
+           "per GPU, dims %d/%d, full training step (sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step "
+           "gather co-scheduled with the layer-0 contraction (horizontal fusion)")
+    workload = fmt % (args.nodes, F, args.classes, args.avg_degree, args.model, s1, s2, B, args.dim_1, args.dim_2,
+                      "+RCCL all-reduce" if world > 1 else "")
+    metric = "sampled-edges/sec, Reddit-shaped %s %s fan-out %dx%d" % (mode, args.model, s1, s2)
+    return metric, workload
+
+
+def parse_args(argv=None):
     if os.environ.get("GS_FAULT_DUMP_S"):
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["GS_FAULT_DUMP_S"]), exit=True)
@@ -84,7 +96,11 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--steps-per-launch", dest="steps_per_launch", type=int, default=8,
                     help="consecutive training steps replayed per hipGraph launch (single GPU)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
 
     rank, local_rank, world = gsd.init_from_env()
     if world != args.gpus and world > 1:
@@ -152,14 +168,9 @@ def main():
     edges_per_step = ((2 * B + 20) if args.unsupervised else B) * (s2 + s2 * s1)
     value = edges_per_step * world * args.steps / dt
 
-    mode = "unsupervised" if args.unsupervised else "supervised"
-    workload = ("Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), " + mode + " %s, fan-out %dx%d, batch %d "
-                "per GPU, dims %d/%d, full training step (sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step "
-                "gather co-scheduled with the layer-0 contraction (horizontal fusion)" %
-                (args.nodes, F, args.classes, args.avg_degree, args.model, s1, s2, B, args.dim_1, args.dim_2,
-                 "+RCCL all-reduce" if world > 1 else ""))
+    metric, workload = describe(args, F, s1, s2, B, world)
     result = {
-        "metric": "sampled-edges/sec, Reddit-shaped %s %s fan-out %dx%d" % (mode, args.model, s1, s2),
+        "metric": metric,
         "value": value, "unit": "sampled-edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

@@ -64,6 +64,8 @@ _PROTOS = {
     "gs_sage_dense_dgrad": [_P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
     "gs_flat_reduce_adam": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_float, _P, _P],
+    "gs_dropout_rows": [_P, c_int64, _P, c_int64, c_int32, _P, _P, c_int64, _P],
+    "gs_gather_mean_dropout_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P, _P],
     "gs_scatter_add_rows": [_P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P, c_int64, _P],
     "gs_copy_cols": [_P, c_int64, _P, c_int64, c_int64, c_int32, _P],
     "gs_advance_counters": [_P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
@@ -94,6 +96,11 @@ class GatherDesc(ctypes.Structure):
     """struct gs_gather_desc (include/graphsage_amd.h)"""
     _fields_ = [("X", c_void_p), ("idx", c_void_p), ("self_src", c_void_p), ("self_idx", c_void_p), ("out", c_void_p),
                 ("ldx", c_int64), ("ld_self", c_int64), ("ldo", c_int64), ("n", c_int64), ("s", c_int32), ("d", c_int32)]
+
+
+class Dropout(ctypes.Structure):
+    """struct gs_dropout (include/graphsage_amd.h)"""
+    _fields_ = [("seed", c_uint64), ("clock_dev", c_void_p), ("site", c_uint32), ("rate", c_float), ("row0", c_int64)]
 
 
 class VarDesc(ctypes.Structure):

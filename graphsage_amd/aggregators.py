@@ -14,7 +14,7 @@ hops are contiguous), and `backward_hops` is its hand-written reverse.  `_call` 
 """
 from . import ops
 from .inits import glorot, zeros
-from .layers import Dense, Layer, Rows, _act_code, _check_dropout, relu
+from .layers import SITE_MLP, SITE_NEIGH, SITE_SELF, Dense, Layer, Rows, _act_code, _rate, relu
 from .ops import ACT_IDENTITY, ACT_RELU
 
 
@@ -74,6 +74,30 @@ class _SageBase(Layer):
     def reset(self):
         del self._saved[:]
 
+    # ---- dropout (tf.nn.dropout on the aggregator inputs, aggregators.py:46-47,104-105; layers.py:107) ----
+    def _drop(self, rate, role, k, row0=0):
+        return self.engine.dropout(rate, self.site + role + 4 * k, row0)
+
+    def _no_dropout_here(self, what):
+        if _rate(self.dropout) > 0:
+            raise NotImplementedError("dropout > 0 with %s: use the sequential schedule (model.pipeline = False)" % what)
+
+    def _drop_self(self, self_all, rate, k):
+        """dropout(self_vecs), materialised once ([n_total, d]; small) so that the GEMMs read it as a dense operand."""
+        e = self.engine
+        sd = e.ws_mat((self.name, "self_drop", k), self_all.n, self_all.src.d)
+        ops.dropout_rows(self_all.src, self_all.ids, self_all.n, self._drop(rate, SITE_SELF, k), sd, stream=e.stream)
+        return Rows(sd, None, self_all.n, self_all.requires_grad)
+
+    def _bwd_dropped(self, d_rows, n, s, scale, rate, role, k, row0, dst, relu_mask, accumulate, tag):
+        """dst (+)= relu'(relu_mask) * dropout_mask * broadcast_s(scale * d_rows): the reverse of `dropout` followed by
+        a (segmented) mean, with the mask regenerated from the counter hash."""
+        e = self.engine
+        tmp = e.ws_mat((self.name, "d_bcast", k, tag), n * s, d_rows.d)
+        ops.mean_bwd(d_rows, n, s, scale, tmp, stream=e.stream)
+        ops.dropout_rows(tmp, None, n * s, self._drop(rate, role, k, row0), tmp, stream=e.stream)
+        ops.mean_bwd(tmp, n * s, 1, 1.0, dst, mask_y=relu_mask, accumulate=accumulate, stream=e.stream)
+
     def _call(self, inputs):
         self_vecs, neigh_vecs = inputs
         return self.call_hops(self_vecs, [neigh_vecs])
@@ -129,18 +153,23 @@ class MeanAggregator(_SageBase):
         e = self.engine
         n_total = self_all.n
         d = neighs[0].shape3[2]
-        means = e.ws_mat((self.name, "mean", len(self._saved), tag), n_total, d)
-        r = 0
+        k = len(self._saved)
+        rate = _rate(self.dropout)
+        means = e.ws_mat((self.name, "mean", k, tag), n_total, d)
+        r = row0 = 0
         for nv in neighs:
             n, s, _ = nv.shape3
-            ops.gather_mean_fwd(nv.src, nv.ids, n, s, out=means.rows_slice(r, r + n), stream=e.stream)
+            ops.gather_mean_fwd(nv.src, nv.ids, n, s, out=means.rows_slice(r, r + n),
+                                drop=self._drop(rate, SITE_NEIGH, k, row0), stream=e.stream)   # dropout(neigh_vecs) (:46)
             r += n
+            row0 += n * s
         assert r == n_total
         return means
 
     def prefetch_jobs(self, self_all, neighs, tag=0):
         """Like prefetch(), but only DESCRIBES the gather+mean launches (one per hop) so that they can be issued
         inside another kernel's launch (horizontal fusion).  Returns (means, jobs)."""
+        self._no_dropout_here("the prefetch pipeline")
         e = self.engine
         n_total = self_all.n
         d = neighs[0].shape3[2]
@@ -153,12 +182,13 @@ class MeanAggregator(_SageBase):
         return means, jobs
 
     def call_hops(self, self_all, neighs, means=None, side_jobs=None):
-        _check_dropout(self.dropout)
         e = self.engine
         n_total = self_all.n
         k = len(self._saved)
+        rate = _rate(self.dropout)
         if means is None:
             means = self.prefetch(self_all, neighs)
+        self_in = self._drop_self(self_all, rate, k) if rate > 0 else self_all           # dropout(self_vecs) (:47)
         # from_neighs / from_self matmuls + concat|add + bias + act   (:51-64): ONE launch for all hops
         n_out = self.output_dim * (2 if self.concat else 1)
         out = e.ws_mat((self.name, "out", k), n_total, n_out)
@@ -169,22 +199,24 @@ class MeanAggregator(_SageBase):
                                         self.vars['self_weights'].value, self.vars['neigh_weights'].value,
                                         self.output_dim, self.concat, self.act_code, b, out, side_jobs, stream=e.stream)
         else:
-            ops.sage_dense_fwd(self_all.src, self_all.ids, means, None, n_total, self.vars['self_weights'].value,
+            ops.sage_dense_fwd(self_in.src, self_in.ids, means, None, n_total, self.vars['self_weights'].value,
                                self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
                                stream=e.stream)
-        self._push((self_all, neighs, means, out))
+        self._push((self_all, neighs, means, out, rate, self_in))
         return out
 
     def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
-        self_all, neighs, means, out = self._saved.pop()
+        self_all, neighs, means, out, rate, self_in = self._saved.pop()
         n_total = self_all.n
         k = len(self._saved)
         o = self.output_dim
         n_out = o * (2 if self.concat else 1)
         dz = self._dz(d_out, out, n_total, n_out, pre_masked)
         col_n = o if self.concat else 0
-        e.wgrad(self.vars['self_weights'], self_all.src, self_all.ids, dz, 0, n_total)
+        if rate > 0 and embed_sink is not None:
+            raise NotImplementedError("dropout > 0 together with identity_dim > 0")
+        e.wgrad(self.vars['self_weights'], self_in.src, self_in.ids, dz, 0, n_total)
         e.wgrad(self.vars['neigh_weights'], means, None, dz, col_n, n_total)
         if self.bias:
             e.bgrad(self.vars['bias'], dz, n_total, n_out)
@@ -216,15 +248,24 @@ class MeanAggregator(_SageBase):
             ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value, d_self_all, stream=e.stream)
             d_means_all = e.ws_mat((self.name, "d_means", k), n_total, self.neigh_input_dim)
             ops.dense_dgrad(dz, col_n, o, n_total, self.vars['neigh_weights'].value, d_means_all, stream=e.stream)
+        if rate > 0:
+            ops.dropout_rows(d_self_all, None, n_total, self._drop(rate, SITE_SELF, k), d_self_all, stream=e.stream)
         self._scatter_self(d_self_all, n_total, d_prev, prev_mask)
-        r = 0
+        r = row0 = 0
         for h, nv in enumerate(neighs):
             n, s, _ = nv.shape3
             r0 = prev_offsets[h + 1]
-            ops.mean_bwd(d_means_all.rows_slice(r, r + n), n, s, 1.0 / s, d_prev.rows_slice(r0, r0 + n * s),
-                         mask_y=prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None,
-                         accumulate=(h + 1 < len(neighs)), stream=e.stream)
+            dst = d_prev.rows_slice(r0, r0 + n * s)
+            mask = prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None
+            acc = (h + 1 < len(neighs))
+            if rate > 0:
+                self._bwd_dropped(d_means_all.rows_slice(r, r + n), n, s, 1.0 / s, rate, SITE_NEIGH, k, row0, dst, mask,
+                                  acc, ("n", h))
+            else:
+                ops.mean_bwd(d_means_all.rows_slice(r, r + n), n, s, 1.0 / s, dst, mask_y=mask, accumulate=acc,
+                             stream=e.stream)
             r += n
+            row0 += n * s
 
 
 class GCNAggregator(_SageBase):
@@ -251,6 +292,7 @@ class GCNAggregator(_SageBase):
         self._saved = []
 
     def prefetch_jobs(self, self_all, neighs, tag=0):
+        self._no_dropout_here("the prefetch pipeline")
         e = self.engine
         d = neighs[0].shape3[2]
         means = e.ws_mat((self.name, "mean", len(self._saved), tag), self_all.n, d)
@@ -267,36 +309,42 @@ class GCNAggregator(_SageBase):
         e = self.engine
         n_total = self_all.n
         d = neighs[0].shape3[2]
-        means = e.ws_mat((self.name, "mean", len(self._saved), tag), n_total, d)
-        r = 0
+        k = len(self._saved)
+        rate = _rate(self.dropout)
+        means = e.ws_mat((self.name, "mean", k, tag), n_total, d)
+        self_in = self._drop_self(self_all, rate, k) if rate > 0 else self_all            # dropout(self_vecs) (:105)
+        r = row0 = 0
         for nv in neighs:
             n, s, _ = nv.shape3
-            sv = self_all.slice(r, r + n)
+            sv = self_in.slice(r, r + n)
             ops.gather_mean_fwd(nv.src, nv.ids, n, s, out=means.rows_slice(r, r + n), self_src=sv.src,
-                                self_idx=sv.ids, stream=e.stream)
+                                self_idx=sv.ids, drop=self._drop(rate, SITE_NEIGH, k, row0), stream=e.stream)
             r += n
+            row0 += n * s
         return means
 
     def call_hops(self, self_all, neighs, means=None, side_jobs=None):
-        _check_dropout(self.dropout)
         e = self.engine
         _run_jobs(e, side_jobs)
         n_total = self_all.n
         k = len(self._saved)
+        rate = _rate(self.dropout)
         if means is None:
             means = self.prefetch(self_all, neighs)
         out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
         ops.sage_dense_fwd(None, None, means, None, n_total, None, self.vars['weights'].value, self.output_dim, False,
                            self.act_code, b, out, stream=e.stream)
-        self._push((self_all, neighs, means, out))
+        self._push((self_all, neighs, means, out, rate))
         return out
 
     def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
-        self_all, neighs, means, out = self._saved.pop()
+        self_all, neighs, means, out, rate = self._saved.pop()
         n_total = self_all.n
         k = len(self._saved)
+        if rate > 0 and embed_sink is not None:
+            raise NotImplementedError("dropout > 0 together with identity_dim > 0")
         dz = self._dz(d_out, out, n_total, self.output_dim, pre_masked)
         e.wgrad(self.vars['weights'], means, None, dz, 0, n_total)
         if self.bias:
@@ -319,19 +367,31 @@ class GCNAggregator(_SageBase):
         d_means = e.ws_mat((self.name, "d_means", k), n_total, d)
         ops.dense_dgrad(dz, 0, self.output_dim, n_total, self.vars['weights'].value, d_means, stream=e.stream)
         r = 0
-        for nv in neighs:           # self parts first: d_self = d_means / (s + 1)
+        for h, nv in enumerate(neighs):           # self parts first: d_self = d_means / (s + 1)
             n, s, _ = nv.shape3
-            ops.mean_bwd(d_means.rows_slice(r, r + n), n, 1, 1.0 / (s + 1), d_prev.rows_slice(r, r + n),
-                         mask_y=prev_mask.rows_slice(r, r + n) if prev_mask is not None else None, stream=e.stream)
+            mask = prev_mask.rows_slice(r, r + n) if prev_mask is not None else None
+            if rate > 0:
+                self._bwd_dropped(d_means.rows_slice(r, r + n), n, 1, 1.0 / (s + 1), rate, SITE_SELF, k, r,
+                                  d_prev.rows_slice(r, r + n), mask, False, ("s", h))
+            else:
+                ops.mean_bwd(d_means.rows_slice(r, r + n), n, 1, 1.0 / (s + 1), d_prev.rows_slice(r, r + n),
+                             mask_y=mask, stream=e.stream)
             r += n
-        r = 0
+        r = row0 = 0
         for h, nv in enumerate(neighs):
             n, s, _ = nv.shape3
             r0 = prev_offsets[h + 1]
-            ops.mean_bwd(d_means.rows_slice(r, r + n), n, s, 1.0 / (s + 1), d_prev.rows_slice(r0, r0 + n * s),
-                         mask_y=prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None,
-                         accumulate=(h + 1 < len(neighs)), stream=e.stream)
+            dst = d_prev.rows_slice(r0, r0 + n * s)
+            mask = prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None
+            acc = (h + 1 < len(neighs))
+            if rate > 0:
+                self._bwd_dropped(d_means.rows_slice(r, r + n), n, s, 1.0 / (s + 1), rate, SITE_NEIGH, k, row0, dst, mask,
+                                  acc, ("n", h))
+            else:
+                ops.mean_bwd(d_means.rows_slice(r, r + n), n, s, 1.0 / (s + 1), dst, mask_y=mask, accumulate=acc,
+                             stream=e.stream)
             r += n
+            row0 += n * s
 
 
 class _PoolingAggregator(_SageBase):
@@ -379,11 +439,11 @@ class _PoolingAggregator(_SageBase):
         return None, []
 
     def call_hops(self, self_all, neighs, means=None, side_jobs=None):
-        _check_dropout(self.dropout)
         e = self.engine
         _run_jobs(e, side_jobs)
         n_total = self_all.n
         k = len(self._saved)
+        rate = _rate(self.dropout)
         mlp = self.mlp_layers[0]
         rows_total = sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)
         # h_reshaped = Dense(reshape(neigh, [n*s, d]))   (aggregators.py:176-179): one GEMM over every neighbor row
@@ -391,6 +451,16 @@ class _PoolingAggregator(_SageBase):
         flat = [Rows(nv.src, nv.ids, nv.shape3[0] * nv.shape3[1], nv.requires_grad) for nv in neighs]
         x_all = _contiguous(flat)
         pieces = [x_all] if x_all is not None else flat
+        if rate > 0:
+            # the Dense's x = tf.nn.dropout(x, 1 - dropout) (layers.py:107) over every gathered neighbor row: the
+            # dropped rows are materialised ([n*s, d]) and feed the MLP GEMM and its weight gradient as a dense operand
+            dropped, r = [], 0
+            for i, x in enumerate(pieces):
+                xd = e.ws_mat((self.name, "x_drop", k, i), x.n, x.src.d)
+                ops.dropout_rows(x.src, x.ids, x.n, self._drop(rate, SITE_MLP, k, r), xd, stream=e.stream)
+                dropped.append(Rows(xd, None, x.n, x.requires_grad))
+                r += x.n
+            pieces = dropped
         r = 0
         for x in pieces:
             ops.sage_dense_fwd(None, None, x.src, x.ids, x.n, None, mlp.vars['weights'].value, self.hidden_dim, False,
@@ -417,14 +487,16 @@ class _PoolingAggregator(_SageBase):
         ops.sage_dense_fwd(self_all.src, self_all.ids, pooled, None, n_total, self.vars['self_weights'].value,
                            self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
                            stream=e.stream)
-        self._push((self_all, neighs, pieces, H, pooled, argmax, out))
+        self._push((self_all, neighs, pieces, H, pooled, argmax, out, rate))
         return out
 
     def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
-        self_all, neighs, pieces, H, pooled, argmax, out = self._saved.pop()
+        self_all, neighs, pieces, H, pooled, argmax, out, rate = self._saved.pop()
         n_total = self_all.n
         k = len(self._saved)
+        if rate > 0 and embed_sink is not None:
+            raise NotImplementedError("dropout > 0 together with identity_dim > 0")
         o = self.output_dim
         n_out = o * (2 if self.concat else 1)
         mlp = self.mlp_layers[0]
@@ -444,7 +516,8 @@ class _PoolingAggregator(_SageBase):
             ops.act_bwd(d_pooled, pooled, n_total, self.hidden_dim, ACT_RELU, dpm, stream=e.stream)
             e.bgrad(mlp.vars['bias'], dpm, n_total, self.hidden_dim)   # column sums of dH == column sums of dpm
         threads = min(512, (self.hidden_dim + 63) // 64 * 64)
-        sparse = (self.POOL == "max" and d_prev is None and embed_sink is None and all(nv.ids is not None for nv in neighs)
+        sparse = (self.POOL == "max" and d_prev is None and embed_sink is None and rate == 0
+                  and all(nv.ids is not None for nv in neighs)
                   and getattr(self, "sparse_wgrad", True)
                   and 16 * max(nv.shape3[1] for nv in neighs) <= 4 * threads)
         if sparse:
@@ -494,6 +567,8 @@ class _PoolingAggregator(_SageBase):
         self._scatter_self(d_self_all, n_total, d_prev, prev_mask)
         d_neigh = e.ws_mat((self.name, "d_neigh", k), H.rows, self.neigh_input_dim)
         ops.dense_dgrad(dH, 0, self.hidden_dim, H.rows, mlp.vars['weights'].value, d_neigh, stream=e.stream)
+        if rate > 0:
+            ops.dropout_rows(d_neigh, None, H.rows, self._drop(rate, SITE_MLP, k), d_neigh, stream=e.stream)
         hr = 0
         for h, nv in enumerate(neighs):
             n, s, _ = nv.shape3

@@ -47,3 +47,55 @@ __host__ __device__ static inline int64_t gs_ceil_div(int64_t a, int64_t b) { re
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// splitmix64 finalizer: xorshift-multiply rounds.  Restated bit-for-bit in oracle/sampler_hash.py.
+__device__ __forceinline__ uint64_t gs_mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+// ---- inverted dropout, tf.nn.dropout(x, keep_prob = 1 - rate) (aggregators.py:46-47,104-105; layers.py:107) ----
+// The keep mask is a pure function of (seed, device step clock, call site, global row, float4 column): one mix64 per
+// float4 gives 16 random bits per element, an element is dropped iff its bits < thresh16 = round(rate * 2^16).
+// Forward and backward regenerate the same mask; nothing is stored.  Restated in oracle/sampler_hash.py.
+struct DropArgs {
+    uint64_t seed;
+    const uint64_t* clock;   // device step counter (nullable = 0): new masks every step, also under hipGraph replay
+    uint32_t site;
+    uint32_t thresh16;       // 0 = dropout off
+    float scale;             // 1 / keep_prob
+    int64_t row0;            // global index of the call's first row
+};
+
+__device__ __forceinline__ uint64_t gs_drop_key(const DropArgs& p) {
+    const uint64_t st = p.clock ? *p.clock : 0ull;
+    return gs_mix64(p.seed ^ (st * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)p.site << 32) ^ (0xD0ull << 56));
+}
+
+__device__ __forceinline__ f32x4 gs_drop4(f32x4 v, uint64_t key, int64_t grow, int q, uint32_t thresh16, float scale) {
+    const uint64_t h = gs_mix64(key + (uint64_t)grow * 0xD1342543DE82EF95ull + (uint64_t)q);
+    v.x = (((uint32_t)h) & 0xffffu) >= thresh16 ? v.x * scale : 0.f;
+    v.y = (((uint32_t)(h >> 16)) & 0xffffu) >= thresh16 ? v.y * scale : 0.f;
+    v.z = (((uint32_t)(h >> 32)) & 0xffffu) >= thresh16 ? v.z * scale : 0.f;
+    v.w = ((uint32_t)(h >> 48)) >= thresh16 ? v.w * scale : 0.f;
+    return v;
+}
+
+// host: C-ABI descriptor -> kernel argument (null / rate 0 = off)
+static inline int gs_drop_args(const gs_dropout* d, DropArgs* out) {
+    DropArgs a = {0ull, nullptr, 0u, 0u, 1.0f, 0};
+    if (d && d->rate > 0.f) {
+        if (!(d->rate < 1.f)) return -1;
+        a.seed = d->seed; a.clock = d->clock_dev; a.site = d->site; a.row0 = d->row0;
+        uint32_t t = (uint32_t)(d->rate * 65536.0f + 0.5f);
+        a.thresh16 = t < 1u ? 1u : (t > 65535u ? 65535u : t);
+        a.scale = 1.0f / (1.0f - d->rate);
+    }
+    *out = a;
+    return 0;
+}
+

@@ -10,24 +10,33 @@
 #include "gs_common.h"
 #include "gs_gather_dev.h"
 
-template <int U>
+template <int U, bool DROP = false>
 __global__ __launch_bounds__(256) void gather_mean_kernel(const GatherArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t n_items = a.n * (int64_t)a.chunks;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_items) return;  // wave-uniform
-    gather_mean_wave<U>(a, w, lane);
+    gather_mean_wave<U, DROP>(a, w, lane);
 }
 
 static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
                               const float* S, int64_t ld_self, const int32_t* sidx, float* out, int64_t ldo,
-                              float scale, hipStream_t st) {
+                              float scale, hipStream_t st, const DropArgs* drop = nullptr) {
     const int d4 = (d + 3) / 4;
     const int chunks = (d4 + 63) / 64;
     const int64_t n_items = n * (int64_t)chunks;
     const int64_t blocks = gs_ceil_div(n_items, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gather: grid too large (%lld blocks)", (long long)blocks);
-    GatherArgs a = {X, ldx, idx, n, s, d, S, ld_self, sidx, out, ldo, scale, chunks};
+    GatherArgs a = {X, ldx, idx, n, s, d, S, ld_self, sidx, out, ldo, scale, chunks, {0ull, nullptr, 0u, 0u, 1.0f, 0}};
+    if (drop && drop->thresh16) {
+        a.drop = *drop;
+        if (s >= 8)
+            hipLaunchKernelGGL((gather_mean_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((gather_mean_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        GS_LAUNCH_CHECK("gather_mean_kernel<dropout>");
+        return GS_OK;
+    }
     if (s >= 8)
         hipLaunchKernelGGL(gather_mean_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     else if (s >= 4)
@@ -38,9 +47,9 @@ static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, i
     return GS_OK;
 }
 
-extern "C" int gs_gather_mean_fwd(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
-                                  const float* self_src, int64_t ld_self, const int32_t* self_idx, float* mean,
-                                  int64_t ldm, void* stream) {
+static int gather_mean_entry(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
+                             const float* self_src, int64_t ld_self, const int32_t* self_idx, float* mean, int64_t ldm,
+                             const DropArgs* drop, void* stream) {
     if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_CHECK_MAT(X, ldx, "gs_gather_mean_fwd X");
     GS_CHECK_MAT(mean, ldm, "gs_gather_mean_fwd mean");
@@ -55,7 +64,54 @@ extern "C" int gs_gather_mean_fwd(const float* X, int64_t ldx, const int32_t* id
     if (n == 0) return GS_OK;
     const float scale = self_src ? 1.0f / (float)(s + 1) : 1.0f / (float)s;
     return launch_gather_mean(X, ldx, idx, n, s, d, self_src, ld_self, self_idx, mean, ldm, scale,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, drop);
+}
+
+extern "C" int gs_gather_mean_fwd(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
+                                  const float* self_src, int64_t ld_self, const int32_t* self_idx, float* mean,
+                                  int64_t ldm, void* stream) {
+    return gather_mean_entry(X, ldx, idx, n, s, d, self_src, ld_self, self_idx, mean, ldm, nullptr, stream);
+}
+
+extern "C" int gs_gather_mean_dropout_fwd(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
+                                          const float* self_src, int64_t ld_self, const int32_t* self_idx, float* mean,
+                                          int64_t ldm, const gs_dropout* drop, void* stream) {
+    DropArgs da;
+    GS_REQUIRE(gs_drop_args(drop, &da) == 0, "gs_gather_mean_dropout_fwd: dropout rate must be in [0, 1)");
+    return gather_mean_entry(X, ldx, idx, n, s, d, self_src, ld_self, self_idx, mean, ldm, &da, stream);
+}
+
+// ------------------------------------------------------------------ dropout of (gathered) rows; its own backward
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ X, int64_t ldx,
+                                                           const int32_t* __restrict__ ids, int64_t n, int32_t d,
+                                                           const DropArgs p, float* __restrict__ out, int64_t ldo) {
+    const int d4 = (d + 3) / 4;
+    const int64_t total = n * (int64_t)d4;
+    const uint64_t key = gs_drop_key(p);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / d4;
+        const int q = (int)(t - r * d4);
+        const int64_t src = ids ? (int64_t)ids[r] : r;
+        f32x4 v = *reinterpret_cast<const f32x4*>(X + src * ldx + q * 4);
+        if (p.thresh16) v = gs_drop4(v, key, p.row0 + r, q, p.thresh16, p.scale);
+        *reinterpret_cast<f32x4*>(out + r * ldo + q * 4) = gs_mask_tail(v, q * 4, d);
+    }
+}
+
+extern "C" int gs_dropout_rows(const float* X, int64_t ldx, const int32_t* ids, int64_t n, int32_t d,
+                               const gs_dropout* drop, float* out, int64_t ldo, void* stream) {
+    if (n == 0) return GS_OK;
+    GS_CHECK_MAT(X, ldx, "gs_dropout_rows X");
+    GS_CHECK_MAT(out, ldo, "gs_dropout_rows out");
+    const int d4x4 = ((d + 3) / 4) * 4;
+    GS_REQUIRE(n > 0 && d > 0 && ldx >= d4x4 && ldo >= d4x4, "gs_dropout_rows: bad sizes / ld");
+    DropArgs da;
+    GS_REQUIRE(gs_drop_args(drop, &da) == 0, "gs_dropout_rows: dropout rate must be in [0, 1)");
+    const int64_t total = n * (int64_t)(d4x4 / 4);
+    const int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 65536);
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, ids, n, d, da, out, ldo);
+    GS_LAUNCH_CHECK("dropout_rows_kernel");
+    return GS_OK;
 }
 
 extern "C" int gs_gather_rows(const float* X, int64_t ldx, const int32_t* ids, int64_t n, int32_t d, float* out,

@@ -16,6 +16,7 @@ struct GatherArgs {
     int64_t ldo;
     float scale;
     int32_t chunks;      // 64-float4 column chunks per row
+    DropArgs drop;       // dropout of the gathered rows (thresh16 == 0: off)
 };
 
 __device__ __forceinline__ f32x4 gs_mask_tail(f32x4 v, int col, int d) {
@@ -30,7 +31,7 @@ __device__ __forceinline__ f32x4 gs_mask_tail(f32x4 v, int col, int d) {
 }
 
 // One wave = one (output row, 64-float4 column chunk) work item `w` (wave-uniform).
-template <int U>
+template <int U, bool DROP = false>
 __device__ __forceinline__ void gather_mean_wave(const GatherArgs& a, const int64_t w, const int lane) {
     const float* __restrict__ X = a.X;
     const int32_t* __restrict__ idx = a.idx;
@@ -40,6 +41,11 @@ __device__ __forceinline__ void gather_mean_wave(const GatherArgs& a, const int6
     const int c = (int)(w - row * chunks);
     const int col = (c * 64 + lane) * 4;
     const bool active = col < d;
+
+    uint64_t dkey = 0;
+    if (DROP) dkey = gs_drop_key(a.drop);
+    const int64_t drow = a.drop.row0 + row * s;   // global index of this output row's first sampled row
+    const int q = c * 64 + lane;
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int jb = 0; jb < s; jb += 64) {
@@ -56,7 +62,10 @@ __device__ __forceinline__ void gather_mean_wave(const GatherArgs& a, const int6
                     v[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + col);
                 }
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc += v[u];
+                for (int u = 0; u < U; ++u) {
+                    if (DROP) v[u] = gs_drop4(v[u], dkey, drow + jb + j + u, q, a.drop.thresh16, a.drop.scale);
+                    acc += v[u];
+                }
             }
             if (j < cnt) {
                 // remainder batch: load everything (index clamped), select afterwards -- keeps the
@@ -71,6 +80,7 @@ __device__ __forceinline__ void gather_mean_wave(const GatherArgs& a, const int6
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float m = (j + u < cnt) ? 1.f : 0.f;
+                    if (DROP) v[u] = gs_drop4(v[u], dkey, drow + jb + min(j + u, cnt - 1), q, a.drop.thresh16, a.drop.scale);
                     acc += v[u] * m;
                 }
             }

@@ -717,7 +717,8 @@ extern "C" int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, co
         if (q.self_src) GS_CHECK_MAT(q.self_src, q.ld_self, "gs_sage_dense_fwd_cogather job self");
         const int chunks = ((q.d + 3) / 4 + 63) / 64;
         J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
-                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks};
+                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
+                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
         J.wave_start[i] = waves;
         waves += q.n * (int64_t)chunks;
     }

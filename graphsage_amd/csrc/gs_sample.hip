@@ -40,15 +40,7 @@ extern "C" int gs_sample_padded(const int32_t* adj, int64_t n_adj_rows, int32_t 
     return GS_OK;
 }
 
-// splitmix64 finalizer: xorshift-multiply rounds.  Restated bit-for-bit in oracle/sampler_hash.py.
-__device__ __forceinline__ uint64_t gs_mix64(uint64_t z) {
-    z ^= z >> 30;
-    z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27;
-    z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
+// gs_mix64 (gs_common.h): splitmix64 finalizer, restated bit-for-bit in oracle/sampler_hash.py.
 
 __global__ __launch_bounds__(256) void sample_csr_kernel(const int64_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col, int64_t n_nodes,

@@ -5,14 +5,6 @@
 //                          and the gradients w.r.t. the three groups of (l2-normalised) embeddings, one wave per pair.
 #include "gs_common.h"
 
-__device__ __forceinline__ uint64_t gs_mix64u(uint64_t z) {
-    z ^= z >> 30;
-    z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27;
-    z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
 
 // ids_out = [batch1 (B) | batch2 (B) | negatives (n_neg)].  pairs: int32 [n_pairs, 2] (may be NULL: roots already
 // staged by the host).  cdf: uint32 [n_nodes], cdf[i] = floor(2^32 * P(node <= i)) with P ~ degree^0.75 (last = 2^32-1);
@@ -31,8 +23,8 @@ __global__ __launch_bounds__(256) void unsup_stage_kernel(const int32_t* __restr
     }
     if (cdf && t < n_neg) {
         const uint64_t st = clock ? *clock : 0ull;
-        const uint64_t key = gs_mix64u(seed ^ (st * 0x9E3779B97F4A7C15ull) ^ (0xFFull << 56));
-        const uint32_t r = (uint32_t)(gs_mix64u(key + (uint64_t)t) >> 32);
+        const uint64_t key = gs_mix64(seed ^ (st * 0x9E3779B97F4A7C15ull) ^ (0xFFull << 56));
+        const uint32_t r = (uint32_t)(gs_mix64(key + (uint64_t)t) >> 32);
         int64_t lo = 0, hi = n_nodes - 1;  // first index with cdf[idx] > r
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;

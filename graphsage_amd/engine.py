@@ -70,6 +70,8 @@ class Engine(object):
         self.finalized = False
         self._pending = []
         self.post_update_hooks = []
+        self.dropout_seed = 123
+        self._n_sites = 0
         # second stream for the data chain (sampling + gathers of the NEXT step overlap this step's compute)
         self._stream2_obj = None
         self.stream2 = None
@@ -81,6 +83,15 @@ class Engine(object):
         v = Variable(name, init, decay, scatter)
         self.variables.append(v)
         return v
+
+    def new_site(self):
+        """A block of 16 dropout call-site ids (role + 4 * call index) for one layer object."""
+        self._n_sites += 1
+        return 16 * self._n_sites
+
+    def dropout(self, rate, site, row0=0):
+        """gs_dropout descriptor keyed by the device step clock (None when rate == 0)."""
+        return ops.dropout_desc(self.dropout_seed, self.sample_clock_dev, site, rate, row0)
 
     def finalize(self):
         """Lay all variables out in one flat buffer (16-byte aligned segments)."""

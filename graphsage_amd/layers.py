@@ -96,6 +96,7 @@ class Layer(object):
         self.logging = kwargs.get('logging', False)
         self.sparse_inputs = False
         self.engine = get_engine()
+        self.site = self.engine.new_site()
 
     def _call(self, inputs):
         return inputs
@@ -107,11 +108,18 @@ class Layer(object):
         pass  # TF histogram summaries (layers.py:68-70) have no equivalent here
 
 
-def _check_dropout(dropout):
+def _rate(dropout):
+    """Current dropout rate of a layer: a number, or the model's `dropout` placeholder (fed per step,
+    supervised_train.py:117; 0 for validation feeds, minibatch.py:269 / supervised_train.py:58-61)."""
     p = dropout.value if hasattr(dropout, "value") else dropout
-    if p is not None and float(p) != 0.0:
-        raise NotImplementedError("dropout > 0 is not implemented in the gfx950 kernels yet "
-                                  "(reference default is 0.0, supervised_train.py:38)")
+    p = float(p) if p is not None else 0.0
+    if not 0.0 <= p < 1.0:
+        raise ops._lib.GraphsageAmdError("dropout rate must be in [0, 1), got %r" % p)
+    return p
+
+
+# dropout call-site roles inside one layer object (site id = layer.site + role + 4 * call index)
+SITE_SELF, SITE_NEIGH, SITE_MLP, SITE_DENSE = 0, 1, 2, 3
 
 
 class Dense(Layer):
@@ -136,20 +144,25 @@ class Dense(Layer):
 
     def _call(self, inputs):
         """inputs: Rows [n, input_dim] (possibly a lazy row gather).  Returns a Mat [n, output_dim]."""
-        _check_dropout(self.dropout)
         x = inputs if isinstance(inputs, Rows) else Rows(inputs)
         e = self.engine
-        out = e.ws_mat((self.name, "out", len(self._saved)), x.n, self.output_dim)
+        k = len(self._saved)
+        rate = _rate(self.dropout)
+        if rate > 0:                                                     # x = tf.nn.dropout(x, 1 - dropout)  (:107)
+            xd = e.ws_mat((self.name, "x_drop", k), x.n, self.input_dim)
+            ops.dropout_rows(x.src, x.ids, x.n, e.dropout(rate, self.site + SITE_DENSE + 4 * k), xd, stream=e.stream)
+            x = Rows(xd, None, x.n, x.requires_grad)
+        out = e.ws_mat((self.name, "out", k), x.n, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
         ops.sage_dense_fwd(None, None, x.src, x.ids, x.n, None, self.vars['weights'].value, self.output_dim, False,
                            self.act_code, b, out, stream=e.stream)
-        self._saved.append((x, out))
+        self._saved.append((x, out, rate))
         return out
 
     def backward(self, d_out, need_input_grad=True, pre_masked=False):
         """d_out: Mat [n, output_dim] = dLoss/d(output).  Returns dLoss/d(input) (Mat) or None."""
         e = self.engine
-        x, out = self._saved.pop()
+        x, out, rate = self._saved.pop()
         dz = d_out
         if self.act_code == ACT_RELU and not pre_masked:
             dz = e.ws_mat((self.name, "dz", len(self._saved)), x.n, self.output_dim)
@@ -161,4 +174,7 @@ class Dense(Layer):
             return None
         dx = e.ws_mat((self.name, "dx", len(self._saved)), x.n, self.input_dim)
         ops.dense_dgrad(dz, 0, self.output_dim, x.n, self.vars['weights'].value, dx, stream=e.stream)
+        if rate > 0:
+            ops.dropout_rows(dx, None, x.n, e.dropout(rate, self.site + SITE_DENSE + 4 * len(self._saved)), dx,
+                             stream=e.stream)
         return dx

@@ -105,6 +105,7 @@ class SampleAndAggregate(object):
         self.weight_decay = float(weight_decay)
         self.neg_sample_size = int(neg_sample_size)
         self.world_size, self.rank = int(world_size), int(rank)
+        self.engine.dropout_seed = 123 + 1000003 * self.rank      # every data-parallel rank draws its own masks
         self.row_offset = 0
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
@@ -257,8 +258,7 @@ class SampleAndAggregate(object):
         b2 = np.ascontiguousarray(np.asarray(feed_dict[ph['batch2']]), dtype=np.int32)
         B = int(b1.shape[0])
         assert b2.shape[0] == B and int(feed_dict.get(ph['batch_size'], B)) == B
-        if float(feed_dict.get(ph['dropout'], 0.0)) != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented in the gfx950 kernels yet")
+        self._feed_dropout(feed_dict)
         roots, n_roots = self._roots(B, parity=0)
         roots[:B].copy_(torch.from_numpy(b1))
         roots[B:2 * B].copy_(torch.from_numpy(b2))
@@ -584,6 +584,7 @@ class SampleAndAggregate(object):
         that name a step's output buffers are snapshotted per key and restored on replay (the Python of `fn` does
         not run again, and other step shapes -- e.g. a validation batch -- may have re-pointed them meanwhile)."""
         e = self.engine
+        key = tuple(key) + (self._dropout_rate(),)     # the rate is baked into the captured launches
         g = self._graphs.get(key)
         if g is not None:
             for name, val in self._graph_outputs[key].items():
@@ -603,6 +604,17 @@ class SampleAndAggregate(object):
         self._graphs[key] = g
         self._graph_outputs[key] = {name: getattr(self, name) for name in self._OUT_ATTRS if hasattr(self, name)}
         g.launch()
+
+    def _feed_dropout(self, feed_dict):
+        """feed_dict[placeholders['dropout']] (supervised_train.py:117; validation feeds omit it = 0): every layer
+        holds the placeholder and reads the rate when it runs."""
+        ph = self.placeholders['dropout']
+        ph.value = float(feed_dict.get(ph, 0.0))
+        return self._dropout_rate()
+
+    def _dropout_rate(self):
+        from .layers import _rate
+        return _rate(self.placeholders['dropout']) if self.placeholders and 'dropout' in self.placeholders else 0.0
 
     def _needs_host_rng(self):
         from .neigh_samplers import PaddedAdjacency

@@ -3,6 +3,8 @@
 `Mat` is a row-major fp32 device matrix with a padded leading dimension (what every kernel expects:
 16-byte aligned base, ld % 4 == 0).  torch only owns the memory.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -127,10 +129,30 @@ def gather_rows(X, ids, out=None, stream=None):
     return out
 
 
-def gather_mean_fwd(X, idx, n, s, out=None, self_src=None, self_idx=None, stream=None):
-    """idx: int32 [n*s] or None (contiguous groups).  self_src (Mat) switches to the GCN mean."""
+def dropout_desc(seed, clock_dev, site, rate, row0=0):
+    """struct gs_dropout; None when rate == 0 (dropout off)."""
+    if not rate:
+        return None
+    return _lib.Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(clock_dev), int(site), float(rate), int(row0))
+
+
+def dropout_rows(X, ids, n, drop, out, stream=None):
+    """out[i] = mask * X[ids[i] or i] / keep_prob (tf.nn.dropout); also its own backward.  In place when ids is None."""
+    call("gs_dropout_rows", X.ptr, X.ld, ptr(ids), n, X.d, ctypes.addressof(drop) if drop is not None else None,
+         out.ptr, out.ld, _s(stream))
+    return out
+
+
+def gather_mean_fwd(X, idx, n, s, out=None, self_src=None, self_idx=None, drop=None, stream=None):
+    """idx: int32 [n*s] or None (contiguous groups).  self_src (Mat) switches to the GCN mean.  `drop`: dropout of
+    every gathered neighbor row before the mean."""
     if out is None:
         out = Mat.zeros(n, X.d, X.buf.device)
+    if drop is not None:
+        call("gs_gather_mean_dropout_fwd", X.ptr, X.ld, ptr(idx), n, s, X.d,
+             self_src.ptr if self_src is not None else None, self_src.ld if self_src is not None else 0,
+             ptr(self_idx), out.ptr, out.ld, ctypes.addressof(drop), _s(stream))
+        return out
     call("gs_gather_mean_fwd", X.ptr, X.ld, ptr(idx), n, s, X.d,
          self_src.ptr if self_src is not None else None, self_src.ld if self_src is not None else 0,
          ptr(self_idx), out.ptr, out.ld, _s(stream))

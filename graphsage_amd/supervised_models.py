@@ -55,7 +55,7 @@ class SupervisedGraphsage(SampleAndAggregate):
     # ------------------------------------------------------------------------------ one step
     def _fused_head_ok(self, d):
         C = self.num_classes
-        return (getattr(self, "fuse_head", True) and d in (64, 128, 256, 512) and C <= 128
+        return (getattr(self, "fuse_head", True) and self._dropout_rate() == 0 and d in (64, 128, 256, 512) and C <= 128
                 and (d * (((C + 3) & ~3) | 1) + 4 + 4 * d) * 4 <= 160 * 1024)
 
     def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None):
@@ -139,9 +139,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         n = int(batch.shape[0])
         bs = feed_dict.get(ph['batch_size'], n)
         assert int(bs) == n, "batch_size feed (%s) != len(batch) (%d)" % (bs, n)
-        drop = feed_dict.get(ph['dropout'], 0.0)
-        if float(drop) != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented in the gfx950 kernels yet")
+        self._feed_dropout(feed_dict)
         batch_dev = self.ids_buffer(n)[0][:n]     # head of the contiguous id buffer (see models.sample)
         batch_dev.copy_(torch.from_numpy(batch))
         labels = np.ascontiguousarray(np.asarray(feed_dict[ph['labels']]), dtype=np.float32)
@@ -218,7 +216,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         of step t (MFMA-bound), as the two branches of ONE fork/join hipGraph.  Buffers alternate by parity; the
         batches, samples and updates are exactly those of the sequential schedule."""
         e = self.engine
-        if not getattr(self, "pipeline", True):
+        if not getattr(self, "pipeline", True) or self._dropout_rate() > 0:
             self._parity = 0
             batch_dev = self.ids_buffer(n)[0][:n]
             labels_dev = e.ws_mat(("labels", 0), n, self.num_classes)
@@ -301,7 +299,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         are replayed per hipGraph launch (amortises the launch gap; the schedule and results are unchanged)."""
         fused = self.grad_hook is None
         k = steps_per_launch - (steps_per_launch % 2)
-        if not (getattr(self, "pipeline", True) and fused and self.use_graphs and k >= 2):
+        if not (getattr(self, "pipeline", True) and self._dropout_rate() == 0 and fused and self.use_graphs and k >= 2):
             for _ in range(steps):
                 self.train_step_device(n)
             return

@@ -329,6 +329,28 @@ int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* par
                         int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,
                         float eps, float clip, float grad_scale, const uint64_t* step_dev, void* stream);
 
+/* Inverted dropout tf.nn.dropout(x, keep_prob = 1 - rate) (aggregators.py:46-47,104-105; layers.py:107): kept
+ * elements are scaled by 1/keep_prob.  The keep mask is a counter hash of (seed, *clock_dev, site, row0 + row,
+ * column), so forward and backward regenerate it and a replayed hipGraph draws new masks every step (clock_dev is the
+ * device step counter).  A NULL descriptor or rate == 0 means "off". */
+typedef struct gs_dropout {
+    uint64_t seed;
+    const uint64_t* clock_dev; /* device pointer, nullable (= 0) */
+    uint32_t site;             /* distinct per dropout call site of a step */
+    float rate;                /* in [0, 1) */
+    int64_t row0;              /* global index of this call's first row */
+} gs_dropout;
+/* out[i, :] = mask(row0 + i, :) * X[ids ? ids[i] : i, :] / keep_prob     (in place allowed when ids == NULL).
+ * The same call is the backward of itself (X = upstream gradient). */
+int gs_dropout_rows(const float* X, int64_t ldx, const int32_t* ids, int64_t n, int32_t d, const gs_dropout* drop,
+                    float* out, int64_t ldo, void* stream);
+/* K2 with dropout applied to every gathered neighbor row BEFORE the mean (aggregators.py:46-48):
+ *   mean[i, :] = (1/s) * sum_j mask(row0 + i*s + j, :) * X[idx[i*s + j], :] / keep_prob
+ * (self_src as in gs_gather_mean_fwd; the caller passes already-dropped self rows). */
+int gs_gather_mean_dropout_fwd(const float* X, int64_t ldx, const int32_t* idx, int64_t n, int32_t s, int32_t d,
+                               const float* self_src, int64_t ld_self, const int32_t* self_idx, float* mean,
+                               int64_t ldm, const gs_dropout* drop, void* stream);
+
 /* Trainable identity features ("node_embeddings", models.py:229-240 / supervised_models.py:49-60): gradient of the
  * layer-0 row gathers w.r.t. the leading `cols` columns of the gathered table, accumulated with fp32 atomics
  * (tf.gradients of embedding_lookup: IndexedSlices summed per id):

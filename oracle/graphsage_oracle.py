@@ -301,27 +301,47 @@ def _agg_bwd(aggregator_type, p, dy, cache, concat, act):
 
 
 def aggregate_fwd(samples, features, dims, num_samples, support_sizes, batch_size, params,
-                  aggregator_type="mean", concat=True):
+                  aggregator_type="mean", concat=True, masks=None):
     """hidden[h] = features[samples[h]] for every hop (:299); for each layer, for
     each hop < K-layer, h = aggregator((hidden[hop], reshape(hidden[hop+1],
     [batch*support[hop], num_samples[K-1-hop], dim_mult*dims[layer]]))) (:321-328);
-    the last layer has identity activation (:307-310).  Returns (out, tape)."""
+    the last layer has identity activation (:307-310).  Returns (out, tape).
+
+    Dropout (tf.nn.dropout(x, 1 - p) = x * mask / (1 - p)) is INJECTED like the sampler's
+    permutations: masks(layer, hop, role, n_rows, d) returns the already scaled mask of
+    role "self" ([n, d]) / "neigh" ([n*s, d]) or None.  Mean/GCN drop both inputs
+    (aggregators.py:46-47, :104-105); the pooling aggregators drop only the neighbor rows,
+    inside their Dense MLP (layers.py:107), so their "self" mask is None."""
     K = len(num_samples)
     hidden = [features[np.asarray(s, dtype=np.int64)] for s in samples]
     tape = []
+    mask_table = []
     for layer in range(K):
         act = "id" if layer == K - 1 else "relu"
         dim_mult = 2 if (concat and layer != 0) else 1
         next_hidden = []
         layer_tape = []
+        layer_masks = []
         for hop in range(K - layer):
             neigh_dims = (batch_size * support_sizes[hop], num_samples[K - hop - 1], dim_mult * dims[layer])
-            y, cache = _agg_fwd(aggregator_type, params[layer], hidden[hop],
-                                hidden[hop + 1].reshape(neigh_dims), concat, act)
+            self_in, neigh_in = hidden[hop], hidden[hop + 1].reshape(neigh_dims)
+            ms = mn = None
+            if masks is not None:
+                ms = masks(layer, hop, "self", neigh_dims[0], neigh_dims[2])
+                mn = masks(layer, hop, "neigh", neigh_dims[0] * neigh_dims[1], neigh_dims[2])
+                if ms is not None:
+                    self_in = self_in * ms
+                if mn is not None:
+                    mn = mn.reshape(neigh_dims)
+                    neigh_in = neigh_in * mn
+            y, cache = _agg_fwd(aggregator_type, params[layer], self_in, neigh_in, concat, act)
             next_hidden.append(y)
             layer_tape.append(cache)
+            layer_masks.append((ms, mn))
         tape.append(layer_tape)
+        mask_table.append(layer_masks)
         hidden = next_hidden
+    tape.append(mask_table)      # tape[K]: the injected dropout masks, tape[layer][hop] stays the aggregator cache
     return hidden[0], tape
 
 
@@ -339,8 +359,12 @@ def aggregate_bwd(d_out, tape, params, num_samples, aggregator_type="mean", conc
         d_prev = [None] * (K - layer + 1)
         g_layer = None
         for hop in range(K - layer):
-            d_self, d_neigh, g = _agg_bwd(aggregator_type, params[layer], d_hidden[hop],
-                                          tape[layer][hop], concat, act)
+            ms, mn = tape[K][layer][hop] if len(tape) > K else (None, None)
+            d_self, d_neigh, g = _agg_bwd(aggregator_type, params[layer], d_hidden[hop], tape[layer][hop], concat, act)
+            if ms is not None:
+                d_self = d_self * ms
+            if mn is not None:
+                d_neigh = d_neigh.reshape(mn.shape) * mn
             if g_layer is None:
                 g_layer = {k: v.copy() for k, v in g.items()}
             else:
@@ -432,18 +456,21 @@ def make_supervised_params(aggregator_type, dims, num_classes, concat, rng, mode
 
 def supervised_fwd_bwd(params, features, samples, support_sizes, labels, dims, num_samples, batch_size,
                        aggregator_type="mean", concat=True, sigmoid_loss=False, weight_decay=0.0,
-                       want_grads=True, identity_dim=0):
+                       want_grads=True, identity_dim=0, masks=None, head_mask=None):
     """SupervisedGraphsage.build/_loss/predict on INJECTED `samples`
     (supervised_models.py:78-126).  Returns dict with loss, preds, outputs1,
     node_preds and (optionally) clipped-free raw grads.  With identity_dim > 0,
     `features` is concat([node_embeddings, fixed features], axis=1)
     (supervised_models.py:49-60) and grads["embeds"] is returned (no weight decay:
-    the embedding is in neither aggregator.vars nor node_pred.vars)."""
+    the embedding is in neither aggregator.vars nor node_pred.vars).  `masks` as in
+    aggregate_fwd; `head_mask` [batch, dim] is the scaled dropout mask of the
+    prediction Dense's input (layers.py:107)."""
     out, tape = aggregate_fwd(samples, features, dims, num_samples, support_sizes, batch_size,
-                              params["agg"], aggregator_type, concat)
+                              params["agg"], aggregator_type, concat, masks=masks)
     out_n, ncache = l2_normalize_fwd(out)                                 # :85
     W, b = params["node_pred"]["weights"], params["node_pred"]["bias"]
-    logits = out_n @ W + b                                                # :88-92 (Dense, identity act)
+    head_in = out_n if head_mask is None else out_n * head_mask
+    logits = head_in @ W + b                                              # :88-92 (Dense, identity act)
     loss_c, dlogits = classification_loss(logits, labels, sigmoid_loss)   # :111-118
     dt = features.dtype
     wd = np.asarray(weight_decay, dtype=dt)
@@ -459,9 +486,11 @@ def supervised_fwd_bwd(params, features, samples, support_sizes, labels, dims, n
     res = {"loss": loss, "preds": preds, "outputs1": out_n, "node_preds": logits, "agg_out": out}
     if not want_grads:
         return res
-    gW = out_n.T @ dlogits + wd * W
+    gW = head_in.T @ dlogits + wd * W
     gb = dlogits.sum(axis=0, dtype=dt) + wd * b
     d_out_n = dlogits @ W.T
+    if head_mask is not None:
+        d_out_n = d_out_n * head_mask
     d_out = l2_normalize_bwd(d_out_n, ncache)
     g_emb = None
     if identity_dim > 0:
@@ -558,14 +587,15 @@ def linkpred_fwd_bwd(o1, o2, neg, neg_sample_weights=1.0):
 
 
 def unsupervised_fwd_bwd(params_agg, features, samples, support_sizes, dims, num_samples, batch_size, n_neg,
-                         aggregator_type="mean", concat=True, weight_decay=0.0, neg_sample_weights=1.0, want_grads=True):
+                         aggregator_type="mean", concat=True, weight_decay=0.0, neg_sample_weights=1.0, want_grads=True,
+                         masks=None):
     """SampleAndAggregate._build/_loss/build (models.py:332-391) on INJECTED samples whose roots are
     [batch1 (B) | batch2 (B) | neg_samples (n_neg)]: the three aggregate() passes of :350-360 share the aggregators,
     and rows are independent, so one pass over the concatenated roots is the same computation.
     loss = (sum wd*l2_loss(aggregator vars) + xent) / batch_size   (:386-390, :378)."""
     n_roots = 2 * batch_size + n_neg
     out, tape = aggregate_fwd(samples, features, dims, num_samples, support_sizes, n_roots, params_agg,
-                              aggregator_type, concat)
+                              aggregator_type, concat, masks=masks)       # masks: injected dropout, see aggregate_fwd
     out_n, ncache = l2_normalize_fwd(out)                                  # :368-370
     B = batch_size
     lp = linkpred_fwd_bwd(out_n[:B], out_n[B:2 * B], out_n[2 * B:], neg_sample_weights)

@@ -65,3 +65,24 @@ def sample_unigram(cdf, n_neg, seed, clock):
         r = (mix64(key + np.arange(n_neg, dtype=np.uint64)) >> np.uint64(32)).astype(np.uint64)
     idx = np.searchsorted(cdf.astype(np.uint64), r, side="right")
     return np.minimum(idx, len(cdf) - 1).astype(np.int32)
+
+
+def dropout_mask(seed, clock, site, row0, n_rows, d, rate):
+    """Scaled keep mask ({0, 1/(1-rate)}, float32 [n_rows, d]) of the device dropout (gs_common.h: gs_drop_key /
+    gs_drop4): element (row, col) is kept iff the 16-bit field (col % 4) of
+    mix64(key + (row0 + row) * R + col // 4) is >= round(rate * 2^16).  The reference draws its masks from TF's RNG
+    (tf.nn.dropout, aggregators.py:46-47); like the sampler's permutations they are injected into the oracle so that
+    both sides see identical masks."""
+    rate32 = np.float32(rate)
+    thresh = int(np.float32(rate32 * np.float32(65536.0) + np.float32(0.5)))
+    thresh = min(max(thresh, 1), 65535)
+    scale = np.float32(1.0) / (np.float32(1.0) - rate32)
+    with np.errstate(over="ignore"):
+        key = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (np.uint64(clock) * _G) ^ (np.uint64(site) << np.uint64(32))
+                    ^ (np.uint64(0xD0) << np.uint64(56)))
+        rows = (np.arange(n_rows, dtype=np.uint64) + np.uint64(row0))[:, None]
+        q = np.arange((d + 3) // 4, dtype=np.uint64)[None, :]
+        h = mix64(key + rows * _R + q)
+    bits = np.stack([(h >> np.uint64(16 * e)) & np.uint64(0xFFFF) for e in range(4)], axis=-1)
+    keep = bits.reshape(n_rows, -1)[:, :d] >= np.uint64(thresh)
+    return keep.astype(np.float32) * scale

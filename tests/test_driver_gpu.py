@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("extra", [["--model", "graphsage_mean"], ["--model", "gcn", "--sampler", "padded", "--max_degree", "16"],
                                    ["--model", "graphsage_maxpool", "--sigmoid"],
-                                   ["--model", "graphsage_mean", "--identity_dim", "16"]])
+                                   ["--model", "graphsage_mean", "--identity_dim", "16"],
+                                   ["--model", "graphsage_mean", "--dropout", "0.2"]])
 def test_supervised_train_driver(dev, tmp_path, capsys, extra):
     from graphsage_amd import engine as eng
     from graphsage_amd import supervised_train as st

@@ -114,3 +114,19 @@ def test_load_data_reference_format(tmp_path):
     assert G.train_removed.tolist() == [False, False, True, True]      # utils.py:55-60
     assert abs(G.feats[:3].mean()) < 1e-6                              # scaler fit on train rows only (:62-68)
     assert G.label_matrix().shape == (6, 2)
+
+
+def test_bench_json_strings_format():
+    """bench.py's metric / workload strings build for every mode (a formatting slip there would lose the round's
+    bench line; the GPU part of bench.py cannot run in the CPU suite)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for argv in ([], ["--model", "graphsage_maxpool"], ["--unsupervised"], ["--gpus", "8"]):
+        args = bench.parse_args(argv)
+        metric, workload = bench.describe(args, args.feat_dim, args.samples_1, args.samples_2, args.batch_size, args.gpus)
+        assert "25x10" in metric and ("unsupervised" in metric) == args.unsupervised
+        assert "N=232965" in workload and args.model in workload
+        assert ("RCCL" in workload) == (args.gpus > 1)

@@ -327,6 +327,58 @@ def test_maxpool_sparse_wgrad(dev, n, s, d, hid, k):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
+# ----------------------------------------------------------------------------- dropout
+@pytest.mark.parametrize("rate", [0.1, 0.5, 0.93])
+def test_dropout_rows_matches_hash(dev, rate):
+    """gs_dropout_rows == X[ids] * mask / keep_prob with the counter-hash mask of oracle/sampler_hash.py, bit exact;
+    masks depend on (clock, site, row0); the kept fraction is 1 - rate."""
+    rng = np.random.default_rng(31)
+    N, n, d = 300, 257, 50
+    X = _asym(rng, (N, d))
+    ids = rng.integers(0, N, size=n).astype(np.int32)
+    clock = torch.tensor([5], dtype=torch.int64, device=dev)
+    Xd, ids_d = Mat.from_numpy(X, dev), torch.from_numpy(ids).to(dev)
+    outs = {}
+    for (site, row0, clk) in [(19, 1000, 5), (20, 1000, 5), (19, 1001, 5), (19, 1000, 6)]:
+        clock.fill_(clk)
+        out = Mat.zeros(n, d, dev)
+        ops.dropout_rows(Xd, ids_d, n, ops.dropout_desc(77, clock, site, rate, row0), out)
+        _sync()
+        m = sampler_hash.dropout_mask(77, clk, site, row0, n, d, rate)
+        assert np.array_equal(out.numpy(), X[ids] * m)
+        outs[(site, row0, clk)] = m
+    base = outs[(19, 1000, 5)]
+    assert abs((base > 0).mean() - (1 - rate)) < 0.02
+    assert not np.array_equal(base, outs[(20, 1000, 5)]) and not np.array_equal(base, outs[(19, 1000, 6)])
+    assert np.array_equal(base[1:], outs[(19, 1001, 5)][:-1])          # row0 shifts the global row index
+    # in place, no ids: the backward use (same mask applied to a gradient)
+    g = Mat.from_numpy(X[:n], dev)
+    clock.fill_(5)
+    ops.dropout_rows(g, None, n, ops.dropout_desc(77, clock, 19, rate, 1000), g)
+    _sync()
+    assert np.array_equal(g.numpy(), X[:n] * base)
+
+
+@pytest.mark.parametrize("n,s,d,gcn", [(65, 25, 602, False), (33, 10, 50, True), (7, 3, 8, False), (5, 70, 36, False)])
+def test_gather_mean_dropout(dev, n, s, d, gcn):
+    """K2 with dropout of every gathered row before the mean (aggregators.py:46-48)."""
+    rng = np.random.default_rng(32)
+    N, rate = 500, 0.4
+    X = _asym(rng, (N, d))
+    idx = rng.integers(0, N, size=n * s).astype(np.int32)
+    clock = torch.tensor([3], dtype=torch.int64, device=dev)
+    selfm = _asym(rng, (n, d)) if gcn else None
+    out = Mat.zeros(n, d, dev)
+    ops.gather_mean_fwd(Mat.from_numpy(X, dev), torch.from_numpy(idx).to(dev), n, s, out=out,
+                        self_src=Mat.from_numpy(selfm, dev) if gcn else None,
+                        drop=ops.dropout_desc(9, clock, 33, rate, 4096))
+    _sync()
+    m = sampler_hash.dropout_mask(9, 3, 33, 4096, n * s, d, rate)
+    rows = (X[idx] * m).reshape(n, s, d).astype(np.float64)
+    want = (rows.sum(axis=1) + selfm) / (s + 1) if gcn else rows.mean(axis=1)
+    np.testing.assert_allclose(out.numpy(), want, rtol=1e-5, atol=1e-6)
+
+
 # ----------------------------------------------------------------------------- K5
 def test_l2norm_fwd_bwd(dev):
     rng = np.random.default_rng(24)

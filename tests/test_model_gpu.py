@@ -175,6 +175,101 @@ def test_identity_features_graph_replay(dev):
     np.testing.assert_array_equal(outs[1][1], outs[1][2])
 
 
+def _device_masks(model, agg_type, rate, clock, ns, n_batch):
+    """The masks the device draws this step (site / global-row conventions of aggregators.py + layers.py), computed
+    with the CPU restatement of the counter hash, for injection into the oracle."""
+    from graphsage_amd.layers import SITE_DENSE, SITE_MLP, SITE_NEIGH, SITE_SELF
+    seed = model.engine.dropout_seed
+    K = len(ns)
+    support = [1]
+    for k in range(K):
+        support.append(support[-1] * ns[K - k - 1])
+    pooling = agg_type in ("maxpool", "meanpool")
+
+    def masks(layer, hop, role, n_rows, d):
+        agg = model.aggregators[layer]
+        if role == "self":
+            if pooling:
+                return None
+            row0 = sum(n_batch * support[h] for h in range(hop))
+            site = agg.site + SITE_SELF
+        else:
+            row0 = sum(n_batch * support[h + 1] for h in range(hop))
+            site = agg.site + (SITE_MLP if pooling else SITE_NEIGH)
+        return sampler_hash.dropout_mask(seed, clock, site, row0, n_rows, d, rate)
+
+    def head_mask(n, d):
+        return sampler_hash.dropout_mask(seed, clock, model.node_pred.site + SITE_DENSE, 0, n, d, rate)
+    return masks, head_mask
+
+
+@pytest.mark.parametrize("agg_type,concat,sigmoid,K", [("mean", True, False, 2), ("mean", False, True, 3), ("gcn", False, False, 2),
+                                                       ("maxpool", True, True, 2), ("meanpool", True, False, 2)])
+def test_dropout_matches_oracle(dev, agg_type, concat, sigmoid, K):
+    """dropout > 0 (supervised_train.py:38,117): tf.nn.dropout on the aggregator inputs / the pooling MLP input / the
+    prediction layer input.  The device masks are a counter hash; the same masks are injected into the oracle, so
+    forward, loss and every gradient must agree as in the dropout-free case.  Step 2 uses the next clock value."""
+    wd, rate = 0.01, 0.3
+    G, it, ph, sampler, model, ns = build(dev, agg_type, concat, sigmoid, wd=wd, K=K)
+    model.use_graphs = False
+    rng = np.random.RandomState(6)
+    batch = rng.choice(it.train_nodes, size=27, replace=False).astype(np.int32)
+    labels = it.label_matrix[batch]
+    feed = {ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch), ph['dropout']: rate}
+    feats = G.padded_features()
+    losses = []
+    for step in range(2):
+        perms = [rng.permutation(it.max_degree) for _ in ns]
+        sampler.inject_perms(perms)
+        params = oracle_params(model, agg_type)
+        clock = int(model.engine.sample_clock_dev.item())
+        assert clock == step
+        loss, preds = model.train_step(feed)
+        samples, support = orc.sample(it.adj, batch, ns, perms)
+        masks, head_mask = _device_masks(model, agg_type, rate, clock, ns, len(batch))
+        res = orc.supervised_fwd_bwd(params, feats, samples, support, labels, model.dims, ns, len(batch), agg_type,
+                                     concat, sigmoid, weight_decay=wd, masks=masks,
+                                     head_mask=head_mask(len(batch), model.agg_out.d))
+        np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(preds, res["preds"], rtol=1e-4, atol=1e-4)
+        got = device_grads(model, agg_type)
+        for (name, g), (_, w) in zip(orc.flat_param_items(got, agg_type), orc.flat_param_items(res["grads"], agg_type)):
+            np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                       err_msg="step %d %s" % (step, name))
+        losses.append(loss)
+    # a validation feed (no dropout key -> 0, minibatch.py:269) runs the dropout-free forward
+    perms = [rng.permutation(it.max_degree) for _ in ns]
+    sampler.inject_perms(perms)
+    params = oracle_params(model, agg_type)
+    loss, preds = model.eval_step({ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)})
+    samples, support = orc.sample(it.adj, batch, ns, perms)
+    res = orc.supervised_fwd_bwd(params, feats, samples, support, labels, model.dims, ns, len(batch), agg_type, concat,
+                                 sigmoid, weight_decay=wd, want_grads=False)
+    np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+
+
+def test_dropout_graph_replay_and_device_epoch(dev):
+    """Masks are keyed by the DEVICE step clock, so replayed hipGraphs draw new masks every step and equal the eager
+    run; the device-epoch path falls back to the sequential schedule under dropout."""
+    outs = []
+    for use_graphs in (False, True):
+        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+        model.use_graphs = use_graphs
+        batch = np.random.RandomState(1).choice(it.train_nodes, size=32, replace=False).astype(np.int32)
+        feed = {ph['batch']: batch, ph['labels']: it.label_matrix[batch], ph['batch_size']: 32, ph['dropout']: 0.5}
+        losses = [model.train_step(feed)[0] for _ in range(5)]
+        outs.append((losses, model.aggregators[0].vars['self_weights'].numpy().copy()))
+    assert len(set(np.round(outs[0][0], 6))) > 1
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-6)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+    # device-resident epoch with the dropout placeholder set: sequential schedule, still trains
+    order = np.random.RandomState(2).permutation(it.train_nodes).astype(np.int32)
+    model.attach_device_epoch(order, np.vstack([it.label_matrix, np.zeros((1, G.num_classes), np.float32)]))
+    ph['dropout'].value = 0.5
+    model.train_steps_device(32, 4)
+    assert np.isfinite(model._fetch(32)[0])
+
+
 def test_three_layer_mean(dev):
     """samples_3 != 0 (supervised_train.py:153-156): a hidden tensor is both a self and a neighbor input."""
     G, it, ph, sampler, model, ns = build(dev, "mean", True, False, K=3)

@@ -152,6 +152,35 @@ def test_unsup_train_step_matches_oracle(dev, agg_type, concat):
                                        err_msg="%d/%s" % (li, k))
 
 
+def test_unsup_dropout_matches_oracle(dev):
+    """dropout > 0 in the unsupervised model (unsupervised_train.py:33,128): masks injected into the oracle."""
+    from test_model_gpu import _device_masks
+    wd, nn, rate = 0.01, 6, 0.25
+    G, it, ph, sampler, model, ns = build("mean", True, wd=wd, nn=nn)
+    model.use_graphs = False
+    rng = np.random.RandomState(5)
+    edges = it.train_edges[:21]
+    B = len(edges)
+    perms = [rng.permutation(it.max_degree) for _ in ns]
+    params = oracle_agg_params(model, "mean")
+    sampler.inject_perms(perms)
+    feed = {ph['batch1']: edges[:, 0], ph['batch2']: edges[:, 1], ph['batch_size']: B, ph['dropout']: rate}
+    loss, ranks, aff_all, mrr, outputs1 = model.train_step(feed)
+    neg = sampler_hash.sample_unigram(sampler_hash.unigram_cdf_u32(it.deg), nn, 123, 0)
+    roots = np.concatenate([edges[:, 0], edges[:, 1], neg]).astype(np.int32)
+    samples, support = orc.sample(it.adj, roots, ns, perms)
+    masks, _ = _device_masks(model, "mean", rate, 0, ns, len(roots))
+    res = orc.unsupervised_fwd_bwd(params, G.padded_features(), samples, support, model.dims, ns, B, nn, "mean", True,
+                                   weight_decay=wd, masks=masks)
+    np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(outputs1, res["outputs1"], rtol=1e-4, atol=1e-4)
+    for li, a in enumerate(model.aggregators):
+        for k, v in a.vars.items():
+            w = res["grads"][li][k]
+            np.testing.assert_allclose(v.grad.numpy().reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                       err_msg="%d/%s" % (li, k))
+
+
 def test_unsup_device_pipeline_equals_feed_path(dev):
     """Device-resident pairs + horizontal-fusion pipeline + hipGraph replay == host-fed eager steps (bitwise)."""
     outs = []
