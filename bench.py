@@ -62,13 +62,52 @@ def build_model(G, it, args, world, rank):
 def describe(args, F, s1, s2, B, world):
     """(metric, config.workload) strings of the JSON line."""
     mode = "unsupervised" if args.unsupervised else "supervised"
-    fmt = ("Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d), " + mode + " %s, fan-out %dx%d, batch %d "
+    if args.workload == "rmat":
+        graph = "RMAT synthetic graph (N=%d, E=%d directed, a/b/c/d=0.57/0.19/0.19/0.05, F=%d U(-1,1), C=%d random labels)" % (
+            args.nodes, args.rmat_edges, F, args.classes)
+        shape = "RMAT %dM-node/%dM-edge" % (args.nodes // 1000000, args.rmat_edges // 1000000)
+    else:
+        graph = "Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d)" % (args.nodes, F, args.classes, args.avg_degree)
+        shape = "Reddit-shaped"
+    fmt = ("%s, " + mode + " %s, fan-out %dx%d, batch %d "
            "per GPU, dims %d/%d, full training step (sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step "
-           "gather co-scheduled with the layer-0 contraction (horizontal fusion)")
-    workload = fmt % (args.nodes, F, args.classes, args.avg_degree, args.model, s1, s2, B, args.dim_1, args.dim_2,
-                      "+RCCL all-reduce" if world > 1 else "")
-    metric = "sampled-edges/sec, Reddit-shaped %s %s fan-out %dx%d" % (mode, args.model, s1, s2)
+           "gather co-scheduled with the layer-0 contraction and the weight-gradient launch (horizontal fusion)")
+    workload = fmt % (graph, args.model, s1, s2, B, args.dim_1, args.dim_2, "+RCCL all-reduce" if world > 1 else "")
+    metric = "sampled-edges/sec, %s %s %s fan-out %dx%d" % (shape, mode, args.model, s1, s2)
     return metric, workload
+
+
+def build_rmat(args, world, rank):
+    """BASELINE configs[4]: RMAT graph + U(-1,1) features + random labels generated directly in HBM (replicated per
+    GPU), supervised graphsage_mean.  Returns (engine, model, placeholders, epoch order)."""
+    from graphsage_amd import engine as eng
+    from graphsage_amd.models import Placeholder, SAGEInfo
+    from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, UniformNeighborSampler
+    from graphsage_amd.ops import Mat
+    from graphsage_amd.supervised_models import SupervisedGraphsage
+    from graphsage_amd.utils import rmat_csr_device
+    eng.reset_engine()
+    e = eng.get_engine()
+    N, F, C = args.nodes, args.feat_dim, args.classes
+    rowptr, col = rmat_csr_device(N, args.rmat_edges, e.device, seed=123)
+    g = torch.Generator(device=e.device)
+    g.manual_seed(123)
+    feats = Mat.zeros(N + 1, F, e.device, ld_multiple=32)            # row N = zero pad row
+    feats.buf[:N, :F].uniform_(-1.0, 1.0, generator=g)
+    labels = Mat.zeros(N + 1, C, e.device)
+    cls = torch.randint(0, C, (N,), device=e.device, generator=g)
+    labels.buf[torch.arange(N, device=e.device), cls] = 1.0
+    order = torch.randperm(N, device=e.device, generator=g).to(torch.int32).cpu().numpy()
+    torch.cuda.synchronize()
+    ph = {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'), 'dropout': Placeholder('dropout', 0.),
+          'batch_size': Placeholder('batch_size')}
+    adj_info = AdjInfo(CSRAdjacency.from_device(rowptr, col, N))
+    sampler = UniformNeighborSampler(adj_info, seed=123)
+    layer_infos = [SAGEInfo("node", sampler, args.samples_1, args.dim_1), SAGEInfo("node", sampler, args.samples_2, args.dim_2)]
+    model = SupervisedGraphsage(C, ph, feats, adj_info, None, layer_infos, concat=True, aggregator_type="mean",
+                                sigmoid_loss=False, learning_rate=0.01, weight_decay=0.0, world_size=world, rank=rank)
+    model.row_offset = rank * args.batch_size
+    return e, model, ph, order, labels, int(col.numel())
 
 
 def parse_args(argv=None):
@@ -90,13 +129,25 @@ def parse_args(argv=None):
     ap.add_argument("--avg_degree", type=int, default=50)
     ap.add_argument("--model", default="graphsage_mean",
                     help="graphsage_mean (headline, BASELINE configs[1]) | graphsage_maxpool (configs[2]) | gcn | graphsage_meanpool")
+    ap.add_argument("--workload", default="reddit", choices=["reddit", "rmat"],
+                    help="reddit: BASELINE configs[1-3] (default, the metric's configuration); rmat: configs[4] "
+                         "(N=10^7, E=2*10^8, F=256, C=64, fan-out 15x10; sets --nodes/--feat_dim/--classes/--samples_1)")
+    ap.add_argument("--rmat-edges", dest="rmat_edges", type=int, default=200000000)
     ap.add_argument("--unsupervised", action="store_true",
                     help="BASELINE configs[3]: unsupervised graphsage_mean on random-walk pairs (20 negatives, xent, MRR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--steps-per-launch", dest="steps_per_launch", type=int, default=8,
                     help="consecutive training steps replayed per hipGraph launch (single GPU)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.workload == "rmat":
+        given = set(a.split("=")[0] for a in (argv if argv is not None else sys.argv[1:]))
+        for flag, val in (("--nodes", 10000000), ("--feat_dim", 256), ("--classes", 64), ("--samples_1", 15)):
+            if flag not in given:
+                setattr(args, flag[2:], val)
+        if args.unsupervised or args.model != "graphsage_mean":
+            ap.error("--workload rmat is the supervised graphsage_mean configuration")
+    return args
 
 
 def main():
@@ -114,17 +165,27 @@ def main():
     from graphsage_amd.utils import reddit_shaped
 
     t0 = time.time()
-    G = reddit_shaped(avg_degree=args.avg_degree, seed=123, n_nodes=args.nodes, feat_dim=args.feat_dim,
-                      num_classes=args.classes)
-    it = NodeMinibatchIterator(G, None, {}, None, G.num_classes, batch_size=args.batch_size, max_degree=128,
-                               build_padded=False)
-    e, model, ph = build_model(G, it, args, world, rank)
-    if rank == 0:
-        log("graph+model ready in %.1fs: N=%d edges=%d train=%d params=%d" %
-            (time.time() - t0, G.n_nodes, len(G.src), len(it.train_nodes), e.n_trainable()))
-
     B, s1, s2, F = args.batch_size, args.samples_1, args.samples_2, args.feat_dim
-    if args.unsupervised:
+    G = it = None
+    if args.workload == "rmat":
+        e, model, ph, epoch, label_table, n_edges = build_rmat(args, world, rank)
+        if rank == 0:
+            log("RMAT graph+model ready in %.1fs: N=%d edges=%d params=%d" % (time.time() - t0, args.nodes, n_edges, e.n_trainable()))
+        order = gsd.shard_order(epoch, rank, world, B) if world > 1 else epoch
+        model.attach_device_epoch(order, label_table)
+    else:
+        G = reddit_shaped(avg_degree=args.avg_degree, seed=123, n_nodes=args.nodes, feat_dim=args.feat_dim,
+                          num_classes=args.classes)
+        it = NodeMinibatchIterator(G, None, {}, None, G.num_classes, batch_size=args.batch_size, max_degree=128,
+                                   build_padded=False)
+        e, model, ph = build_model(G, it, args, world, rank)
+        if rank == 0:
+            log("graph+model ready in %.1fs: N=%d edges=%d train=%d params=%d" %
+                (time.time() - t0, G.n_nodes, len(G.src), len(it.train_nodes), e.n_trainable()))
+
+    if args.workload == "rmat":
+        pass
+    elif args.unsupervised:
         from graphsage_amd.utils import run_random_walks
         pairs = run_random_walks(it.train_csr[0], it.train_csr[1], it.train_nodes, max_pairs=2000000, seed=123)
         pairs = np.random.RandomState(123).permutation(pairs)
@@ -206,7 +267,7 @@ def main():
                               "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gather_mean_kernel<8> (K2, hop-2: [%d x %d] rows of %d fp32)" % (n2, s1, F),
                               "avg_launch_us": k2_us, "algorithmic_bytes_per_launch": alg_bytes}
-        if rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "graphsage_mean":
+        if rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "graphsage_mean" and G is not None:
             from oracle.cpu_baseline import time_cpu_baseline
             from graphsage_amd.utils import padded_from_csr
             tc = time.time()

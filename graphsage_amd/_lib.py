@@ -61,6 +61,7 @@ _PROTOS = {
     "gs_event_destroy": [_P],
     "gs_build_csr_host": [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int64, POINTER(c_int64)],
     "gs_dense_wgrad_grouped": [_P, c_int32, _P],
+    "gs_dense_wgrad_grouped_cogather": [_P, c_int32, _P, c_int32, _P],
     "gs_sage_dense_dgrad": [_P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
     "gs_flat_reduce_adam": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_float, _P, _P],

@@ -575,6 +575,35 @@ __global__ __launch_bounds__(256) void sage_dense_cogather_kernel(const GemmArgs
         gather_mean_wave<1>(a, w - J.wave_start[k], lane);
 }
 
+// The same horizontal fusion for the grouped weight-gradient launch: the second part of the NEXT step's gather rides
+// along with the (latency-bound) split-K wgrad tiles, so the HBM-bound gather is spread over both big GEMM launches
+// of a step instead of stretching only the layer-0 forward.
+__global__ __launch_bounds__(256) void gemm_grouped_tn_cogather_kernel(const GroupedArgs G, const int gemm_blocks,
+                                                                       const CoGather J) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (32 * 64 + 32 * 64) + GS_IDXCAP];
+    const int bid = blockIdx.x;
+    if (bid < gemm_blocks) {
+        int p = 0;
+        while (p + 1 < G.n && bid >= G.block_start[p + 1]) ++p;
+        const GemmArgs& g = G.p[p];
+        const int local = bid - G.block_start[p];
+        const int tiles = g.tiles_m * g.tiles_n;
+        const int z = local / tiles;
+        gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)bid - gemm_blocks) * 4 + (threadIdx.x >> 6);
+    if (w >= J.wave_start[J.n]) return;  // wave-uniform
+    int k = 0;
+    while (k + 1 < J.n && w >= J.wave_start[k + 1]) ++k;
+    const GatherArgs& a = J.job[k];
+    if (a.s >= 8)
+        gather_mean_wave<8>(a, w - J.wave_start[k], lane);
+    else
+        gather_mean_wave<1>(a, w - J.wave_start[k], lane);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 template <int BM, int BN, bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs& g, int nz, hipStream_t st) {
@@ -613,6 +642,30 @@ static int dispatch_gemm(GemmArgs& g, int nz, hipStream_t st) {
 }
 
 static inline int rup4(int x) { return (x + 3) & ~3; }
+
+// gather+mean job descriptors (C ABI) -> kernel argument block
+static int build_cojobs(const gs_gather_desc* jobs_host, int32_t n_jobs, CoGather* Jout, int64_t* waves_out) {
+    GS_REQUIRE(n_jobs >= 0 && n_jobs <= GS_MAX_COJOBS && (n_jobs == 0 || jobs_host), "co-gather: 0..%d jobs", GS_MAX_COJOBS);
+    CoGather& J = *Jout;
+    J.n = n_jobs;
+    int64_t waves = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const gs_gather_desc& q = jobs_host[i];
+        GS_CHECK_MAT(q.X, q.ldx, "co-gather job X");
+        GS_CHECK_MAT(q.out, q.ldo, "co-gather job out");
+        GS_REQUIRE(q.n > 0 && q.s > 0 && q.d > 0 && q.ldx >= rup4(q.d) && q.ldo >= rup4(q.d), "co-gather: bad job %d", i);
+        if (q.self_src) GS_CHECK_MAT(q.self_src, q.ld_self, "co-gather job self");
+        const int chunks = ((q.d + 3) / 4 + 63) / 64;
+        J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
+                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
+                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
+        J.wave_start[i] = waves;
+        waves += q.n * (int64_t)chunks;
+    }
+    J.wave_start[n_jobs] = waves;
+    *waves_out = waves;
+    return GS_OK;
+}
 
 extern "C" int gs_gemm_f32(int transA, int transB, int64_t M, int32_t N, int64_t K, const float* A, int64_t lda,
                            const int32_t* a_row_idx, const float* B, int64_t ldb, const float* bias, int act,
@@ -707,22 +760,11 @@ extern "C" int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, co
     g.tiles_n = (int)gs_ceil_div(out_dim, 64);
     const int64_t gemm_blocks = (int64_t)g.tiles_m * g.tiles_n * (concat ? 2 : 1);
     CoGather J = {};
-    J.n = n_jobs;
     int64_t waves = 0;
-    for (int i = 0; i < n_jobs; ++i) {
-        const gs_gather_desc& q = jobs_host[i];
-        GS_CHECK_MAT(q.X, q.ldx, "gs_sage_dense_fwd_cogather job X");
-        GS_CHECK_MAT(q.out, q.ldo, "gs_sage_dense_fwd_cogather job out");
-        GS_REQUIRE(q.n > 0 && q.s > 0 && q.d > 0 && q.ldx >= rup4(q.d) && q.ldo >= rup4(q.d), "gs_sage_dense_fwd_cogather: bad job %d", i);
-        if (q.self_src) GS_CHECK_MAT(q.self_src, q.ld_self, "gs_sage_dense_fwd_cogather job self");
-        const int chunks = ((q.d + 3) / 4 + 63) / 64;
-        J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
-                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
-                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
-        J.wave_start[i] = waves;
-        waves += q.n * (int64_t)chunks;
+    {
+        int rc = build_cojobs(jobs_host, n_jobs, &J, &waves);
+        if (rc != GS_OK) return rc;
     }
-    J.wave_start[n_jobs] = waves;
     const int64_t blocks = gemm_blocks + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_dense_fwd_cogather: grid too large");
     hipLaunchKernelGGL(sage_dense_cogather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g,
@@ -779,7 +821,8 @@ extern "C" int gs_sage_dense_dgrad(const float* dZ, int64_t ldz, int64_t n, int3
     return dispatch_gemm<true, true>(g, 1, (hipStream_t)stream);
 }
 
-extern "C" int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, void* stream) {
+static int wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host, int32_t n_jobs,
+                         void* stream) {
     GS_REQUIRE(descs_host && n_desc > 0, "gs_dense_wgrad_grouped: bad args");
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n_desc; base += GS_MAX_GROUP) {
@@ -810,10 +853,31 @@ extern "C" int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n
         }
         G.block_start[cnt] = (int32_t)blocks;
         GS_REQUIRE(blocks > 0 && blocks < (1ll << 31), "gs_dense_wgrad_grouped: bad grid");
-        hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G);
-        GS_LAUNCH_CHECK("gemm_grouped_tn_kernel");
+        const bool last = base + GS_MAX_GROUP >= n_desc;
+        if (last && n_jobs > 0) {          // the gather jobs ride along with the last group
+            CoGather J = {};
+            int64_t waves = 0;
+            int rc = build_cojobs(jobs_host, n_jobs, &J, &waves);
+            if (rc != GS_OK) return rc;
+            const int64_t total = blocks + gs_ceil_div(waves, 4);
+            GS_REQUIRE(total < (1ll << 31), "gs_dense_wgrad_grouped_cogather: grid too large");
+            hipLaunchKernelGGL(gemm_grouped_tn_cogather_kernel, dim3((unsigned)total), dim3(256), 0, st, G, (int)blocks, J);
+            GS_LAUNCH_CHECK("gemm_grouped_tn_cogather_kernel");
+        } else {
+            hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G);
+            GS_LAUNCH_CHECK("gemm_grouped_tn_kernel");
+        }
     }
     return GS_OK;
+}
+
+extern "C" int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, void* stream) {
+    return wgrad_grouped(descs_host, n_desc, nullptr, 0, stream);
+}
+
+extern "C" int gs_dense_wgrad_grouped_cogather(const gs_wgrad_desc* descs_host, int32_t n_desc,
+                                               const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    return wgrad_grouped(descs_host, n_desc, jobs_host, n_jobs, stream);
 }
 
 extern "C" int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n, const float* W,

@@ -214,11 +214,21 @@ class Engine(object):
         ops.scatter_add_rows(d, n, s, var.cols, scale, ids, Mat(var.slabs.view(var.rows, var.ld), var.cols),
                              stream=self.stream)
 
-    def launch_wgrads(self):
+    def launch_wgrads(self, side_jobs=None):
+        """ONE grouped launch for every queued weight gradient; `side_jobs` (gather+mean descriptors of the next step)
+        ride along in the same launch (horizontal fusion)."""
         if not self._pending:
+            for j in side_jobs or ():
+                ops.call("gs_gather_mean_fwd", j.X, j.ldx, j.idx, j.n, j.s, j.d, j.self_src, j.ld_self, j.self_idx, j.out,
+                         j.ldo, self.stream)
             return
         arr = (ops._lib.WgradDesc * len(self._pending))(*self._pending)
-        ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr), len(self._pending), self.stream)
+        if side_jobs:
+            jarr = (ops._lib.GatherDesc * len(side_jobs))(*side_jobs)
+            ops.call("gs_dense_wgrad_grouped_cogather", ctypes.addressof(arr), len(self._pending), ctypes.addressof(jarr),
+                     len(side_jobs), self.stream)
+        else:
+            ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr), len(self._pending), self.stream)
         self._pending = []
 
     def _var_descs(self):
@@ -230,10 +240,10 @@ class Engine(object):
             arr[i].clear = 1 if v.scatter else 0
         return arr
 
-    def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0):
+    def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0, side_jobs=None):
         """One grouped launch for every queued weight gradient, then ONE launch that sums the slabs into the
         flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass."""
-        self.launch_wgrads()
+        self.launch_wgrads(side_jobs)
         arr = self._var_descs()
         ops.call("gs_flat_reduce_adam", ctypes.addressof(arr), len(self.variables), ops.ptr(self.params),
                  ops.ptr(self.grads), ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats,

@@ -10,6 +10,7 @@ engine's HIP stream, is captured into a hipGraph on its second execution for a g
 and replayed afterwards.  `aggregate_backward` is the hand-written reverse schedule (TF:
 optimizer.compute_gradients, models.py:379).
 """
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -107,6 +108,7 @@ class SampleAndAggregate(object):
         self.world_size, self.rank = int(world_size), int(rank)
         self.engine.dropout_seed = 123 + 1000003 * self.rank      # every data-parallel rank draws its own masks
         self.row_offset = 0
+        self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.7))   # share of the prefetch gather in the L0 launch
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
         self.grad_hook = None
@@ -231,14 +233,15 @@ class SampleAndAggregate(object):
             self._loss_accumulate = not first
         ops.sum_scaled(self._rr_rows, B, 1.0 / B, self.mrr_dev, stream=e.stream)                    # mrr (:404)
 
-    def _backward_unsup(self, B, n_roots, fuse_adam):
+    def _backward_unsup(self, B, n_roots, fuse_adam, wgrad_jobs=None):
         e = self.engine
         e.begin_backward()
         d_out = e.ws_mat("d_agg_out", n_roots, self.agg_out.d)
         ops.l2norm_bwd(self._dY, self.outputs_all, self._inv_norm, n_roots, d_out, stream=e.stream)
         self.aggregate_backward(d_out)
         # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
-        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0)
+        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
+                          side_jobs=wgrad_jobs)
 
     def _epilogue_unsup(self, B, **counters):
         self.engine.advance(loss_rows=self._loss_rows, n=B, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
@@ -381,8 +384,9 @@ class SampleAndAggregate(object):
                 self._prefetched[(B, q)] = (roots_q, n_roots_q, (samples, support, means_q))
                 roots, n_roots, pre = self._prefetched[(B, p)]
                 self._parity = p
-                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=jobs)
-                self._backward_unsup(B, n_roots, fuse_adam=fused)
+                fwd_jobs, wgrad_jobs = ops.split_gather_jobs(jobs, self.cogather_split)
+                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs)
+                self._backward_unsup(B, n_roots, fuse_adam=fused, wgrad_jobs=wgrad_jobs)
                 self._epilogue_unsup(B, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=B)
                 p = q
 

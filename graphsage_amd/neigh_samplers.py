@@ -36,6 +36,14 @@ class CSRAdjacency(object):
         self.col = torch.from_numpy(col).to(device)
         self.n_nodes = int(n_nodes)
 
+    @classmethod
+    def from_device(cls, rowptr, col, n_nodes):
+        """Wrap CSR arrays that already live in HBM (int64 rowptr [N+1], int32 col [E])."""
+        assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and rowptr.numel() == n_nodes + 1
+        self = cls.__new__(cls)
+        self.rowptr, self.col, self.n_nodes = rowptr.contiguous(), col.contiguous(), int(n_nodes)
+        return self
+
 
 class AdjInfo(object):
     """Mutable handle: `assign()` swaps the adjacency every sampler sees (tf.assign(adj_info, ...))."""

@@ -188,6 +188,40 @@ def gather_job(X, idx, n, s, out, self_src=None, self_idx=None):
     return j
 
 
+def split_gather_jobs(jobs, frac):
+    """Split a gather job list into (head, tail): `tail` gets the last (1 - frac) of the ROWS of the largest job (its
+    idx / out / self pointers advanced accordingly), `head` everything else.  Used to spread one step's gather over
+    two horizontally fused launches."""
+    if not jobs or frac >= 1.0:
+        return list(jobs or ()), []
+    big = max(range(len(jobs)), key=lambda i: jobs[i].n * jobs[i].s)
+    j = jobs[big]
+    n_head = int(j.n * max(frac, 0.0))
+    if n_head >= j.n:
+        return list(jobs), []
+    tail = _lib.GatherDesc()
+    for name, _ in _lib.GatherDesc._fields_:
+        setattr(tail, name, getattr(j, name))
+    tail.n = j.n - n_head
+    tail.idx = (j.idx + 4 * n_head * j.s) if j.idx else None
+    tail.out = j.out + 4 * n_head * j.ldo
+    if j.self_src:
+        if j.self_idx:
+            tail.self_idx = j.self_idx + 4 * n_head
+        else:
+            tail.self_src = j.self_src + 4 * n_head * j.ld_self
+    head = list(jobs)
+    if n_head == 0:
+        del head[big]
+    else:
+        h = _lib.GatherDesc()
+        for name, _ in _lib.GatherDesc._fields_:
+            setattr(h, name, getattr(j, name))
+        h.n = n_head
+        head[big] = h
+    return head, [tail]
+
+
 def sage_dense_fwd_cogather(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, out_dim, concat, act, bias, out,
                             jobs, stream=None):
     """gs_sage_dense_fwd + the gather jobs in ONE horizontally fused launch."""

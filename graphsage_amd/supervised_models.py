@@ -101,7 +101,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                     first = False
             self._loss_accumulate = not first
 
-    def _backward(self, n, fuse_adam):
+    def _backward(self, n, fuse_adam, wgrad_jobs=None):
         """Reverse of _forward.  Every weight gradient of the pass is ONE grouped launch; the slab reduction
         (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
@@ -115,7 +115,8 @@ class SupervisedGraphsage(SampleAndAggregate):
             d_out = e.ws_mat("d_agg_out", n, self.agg_out.d)
             ops.l2norm_bwd(d_outputs1, self.outputs1, self._inv_norm, n, d_out, stream=e.stream)
         self.aggregate_backward(d_out)
-        e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0)
+        e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
+                          side_jobs=wgrad_jobs)
 
     def _epilogue(self, n, **counters):
         self.engine.advance(loss_rows=self._loss_rows, n=n, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
@@ -261,8 +262,11 @@ class SupervisedGraphsage(SampleAndAggregate):
         def compute(p, side_jobs=None):
             batch_dev, labels_dev, pre = self._prefetched[(n, p)]
             self._parity = p
-            self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=side_jobs)
-            self._backward(n, fuse_adam=fused)
+            # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
+            # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
+            fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
+            self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs)
+            self._backward(n, fuse_adam=fused, wgrad_jobs=wgrad_jobs)
 
         def body():
             p = p0

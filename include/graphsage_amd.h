@@ -190,6 +190,11 @@ typedef struct gs_wgrad_desc {
     int32_t d, col0, out_dim, n_slabs;
 } gs_wgrad_desc;
 int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, void* stream);
+/* The grouped weight-gradient launch + up to 4 gather+mean jobs (see gs_sage_dense_fwd_cogather) in ONE horizontally
+ * fused launch: lets the next step's HBM-bound gather be split between the layer-0 forward and the weight-gradient
+ * launch of the current step.  Results are those of the separate calls. */
+int gs_dense_wgrad_grouped_cogather(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                    int32_t n_jobs, void* stream);
 
 /* Input gradient:  dX[n, d] (+)= dZ[:, col0:col0+out_dim] · W[d, out_dim]^T */
 int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,

@@ -130,3 +130,7 @@ def test_bench_json_strings_format():
         assert "25x10" in metric and ("unsupervised" in metric) == args.unsupervised
         assert "N=232965" in workload and args.model in workload
         assert ("RCCL" in workload) == (args.gpus > 1)
+    args = bench.parse_args(["--workload", "rmat"])                       # BASELINE configs[4]
+    assert (args.nodes, args.feat_dim, args.classes, args.samples_1, args.samples_2) == (10000000, 256, 64, 15, 10)
+    metric, workload = bench.describe(args, args.feat_dim, args.samples_1, args.samples_2, args.batch_size, 1)
+    assert "RMAT 10M-node/200M-edge" in metric and "15x10" in metric and "E=200000000" in workload
