@@ -69,6 +69,7 @@ _PROTOS = {
     "gs_gather_mean_dropout_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P, _P],
     "gs_scatter_add_rows": [_P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P, c_int64, _P],
     "gs_copy_cols": [_P, c_int64, _P, c_int64, c_int64, c_int32, _P],
+    "gs_input_grad_pull": [_P, _P],
     "gs_advance_counters": [_P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_head_fwd_bwd": [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int64, c_int32, c_int, _P, c_int64, _P,
                         c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P],
@@ -102,6 +103,17 @@ class GatherDesc(ctypes.Structure):
 class Dropout(ctypes.Structure):
     """struct gs_dropout (include/graphsage_amd.h)"""
     _fields_ = [("seed", c_uint64), ("clock_dev", c_void_p), ("site", c_uint32), ("rate", c_float), ("row0", c_int64)]
+
+
+GS_PULL_MAX = 6
+
+
+class PullDesc(ctypes.Structure):
+    """struct gs_pull_desc (include/graphsage_amd.h)"""
+    _fields_ = [("d_self", c_void_p), ("ld_self", c_int64), ("n_self", c_int64), ("n_seg", c_int32), ("d", c_int32),
+                ("src", c_void_p * GS_PULL_MAX), ("ld_src", c_int64 * GS_PULL_MAX), ("row0", c_int64 * GS_PULL_MAX),
+                ("n", c_int64 * GS_PULL_MAX), ("s", c_int32 * GS_PULL_MAX), ("scale", c_float * GS_PULL_MAX),
+                ("mask_y", c_void_p), ("ldy", c_int64), ("out", c_void_p), ("ldo", c_int64), ("rows", c_int64)]
 
 
 class VarDesc(ctypes.Structure):

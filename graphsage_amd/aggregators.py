@@ -248,8 +248,17 @@ class MeanAggregator(_SageBase):
             ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value, d_self_all, stream=e.stream)
             d_means_all = e.ws_mat((self.name, "d_means", k), n_total, self.neigh_input_dim)
             ops.dense_dgrad(dz, col_n, o, n_total, self.vars['neigh_weights'].value, d_means_all, stream=e.stream)
-        if rate > 0:
-            ops.dropout_rows(d_self_all, None, n_total, self._drop(rate, SITE_SELF, k), d_self_all, stream=e.stream)
+        if rate == 0:
+            # ONE launch: d_prev = relu'(prev) * (d_self on the self rows + d_means / s broadcast over each hop's samples)
+            segs, r = [], 0
+            for h, nv in enumerate(neighs):
+                n, s, _ = nv.shape3
+                segs.append((d_means_all.rows_slice(r, r + n), prev_offsets[h + 1], n, s, 1.0 / s))
+                r += n
+            ops.input_grad_pull(d_prev, d_prev.rows, d_prev.d, d_self=d_self_all, n_self=n_total, segments=segs,
+                                mask_y=prev_mask, stream=e.stream)
+            return
+        ops.dropout_rows(d_self_all, None, n_total, self._drop(rate, SITE_SELF, k), d_self_all, stream=e.stream)
         self._scatter_self(d_self_all, n_total, d_prev, prev_mask)
         r = row0 = 0
         for h, nv in enumerate(neighs):
@@ -257,13 +266,8 @@ class MeanAggregator(_SageBase):
             r0 = prev_offsets[h + 1]
             dst = d_prev.rows_slice(r0, r0 + n * s)
             mask = prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None
-            acc = (h + 1 < len(neighs))
-            if rate > 0:
-                self._bwd_dropped(d_means_all.rows_slice(r, r + n), n, s, 1.0 / s, rate, SITE_NEIGH, k, row0, dst, mask,
-                                  acc, ("n", h))
-            else:
-                ops.mean_bwd(d_means_all.rows_slice(r, r + n), n, s, 1.0 / s, dst, mask_y=mask, accumulate=acc,
-                             stream=e.stream)
+            self._bwd_dropped(d_means_all.rows_slice(r, r + n), n, s, 1.0 / s, rate, SITE_NEIGH, k, row0, dst, mask,
+                              (h + 1 < len(neighs)), ("n", h))
             r += n
             row0 += n * s
 
@@ -366,16 +370,23 @@ class GCNAggregator(_SageBase):
         d = means.d
         d_means = e.ws_mat((self.name, "d_means", k), n_total, d)
         ops.dense_dgrad(dz, 0, self.output_dim, n_total, self.vars['weights'].value, d_means, stream=e.stream)
+        if rate == 0:
+            # ONE launch; the self term of hop h is one more "neighbor" of weight 1/(s+1)
+            segs, r = [], 0
+            for h, nv in enumerate(neighs):
+                n, s, _ = nv.shape3
+                dm = d_means.rows_slice(r, r + n)
+                segs.append((dm, r, n, 1, 1.0 / (s + 1)))
+                segs.append((dm, prev_offsets[h + 1], n, s, 1.0 / (s + 1)))
+                r += n
+            ops.input_grad_pull(d_prev, d_prev.rows, d_prev.d, segments=segs, mask_y=prev_mask, stream=e.stream)
+            return
         r = 0
         for h, nv in enumerate(neighs):           # self parts first: d_self = d_means / (s + 1)
             n, s, _ = nv.shape3
             mask = prev_mask.rows_slice(r, r + n) if prev_mask is not None else None
-            if rate > 0:
-                self._bwd_dropped(d_means.rows_slice(r, r + n), n, 1, 1.0 / (s + 1), rate, SITE_SELF, k, r,
-                                  d_prev.rows_slice(r, r + n), mask, False, ("s", h))
-            else:
-                ops.mean_bwd(d_means.rows_slice(r, r + n), n, 1, 1.0 / (s + 1), d_prev.rows_slice(r, r + n),
-                             mask_y=mask, stream=e.stream)
+            self._bwd_dropped(d_means.rows_slice(r, r + n), n, 1, 1.0 / (s + 1), rate, SITE_SELF, k, r,
+                              d_prev.rows_slice(r, r + n), mask, False, ("s", h))
             r += n
         r = row0 = 0
         for h, nv in enumerate(neighs):
@@ -383,13 +394,8 @@ class GCNAggregator(_SageBase):
             r0 = prev_offsets[h + 1]
             dst = d_prev.rows_slice(r0, r0 + n * s)
             mask = prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None
-            acc = (h + 1 < len(neighs))
-            if rate > 0:
-                self._bwd_dropped(d_means.rows_slice(r, r + n), n, s, 1.0 / (s + 1), rate, SITE_NEIGH, k, row0, dst, mask,
-                                  acc, ("n", h))
-            else:
-                ops.mean_bwd(d_means.rows_slice(r, r + n), n, s, 1.0 / (s + 1), dst, mask_y=mask, accumulate=acc,
-                             stream=e.stream)
+            self._bwd_dropped(d_means.rows_slice(r, r + n), n, s, 1.0 / (s + 1), rate, SITE_NEIGH, k, row0, dst, mask,
+                              (h + 1 < len(neighs)), ("n", h))
             r += n
             row0 += n * s
 
@@ -564,19 +570,17 @@ class _PoolingAggregator(_SageBase):
             return
         d_self_all = e.ws_mat((self.name, "d_self", k), n_total, self.input_dim)
         ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value, d_self_all, stream=e.stream)
-        self._scatter_self(d_self_all, n_total, d_prev, prev_mask)
         d_neigh = e.ws_mat((self.name, "d_neigh", k), H.rows, self.neigh_input_dim)
         ops.dense_dgrad(dH, 0, self.hidden_dim, H.rows, mlp.vars['weights'].value, d_neigh, stream=e.stream)
         if rate > 0:
             ops.dropout_rows(d_neigh, None, H.rows, self._drop(rate, SITE_MLP, k), d_neigh, stream=e.stream)
-        hr = 0
-        for h, nv in enumerate(neighs):
+        segs, hr = [], 0
+        for h, nv in enumerate(neighs):         # every neighbor row has its own gradient row (s = 1)
             n, s, _ = nv.shape3
-            r0 = prev_offsets[h + 1]
-            ops.mean_bwd(d_neigh.rows_slice(hr, hr + n * s), n * s, 1, 1.0, d_prev.rows_slice(r0, r0 + n * s),
-                         mask_y=prev_mask.rows_slice(r0, r0 + n * s) if prev_mask is not None else None,
-                         accumulate=(h + 1 < len(neighs)), stream=e.stream)
+            segs.append((d_neigh.rows_slice(hr, hr + n * s), prev_offsets[h + 1], n * s, 1, 1.0))
             hr += n * s
+        ops.input_grad_pull(d_prev, d_prev.rows, d_prev.d, d_self=d_self_all, n_self=n_total, segments=segs,
+                            mask_y=prev_mask, stream=e.stream)
 
 
 class MaxPoolingAggregator(_PoolingAggregator):

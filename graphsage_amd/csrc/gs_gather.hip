@@ -166,3 +166,80 @@ extern "C" int gs_mean_bwd(const float* d_mean, int64_t ldd, int64_t n, int32_t 
     GS_LAUNCH_CHECK("mean_bwd_kernel");
     return GS_OK;
 }
+
+// ------------------------------------------------------------------ input gradients of a layer, one launch
+struct PullArgs {
+    const float* d_self;
+    int64_t ld_self, n_self;
+    int32_t n_seg, d;
+    const float* src[GS_PULL_MAX];
+    int64_t ld_src[GS_PULL_MAX], row0[GS_PULL_MAX], row1[GS_PULL_MAX];
+    int32_t s[GS_PULL_MAX];
+    float scale[GS_PULL_MAX];
+    const float* mask_y;
+    int64_t ldy;
+    float* out;
+    int64_t ldo, rows;
+};
+
+__global__ __launch_bounds__(256) void input_grad_pull_kernel(const PullArgs a) {
+    const int d4 = (a.d + 3) / 4;
+    const int64_t total = a.rows * (int64_t)d4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / d4;
+        const int col = (int)(t - r * d4) * 4;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        bool any = false;
+        if (a.d_self && r < a.n_self) {
+            g = *reinterpret_cast<const f32x4*>(a.d_self + r * a.ld_self + col);
+            any = true;
+        }
+#pragma unroll
+        for (int k = 0; k < GS_PULL_MAX; ++k) {
+            if (k < a.n_seg && r >= a.row0[k] && r < a.row1[k]) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.src[k] + ((r - a.row0[k]) / a.s[k]) * a.ld_src[k] + col) * a.scale[k];
+                g = any ? v + g : v;     // (the compiler may contract scale*x + g into an fma)
+                any = true;
+            }
+        }
+        if (a.mask_y) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(a.mask_y + r * a.ldy + col);
+            g.x = y.x > 0.f ? g.x : 0.f;
+            g.y = y.y > 0.f ? g.y : 0.f;
+            g.z = y.z > 0.f ? g.z : 0.f;
+            g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.out + r * a.ldo + col) = gs_mask_tail(g, col, a.d);
+    }
+}
+
+extern "C" int gs_input_grad_pull(const gs_pull_desc* q, void* stream) {
+    GS_REQUIRE(q && q->rows >= 0 && q->d > 0 && q->n_seg >= 0 && q->n_seg <= GS_PULL_MAX, "gs_input_grad_pull: bad args");
+    if (q->rows == 0) return GS_OK;
+    const int d4x4 = ((q->d + 3) / 4) * 4;
+    GS_CHECK_MAT(q->out, q->ldo, "gs_input_grad_pull out");
+    GS_REQUIRE(q->ldo >= d4x4, "gs_input_grad_pull: ldo too small");
+    PullArgs a = {};
+    a.d_self = q->d_self; a.ld_self = q->ld_self; a.n_self = q->n_self; a.n_seg = q->n_seg; a.d = q->d;
+    if (q->d_self) {
+        GS_CHECK_MAT(q->d_self, q->ld_self, "gs_input_grad_pull d_self");
+        GS_REQUIRE(q->ld_self >= d4x4 && q->n_self >= 0 && q->n_self <= q->rows, "gs_input_grad_pull: bad d_self");
+    }
+    for (int k = 0; k < q->n_seg; ++k) {
+        GS_CHECK_MAT(q->src[k], q->ld_src[k], "gs_input_grad_pull src");
+        GS_REQUIRE(q->ld_src[k] >= d4x4 && q->s[k] > 0 && q->n[k] >= 0 && q->row0[k] >= 0 &&
+                   q->row0[k] + q->n[k] * q->s[k] <= q->rows, "gs_input_grad_pull: bad segment %d", k);
+        a.src[k] = q->src[k]; a.ld_src[k] = q->ld_src[k]; a.row0[k] = q->row0[k];
+        a.row1[k] = q->row0[k] + q->n[k] * q->s[k]; a.s[k] = q->s[k]; a.scale[k] = q->scale[k];
+    }
+    if (q->mask_y) {
+        GS_CHECK_MAT(q->mask_y, q->ldy, "gs_input_grad_pull mask_y");
+        GS_REQUIRE(q->ldy >= d4x4, "gs_input_grad_pull: ldy too small");
+    }
+    a.mask_y = q->mask_y; a.ldy = q->ldy; a.out = q->out; a.ldo = q->ldo; a.rows = q->rows;
+    const int64_t total = q->rows * (int64_t)(d4x4 / 4);
+    const int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(input_grad_pull_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    GS_LAUNCH_CHECK("input_grad_pull_kernel");
+    return GS_OK;
+}

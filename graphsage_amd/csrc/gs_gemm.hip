@@ -791,7 +791,8 @@ extern "C" int gs_dense_wgrad(const float* A, int64_t lda, const int32_t* a_idx,
     g.act = GS_ACT_IDENTITY;
     // long reductions over wide outputs (the MaxPool MLP gradient: [602 x 512] <- 133,120 rows) are throughput-bound:
     // 128x128 tiles (2x2 MFMA tiles per wave) double the flops per LDS byte; short ones are latency-bound -> 64x64
-    if (n >= 16384 && d >= 128 && out_dim >= 128) return launch_gemm<128, 128, false, false>(g, n_slabs, (hipStream_t)stream);
+    static const int64_t big_n = getenv("GS_WGRAD_BIG_N") ? atoll(getenv("GS_WGRAD_BIG_N")) : 16384;
+    if (n >= big_n && d >= 128 && out_dim >= 128) return launch_gemm<128, 128, false, false>(g, n_slabs, (hipStream_t)stream);
     // experiment hook (benchmarks/micro.py): GS_WGRAD_TILE=12864 | 128128 selects a larger split-K tile
     static const char* tile_env = getenv("GS_WGRAD_TILE");
     if (tile_env && atoi(tile_env) == 12864) return launch_gemm<128, 64, false, false>(g, n_slabs, (hipStream_t)stream);

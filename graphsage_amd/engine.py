@@ -159,8 +159,10 @@ class Engine(object):
         """Split-K slices for a weight gradient.  The kernel is latency-bound per workgroup (one global round trip
         per 32-row stage), so the goal is many short workgroups: ~768 (tile x slice) workgroups per problem, at
         least 64 reduction rows per slice, at most 32 slices."""
-        want = max(1, (768 + tiles - 1) // tiles)
-        return int(max(1, min(32, want, (n_rows + 63) // 64)))
+        target = int(os.environ.get("GS_WGRAD_BLOCKS", 768))      # tuning hooks (benchmarks/slab_sweep.sh)
+        cap = int(os.environ.get("GS_WGRAD_MAX_SLABS", 32))
+        want = max(1, (target + tiles - 1) // tiles)
+        return int(max(1, min(cap, want, (n_rows + 63) // 64)))
 
     def ones(self, n):
         """[n, 1] matrix of ones: bias gradients are the grouped-GEMM problem ones^T · dZ."""
@@ -175,7 +177,7 @@ class Engine(object):
         """Queue var.slabs += A[a_idx]^T · dZ[:, col0:col0+var.cols] (split-K slabs); all queued problems of a
         backward pass are issued as ONE grouped launch by launch_wgrads()."""
         assert A.d == var.rows, (var.name, A.d, var.rows)
-        big = n >= 16384 and var.rows >= 128 and var.cols >= 128   # throughput-bound: own launch with 128x128 tiles
+        big = n >= int(os.environ.get("GS_WGRAD_BIG_N", 16384)) and var.rows >= 128 and var.cols >= 128   # throughput-bound: own launch with 128x128 tiles
         t = 128 if big else 64
         tiles = ((var.rows + t - 1) // t) * ((var.cols + t - 1) // t)
         k = self.pick_slabs(n, tiles)

@@ -233,7 +233,7 @@ class SampleAndAggregate(object):
             self._loss_accumulate = not first
         ops.sum_scaled(self._rr_rows, B, 1.0 / B, self.mrr_dev, stream=e.stream)                    # mrr (:404)
 
-    def _backward_unsup(self, B, n_roots, fuse_adam, wgrad_jobs=None):
+    def _backward_unsup(self, B, n_roots, fuse_adam, wgrad_jobs=None, epilogue=None):
         e = self.engine
         e.begin_backward()
         d_out = e.ws_mat("d_agg_out", n_roots, self.agg_out.d)
@@ -242,6 +242,8 @@ class SampleAndAggregate(object):
         # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
         e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
                           side_jobs=wgrad_jobs)
+        if epilogue is not None:
+            self._epilogue_unsup(B, **epilogue)
 
     def _epilogue_unsup(self, B, **counters):
         self.engine.advance(loss_rows=self._loss_rows, n=B, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
@@ -286,8 +288,7 @@ class SampleAndAggregate(object):
         def fwd_bwd():
             self._stage_negatives(roots, B)
             self._forward_unsup(roots, B, n_roots, True)
-            self._backward_unsup(B, n_roots, fuse_adam=fused)
-            self._epilogue_unsup(B, step=1 if fused else 0, clock=1)
+            self._backward_unsup(B, n_roots, fuse_adam=fused, epilogue=dict(step=1 if fused else 0, clock=1))
 
         self._run(("utrain" if fused else "utrain_fb", B, self._adj_version()), fwd_bwd)
         if not fused:
@@ -386,8 +387,8 @@ class SampleAndAggregate(object):
                 self._parity = p
                 fwd_jobs, wgrad_jobs = ops.split_gather_jobs(jobs, self.cogather_split)
                 self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs)
-                self._backward_unsup(B, n_roots, fuse_adam=fused, wgrad_jobs=wgrad_jobs)
-                self._epilogue_unsup(B, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=B)
+                self._backward_unsup(B, n_roots, fuse_adam=fused, wgrad_jobs=wgrad_jobs,
+                                     epilogue=dict(step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=B))
                 p = q
 
         self._run(("updtrain" if fused else "updtrain_fb", B, k, p0, self._adj_version()), body)

@@ -129,6 +129,21 @@ def gather_rows(X, ids, out=None, stream=None):
     return out
 
 
+def input_grad_pull(out, rows, d, d_self=None, n_self=0, segments=(), mask_y=None, stream=None):
+    """One-launch input gradient of a layer (gs_input_grad_pull).  segments: (src Mat, row0, n, s, scale) tuples:
+    out[row0 + i*s + j] += scale * src[i]."""
+    q = _lib.PullDesc()
+    q.d_self, q.ld_self, q.n_self = (d_self.ptr, d_self.ld, n_self) if d_self is not None else (None, 0, 0)
+    assert len(segments) <= _lib.GS_PULL_MAX
+    q.n_seg, q.d = len(segments), d
+    for k, (src, row0, n, s, scale) in enumerate(segments):
+        q.src[k], q.ld_src[k], q.row0[k], q.n[k], q.s[k], q.scale[k] = src.ptr, src.ld, row0, n, s, scale
+    q.mask_y, q.ldy = (mask_y.ptr, mask_y.ld) if mask_y is not None else (None, 0)
+    q.out, q.ldo, q.rows = out.ptr, out.ld, rows
+    call("gs_input_grad_pull", ctypes.addressof(q), _s(stream))
+    return out
+
+
 def dropout_desc(seed, clock_dev, site, rate, row0=0):
     """struct gs_dropout; None when rate == 0 (dropout off)."""
     if not rate:

@@ -101,7 +101,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                     first = False
             self._loss_accumulate = not first
 
-    def _backward(self, n, fuse_adam, wgrad_jobs=None):
+    def _backward(self, n, fuse_adam, wgrad_jobs=None, epilogue=None):
         """Reverse of _forward.  Every weight gradient of the pass is ONE grouped launch; the slab reduction
         (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
@@ -117,6 +117,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         self.aggregate_backward(d_out)
         e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
                           side_jobs=wgrad_jobs)
+        if epilogue is not None:      # (doing this in the optimizer launch's last workgroup measured 9 us SLOWER)
+            self._epilogue(n, **epilogue)
 
     def _epilogue(self, n, **counters):
         self.engine.advance(loss_rows=self._loss_rows, n=n, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
@@ -168,8 +170,8 @@ class SupervisedGraphsage(SampleAndAggregate):
             if prologue is not None:
                 prologue()
             self._forward(batch_dev, labels_dev, n, train=True)
-            self._backward(n, fuse_adam=fused)
-            self._epilogue(n, step=1 if fused else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
+            self._backward(n, fuse_adam=fused, epilogue=dict(step=1 if fused else 0, clock=1, cursor=cursor,
+                                                             cursor_delta=n if cursor is not None else 0))
 
         if fused:
             self._run((key, n, self._adj_version()), fwd_bwd)     # the whole step: one hipGraph
@@ -259,22 +261,21 @@ class SupervisedGraphsage(SampleAndAggregate):
         p0 = self._pipe_parity
         mode = "streams" if self.pipeline == "streams" else "fused"
 
-        def compute(p, side_jobs=None):
+        def compute(p, side_jobs=None, epilogue=None):
             batch_dev, labels_dev, pre = self._prefetched[(n, p)]
             self._parity = p
             # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
             fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
             self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs)
-            self._backward(n, fuse_adam=fused, wgrad_jobs=wgrad_jobs)
+            self._backward(n, fuse_adam=fused, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
 
         def body():
             p = p0
             for _ in range(k):
                 if mode == "streams":
                     def main(p=p):
-                        compute(p)
-                        self._epilogue(n, step=1 if fused else 0)
+                        compute(p, epilogue=dict(step=1 if fused else 0))
                     e.fork_join(main, lambda p=p: data(1 - p))
                 else:
                     q = 1 - p
@@ -285,8 +286,8 @@ class SupervisedGraphsage(SampleAndAggregate):
                     self_all, neighs = self._layer0_inputs(samples, support, n)
                     means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
                     self._prefetched[(n, q)] = (batch_q, labels_q, (samples, support, means_q))
-                    compute(p, side_jobs=jobs)
-                    self._epilogue(n, step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=n)
+                    compute(p, side_jobs=jobs, epilogue=dict(step=1 if fused else 0, clock=1, cursor=self._cursor,
+                                                             cursor_delta=n))
                 p = 1 - p
 
         key = ("ptrain" if fused else "ptrain_fb", mode, n, k, p0, self._adj_version())

@@ -366,6 +366,28 @@ int gs_scatter_add_rows(const float* d, int64_t ldd, int64_t n, int32_t s, int32
  * tf.concat([embeds, features], axis=1) of models.py:240, kept materialised) after an optimizer step. */
 int gs_copy_cols(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t cols, void* stream);
 
+/* Input gradient of one aggregator layer w.r.t. the previous layer's hidden rows, in ONE launch ("pull" form: every
+ * output row sums the contributions it receives, so no accumulation order is involved):
+ *   out[r, :] = relu'(mask_y[r, :]) * ( [r < n_self] d_self[r, :]
+ *                                       + sum_k [row0_k <= r < row0_k + n_k*s_k] scale_k * src_k[(r - row0_k) / s_k, :] )
+ * Segment k is the reverse of a segmented mean over s_k rows (scale 1/s_k), of a GCN self term (s = 1, scale
+ * 1/(s+1)) or of a plain row copy (s = 1, scale 1).  Replaces gs_act_bwd + one gs_mean_bwd per hop. */
+#define GS_PULL_MAX 6
+typedef struct gs_pull_desc {
+    const float* d_self;   /* [n_self, ld_self], nullable */
+    int64_t ld_self, n_self;
+    int32_t n_seg, d;
+    const float* src[GS_PULL_MAX];
+    int64_t ld_src[GS_PULL_MAX], row0[GS_PULL_MAX], n[GS_PULL_MAX];
+    int32_t s[GS_PULL_MAX];
+    float scale[GS_PULL_MAX];
+    const float* mask_y;   /* [rows, ldy] activations of the previous layer (relu mask), nullable */
+    int64_t ldy;
+    float* out;            /* [rows, ldo] */
+    int64_t ldo, rows;
+} gs_pull_desc;
+int gs_input_grad_pull(const gs_pull_desc* desc_host, void* stream);
+
 /* Up to three device counters advanced by one launch (cursor / sampler clock / optimizer step). */
 int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);
 

@@ -428,6 +428,55 @@ def test_adam_matches_tf_formula(dev):
     np.testing.assert_allclose(pd.cpu().numpy(), po, rtol=1e-5, atol=1e-6)
 
 
+def test_input_grad_pull(dev):
+    """gs_input_grad_pull == act_bwd(self rows) followed by one accumulate mean_bwd per hop (3-layer shape: the rows
+    of the middle hop are self rows AND neighbor rows), up to fma contraction of scale*x + y (last bit)."""
+    rng = np.random.default_rng(41)
+    B, s2, s1, d = 6, 3, 5, 22
+    n_self = B + B * s2                       # self rows of hops 0 and 1
+    rows = n_self + B * s2 * s1               # + neighbor rows of hop 1
+    d_self = _asym(rng, (n_self, d))
+    dm = _asym(rng, (n_self, d))              # d_means of hop 0 (B rows) and hop 1 (B*s2 rows)
+    y = _asym(rng, (rows, d))
+    dS, dM, Y = Mat.from_numpy(d_self, dev), Mat.from_numpy(dm, dev), Mat.from_numpy(y, dev)
+    want = Mat.zeros(rows, d, dev)
+    ops.act_bwd(dS, Y.rows_slice(0, n_self), n_self, d, ops.ACT_RELU, want.rows_slice(0, n_self))
+    ops.mean_bwd(dM.rows_slice(0, B), B, s2, 1.0 / s2, want.rows_slice(B, B + B * s2), mask_y=Y.rows_slice(B, B + B * s2),
+                 accumulate=True)
+    ops.mean_bwd(dM.rows_slice(B, n_self), B * s2, s1, 1.0 / s1, want.rows_slice(n_self, rows),
+                 mask_y=Y.rows_slice(n_self, rows), accumulate=False)
+    got = Mat.from_numpy(np.full((rows, d), np.nan, np.float32), dev)
+    ops.input_grad_pull(got, rows, d, d_self=dS, n_self=n_self,
+                        segments=[(dM.rows_slice(0, B), B, B, s2, 1.0 / s2), (dM.rows_slice(B, n_self), n_self, B * s2, s1, 1.0 / s1)],
+                        mask_y=Y)
+    _sync()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    ref = np.zeros((rows, d), np.float32)
+    ref[:n_self] += d_self
+    ref[B:B + B * s2] += np.repeat(dm[:B] * np.float32(1.0 / s2), s2, axis=0)
+    ref[n_self:] += np.repeat(dm[B:] * np.float32(1.0 / s1), s1, axis=0)
+    np.testing.assert_allclose(got.numpy(), ref * (y > 0), rtol=1e-5, atol=1e-6)
+
+
+def test_scatter_add_rows_and_copy_cols(dev):
+    """Identity features: gradient scatter (atomics; duplicate ids accumulate) and the table refresh."""
+    rng = np.random.default_rng(42)
+    N, n, s, c, ld = 50, 40, 7, 6, 16
+    d = _asym(rng, (n, c))
+    ids = rng.integers(0, N, size=n * s).astype(np.int32)
+    table = Mat.zeros(N, ld, dev)
+    ops.scatter_add_rows(Mat.from_numpy(d, dev), n, s, c, 0.25, torch.from_numpy(ids).to(dev), table)
+    _sync()
+    want = np.zeros((N, ld), np.float64)
+    np.add.at(want, (ids[:, None], np.arange(c)[None, :]), np.repeat(d.astype(np.float64) * 0.25, s, axis=0))
+    np.testing.assert_allclose(table.numpy(), want, rtol=1e-5, atol=1e-6)
+    dst = Mat.from_numpy(np.full((N, 24), 7.0, np.float32), dev)
+    ops.copy_cols(table, dst, N, c)
+    _sync()
+    out = dst.numpy()
+    assert np.array_equal(out[:, :c], table.numpy()[:, :c]) and np.all(out[:, c:] == 7.0)
+
+
 def test_sum_kernels(dev):
     x = torch.arange(10000, dtype=torch.float32, device=dev) / 1000.0
     out = torch.zeros(1, device=dev)
