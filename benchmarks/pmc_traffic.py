@@ -22,10 +22,10 @@ def values(db, counter, pred):
 
 def main():
     fetch_db, write_db, cal_db, out = sys.argv[1:5]
-    hop2 = lambda k, g: "gather_mean_kernel<8>" in k and g == 983040      # [5120 x 25] rows, 3 chunks, 4 waves/block
+    hop2 = lambda k, g: "gather_mean_kernel<8" in k and g == 983040      # [5120 x 25] rows, 3 chunks, 4 waves/block
     f = values(fetch_db, "FETCH_SIZE", hop2)
     w = values(write_db, "WRITE_SIZE", hop2)
-    cal = values(cal_db, "FETCH_SIZE", lambda k, g: "gather_mean_kernel<1>" in k)
+    cal = values(cal_db, "FETCH_SIZE", lambda k, g: "gather_mean_kernel<1" in k)
     cal_kb = float(np.median([v for v, _ in cal]))
     factor = KNOWN_CAL_BYTES / (cal_kb * 1024.0)
     fetch_b = float(np.mean([v for v, _ in f])) * 1024.0
