@@ -329,7 +329,6 @@ class GCNAggregator(_SageBase):
 
     def call_hops(self, self_all, neighs, means=None, side_jobs=None):
         e = self.engine
-        _run_jobs(e, side_jobs)
         n_total = self_all.n
         k = len(self._saved)
         rate = _rate(self.dropout)
@@ -337,8 +336,13 @@ class GCNAggregator(_SageBase):
             means = self.prefetch(self_all, neighs)
         out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
-        ops.sage_dense_fwd(None, None, means, None, n_total, None, self.vars['weights'].value, self.output_dim, False,
-                           self.act_code, b, out, stream=e.stream)
+        if side_jobs:
+            # horizontally fused launch: these GEMM tiles + the NEXT step's gather-mean waves share the CUs
+            ops.sage_dense_fwd_cogather(None, None, means, None, n_total, None, self.vars['weights'].value, self.output_dim,
+                                        False, self.act_code, b, out, side_jobs, stream=e.stream)
+        else:
+            ops.sage_dense_fwd(None, None, means, None, n_total, None, self.vars['weights'].value, self.output_dim, False,
+                               self.act_code, b, out, stream=e.stream)
         self._push((self_all, neighs, means, out, rate))
         return out
 

@@ -729,22 +729,28 @@ extern "C" int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, co
                                           int64_t ldw_neigh, int32_t out_dim, int concat, int act, const float* bias,
                                           float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs,
                                           void* stream) {
-    GS_REQUIRE(n > 0 && self && agg && W_self && W_neigh && out, "gs_sage_dense_fwd_cogather: needs the two-term SAGE form");
+    GS_REQUIRE(n > 0 && agg && W_neigh && out, "gs_sage_dense_fwd_cogather: bad args");
     GS_REQUIRE(n_jobs >= 0 && n_jobs <= GS_MAX_COJOBS && (n_jobs == 0 || jobs_host), "gs_sage_dense_fwd_cogather: 0..%d jobs", GS_MAX_COJOBS);
     GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_cogather agg");
-    GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_cogather self");
-    GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd_cogather W_self");
     GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_fwd_cogather W_neigh");
     GS_CHECK_MAT(out, ldo, "gs_sage_dense_fwd_cogather out");
-    GS_REQUIRE(d_self > 0 && d_agg > 0 && out_dim > 0 && ld_self >= rup4(d_self) && ld_agg >= rup4(d_agg) &&
-               ldw_self >= rup4(out_dim) && ldw_neigh >= rup4(out_dim), "gs_sage_dense_fwd_cogather: ld too small");
-    if (concat) GS_REQUIRE(out_dim % 4 == 0, "gs_sage_dense_fwd_cogather: concat needs out_dim %% 4 == 0");
-    GS_REQUIRE(ldo >= rup4(out_dim * (concat ? 2 : 1)), "gs_sage_dense_fwd_cogather: ldo too small");
+    GS_REQUIRE(d_agg > 0 && out_dim > 0 && ld_agg >= rup4(d_agg) && ldw_neigh >= rup4(out_dim), "gs_sage_dense_fwd_cogather: ld too small");
     GemmArgs g = {};
-    g.t[0] = GemmTerm{self, self_idx, W_self, ld_self, ldw_self, d_self};
-    g.t[1] = GemmTerm{agg, agg_idx, W_neigh, ld_agg, ldw_neigh, d_agg};
-    g.nterms = 2;
-    g.concat = concat ? 1 : 0;
+    if (self) {                                   // two-term SAGE form (Mean / pooling aggregators)
+        GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_cogather self");
+        GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd_cogather W_self");
+        GS_REQUIRE(d_self > 0 && ld_self >= rup4(d_self) && ldw_self >= rup4(out_dim), "gs_sage_dense_fwd_cogather: self ld too small");
+        if (concat) GS_REQUIRE(out_dim % 4 == 0, "gs_sage_dense_fwd_cogather: concat needs out_dim %% 4 == 0");
+        g.t[0] = GemmTerm{self, self_idx, W_self, ld_self, ldw_self, d_self};
+        g.t[1] = GemmTerm{agg, agg_idx, W_neigh, ld_agg, ldw_neigh, d_agg};
+        g.nterms = 2;
+        g.concat = concat ? 1 : 0;
+    } else {                                      // single contraction (GCN: means . W)
+        g.t[0] = GemmTerm{agg, agg_idx, W_neigh, ld_agg, ldw_neigh, d_agg};
+        g.nterms = 1;
+    }
+    const bool two_halves = g.nterms == 2 && g.concat;
+    GS_REQUIRE(ldo >= rup4(out_dim * (two_halves ? 2 : 1)), "gs_sage_dense_fwd_cogather: ldo too small");
     g.M = n; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
     if (n <= 2048) {
         // small contraction: nothing worth overlapping with -> issue the gather jobs and the (K-split) GEMM as the
@@ -758,7 +764,7 @@ extern "C" int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, co
     }
     g.tiles_m = (int)gs_ceil_div(n, 64);
     g.tiles_n = (int)gs_ceil_div(out_dim, 64);
-    const int64_t gemm_blocks = (int64_t)g.tiles_m * g.tiles_n * (concat ? 2 : 1);
+    const int64_t gemm_blocks = (int64_t)g.tiles_m * g.tiles_n * (two_halves ? 2 : 1);
     CoGather J = {};
     int64_t waves = 0;
     {

@@ -242,8 +242,10 @@ def sage_dense_fwd_cogather(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, 
     """gs_sage_dense_fwd + the gather jobs in ONE horizontally fused launch."""
     import ctypes
     arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
-    call("gs_sage_dense_fwd_cogather", self_m.ptr, self_m.ld, ptr(self_idx), self_m.d, agg.ptr, agg.ld, ptr(agg_idx),
-         agg.d, n, W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld, out_dim, 1 if concat else 0, act, ptr(bias),
+    call("gs_sage_dense_fwd_cogather", self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0,
+         ptr(self_idx), self_m.d if self_m is not None else 0, agg.ptr, agg.ld, ptr(agg_idx),
+         agg.d, n, W_self.ptr if W_self is not None else None, W_self.ld if W_self is not None else 0,
+         W_neigh.ptr, W_neigh.ld, out_dim, 1 if concat else 0, act, ptr(bias),
          out.ptr, out.ld, ctypes.addressof(arr), len(jobs), _s(stream))
     return out
 

@@ -354,6 +354,25 @@ def test_csr_training_graph_replay_equals_eager(dev):
     assert outs[0][0][2] < outs[0][0][0] + 0.5  # training is not diverging
 
 
+@pytest.mark.parametrize("agg_type,concat", [("gcn", False), ("meanpool", True)])
+def test_pipelined_equals_sequential_other_aggregators(dev, agg_type, concat):
+    """The prefetch pipeline (GCN: single-term co-gather launch + split into the weight-gradient launch; pooling:
+    nothing to prefetch) gives the bits of the sequential eager schedule."""
+    outs = []
+    for use_graphs, pipe in ((False, False), (True, True)):
+        G, it, ph, sampler, model, ns = build(dev, agg_type, concat, False, csr=True)
+        model.use_graphs, model.pipeline = use_graphs, pipe
+        model.attach_device_epoch(it.train_nodes[:160], it.label_matrix)
+        if pipe:
+            model.train_steps_device(32, 5, steps_per_launch=2)
+        else:
+            for _ in range(5):
+                model.train_step_device(32)
+        eng.get_engine().sync()
+        outs.append(eng.get_engine().params.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_training_learns(dev):
     """A few epochs on a planted-community graph reach a high val micro-F1 (the metric's quality half)."""
     G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True, n_nodes=3000, dim=32)
