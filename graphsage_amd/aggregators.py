@@ -89,6 +89,18 @@ class _SageBase(Layer):
         ops.dropout_rows(self_all.src, self_all.ids, self_all.n, self._drop(rate, SITE_SELF, k), sd, stream=e.stream)
         return Rows(sd, None, self_all.n, self_all.requires_grad)
 
+    def _sink(self, var, d_rows, ids, n, s, scale, rate, role, k, row0, tag):
+        """Scatter scale * d_rows[i] to the s sampled ids of row i of a trainable table (identity features); with
+        dropout the per-sampled-row mask is applied first (the table rows went through `dropout` before the mean)."""
+        e = self.engine
+        if rate == 0 or role is None:
+            e.scatter_grad(var, d_rows, ids, n, s, scale)
+            return
+        tmp = e.ws_mat((self.name, "d_sink", k, tag), n * s, var.cols)
+        ops.mean_bwd(d_rows, n, s, scale, tmp, stream=e.stream)
+        ops.dropout_rows(tmp, None, n * s, self._drop(rate, role, k, row0), tmp, stream=e.stream)
+        e.scatter_grad(var, tmp, ids, n * s, 1, 1.0)
+
     def _bwd_dropped(self, d_rows, n, s, scale, rate, role, k, row0, dst, relu_mask, accumulate, tag):
         """dst (+)= relu'(relu_mask) * dropout_mask * broadcast_s(scale * d_rows): the reverse of `dropout` followed by
         a (segmented) mean, with the mask regenerated from the counter hash."""
@@ -214,8 +226,6 @@ class MeanAggregator(_SageBase):
         n_out = o * (2 if self.concat else 1)
         dz = self._dz(d_out, out, n_total, n_out, pre_masked)
         col_n = o if self.concat else 0
-        if rate > 0 and embed_sink is not None:
-            raise NotImplementedError("dropout > 0 together with identity_dim > 0")
         e.wgrad(self.vars['self_weights'], self_in.src, self_in.ids, dz, 0, n_total)
         e.wgrad(self.vars['neigh_weights'], means, None, dz, col_n, n_total)
         if self.bias:
@@ -229,12 +239,13 @@ class MeanAggregator(_SageBase):
             d_means_e = e.ws_mat((self.name, "d_means_e", k), n_total, c)
             ops.dense_dgrad(dz, col_n, o, n_total, self.vars['neigh_weights'].value.rows_slice(0, c), d_means_e,
                             stream=e.stream)
-            e.scatter_grad(var, d_self_e, self_all.ids, n_total, 1, 1.0)
-            r = 0
-            for nv in neighs:
+            self._sink(var, d_self_e, self_all.ids, n_total, 1, 1.0, rate, SITE_SELF, k, 0, "s")
+            r = row0 = 0
+            for h, nv in enumerate(neighs):
                 n, s, _ = nv.shape3
-                e.scatter_grad(var, d_means_e.rows_slice(r, r + n), nv.ids, n, s, 1.0 / s)
+                self._sink(var, d_means_e.rows_slice(r, r + n), nv.ids, n, s, 1.0 / s, rate, SITE_NEIGH, k, row0, ("n", h))
                 r += n
+                row0 += n * s
         if d_prev is None:
             return
         d_in = self.input_dim
@@ -351,8 +362,6 @@ class GCNAggregator(_SageBase):
         self_all, neighs, means, out, rate = self._saved.pop()
         n_total = self_all.n
         k = len(self._saved)
-        if rate > 0 and embed_sink is not None:
-            raise NotImplementedError("dropout > 0 together with identity_dim > 0")
         dz = self._dz(d_out, out, n_total, self.output_dim, pre_masked)
         e.wgrad(self.vars['weights'], means, None, dz, 0, n_total)
         if self.bias:
@@ -362,13 +371,14 @@ class GCNAggregator(_SageBase):
             d_means_e = e.ws_mat((self.name, "d_means_e", k), n_total, c)
             ops.dense_dgrad(dz, 0, self.output_dim, n_total, self.vars['weights'].value.rows_slice(0, c), d_means_e,
                             stream=e.stream)
-            r = 0
-            for nv in neighs:
+            r = row0 = 0
+            for h, nv in enumerate(neighs):
                 n, s, _ = nv.shape3
                 dm = d_means_e.rows_slice(r, r + n)
-                e.scatter_grad(var, dm, self_all.slice(r, r + n).ids, n, 1, 1.0 / (s + 1))
-                e.scatter_grad(var, dm, nv.ids, n, s, 1.0 / (s + 1))
+                self._sink(var, dm, self_all.slice(r, r + n).ids, n, 1, 1.0 / (s + 1), rate, SITE_SELF, k, r, ("s", h))
+                self._sink(var, dm, nv.ids, n, s, 1.0 / (s + 1), rate, SITE_NEIGH, k, row0, ("n", h))
                 r += n
+                row0 += n * s
         if d_prev is None:
             return
         d = means.d
@@ -505,8 +515,7 @@ class _PoolingAggregator(_SageBase):
         self_all, neighs, pieces, H, pooled, argmax, out, rate = self._saved.pop()
         n_total = self_all.n
         k = len(self._saved)
-        if rate > 0 and embed_sink is not None:
-            raise NotImplementedError("dropout > 0 together with identity_dim > 0")
+
         o = self.output_dim
         n_out = o * (2 if self.concat else 1)
         mlp = self.mlp_layers[0]
@@ -561,10 +570,12 @@ class _PoolingAggregator(_SageBase):
             var, c = embed_sink                    # see MeanAggregator.backward_hops; every neighbor row has its own dH
             d_self_e = e.ws_mat((self.name, "d_self_e", k), n_total, c)
             ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value.rows_slice(0, c), d_self_e, stream=e.stream)
-            e.scatter_grad(var, d_self_e, self_all.ids, n_total, 1, 1.0)
+            e.scatter_grad(var, d_self_e, self_all.ids, n_total, 1, 1.0)      # the pooling aggregators do not drop self
             d_neigh_e = e.ws_mat((self.name, "d_neigh_e", k), H.rows, c)
             ops.dense_dgrad(dH, 0, self.hidden_dim, H.rows, mlp.vars['weights'].value.rows_slice(0, c), d_neigh_e,
                             stream=e.stream)
+            if rate > 0:
+                ops.dropout_rows(d_neigh_e, None, H.rows, self._drop(rate, SITE_MLP, k), d_neigh_e, stream=e.stream)
             hr = 0
             for nv in neighs:
                 n, s, _ = nv.shape3

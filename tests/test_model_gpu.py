@@ -248,6 +248,36 @@ def test_dropout_matches_oracle(dev, agg_type, concat, sigmoid, K):
     np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("agg_type,concat", [("mean", True), ("gcn", False), ("maxpool", True)])
+def test_identity_with_dropout_matches_oracle(dev, agg_type, concat):
+    """identity_dim > 0 AND dropout > 0: the embedding gradient goes through the per-sampled-row dropout masks."""
+    wd, rate, idim = 0.0, 0.4, 6
+    G, it, ph, sampler, model, ns = build(dev, agg_type, concat, False, wd=wd, identity_dim=idim)
+    model.use_graphs = False
+    rng = np.random.RandomState(8)
+    batch = rng.choice(it.train_nodes, size=25, replace=False).astype(np.int32)
+    labels = it.label_matrix[batch]
+    perms = [rng.permutation(it.max_degree) for _ in ns]
+    sampler.inject_perms(perms)
+    params = oracle_params(model, agg_type)
+    emb0 = model.embeds.numpy().copy()
+    feats = np.concatenate([emb0, G.padded_features()], axis=1)
+    loss, preds = model.train_step({ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch),
+                                    ph['dropout']: rate})
+    samples, support = orc.sample(it.adj, batch, ns, perms)
+    masks, head_mask = _device_masks(model, agg_type, rate, 0, ns, len(batch))
+    res = orc.supervised_fwd_bwd(params, feats, samples, support, labels, model.dims, ns, len(batch), agg_type, concat,
+                                 False, weight_decay=wd, identity_dim=idim, masks=masks,
+                                 head_mask=head_mask(len(batch), model.agg_out.d))
+    np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+    w = res["grads"]["embeds"]
+    assert np.count_nonzero(w) > 0
+    np.testing.assert_allclose(model.embeds.grad.numpy(), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()))
+    got = device_grads(model, agg_type)
+    for (name, g), (_, w) in zip(orc.flat_param_items(got, agg_type), orc.flat_param_items(res["grads"], agg_type)):
+        np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()), err_msg=name)
+
+
 def test_dropout_graph_replay_and_device_epoch(dev):
     """Masks are keyed by the DEVICE step clock, so replayed hipGraphs draw new masks every step and equal the eager
     run; the device-epoch path falls back to the sequential schedule under dropout."""
