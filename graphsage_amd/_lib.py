@@ -131,6 +131,11 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64 (SONAME libamdhip64.so.7); it must be mapped BEFORE this library so that the
+    # dynamic linker binds our NEEDED libamdhip64.so.7 to that same runtime.  Loading ours first would map
+    # /opt/rocm's copy and torch would then bring in a second HIP runtime (its NEEDED entry is the un-versioned
+    # name) -- two runtimes in one process do not share streams or allocations ("no ROCm-capable device").
+    import torch  # noqa: F401
     if build_if_missing:
         try:
             from . import build as _build

@@ -134,3 +134,17 @@ def test_bench_json_strings_format():
     assert (args.nodes, args.feat_dim, args.classes, args.samples_1, args.samples_2) == (10000000, 256, 64, 15, 10)
     metric, workload = bench.describe(args, args.feat_dim, args.samples_1, args.samples_2, args.batch_size, 1)
     assert "RMAT 10M-node/200M-edge" in metric and "15x10" in metric and "E=200000000" in workload
+
+
+def test_single_hip_runtime_mapped():
+    """Loading the C-ABI library before torch must not map a second libamdhip64 (torch bundles its own copy; two HIP
+    runtimes in one process cannot share streams or memory).  _lib.load() imports torch first for that reason."""
+    import subprocess
+    import sys
+    code = ("from graphsage_amd import _lib; _lib.load(build_if_missing=False); import torch; "
+            "paths = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); print(paths)")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.join(os.path.dirname(__file__), ".."))
+    assert out.returncode == 0, out.stderr[-2000:]
+    paths = eval(out.stdout.strip().splitlines()[-1])
+    assert len(paths) == 1, paths
