@@ -327,6 +327,25 @@ def test_maxpool_sparse_wgrad(dev, n, s, d, hid, k):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
+def test_device_hash_known_answers(dev):
+    """The device sampler and dropout kernels against tests/golden/hash_kat.npz (computed with Python big ints)."""
+    import os
+    k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hash_kat.npz"))
+    ns, seed, step, hop, row_off, pad = [int(v) for v in k["csr_args"]]
+    out = ops.sample_uniform_csr(torch.from_numpy(k["rowptr"]).to(dev), torch.from_numpy(k["col"]).to(dev), 4, pad,
+                                 torch.from_numpy(k["ids"]).to(dev), ns, seed, step=step, hop=hop, global_row_offset=row_off)
+    _sync()
+    assert np.array_equal(out.cpu().numpy().reshape(-1, ns), k["picked"])
+    dseed, clock, site, row0, n_rows, d = [int(v) for v in k["drop_args"]]
+    rate = float(k["drop_rate"])
+    clk = torch.tensor([clock], dtype=torch.int64, device=dev)
+    ones = Mat.from_numpy(np.ones((n_rows, d), np.float32), dev)
+    ops.dropout_rows(ones, None, n_rows, ops.dropout_desc(dseed, clk, site, rate, row0), ones)
+    _sync()
+    assert np.array_equal(ones.numpy() > 0, k["keep"] == 1)
+    assert np.allclose(ones.numpy()[k["keep"] == 1], 1.0 / (1.0 - rate))
+
+
 # ----------------------------------------------------------------------------- dropout
 @pytest.mark.parametrize("rate", [0.1, 0.5, 0.93])
 def test_dropout_rows_matches_hash(dev, rate):

@@ -160,3 +160,33 @@ def test_csr_sampler_hash_properties():
             assert (a[i] == N).all()
         else:
             assert np.isin(a[i], col[rowptr[node]:rowptr[node + 1]]).all()
+
+
+GOLD_DIR = os.path.dirname(GOLD)
+
+
+def test_golden_gcn_and_maxpool_calls():
+    """One GCN and one MaxPool aggregator call on the tiny graph vs plain-loop arithmetic (make_golden_more.py)."""
+    g, m = np.load(GOLD), np.load(os.path.join(GOLD_DIR, "tiny_gcn_maxpool.npz"))
+    X, batch, s = g["feats"], g["batch"], 2
+    self_vecs = X[batch]
+    neigh = X[g["samples1"]].reshape(len(batch), s, X.shape[1])
+    y, _ = orc.gcn_aggregator_fwd(self_vecs, neigh, m["W_gcn"], "relu")
+    np.testing.assert_allclose(y, m["gcn_out"], rtol=1e-6, atol=1e-6)     # thirds: not exact in fp32
+    y, _ = orc.maxpool_aggregator_fwd(self_vecs, neigh, m["W_mlp"], m["b_mlp"], m["W_self"], m["W_neigh"], True, "relu",
+                                      pool="max")
+    assert np.array_equal(y, m["maxpool_out"])                            # integers: exact
+
+
+def test_hash_known_answers():
+    """mix64 / CSR sampler / dropout mask of oracle/sampler_hash.py vs arbitrary-precision Python ints."""
+    k = np.load(os.path.join(GOLD_DIR, "hash_kat.npz"))
+    assert np.array_equal(sampler_hash.mix64(k["mix_in"]), k["mix_out"])
+    ns, seed, step, hop, row_off, pad = [int(v) for v in k["csr_args"]]
+    got = sampler_hash.sample_uniform_csr(k["rowptr"], k["col"], 4, pad, k["ids"], ns, seed, step, hop, row_off)
+    assert np.array_equal(got, k["picked"])
+    dseed, clock, site, row0, n_rows, d = [int(v) for v in k["drop_args"]]
+    rate = float(k["drop_rate"])
+    m = sampler_hash.dropout_mask(dseed, clock, site, row0, n_rows, d, rate)
+    assert np.array_equal(m > 0, k["keep"] == 1)
+    assert np.allclose(m[m > 0], 1.0 / (1.0 - rate))
