@@ -65,7 +65,8 @@ def describe(args, F, s1, s2, B, world):
     if args.workload == "rmat":
         graph = "RMAT synthetic graph (N=%d, E=%d directed, a/b/c/d=0.57/0.19/0.19/0.05, F=%d U(-1,1), C=%d random labels)" % (
             args.nodes, args.rmat_edges, F, args.classes)
-        shape = "RMAT %dM-node/%dM-edge" % (args.nodes // 1000000, args.rmat_edges // 1000000)
+        size = lambda v: ("%dM" % (v // 1000000)) if v >= 1000000 else str(v)
+        shape = "RMAT %s-node/%s-edge" % (size(args.nodes), size(args.rmat_edges))
     else:
         graph = "Reddit-shaped synthetic graph (N=%d, F=%d, C=%d, avg_degree=%d)" % (args.nodes, F, args.classes, args.avg_degree)
         shape = "Reddit-shaped"
