@@ -268,6 +268,32 @@ def main():
                               "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                               "kernel": "gather_mean_kernel<8> (K2, hop-2: [%d x %d] rows of %d fp32)" % (n2, s1, F),
                               "avg_launch_us": k2_us, "algorithmic_bytes_per_launch": alg_bytes}
+        if args.model in ("graphsage_maxpool", "graphsage_meanpool") and not args.unsupervised:
+            # pooling aggregators: the dominant kernel is the MLP contraction over every gathered neighbor row
+            # ([n2*s1 + B*s2 rows, F] x [F, hidden], fp32 MFMA) -> report ITS roofline; the K2 numbers stay as "gather"
+            agg0 = model.aggregators[0]
+            mlp = agg0.mlp_layers[0]
+            rows_all = n2 * s1 + B * s2
+            ids_all = torch.as_strided(model.samples1[1], (rows_all,), (1,))     # hop-1 and hop-2 ids are adjacent
+            H = ops.Mat.zeros(rows_all, agg0.hidden_dim, e.device)
+            torch.cuda.synchronize()
+            evs = [(ops.Event(), ops.Event()) for _ in range(max(10, min(args.steps, 50)))]
+            for a, b in evs:
+                run_steps(1)
+                a.record(e.stream)
+                ops.sage_dense_fwd(None, None, model.features, ids_all, rows_all, None, mlp.vars['weights'].value,
+                                   agg0.hidden_dim, False, ops.ACT_RELU, mlp.vars['bias'].value.buf, H, stream=e.stream)
+                b.record(e.stream)
+            e.sync()
+            mlp_us = float(np.mean([a.elapsed_ms(b) for a, b in evs])) * 1e3
+            flops = 2.0 * rows_all * F * agg0.hidden_dim
+            tf = flops / (mlp_us * 1e-6) / 1e12
+            result["roofline_gather"] = result["roofline"]
+            result["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                                  "traffic": None,
+                                  "kernel": "gemm_f32_mfma_kernel<128,128> (pooling MLP forward: [%d gathered rows x %d] . "
+                                            "[%d x %d], v_mfma_f32_32x32x2_f32)" % (rows_all, F, F, agg0.hidden_dim),
+                                  "avg_launch_us": mlp_us, "algorithmic_flops_per_launch": flops}
         if rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "graphsage_mean" and G is not None:
             from oracle.cpu_baseline import time_cpu_baseline
             from graphsage_amd.utils import padded_from_csr
