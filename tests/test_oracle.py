@@ -78,6 +78,68 @@ def test_backward_finite_differences(agg, concat, sig):
             assert abs(fd - g[idx]) <= 1e-6 + 1e-5 * (abs(fd) + abs(g[idx])), (name, idx, fd, g[idx])
 
 
+@pytest.mark.parametrize("agg,concat", [("mean", True), ("gcn", False), ("maxpool", True)])
+def test_identity_and_dropout_finite_differences(agg, concat):
+    """The oracle's embedding gradient (identity_dim > 0) and its injected-dropout backward, checked by central
+    differences in fp64 (the device parity tests for these options rest on this)."""
+    rng = np.random.default_rng(5)
+    N, F, idim, C, B = 30, 4, 3, 4, 5
+    fixed = np.vstack([rng.normal(size=(N, F)), np.zeros((1, F))])
+    emb = rng.normal(size=(N + 1, idim)) * 0.5
+    neigh = [list(rng.choice(N, size=rng.integers(1, 8), replace=False)) for _ in range(N)]
+    adj, _ = orc.construct_adj(neigh, 8, rng)
+    ns, dims = [3, 2], [F + idim, 4, 4]
+    params = orc.make_supervised_params(agg, dims, C, concat, rng, dtype=np.float64)
+    if agg == "maxpool":
+        for p in params["agg"]:
+            p["mlp_weights"] = p["mlp_weights"][:, :6].copy()
+            p["mlp_bias"] = rng.normal(size=6) * 0.1
+            p["neigh_weights"] = orc.glorot((6, p["neigh_weights"].shape[1]), rng, np.float64)
+    perms = [rng.permutation(8), rng.permutation(8)]
+    batch = rng.choice(N, B, replace=False)
+    samples, ss = orc.sample(adj, batch, ns, perms)
+    labels = np.eye(C)[rng.integers(0, C, B)]
+    keep = 0.7
+    cache = {}
+
+    def masks(layer, hop, role, n_rows, d):      # fixed random masks, scaled by 1/keep like tf.nn.dropout
+        if role == "self" and agg == "maxpool":
+            return None
+        key = (layer, hop, role)
+        if key not in cache:
+            cache[key] = (rng.random((n_rows, d)) < keep) / keep
+        return cache[key]
+
+    out_dim = dims[-1] * (2 if concat else 1)
+    head_mask = (rng.random((B, out_dim)) < keep) / keep
+
+    def f():
+        feats = np.concatenate([emb, fixed], axis=1)
+        return orc.supervised_fwd_bwd(params, feats, samples, ss, labels, dims, ns, B, agg, concat, False,
+                                      weight_decay=0.0, identity_dim=idim, masks=masks, head_mask=head_mask)
+    r = f()
+    g_emb = r["grads"]["embeds"]
+    touched = np.unique(np.concatenate(samples))
+    assert np.count_nonzero(g_emb) > 0 and not g_emb[np.setdiff1d(np.arange(N + 1), touched)].any()
+    for _ in range(12):
+        idx = (int(rng.choice(touched)), int(rng.integers(0, idim)))
+        old = emb[idx]
+        emb[idx] = old + 1e-6; lp = f()["loss"]
+        emb[idx] = old - 1e-6; lm = f()["loss"]
+        emb[idx] = old
+        fd = (lp - lm) / 2e-6
+        assert abs(fd - g_emb[idx]) <= 1e-6 + 1e-5 * (abs(fd) + abs(g_emb[idx])), (idx, fd, g_emb[idx])
+    for (name, p), (_, g) in zip(orc.flat_param_items(params, agg), orc.flat_param_items(r["grads"], agg)):
+        for _ in range(3):
+            idx = tuple(rng.integers(0, s) for s in p.shape)
+            old = p[idx]
+            p[idx] = old + 1e-6; lp = f()["loss"]
+            p[idx] = old - 1e-6; lm = f()["loss"]
+            p[idx] = old
+            fd = (lp - lm) / 2e-6
+            assert abs(fd - g[idx]) <= 1e-6 + 1e-5 * (abs(fd) + abs(g[idx])), (name, idx, fd, g[idx])
+
+
 def test_reference_schedule_semantics():
     """Appendix A: support sizes, concat order, identity act on the last layer, pad row in the mean."""
     rng = np.random.default_rng(2)
