@@ -12,7 +12,7 @@ tf.nn.embedding_lookup, models.py:299) instead of tf.Tensors.
 from . import ops
 from .engine import get_engine
 from .inits import glorot, zeros
-from .ops import ACT_IDENTITY, ACT_RELU, Mat
+from .ops import ACT_IDENTITY, ACT_RELU
 
 # global unique layer ID dictionary for layer name assignment (layers.py:16-26)
 _LAYER_UIDS = {}

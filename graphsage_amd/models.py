@@ -20,7 +20,7 @@ from . import ops
 from .aggregators import GCNAggregator, MaxPoolingAggregator, MeanAggregator, MeanPoolingAggregator
 from .engine import get_engine
 from .inits import glorot
-from .layers import Rows, identity, relu
+from .layers import Rows, identity
 from .ops import Mat
 
 # SAGEInfo is a namedtuple that specifies the parameters of the recursive GraphSAGE layers

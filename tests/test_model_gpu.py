@@ -2,10 +2,9 @@
 IDENTICAL sampled neighbor sets (north_star: within 1e-4 fp32), for every aggregator of SURVEY §8a."""
 import numpy as np
 import pytest
-import torch
 
 from graphsage_amd import engine as eng
-from graphsage_amd import inits, ops
+from graphsage_amd import inits
 from graphsage_amd.minibatch import NodeMinibatchIterator
 from graphsage_amd.models import Placeholder, SAGEInfo
 from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, PaddedAdjacency, UniformNeighborSampler
