@@ -201,6 +201,10 @@ def main():
         model.attach_device_epoch(order, it.label_matrix)
     if world > 1:
         model.grad_hook = gsd.GradAllReduce(e)
+    elif os.environ.get("GS_PROBE_DP_SCHEDULE"):
+        # diagnostic: run the data-parallel step schedule (backward graph | hook | optimizer graph, one step per launch)
+        # on one GPU with a no-op hook, to see its host-side cost without RCCL
+        model.grad_hook = lambda m: None
 
     def barrier():
         if world > 1:
