@@ -148,3 +148,45 @@ def test_single_hip_runtime_mapped():
     assert out.returncode == 0, out.stderr[-2000:]
     paths = eval(out.stdout.strip().splitlines()[-1])
     assert len(paths) == 1, paths
+
+
+def test_split_gather_jobs_pointer_arithmetic():
+    """ops.split_gather_jobs: the tail job covers the last rows of the largest job with idx / out / self pointers
+    advanced by whole rows; head + tail partition the rows (pure host logic on descriptor structs)."""
+    from graphsage_amd import _lib, ops
+
+    def job(n, s, idx=0x1000, out=0x9000, self_src=None, self_idx=None, ldo=608, ld_self=608):
+        j = _lib.GatherDesc()
+        j.X, j.idx, j.out, j.self_src, j.self_idx = 0x100, idx, out, self_src, self_idx
+        j.ldx, j.ld_self, j.ldo, j.n, j.s, j.d = 608, ld_self, ldo, n, s, 602
+        return j
+
+    small, big = job(512, 10, idx=0x2000, out=0x5000), job(5120, 25)
+    head, tail = ops.split_gather_jobs([small, big], 0.7)
+    assert len(head) == 2 and len(tail) == 1
+    n_head = int(5120 * 0.7)
+    assert head[0].n == 512 and head[1].n == n_head and tail[0].n == 5120 - n_head
+    assert tail[0].idx == 0x1000 + 4 * n_head * 25 and tail[0].out == 0x9000 + 4 * n_head * 608
+    assert head[1].idx == 0x1000 and head[1].out == 0x9000 and tail[0].s == 25 and tail[0].d == 602
+    # GCN jobs carry self rows: through an index vector (advance the indices) or dense (advance the rows)
+    _, t = ops.split_gather_jobs([job(100, 5, self_src=0x7000, self_idx=0x8000)], 0.25)
+    assert t[0].self_idx == 0x8000 + 4 * 25 and t[0].self_src == 0x7000 and t[0].n == 75
+    _, t = ops.split_gather_jobs([job(100, 5, self_src=0x7000, ld_self=256)], 0.25)
+    assert t[0].self_src == 0x7000 + 4 * 25 * 256 and not t[0].self_idx
+    # degenerate fractions
+    h, t = ops.split_gather_jobs([big], 1.0)
+    assert len(h) == 1 and not t
+    h, t = ops.split_gather_jobs([small, big], 0.0)
+    assert len(h) == 1 and h[0].n == 512 and t[0].n == 5120 and t[0].idx == 0x1000
+    assert ops.split_gather_jobs([], 0.5) == ([], [])
+
+
+def test_rmat_generator_on_cpu():
+    """The R-MAT generator is plain torch: its CSR invariants hold on the CPU device too (BASELINE configs[4])."""
+    import torch
+    from graphsage_amd.utils import rmat_csr_device
+    rowptr, col = rmat_csr_device(3000, 60000, torch.device("cpu"), seed=9)
+    rp, c = rowptr.numpy(), col.numpy()
+    assert rp[0] == 0 and rp[-1] == 60000 and np.all(np.diff(rp) >= 0) and c.min() >= 0 and c.max() < 3000
+    deg = np.diff(rp)
+    assert deg.max() > 10 * deg.mean() and (deg == 0).any()       # skewed: hubs and isolated nodes
