@@ -48,7 +48,10 @@ class GraphData(object):
         return out
 
     def padded_features(self):
-        """features = vstack([features, zeros(F)])  (supervised_train.py:133-135); cached."""
+        """features = vstack([features, zeros(F)])  (supervised_train.py:133-135); cached.  None when the dataset has
+        no feature file (identity features only, utils.py:41-43 / supervised_train.py:132)."""
+        if self.feats is None:
+            return None
         if getattr(self, "_padded", None) is None:
             self._padded = np.vstack([self.feats, np.zeros((1, self.feats.shape[1]), dtype=np.float32)])
         return self._padded
@@ -201,7 +204,8 @@ def load_data(prefix, normalize=True):
     if os.path.exists(prefix + "-feats.npy"):
         feats = np.load(prefix + "-feats.npy").astype(np.float32)
     else:
-        raise Exception("No features present.. identity features are not supported by this engine yet")
+        print("No features present.. Only identity features will be used.")       # utils.py:41-43
+        feats = None
     first = next(iter(class_map.values()))
     multilabel = isinstance(first, list)
     if multilabel:
@@ -212,7 +216,7 @@ def load_data(prefix, normalize=True):
         labels = np.zeros(n, dtype=np.int64)
         for k, v in class_map.items():
             labels[id_map[str(k)]] = int(v)
-    if normalize:
+    if normalize and feats is not None:
         feats = standardize_on_train(feats, ~(val_mask | test_mask))
     return GraphData(n, src, dst, feats, labels, val_mask, test_mask, multilabel=multilabel)
 

@@ -114,6 +114,10 @@ def test_load_data_reference_format(tmp_path):
     assert G.train_removed.tolist() == [False, False, True, True]      # utils.py:55-60
     assert abs(G.feats[:3].mean()) < 1e-6                              # scaler fit on train rows only (:62-68)
     assert G.label_matrix().shape == (6, 2)
+    # no feature file -> identity features only (utils.py:41-43): feats is None, the model then needs identity_dim > 0
+    os.remove(prefix + "-feats.npy")
+    G2 = load_data(prefix)
+    assert G2.feats is None and G2.padded_features() is None and G2.n_nodes == 5
 
 
 def test_bench_json_strings_format():
