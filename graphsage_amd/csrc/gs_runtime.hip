@@ -60,7 +60,7 @@ extern "C" int gs_capture_end(void* stream, void** graph_exec_out) {
     GS_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);  // the executable graph keeps what it needs
     if (e != hipSuccess) {
         gs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
         return GS_EHIP;
