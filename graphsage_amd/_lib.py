@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "_C", "libgraphsage_amd.so")
 
 ACT_IDENTITY = 0
 ACT_RELU = 1
+GS_ABI_VERSION = 2      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -150,6 +151,11 @@ def load(build_if_missing=True):
     lib.gs_last_error.argtypes = []
     lib.gs_abi_version.restype = c_int
     lib.gs_abi_version.argtypes = []
+    got = lib.gs_abi_version()
+    if got != GS_ABI_VERSION:
+        raise GraphsageAmdError("%s has ABI version %d but this package binds version %d: the ctypes struct layouts "
+                                "would not match (rebuild with python -m graphsage_amd.build --force)"
+                                % (LIB_PATH, got, GS_ABI_VERSION))
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = c_int

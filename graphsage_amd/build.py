@@ -44,7 +44,10 @@ def build(force=False, verbose=False):
                 return LIB_PATH
     if not os.path.exists(HIPCC):
         if os.path.exists(LIB_PATH):
-            # GPU box without a matching source digest but with a prebuilt library: use it.
+            # GPU box without a matching source digest but with a prebuilt library: use it (its ABI version is checked
+            # against the Python binding in _lib.load()).
+            sys.stderr.write("graphsage_amd: hipcc not found; using the prebuilt %s although its source digest differs "
+                             "from the checked-out sources\n" % LIB_PATH)
             return LIB_PATH
         raise RuntimeError("hipcc not found at %s and no prebuilt %s" % (HIPCC, LIB_PATH))
     objs = []

@@ -170,6 +170,8 @@ class Engine(object):
         if m is None or m.rows < n:
             m = Mat(torch.ones((max(n, 1024), 4), dtype=torch.float32, device=self.device), 1)
             torch.cuda.synchronize()
+            # captured hipGraphs hold the pointer of every earlier (smaller) buffer: keep them all alive
+            self._ws.setdefault(("ones_keepalive",), []).append(m)
             self._ws[("ones",)] = m
         return m.rows_slice(0, n)
 

@@ -29,7 +29,7 @@ class NodeMinibatchIterator(object):
     def __init__(self, G, id2idx, placeholders, label_map, num_classes, batch_size=100, max_degree=25,
                  build_padded=True, **kwargs):
         self.G = G
-        self.nodes = np.arange(G.n_nodes)
+        self.nodes = np.where(G.present)[0]          # G.nodes(): nodes removed by load_data are not iterated
         self.id2idx = id2idx
         self.placeholders = placeholders
         self.batch_size = batch_size
@@ -136,7 +136,7 @@ class EdgeMinibatchIterator(object):
         self.batch_size = batch_size
         self.max_degree = max_degree
         self.batch_num = 0
-        self.nodes = np.random.permutation(G.n_nodes)
+        self.nodes = np.random.permutation(np.where(G.present)[0])
         no_train = G.val_mask | G.test_mask
         self.train_csr = build_csr(G.n_nodes, G.src, G.dst, keep=~G.train_removed)
         self.test_csr = build_csr(G.n_nodes, G.src, G.dst)
@@ -155,7 +155,7 @@ class EdgeMinibatchIterator(object):
         self.train_edges = self.edges = np.random.permutation(edges)
         self.train_edges = self._remove_isolated(self.train_edges)
         self.val_edges = np.stack([G.src, G.dst], axis=1)[G.train_removed]          # minibatch.py:45
-        print(int((~no_train).sum()), 'train nodes')
+        print(int((~no_train & G.present).sum()), 'train nodes')
         print(int(no_train.sum()), 'test nodes')
         self.val_set_size = len(self.val_edges)
 

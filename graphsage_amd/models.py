@@ -257,14 +257,15 @@ class SampleAndAggregate(object):
     def _stage_feed_unsup(self, feed_dict):
         e = self.engine
         ph = self.placeholders
-        self._parity = 0
+        self._parity = "h"         # host-fed batches own their buffers (see SupervisedGraphsage._stage_feed)
         self._pending_stage = None
+        e.sync()
         b1 = np.ascontiguousarray(np.asarray(feed_dict[ph['batch1']]), dtype=np.int32)
         b2 = np.ascontiguousarray(np.asarray(feed_dict[ph['batch2']]), dtype=np.int32)
         B = int(b1.shape[0])
         assert b2.shape[0] == B and int(feed_dict.get(ph['batch_size'], B)) == B
         self._feed_dropout(feed_dict)
-        roots, n_roots = self._roots(B, parity=0)
+        roots, n_roots = self._roots(B, parity="h")
         roots[:B].copy_(torch.from_numpy(b1))
         roots[B:2 * B].copy_(torch.from_numpy(b2))
         torch.cuda.current_stream().synchronize()

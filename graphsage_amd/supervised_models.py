@@ -136,8 +136,11 @@ class SupervisedGraphsage(SampleAndAggregate):
         """Copy the host feed (batch ids + label matrix) into persistent device buffers."""
         e = self.engine
         ph = self.placeholders
-        self._parity = 0
+        # host-fed batches own their buffers (key "h"): a device-epoch batch prefetched into the parity-0/1 buffers
+        # must survive an interleaved eval_step / train_step(feed) of the same size
+        self._parity = "h"
         self._pending_stage = None
+        e.sync()          # earlier steps still queued on the engine stream read these persistent buffers
         batch = np.ascontiguousarray(np.asarray(feed_dict[ph['batch']]), dtype=np.int32)
         n = int(batch.shape[0])
         bs = feed_dict.get(ph['batch_size'], n)
@@ -146,7 +149,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         batch_dev = self.ids_buffer(n)[0][:n]     # head of the contiguous id buffer (see models.sample)
         batch_dev.copy_(torch.from_numpy(batch))
         labels = np.ascontiguousarray(np.asarray(feed_dict[ph['labels']]), dtype=np.float32)
-        labels_dev = e.ws_mat(("labels", 0), n, self.num_classes)
+        labels_dev = e.ws_mat(("labels", "h"), n, self.num_classes)
         labels_dev.buf[:, : self.num_classes].copy_(torch.from_numpy(labels.reshape(n, self.num_classes)))
         torch.cuda.current_stream().synchronize()
         return batch_dev, labels_dev, n

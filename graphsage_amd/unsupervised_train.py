@@ -106,7 +106,8 @@ def save_val_embeddings(model, minibatch_iter, size, out_dir, mod=""):
         for i, edge in enumerate(edges):
             if not edge[0] in seen:
                 val_embeddings.append(outputs1[i, :])
-                nodes.append(edge[0])
+                ids = getattr(minibatch_iter.G, "node_ids", None)     # val.txt lists ORIGINAL node ids (:106-110)
+                nodes.append(ids[edge[0]] if ids is not None else edge[0])
                 seen.add(edge[0])
     if not os.path.exists(out_dir):
         os.makedirs(out_dir)
@@ -225,7 +226,7 @@ def main(argv=None):
     if FLAGS.random_context:
         walks = FLAGS.train_prefix + "-walks.txt"
         if FLAGS.train_prefix and os.path.exists(walks):          # utils.py:70-74
-            pairs = np.loadtxt(walks, dtype=np.int64).astype(np.int32).reshape(-1, 2)
+            pairs = utils.load_walk_pairs(walks, G)                # original ids -> rows via id_map
         else:
             rp, col = utils.build_csr(G.n_nodes, G.src, G.dst, keep=~G.train_removed)
             train_nodes = np.where(~(G.val_mask | G.test_mask))[0]

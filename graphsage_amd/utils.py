@@ -18,8 +18,15 @@ import numpy as np
 class GraphData(object):
     """Undirected graph as an edge list plus node attributes (what load_data returns, in arrays)."""
 
-    def __init__(self, n_nodes, src, dst, feats, labels, val_mask, test_mask, multilabel=False):
+    def __init__(self, n_nodes, src, dst, feats, labels, val_mask, test_mask, multilabel=False, present=None,
+                 id_map=None, node_ids=None):
         self.n_nodes = int(n_nodes)
+        # present[i] is False for rows of the id map whose node was dropped from the graph (utils.py:43-50: nodes
+        # lacking val/test annotations are removed); such rows keep their feature row but have no edges and belong to
+        # no split.  id_map: original node id (str) -> row; node_ids: row -> original node id (utils.py:32-33).
+        self.present = np.ones(self.n_nodes, dtype=bool) if present is None else np.asarray(present, dtype=bool)
+        self.id_map = id_map
+        self.node_ids = node_ids
         self.src = np.ascontiguousarray(src, dtype=np.int32)
         self.dst = np.ascontiguousarray(dst, dtype=np.int32)
         self.feats = feats                      # float32 [N, F] (no pad row yet)
@@ -180,10 +187,13 @@ def reddit_shaped(avg_degree=50, seed=123, n_nodes=232965, feat_dim=602, num_cla
                            seed=seed, val_frac=0.10, test_frac=0.24, feat_signal=feat_signal)
 
 
-def load_data(prefix, normalize=True):
+def load_data(prefix, normalize=True, load_walks=False):
     """Reader for the reference's on-disk format (utils.py:19-75): <prefix>-G.json (node-link),
-    -id_map.json, -class_map.json, -feats.npy.  Returns a GraphData (random-walk pairs are only
-    needed by the unsupervised driver)."""
+    -id_map.json, -class_map.json, -feats.npy [, -walks.txt].  Returns a GraphData whose rows are the id map's
+    indices; `.id_map` / `.node_ids` translate between original node ids and rows, `.present` marks the nodes kept
+    in the graph (nodes without 'val'/'test' annotations are removed, utils.py:43-50) and, with load_walks,
+    `.walks` holds the co-occurrence pairs of -walks.txt mapped to rows (minibatch.py:116-118; pairs naming a node
+    that is not in the graph are dropped, minibatch.py:64-66)."""
     G = json.load(open(prefix + "-G.json"))
     id_map = json.load(open(prefix + "-id_map.json"))
     class_map = json.load(open(prefix + "-class_map.json"))
@@ -192,15 +202,29 @@ def load_data(prefix, normalize=True):
     nodes = G["nodes"]
     val_mask = np.zeros(n, dtype=bool)
     test_mask = np.zeros(n, dtype=bool)
-    node_ids = []
+    present = np.zeros(n, dtype=bool)
+    node_ids = [None] * n
+    for k, v in id_map.items():
+        node_ids[v] = k
+    link_ids = []
+    broken_count = 0
     for nd in nodes:
+        link_ids.append(nd["id"])
         i = id_map[str(nd["id"])]
-        node_ids.append(nd["id"])
-        val_mask[i] = bool(nd.get("val", False))
-        test_mask[i] = bool(nd.get("test", False))
+        node_ids[i] = nd["id"]                  # keep the original type (int ids stay ints in val.txt)
+        if 'val' not in nd or 'test' not in nd:
+            broken_count += 1                   # G.remove_node(node) (utils.py:46-49)
+            continue
+        present[i] = True
+        val_mask[i] = bool(nd["val"])
+        test_mask[i] = bool(nd["test"])
+    print("Removed {:d} nodes that lacked proper annotations due to networkx versioning issues".format(broken_count))
     # networkx<=1.11 node-link JSON: "source"/"target" are positions in the "nodes" list
-    src = np.array([id_map[str(node_ids[l["source"]])] for l in G["links"]], dtype=np.int32)
-    dst = np.array([id_map[str(node_ids[l["target"]])] for l in G["links"]], dtype=np.int32)
+    src = np.array([id_map[str(link_ids[l["source"]])] for l in G["links"]], dtype=np.int32)
+    dst = np.array([id_map[str(link_ids[l["target"]])] for l in G["links"]], dtype=np.int32)
+    if src.size:
+        keep = present[src] & present[dst]      # removing a node removes its edges
+        src, dst = src[keep], dst[keep]
     if os.path.exists(prefix + "-feats.npy"):
         feats = np.load(prefix + "-feats.npy").astype(np.float32)
     else:
@@ -217,8 +241,34 @@ def load_data(prefix, normalize=True):
         for k, v in class_map.items():
             labels[id_map[str(k)]] = int(v)
     if normalize and feats is not None:
-        feats = standardize_on_train(feats, ~(val_mask | test_mask))
-    return GraphData(n, src, dst, feats, labels, val_mask, test_mask, multilabel=multilabel)
+        feats = standardize_on_train(feats, present & ~(val_mask | test_mask))   # utils.py:62-68
+    data = GraphData(n, src, dst, feats, labels, val_mask, test_mask, multilabel=multilabel, present=present,
+                     id_map=id_map, node_ids=node_ids)
+    if load_walks:
+        data.walks = load_walk_pairs(prefix + "-walks.txt", data)
+    return data
+
+
+def load_walk_pairs(path, G):
+    """<prefix>-walks.txt (one "node1 node2" pair of ORIGINAL node ids per line, utils.py:70-74) -> int32 [n, 2] rows
+    of the id map (minibatch.py:116-118).  Pairs naming an unknown or removed node are dropped (minibatch.py:64-66)."""
+    pairs = []
+    missing = 0
+    id_map = G.id_map
+    with open(path) as fp:
+        for line in fp:
+            tok = line.split()
+            if len(tok) < 2:
+                continue
+            a = id_map.get(tok[0]) if id_map is not None else int(tok[0])
+            b = id_map.get(tok[1]) if id_map is not None else int(tok[1])
+            if a is None or b is None or not (0 <= a < G.n_nodes and 0 <= b < G.n_nodes) \
+                    or not (G.present[a] and G.present[b]):
+                missing += 1
+                continue
+            pairs.append((a, b))
+    print("Unexpected missing:", missing)
+    return np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
 
 
 WALK_LEN = 5      # utils.py:16

@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 const char* gs_last_error(void);
 int gs_abi_version(void);

@@ -1,0 +1,161 @@
+"""-m gpu end-to-end parity AT THE BENCHED CONFIGURATION (BASELINE.json configs[1]/[2]: B=512, fan-out 25x10,
+F=602, dims 128/128, C=41) THROUGH THE PATH bench.py TIMES: device-resident epoch, fused CSR fan-out sampler,
+hipGraph capture/replay and the cross-step prefetch pipeline whose gather+mean rides inside the layer-0 contraction
+and the weight-gradient launches (SupervisedGraphsage.train_step_device / train_steps_device).
+
+For >= 5 consecutive steps (eager, eager, capture, capture, replay of the two parity graphs) the test
+  * reads the sampled ids back and checks them bit-exactly against the CPU restatement of the sampler hash,
+  * feeds THOSE ids to the NumPy oracle (models.py:254-330 + supervised_models.py:78-126 restated) and compares loss,
+    preds, every gradient (1e-4, north_star) and the parameters after clip + TF-Adam,
+so the prefetched / co-scheduled schedule is checked against the reference semantics and not only against itself.
+The graph is Reddit-shaped but smaller (N=60,000) so that the CPU oracle finishes in seconds per step."""
+import numpy as np
+import pytest
+
+from graphsage_amd import engine as eng
+from graphsage_amd import inits
+from graphsage_amd.minibatch import NodeMinibatchIterator
+from graphsage_amd.models import Placeholder, SAGEInfo
+from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, UniformNeighborSampler
+from graphsage_amd.supervised_models import SupervisedGraphsage
+from graphsage_amd.utils import reddit_shaped
+from oracle import graphsage_oracle as orc
+from oracle import sampler_hash
+
+pytestmark = pytest.mark.gpu
+
+B, S1, S2, F, C, DIM = 512, 25, 10, 602, 41, 128
+N_NODES = 60000
+_cache = {}
+
+
+def graph():
+    if "G" not in _cache:
+        G = reddit_shaped(avg_degree=60, seed=123, n_nodes=N_NODES, feat_dim=F, num_classes=C)
+        it = NodeMinibatchIterator(G, None, {}, None, G.num_classes, batch_size=B, max_degree=128, build_padded=False)
+        _cache["G"] = (G, it)
+    return _cache["G"]
+
+
+def build(agg_type, lr=0.01):
+    G, it = graph()
+    eng.reset_engine()
+    inits.set_seed(11)
+    e = eng.get_engine()
+    ph = {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'), 'dropout': Placeholder('dropout', 0.),
+          'batch_size': Placeholder('batch_size')}
+    adj_info = AdjInfo(CSRAdjacency(it.train_csr[0], it.train_csr[1], G.n_nodes, e.device))
+    sampler = UniformNeighborSampler(adj_info, seed=123)
+    mult = 2 if agg_type == "gcn" else 1                          # supervised_train.py:175-176
+    layer_infos = [SAGEInfo("node", sampler, S1, mult * DIM), SAGEInfo("node", sampler, S2, mult * DIM)]
+    model = SupervisedGraphsage(G.num_classes, ph, G.padded_features(), adj_info, it.deg, layer_infos,
+                                concat=(agg_type != "gcn"), aggregator_type=agg_type, sigmoid_loss=False,
+                                learning_rate=lr, weight_decay=0.0)
+    order = np.random.RandomState(123).permutation(it.train_nodes).astype(np.int32)
+    model.attach_device_epoch(order, it.label_matrix)
+    return G, it, model, order
+
+
+def np_params(model, agg_type):
+    agg = []
+    for a in model.aggregators:
+        p = {k: v.numpy().copy() for k, v in a.vars.items()}
+        if agg_type in ("maxpool", "meanpool"):
+            p["mlp_weights"] = a.mlp_layers[0].vars['weights'].numpy().copy()
+            p["mlp_bias"] = a.mlp_layers[0].vars['bias'].numpy().reshape(-1).copy()
+        agg.append(p)
+    return {"agg": agg, "node_pred": {"weights": model.node_pred.vars['weights'].numpy().copy(),
+                                      "bias": model.node_pred.vars['bias'].numpy().reshape(-1).copy()}}
+
+
+def np_grads(model, agg_type):
+    agg = []
+    for a in model.aggregators:
+        g = {k: v.grad.numpy().copy() for k, v in a.vars.items()}
+        if agg_type in ("maxpool", "meanpool"):
+            g["mlp_weights"] = a.mlp_layers[0].vars['weights'].grad.numpy().copy()
+            g["mlp_bias"] = a.mlp_layers[0].vars['bias'].grad.numpy().reshape(-1).copy()
+        agg.append(g)
+    return {"agg": agg, "node_pred": {"weights": model.node_pred.vars['weights'].grad.numpy().copy(),
+                                      "bias": model.node_pred.vars['bias'].grad.numpy().reshape(-1).copy()}}
+
+
+@pytest.mark.parametrize("agg_type,steps", [("mean", 5), ("gcn", 5), ("maxpool", 3)])
+def test_bench_path_matches_oracle(dev, agg_type, steps):
+    G, it, model, order = build(agg_type)
+    ns = [S1, S2]
+    feats = G.padded_features()
+    rowptr, col = it.train_csr
+    concat = agg_type != "gcn"
+    adam_state = None
+    assert getattr(model, "pipeline", False) and model.use_graphs          # the schedule bench.py runs
+    for t in range(steps):
+        before = np_params(model, agg_type)
+        loss, preds = model.train_step_device(B, fetch=True)
+        # ---- S1/S2: the ids the device drew == the CPU restatement of the counter hash (bit exact)
+        batch = order[t * B:(t + 1) * B]
+        got = [s.cpu().numpy() for s in model.samples1]
+        assert np.array_equal(got[0], batch)
+        hop1 = sampler_hash.sample_uniform_csr(rowptr, col, G.n_nodes, G.n_nodes, batch, S2, 123, t, 0)
+        hop2 = sampler_hash.sample_uniform_csr(rowptr, col, G.n_nodes, G.n_nodes, hop1.reshape(-1), S1, 123, t, 1)
+        assert np.array_equal(got[1], hop1.reshape(-1)) and np.array_equal(got[2], hop2.reshape(-1))
+        assert (got[2] != G.n_nodes).mean() > 0.9                             # real neighbors, not pad rows
+        # ---- the oracle on exactly these neighbor sets
+        labels = it.label_matrix[batch]
+        res = orc.supervised_fwd_bwd(before, feats, got, [1, S2, S2 * S1], labels, model.dims, ns, B, agg_type, concat,
+                                     False, weight_decay=0.0)
+        np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5, err_msg="step %d" % t)
+        np.testing.assert_allclose(preds, res["preds"], rtol=1e-4, atol=1e-4, err_msg="step %d" % t)
+        np.testing.assert_allclose(model.outputs1.numpy(), res["outputs1"], rtol=1e-4, atol=1e-4)
+        dev_g = np_grads(model, agg_type)
+        for (name, g), (_, w) in zip(orc.flat_param_items(dev_g, agg_type), orc.flat_param_items(res["grads"], agg_type)):
+            assert np.abs(w).max() > 0, name
+            np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                       err_msg="step %d %s" % (t, name))
+        # ---- clip +-5 and TF Adam (supervised_models.py:95-99): moments carried by the test across steps
+        after = np_params(model, agg_type)
+        if adam_state is None:
+            adam_state = [(np.zeros_like(p), np.zeros_like(p)) for _, p in orc.flat_param_items(before, agg_type)]
+        for (name, p0), (_, g), (_, p1), (m, v) in zip(orc.flat_param_items(before, agg_type),
+                                                       orc.flat_param_items(dev_g, agg_type),
+                                                       orc.flat_param_items(after, agg_type), adam_state):
+            want = p0.copy()
+            orc.adam_tf_update(want, orc.clip_by_value(g).reshape(want.shape), m, v, t + 1, 0.01)
+            np.testing.assert_allclose(p1.reshape(want.shape), want, rtol=1e-5, atol=2e-6, err_msg="step %d %s" % (t, name))
+            # and against the oracle's gradient: Adam normalises the step, so only elements whose gradient is not
+            # vanishing are comparable at 1e-4
+        for (name, p0), (_, gw), (_, p1) in zip(orc.flat_param_items(before, agg_type),
+                                                orc.flat_param_items(res["grads"], agg_type),
+                                                orc.flat_param_items(after, agg_type)):
+            if t == 0:
+                want = p0.copy()
+                orc.adam_tf_update(want, orc.clip_by_value(gw).reshape(want.shape), np.zeros_like(want),
+                                   np.zeros_like(want), 1, 0.01)
+                big = np.abs(gw).reshape(want.shape) > 1e-3 * np.abs(gw).max()
+                np.testing.assert_allclose(p1.reshape(want.shape)[big], want[big], rtol=1e-4, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("agg_type", ["mean", "gcn"])
+def test_bench_multistep_graphs_equal_single_steps(dev, agg_type):
+    """bench.py replays 8 consecutive steps per hipGraph launch (steps_per_launch=8): same bits as one step per
+    launch and as the eager sequential schedule without prefetch, at the benched shapes."""
+    outs = []
+    for mode in ("multi", "single", "sequential"):
+        G, it, model, order = build(agg_type)
+        if mode == "multi":
+            model.train_steps_device(B, 33, steps_per_launch=8)      # priming + eager / capture / replay of the 8-step graph
+        elif mode == "single":
+            for _ in range(33):
+                model.train_step_device(B)
+        else:
+            model.pipeline = False
+            model.use_graphs = False
+            for _ in range(33):
+                model.train_step_device(B)
+        loss, preds = model._fetch(B)
+        outs.append((loss, preds.copy(), model.engine.params.cpu().numpy().copy()))
+    for other in outs[1:]:
+        assert outs[0][0] == other[0]
+        assert np.array_equal(outs[0][1], other[1])
+        assert np.array_equal(outs[0][2], other[2])
+    assert np.isfinite(outs[0][0])

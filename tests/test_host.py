@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "header declares %s but the library does not export it" % name
     assert sorted(declared) == _lib.EXPORTED_SYMBOLS, set(declared) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.gs_abi_version() == 1
+    assert lib.gs_abi_version() == _lib.GS_ABI_VERSION
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -118,6 +118,42 @@ def test_load_data_reference_format(tmp_path):
     os.remove(prefix + "-feats.npy")
     G2 = load_data(prefix)
     assert G2.feats is None and G2.padded_features() is None and G2.n_nodes == 5
+
+
+def test_load_data_id_map_walks_and_removed_nodes(tmp_path):
+    """A non-identity id map, string node ids, a node without val/test annotations (removed, utils.py:43-50) and a
+    walks file in ORIGINAL ids (mapped through id_map, minibatch.py:116-118; pairs naming removed/unknown nodes are
+    dropped, :64-66)."""
+    from graphsage_amd.minibatch import EdgeMinibatchIterator, NodeMinibatchIterator
+    from graphsage_amd.utils import load_data
+    prefix = str(tmp_path / "toy2")
+    names = ["a", "b", "c", "d", "e", "f"]
+    rows = {"a": 4, "b": 0, "c": 5, "d": 1, "e": 3, "f": 2}                       # NOT the identity
+    nodes = [{"id": nm, "val": nm == "d", "test": nm == "e"} for nm in names]
+    del nodes[5]["val"]                                                           # "f" lacks an annotation -> removed
+    links = [{"source": 0, "target": 1}, {"source": 1, "target": 2}, {"source": 2, "target": 3},
+             {"source": 3, "target": 4}, {"source": 4, "target": 5}, {"source": 0, "target": 5}]
+    json.dump({"directed": False, "graph": {}, "nodes": nodes, "links": links, "multigraph": False}, open(prefix + "-G.json", "w"))
+    json.dump(rows, open(prefix + "-id_map.json", "w"))
+    json.dump({nm: i % 2 for i, nm in enumerate(names)}, open(prefix + "-class_map.json", "w"))
+    np.save(prefix + "-feats.npy", np.arange(18, dtype=np.float32).reshape(6, 3))
+    with open(prefix + "-walks.txt", "w") as fp:
+        fp.write("a\tb\nb\tc\na\tf\nzz\ta\nc\ta\n")
+    G = load_data(prefix, load_walks=True)
+    assert G.n_nodes == 6 and G.present.tolist() == [True, True, False, True, True, True]
+    assert G.val_mask.tolist() == [False, True, False, False, False, False] and G.test_mask[3]
+    # edges touching the removed node "f" (row 2) are gone; the others are in id-map rows
+    assert sorted(zip(G.src.tolist(), G.dst.tolist())) == [(0, 5), (1, 3), (4, 0), (5, 1)]
+    assert G.walks.tolist() == [[4, 0], [0, 5], [5, 4]]                            # a-f and zz-a dropped
+    assert G.node_ids[4] == "a" and G.id_map["c"] == 5
+    ph = {}
+    it = NodeMinibatchIterator(G, None, ph, None, G.num_classes, batch_size=2, max_degree=3)
+    assert sorted(it.train_nodes.tolist()) == [0, 4, 5] and 2 not in it.nodes.tolist()   # b, a, c; "f" is nowhere
+    assert (it.adj[2] == 6).all() and (it.test_adj[2] == 6).all()
+    from graphsage_amd.models import Placeholder
+    ph = {'batch1': Placeholder('b1'), 'batch2': Placeholder('b2'), 'batch_size': Placeholder('bs')}
+    eit = EdgeMinibatchIterator(G, None, ph, context_pairs=G.walks, batch_size=2, max_degree=3)
+    assert sorted(map(tuple, eit.train_edges.tolist())) == [(0, 5), (4, 0), (5, 4)] and 2 not in eit.nodes.tolist()
 
 
 def test_bench_json_strings_format():

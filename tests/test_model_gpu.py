@@ -417,3 +417,24 @@ def test_training_learns(dev):
     loss, preds = model.eval_step({ph['batch']: val, ph['labels']: it.label_matrix[val], ph['batch_size']: len(val)})
     f1 = orc.calc_f1_micro(it.label_matrix[val], preds, False)
     assert f1 > 0.8, f1
+
+
+def test_eval_between_device_steps_keeps_the_prefetched_batch(dev):
+    """A host-fed step (eval_step / train_step(feed)) of the SAME batch size between two device-epoch steps must not
+    touch the batch the pipeline has already prefetched (ids, labels, samples, layer-0 means live in parity buffers;
+    host-fed batches own theirs): the next device step equals the one of an uninterleaved run, bitwise."""
+    outs = []
+    for interleave in (False, True):
+        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+        model.attach_device_epoch(it.train_nodes[:160], it.label_matrix)
+        for _ in range(2):
+            model.train_step_device(32)
+        if interleave:
+            val = it.val_nodes[:32].astype(np.int32)
+            loss_v, preds_v = model.eval_step({ph['batch']: val, ph['labels']: it.label_matrix[val], ph['batch_size']: 32})
+            assert np.isfinite(loss_v) and preds_v.shape == (32, G.num_classes)
+        loss, preds = model.train_step_device(32, fetch=True)
+        assert np.array_equal(model.samples1[0].cpu().numpy(), it.train_nodes[64:96])
+        outs.append((loss, preds.copy(), eng.get_engine().params.cpu().numpy().copy()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
