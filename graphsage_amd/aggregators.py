@@ -207,9 +207,20 @@ class MeanAggregator(_SageBase):
         b = self.vars['bias'].value.buf if self.bias else None
         if side_jobs:
             # horizontally fused launch: these GEMM tiles + the NEXT step's gather-mean waves share the CUs
-            ops.sage_dense_fwd_cogather(self_all.src, self_all.ids, means, None, n_total,
-                                        self.vars['self_weights'].value, self.vars['neigh_weights'].value,
-                                        self.output_dim, self.concat, self.act_code, b, out, side_jobs, stream=e.stream)
+            def launch(jobs=list(side_jobs)):
+                ops.sage_dense_fwd_cogather(self_all.src, self_all.ids, means, None, n_total,
+                                            self.vars['self_weights'].value, self.vars['neigh_weights'].value,
+                                            self.output_dim, self.concat, self.act_code, b, out, jobs, stream=e.stream)
+            launch()
+            # bench.py re-issues exactly this launch between HIP events (roofline of the step's dominant kernel)
+            d_in = self_all.src.d
+            self.last_fused_launch = (launch, {
+                "kernel": "sage_dense_cogather_kernel: [%d x %d|%d] . [%d x %d] x2 (fp32 MFMA) + %d co-scheduled "
+                          "gather+mean jobs of the next step" % (n_total, d_in, means.d, d_in, self.output_dim, len(side_jobs)),
+                "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in side_jobs),
+                "gemm_bytes": n_total * (d_in + means.d) * 4 + (d_in + means.d) * self.output_dim * 4 + n_total * n_out * 4,
+                "flops": 2.0 * n_total * (d_in + means.d) * self.output_dim,
+                "gather_share": sum(j.n * j.s for j in side_jobs) / float(max(1, sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)))})
         else:
             ops.sage_dense_fwd(self_in.src, self_in.ids, means, None, n_total, self.vars['self_weights'].value,
                                self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,

@@ -56,3 +56,8 @@ class GradAllReduce(object):
     def __call__(self, model):
         with torch.cuda.stream(self.ext_stream):
             allreduce_sum_(self.engine.grads)
+
+
+def make_grad_hook(engine):
+    """The gradient all-reduce hook of a data-parallel run (see GradAllReduce)."""
+    return GradAllReduce(engine)

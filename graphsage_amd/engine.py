@@ -113,8 +113,23 @@ class Engine(object):
             v.value.buf[:, : v.cols].copy_(torch.from_numpy(v.init))
             v.slabs = torch.zeros((1 if v.scatter else MAX_SLABS) * v.size, dtype=torch.float32, device=self.device)
             v.n_slabs = 1 if v.scatter else 0
+        self._init_params = self.params.clone()
         torch.cuda.synchronize()
         self.finalized = True
+
+    def reset_parameters(self):
+        """Back to the initial weights with fresh optimizer state (Adam moments, step counter, sampler clock): a second
+        training run on the same model / captured graphs (bench.py's micro-F1 leg)."""
+        self.sync()
+        self.params.copy_(self._init_params)
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.grads.zero_()
+        self.step_dev.zero_()
+        self.sample_clock_dev.zero_()
+        torch.cuda.synchronize()
+        self._params_updated()
+        self.sync()
 
     def n_trainable(self):
         return sum(v.rows * v.cols for v in self.variables)

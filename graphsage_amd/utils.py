@@ -333,3 +333,140 @@ def rmat_csr_device(n_nodes, n_edges, device, abcd=(0.57, 0.19, 0.19, 0.05), see
     rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=device)
     torch.cumsum(counts, dim=0, out=rowptr[1:])
     return rowptr, col
+
+
+class DeviceGraph(object):
+    """A synthetic Reddit-shaped dataset generated and kept in HBM (see reddit_shaped_device): CSR train / test views,
+    the [N+1, ld] feature table (row N = zero pad row), the [N+1, C] label table, split masks.  `host_view()` copies what
+    the CPU baseline needs back to the host."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def host_view(self, max_degree=128, seed=123):
+        """(features [N+1, F], train padded adjacency, test padded adjacency, label matrix [N+1, C]) as NumPy arrays --
+        the inputs of the torch-CPU port of the reference graph (minibatch.py:227-259 tables from the same edges)."""
+        rng = np.random.RandomState(seed)
+        feats = self.feats.numpy()
+        rp, col = self.train_csr[0].cpu().numpy(), self.train_csr[1].cpu().numpy()
+        adj, _ = padded_from_csr(rp, col, self.n_nodes, max_degree, rng)
+        rp, col = self.test_csr[0].cpu().numpy(), self.test_csr[1].cpu().numpy()
+        test_adj, _ = padded_from_csr(rp, col, self.n_nodes, max_degree, rng)
+        return feats, adj, test_adj, self.label_table.numpy()
+
+
+def reddit_shaped_device(device, n_nodes=232965, feat_dim=602, num_classes=41, avg_degree=492, seed=123, p_in=0.8,
+                         val_frac=0.10, test_frac=0.24, feat_signal=0.5):
+    """The planted-community generator of synthetic_graph()/reddit_shaped() run ON THE DEVICE (torch as plumbing for
+    synthetic data only, like rmat_csr_device): Reddit's real average degree (~492) means 57 M undirected
+    edges, which the NumPy generator needs minutes for.  Same construction: power-law (Pareto-2, capped) endpoint
+    weights, destination in the source's community with probability p_in, one edge per node pair (networkx.Graph),
+    66/10/24 split, features = community centroid * feat_signal + N(0,1) standardised on the train rows
+    (utils.py:62-68), train view = edges between train nodes (utils.py:55-60 + minibatch.py:232-236).
+    Returns a DeviceGraph."""
+    import torch
+    from .ops import Mat
+    N, C = int(n_nodes), int(num_classes)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    comm = torch.randint(0, C, (N,), device=device, generator=g)
+    u = torch.rand(N, device=device, generator=g, dtype=torch.float64)
+    w = (1.0 - u).clamp_(min=1e-12).pow(-0.5)                               # Pareto(2) + 1
+    w = torch.minimum(w, torch.quantile(w, 0.999))
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    n_edges = int(N * avg_degree / 2)
+
+    def draw(n):
+        return torch.searchsorted(cdf, torch.rand(n, device=device, generator=g, dtype=torch.float64)).clamp_(max=N - 1)
+
+    src = draw(n_edges)
+    dst = draw(n_edges)
+    order = torch.argsort(comm, stable=True)
+    counts = torch.bincount(comm, minlength=C)
+    starts = torch.cumsum(counts, 0) - counts
+    cs = comm[src]
+    span = counts[cs].clamp(min=1)
+    pick = (torch.rand(n_edges, device=device, generator=g, dtype=torch.float64) * span).long()
+    dst_same = order[starts[cs] + torch.minimum(pick, span - 1)]
+    same = torch.rand(n_edges, device=device, generator=g) < p_in
+    dst = torch.where(same, dst_same, dst)
+    del dst_same, same, pick, span, cs
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    del keep
+    key = torch.cat([src * N + dst, dst * N + src])                         # symmetric, one entry per ordered pair
+    del src, dst
+    key = torch.unique(key)                                                 # sorted by (row, col); duplicates dropped
+    s, d = key // N, key % N
+    del key
+    r = torch.rand(N, device=device, generator=g)
+    val_mask = r < val_frac
+    test_mask = (r >= val_frac) & (r < val_frac + test_frac)
+    nt = val_mask | test_mask
+
+    def csr(rows, cols):
+        rowptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+        torch.cumsum(torch.bincount(rows, minlength=N), 0, out=rowptr[1:])
+        return rowptr, cols.to(torch.int32).contiguous()
+
+    test_csr = csr(s, d)
+    tr = ~(nt[s] | nt[d])
+    train_csr = csr(s[tr], d[tr])
+    del s, d, tr
+    deg = (train_csr[0][1:] - train_csr[0][:-1])
+    train_nodes = torch.nonzero(~nt & (deg > 0)).reshape(-1).to(torch.int32)
+    # features, standardised on the train rows, written straight into the padded [N+1, ld] table
+    feats = Mat.zeros(N + 1, feat_dim, device, ld_multiple=32)
+    centroids = torch.randn(C, feat_dim, device=device, generator=g)
+    x = feats.buf[:N, :feat_dim]
+    x.normal_(generator=g)
+    x += centroids[comm] * float(feat_signal)
+    xt = x[~nt]
+    mean = xt.mean(dim=0, dtype=torch.float64)
+    std = (xt.to(torch.float64) - mean).pow_(2).mean(dim=0).sqrt_()
+    del xt
+    std[std == 0] = 1.0
+    x -= mean.to(torch.float32)
+    x *= (1.0 / std).to(torch.float32)
+    label_table = Mat.zeros(N + 1, C, device)
+    label_table.buf[torch.arange(N, device=device), comm] = 1.0
+    torch.cuda.synchronize() if device.type == "cuda" else None
+    deg_np = deg.cpu().numpy().astype(np.int64)
+    deg_np[nt.cpu().numpy()] = 0
+    return DeviceGraph(n_nodes=N, num_classes=C, feat_dim=int(feat_dim), feats=feats, label_table=label_table, labels=comm,
+                       val_mask=val_mask, test_mask=test_mask, train_csr=train_csr, test_csr=test_csr,
+                       train_nodes=train_nodes.cpu().numpy(), val_nodes=torch.nonzero(val_mask).reshape(-1).to(torch.int32).cpu().numpy(),
+                       deg=deg_np, n_edges_undirected=int(test_csr[1].numel() // 2), avg_degree=avg_degree)
+
+
+def random_walk_pairs_device(rowptr, col, nodes, num_walks=N_WALKS, walk_len=WALK_LEN, seed=123, max_pairs=None):
+    """run_random_walks() on the device (CSR tensors in HBM): (start, current) co-occurrence pairs of uniform walks
+    (utils.py:77-92).  Returns an int32 [n_pairs, 2] device tensor."""
+    import torch
+    device = rowptr.device
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nodes = torch.as_tensor(nodes, device=device).to(torch.int64)
+    deg = rowptr[1:] - rowptr[:-1]
+    nodes = nodes[deg[nodes] > 0]
+    if max_pairs is not None:
+        per_node = max(1, (walk_len - 1) * num_walks)
+        keep = max(1, min(int(nodes.numel()), int(np.ceil(max_pairs / per_node))))
+        nodes = nodes[torch.randperm(nodes.numel(), device=device, generator=g)[:keep]]
+    start = nodes.repeat_interleave(num_walks)
+    cur = start.clone()
+    out = []
+    for j in range(walk_len):
+        if j > 0:
+            m = cur != start
+            out.append(torch.stack([start[m], cur[m]], dim=1))
+        dcur = deg[cur]
+        off = (torch.rand(cur.numel(), device=device, generator=g, dtype=torch.float64) * dcur).long()
+        off = torch.minimum(off, (dcur - 1).clamp(min=0))
+        nxt = col[(rowptr[cur] + off).clamp(max=col.numel() - 1)].to(torch.int64)
+        cur = torch.where(dcur > 0, nxt, cur)
+    pairs = torch.cat(out, dim=0).to(torch.int32)
+    if max_pairs is not None and pairs.shape[0] > max_pairs:
+        pairs = pairs[torch.randperm(pairs.shape[0], device=device, generator=g)[:max_pairs]]
+    return pairs

@@ -112,27 +112,52 @@ class CpuSupervisedMean(object):
 
 
 def time_cpu_baseline(features, adj, label_matrix, train_nodes, num_classes, batch_size=512, num_samples=(25, 10),
-                      dims=(602, 128, 128), budget_s=15.0, warmup=2, max_steps=100):
-    """Times full training steps of the port on a bounded sample of the workload (~budget_s of CPU time)."""
+                      dims=(602, 128, 128), budget_s=15.0, warmup=2, max_steps=100, order=None, fixed_steps=None,
+                      return_model=False):
+    """Times full training steps of the port on a bounded sample of the workload (~budget_s of CPU time).
+    `order` (epoch order of root nodes) and `fixed_steps` make the run reproducible step for step (bench.py's micro-F1
+    leg trains the MI355X engine on the same order for the same number of steps)."""
     model = CpuSupervisedMean(features, adj, list(dims), num_classes, list(num_samples))
-    rng = np.random.RandomState(123)
-    order = rng.permutation(train_nodes)
+    if order is None:
+        order = np.random.RandomState(123).permutation(train_nodes)
     times, i = [], 0
     t_start = time.time()
     while True:
-        b = order[(i * batch_size) % max(1, len(order) - batch_size):][:batch_size]
+        if fixed_steps is not None:
+            b = order[i * batch_size:(i + 1) * batch_size]
+        else:
+            b = order[(i * batch_size) % max(1, len(order) - batch_size):][:batch_size]
         t0 = time.time()
         model.train_step(b, label_matrix[b])
         dt = time.time() - t0
         if i >= warmup:
             times.append(dt)
         i += 1
-        if (time.time() - t_start > budget_s and len(times) >= 3) or len(times) >= max_steps:
+        if fixed_steps is not None:
+            if i >= fixed_steps:
+                break
+        elif (time.time() - t_start > budget_s and len(times) >= 3) or len(times) >= max_steps:
             break
     med = float(np.median(times))
     edges = batch_size * (num_samples[1] + num_samples[1] * num_samples[0])
-    return {"value": edges / med, "unit": "sampled-edges/s", "cores": int(model.threads), "kind": "port",
-            "sample": "%d full training steps (B=%d, fan-out %dx%d, F=%d) of the torch-CPU restatement of the "
-                      "reference TF graph (TF 1.x not installable), median step %.1f ms" %
-                      (len(times), batch_size, num_samples[0], num_samples[1], dims[0], med * 1e3),
-            "s_per_step": med}
+    res = {"value": edges / med, "unit": "sampled-edges/s", "cores": int(model.threads), "kind": "port",
+           "sample": "%d full training steps (B=%d, fan-out %dx%d, F=%d) of the torch-CPU restatement of the "
+                     "reference TF graph (TF 1.x not installable), median step %.1f ms" %
+                     (len(times), batch_size, num_samples[0], num_samples[1], dims[0], med * 1e3),
+           "s_per_step": med, "steps_trained": i}
+    return (res, model) if return_model else res
+
+
+def port_micro_f1(model, test_adj, label_matrix, val_nodes, batch_size=512, sigmoid=False):
+    """Validation micro-F1 of the port (supervised_train.py:63-70, 73-79): forward on the TEST adjacency
+    (supervised_train.py:280), argmax / 0.5-threshold, micro average."""
+    from . import graphsage_oracle as orc
+    model.adj = torch.from_numpy(np.ascontiguousarray(test_adj, dtype=np.int64))
+    preds = []
+    with torch.no_grad():
+        for a in range(0, len(val_nodes), batch_size):
+            b = val_nodes[a:a + batch_size]
+            samples, sizes = model.sample(b)
+            _, logits = model.forward(samples, sizes, label_matrix[b])
+            preds.append((torch.sigmoid(logits) if sigmoid else torch.softmax(logits, dim=1)).numpy())
+    return orc.calc_f1_micro(label_matrix[val_nodes], np.vstack(preds), sigmoid)
