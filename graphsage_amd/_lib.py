@@ -65,7 +65,9 @@ _PROTOS = {
     "gs_dense_wgrad_grouped_cogather": [_P, c_int32, _P, c_int32, _P],
     "gs_sage_dense_dgrad": [_P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
     "gs_flat_reduce_adam": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
-                            c_float, c_float, _P, _P],
+                            c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P],
+    "gs_sage_tail_supported": [c_int32, c_int32, c_int32],
+    "gs_sage_tail_fwd_bwd": [_P, _P],
     "gs_dropout_rows": [_P, c_int64, _P, c_int64, c_int32, _P, _P, c_int64, _P],
     "gs_gather_mean_dropout_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P, _P],
     "gs_scatter_add_rows": [_P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P, c_int64, _P],
@@ -115,6 +117,21 @@ class PullDesc(ctypes.Structure):
                 ("src", c_void_p * GS_PULL_MAX), ("ld_src", c_int64 * GS_PULL_MAX), ("row0", c_int64 * GS_PULL_MAX),
                 ("n", c_int64 * GS_PULL_MAX), ("s", c_int32 * GS_PULL_MAX), ("scale", c_float * GS_PULL_MAX),
                 ("mask_y", c_void_p), ("ldy", c_int64), ("out", c_void_p), ("ldo", c_int64), ("rows", c_int64)]
+
+
+class TailDesc(ctypes.Structure):
+    """struct gs_tail_desc (include/graphsage_amd.h)"""
+    _fields_ = [("h0", c_void_p), ("ldh", c_int64), ("n", c_int64),
+                ("W_self", c_void_p), ("ldws", c_int64), ("W_neigh", c_void_p), ("ldwn", c_int64),
+                ("W_head", c_void_p), ("ldwh", c_int64), ("b_head", c_void_p),
+                ("labels", c_void_p), ("ldlab", c_int64),
+                ("means", c_void_p), ("ldm", c_int64), ("z", c_void_p), ("ldz", c_int64), ("y", c_void_p), ("ldy", c_int64),
+                ("logits", c_void_p), ("ldlo", c_int64), ("preds", c_void_p), ("ldp", c_int64),
+                ("dlogits", c_void_p), ("lddl", c_int64), ("loss_rows", c_void_p),
+                ("dz", c_void_p), ("lddz", c_int64), ("d_h0", c_void_p), ("lddh", c_int64),
+                ("c0", c_void_p), ("d0", c_uint64), ("c1", c_void_p), ("d1", c_uint64), ("c2", c_void_p), ("d2", c_uint64),
+                ("s", c_int32), ("d_in", c_int32), ("out_dim", c_int32), ("C", c_int32), ("sigmoid", c_int32),
+                ("train", c_int32)]
 
 
 class VarDesc(ctypes.Structure):

@@ -154,11 +154,22 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
                                                                float* __restrict__ v, int64_t total4, float wd,
                                                                int fuse_adam, float lr, float b1, float b2, float eps,
                                                                float clip, float gscale,
-                                                               const uint64_t* __restrict__ step_dev) {
+                                                               const uint64_t* __restrict__ step_dev, int step_offset,
+                                                               const float* __restrict__ loss_rows, int64_t loss_n,
+                                                               float loss_scale, float* __restrict__ loss_out,
+                                                               int loss_accumulate) {
     float lr_t = 0.f;
     if (fuse_adam) {
-        const float t = (float)((step_dev ? *step_dev : 0ull) + 1ull);
+        const float t = (float)((step_dev ? *step_dev : 0ull) + (uint64_t)step_offset);
         lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    }
+    if (loss_rows && blockIdx.x == 0) {
+        // the step's scalar loss (supervised_models.py:111-118 reduce_mean): one wave, fixed order
+        float sacc = 0.f;
+        for (int64_t i = threadIdx.x; i < loss_n; i += 64) sacc += loss_rows[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+        if (threadIdx.x == 0) loss_out[0] = loss_accumulate ? loss_out[0] + sacc * loss_scale : sacc * loss_scale;
     }
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = q * 4;  // every segment offset/size is a multiple of 4 floats
@@ -206,7 +217,9 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
 extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
                                    float* v, int64_t total, float weight_decay, int fuse_adam, float lr, float beta1,
                                    float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
-                                   void* stream) {
+                                   int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
+                                   float* loss_out, int loss_accumulate, void* stream) {
+    GS_REQUIRE(!loss_rows || (loss_out && loss_n > 0), "gs_flat_reduce_adam: loss_out missing");
     GS_REQUIRE(vars_host && n_vars > 0 && n_vars <= GS_MAX_VARS, "gs_flat_reduce_adam: need 1..%d variables", GS_MAX_VARS);
     GS_REQUIRE(params && grads && total > 0 && total % 4 == 0, "gs_flat_reduce_adam: bad flat buffer");
     GS_REQUIRE(!fuse_adam || (m && v), "gs_flat_reduce_adam: Adam state missing");
@@ -231,7 +244,8 @@ extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars,
     const int64_t total4 = expect / 4;
     int blocks = (int)std::min<int64_t>(gs_ceil_div(total4, 64), 4096);
     hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, V, params, grads, m, v,
-                       total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev);
+                       total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev, step_offset,
+                       loss_rows, loss_n, loss_scale, loss_out, loss_accumulate);
     GS_LAUNCH_CHECK("flat_reduce_adam_kernel");
     return GS_OK;
 }

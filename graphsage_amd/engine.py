@@ -259,15 +259,20 @@ class Engine(object):
             arr[i].clear = 1 if v.scatter else 0
         return arr
 
-    def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0, side_jobs=None):
+    def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0, side_jobs=None,
+                        loss=None, step_offset=1):
         """One grouped launch for every queued weight gradient, then ONE launch that sums the slabs into the
-        flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass."""
+        flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass.
+        loss = (loss_rows, n, scale, loss_out, accumulate): the step's scalar loss is formed by that launch too;
+        step_offset = 0 when an earlier launch of the step has already advanced the optimizer step counter."""
         self.launch_wgrads(side_jobs)
         arr = self._var_descs()
+        lr_, ln, lscale, lout, lacc = loss if loss is not None else (None, 0, 0.0, None, False)
         ops.call("gs_flat_reduce_adam", ctypes.addressof(arr), len(self.variables), ops.ptr(self.params),
                  ops.ptr(self.grads), ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats,
                  float(weight_decay), 1 if fuse_adam else 0, lr, 0.9, 0.999, 1e-8, clip, grad_scale,
-                 ops.ptr(self.step_dev), self.stream)
+                 ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
+                 1 if lacc else 0, self.stream)
         if fuse_adam:
             self._params_updated()
 

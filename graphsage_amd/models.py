@@ -503,7 +503,7 @@ class SampleAndAggregate(object):
 
     def aggregate(self, samples, input_features, dims, num_samples, support_sizes, batch_size=None,
                   aggregators=None, name=None, concat=False, model_size="small", layer0_means=None,
-                  layer0_side_jobs=None):
+                  layer0_side_jobs=None, _stop_after_layer=None):
         from .aggregators import _contiguous
         if batch_size is None:
             batch_size = samples[0].numel()
@@ -531,6 +531,8 @@ class SampleAndAggregate(object):
                 outs = [aggregator((hidden[hop], neighs[hop])) for hop in range(n_hops)]
                 tape.append(("per_hop", aggregator, rows, offsets, outs))
             hidden = [Rows(o, None, requires_grad=True) for o in outs]
+            if _stop_after_layer is not None and layer == _stop_after_layer:
+                break          # the remaining layers run inside a fused launch (SupervisedGraphsage._forward)
         self._tape = tape
         return hidden[0].src, aggregators
 

@@ -338,6 +338,33 @@ def head_fwd_bwd(x, n, W, bias, labels, C, sigmoid_loss, y, logits, preds, dlogi
          dx.ptr if dx is not None else None, dx.ld if dx is not None else 0, _s(stream))
 
 
+def sage_tail_supported(d_in, out_dim, C):
+    return bool(_lib.load().gs_sage_tail_supported(int(d_in), int(out_dim), int(C)))
+
+
+def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels, C, sigmoid_loss, means, z, y, logits,
+                      preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), stream=None):
+    """gs_sage_tail_fwd_bwd: layer 1 + head (+ their input gradients when dz / d_h0 are given) in ONE launch.
+    counters: up to three (device int64 tensor, delta) pairs advanced at the end of the launch."""
+    q = _lib.TailDesc()
+    q.h0, q.ldh, q.n = h0.ptr, h0.ld, n
+    q.W_self, q.ldws, q.W_neigh, q.ldwn = W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld
+    q.W_head, q.ldwh, q.b_head = W_head.ptr, W_head.ld, ptr(b_head)
+    q.labels, q.ldlab = labels.ptr, labels.ld
+    q.means, q.ldm, q.z, q.ldz, q.y, q.ldy = means.ptr, means.ld, z.ptr, z.ld, y.ptr, y.ld
+    q.logits, q.ldlo = (logits.ptr, logits.ld) if logits is not None else (None, 0)
+    q.preds, q.ldp = (preds.ptr, preds.ld) if preds is not None else (None, 0)
+    q.dlogits, q.lddl, q.loss_rows = dlogits.ptr, dlogits.ld, ptr(loss_rows)
+    train = dz is not None and d_h0 is not None
+    q.dz, q.lddz = (dz.ptr, dz.ld) if train else (None, 0)
+    q.d_h0, q.lddh = (d_h0.ptr, d_h0.ld) if train else (None, 0)
+    cs = [(ptr(c), int(d)) for c, d in counters if c is not None and d]
+    cs += [(None, 0)] * (3 - len(cs))
+    (q.c0, q.d0), (q.c1, q.d1), (q.c2, q.d2) = cs[:3]
+    q.s, q.d_in, q.out_dim, q.C, q.sigmoid, q.train = s, h0.d, out_dim, C, 1 if sigmoid_loss else 0, 1 if train else 0
+    call("gs_sage_tail_fwd_bwd", ctypes.addressof(q), _s(stream))
+
+
 # ------------------------------------------------------------------------------------------ K6
 def reduce_slabs(slabs, n_slabs, slab_stride, rows, cols, ld_slab, weight_decay, w_ptr, ldw, grad_ptr, ldg,
                  accumulate=False, stream=None):

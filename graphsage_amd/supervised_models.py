@@ -37,7 +37,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         self.build()
 
     _OUT_ATTRS = ("preds", "samples1", "outputs1", "node_preds", "agg_out", "_loss_rows", "_dlogits", "_loss_accumulate",
-                  "_head_fused", "_d_agg_out", "_tape")
+                  "_head_fused", "_d_agg_out", "_tape", "_tail_used", "_tail_means", "_tail_dz", "_tail_dh0", "_tail_h0",
+                  "_tail_step_advanced")
 
     # ------------------------------------------------------------------------------ build (:78-100)
     def build(self):
@@ -58,38 +59,83 @@ class SupervisedGraphsage(SampleAndAggregate):
         return (getattr(self, "fuse_head", True) and self._dropout_rate() == 0 and d in (64, 128, 256, 512) and C <= 128
                 and (d * (((C + 3) & ~3) | 1) + 4 + 4 * d) * 4 <= 160 * 1024)
 
-    def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None):
-        """sample -> aggregate -> l2_normalize -> node_pred -> loss/preds  (supervised_models.py:79-92,102-126)."""
+    def _tail_ok(self):
+        """The fused layer-1 + head launch (gs_sage_tail_fwd_bwd) applies to the supervised two-layer mean model with
+        concat, no dropout, no trainable identity features and shapes the kernel supports."""
+        if not getattr(self, "fuse_tail", True) or len(self.layer_infos) != 2 or self.aggregator_type != "mean":
+            return False
+        a1 = self.aggregators[1]
+        return (self.concat and not a1.bias and self._dropout_rate() == 0 and self.embeds is None
+                and ops.sage_tail_supported(2 * self.dims[1], self.dims[2], self.num_classes))
+
+    def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None, epilogue=None):
+        """sample -> aggregate -> l2_normalize -> node_pred -> loss/preds  (supervised_models.py:79-92,102-126).
+        `epilogue`: the step's device-counter increments; when the fused tail launch runs it advances them itself
+        (and `_backward` then skips the separate epilogue launch)."""
         e = self.engine
         self.reset_tapes()
         del self.node_pred._saved[:]
         if prefetched is None:
             prefetched = self._data_phase(batch, n, getattr(self, "_parity", 0), stage=getattr(self, "_pending_stage", None))
         samples1, support_sizes1, means0 = prefetched
+        C = self.num_classes
+        self._tail_used = bool(train and self._tail_ok())
         out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n,
                                 aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
-                                layer0_means=means0, layer0_side_jobs=side_jobs)
+                                layer0_means=means0, layer0_side_jobs=side_jobs,
+                                _stop_after_layer=0 if self._tail_used else None)
         self.samples1 = samples1
-        self.agg_out = out
-        C = self.num_classes
-        self.outputs1 = e.ws_mat("outputs1", n, out.d)
+        if self._tail_used and self._tape[0][0] != "batched":
+            raise ops._lib.GraphsageAmdError("fused tail needs the contiguous id buffer (model.sample on ids_buffer)")
         self._loss_rows = e.ws_f32("loss_rows", n)
         self.preds = e.ws_mat("preds", n, C)
         self._dlogits = e.ws_mat("dlogits", n, C)
-        self._head_fused = self._fused_head_ok(out.d)
-        if self._head_fused:
-            # l2_normalize (:85) + Dense head (:88-92) + loss/preds (:111-126) + their gradients: ONE launch
+        if self._tail_used:
+            # layer 1 + l2_normalize + head + loss + every input gradient down to layer 0's pre-activations: ONE launch
+            h0 = self._tape[0][4]                       # [n + n*s, 2*dim_1]: layer-0 outputs of both hops
+            a1 = self.aggregators[1]
+            Z = 2 * self.dims[2]
+            s = self.num_samples[len(self.num_samples) - 1]
+            self._tail_means = e.ws_mat("tail_means", n, h0.d)
+            self.agg_out = e.ws_mat("tail_z", n, Z)
+            self.outputs1 = e.ws_mat("outputs1", n, Z)
             self.node_preds = e.ws_mat("node_preds", n, C)
-            self._d_agg_out = e.ws_mat("d_agg_out", n, out.d) if train else None
-            ops.head_fwd_bwd(out, n, self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels,
-                             C, self.sigmoid_loss, self.outputs1, self.node_preds, self.preds, self._dlogits,
-                             self._loss_rows, self._d_agg_out, stream=e.stream)
+            self._tail_dz = e.ws_mat("tail_dz", n, Z)
+            self._tail_dh0 = e.ws_mat((self.name, "d_hidden", 0), h0.rows, h0.d)
+            self._tail_h0 = h0
+            self._head_fused = True
+            counters = []
+            self._tail_step_advanced = False
+            if epilogue:
+                if epilogue.get("step"):
+                    counters.append((e.step_dev, epilogue["step"]))
+                    self._tail_step_advanced = True
+                if epilogue.get("clock"):
+                    counters.append((e.sample_clock_dev, epilogue["clock"]))
+                if epilogue.get("cursor") is not None and epilogue.get("cursor_delta"):
+                    counters.append((epilogue["cursor"], epilogue["cursor_delta"]))
+            ops.sage_tail_fwd_bwd(h0, n, s, a1.vars['self_weights'].value, a1.vars['neigh_weights'].value, self.dims[2],
+                                  self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels, C,
+                                  self.sigmoid_loss, self._tail_means, self.agg_out, self.outputs1, self.node_preds,
+                                  self.preds, self._dlogits, self._loss_rows, dz=self._tail_dz, d_h0=self._tail_dh0,
+                                  counters=counters, stream=e.stream)
         else:
-            self._inv_norm = e.ws_f32("inv_norm", n)
-            ops.l2norm_fwd(out, n, self.outputs1, self._inv_norm, stream=e.stream)                      # :85
-            self.node_preds = self.node_pred(Rows(self.outputs1, None, requires_grad=True))             # :88-92
-            ops.class_loss(self.node_preds, labels, n, C, self.sigmoid_loss, self._loss_rows, self.preds,
-                           self._dlogits, stream=e.stream)                                               # :111-126
+            self.agg_out = out
+            self.outputs1 = e.ws_mat("outputs1", n, out.d)
+            self._head_fused = self._fused_head_ok(out.d)
+            if self._head_fused:
+                # l2_normalize (:85) + Dense head (:88-92) + loss/preds (:111-126) + their gradients: ONE launch
+                self.node_preds = e.ws_mat("node_preds", n, C)
+                self._d_agg_out = e.ws_mat("d_agg_out", n, out.d) if train else None
+                ops.head_fwd_bwd(out, n, self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels,
+                                 C, self.sigmoid_loss, self.outputs1, self.node_preds, self.preds, self._dlogits,
+                                 self._loss_rows, self._d_agg_out, stream=e.stream)
+            else:
+                self._inv_norm = e.ws_f32("inv_norm", n)
+                ops.l2norm_fwd(out, n, self.outputs1, self._inv_norm, stream=e.stream)                      # :85
+                self.node_preds = self.node_pred(Rows(self.outputs1, None, requires_grad=True))             # :88-92
+                ops.class_loss(self.node_preds, labels, n, C, self.sigmoid_loss, self._loss_rows, self.preds,
+                               self._dlogits, stream=e.stream)                                               # :111-126
         # loss = weight decay terms (:104-108) + mean classification loss (the mean is added by the step epilogue)
         self._loss_accumulate = False
         if self.weight_decay != 0.0:
@@ -106,6 +152,22 @@ class SupervisedGraphsage(SampleAndAggregate):
         (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
         e.begin_backward()
+        if getattr(self, "_tail_used", False):
+            # the fused tail launch already produced every input gradient; queue the weight gradients it feeds
+            a1 = self.aggregators[1]
+            o = self.dims[2]
+            h0 = self._tail_h0
+            e.wgrad(self.node_pred.vars['weights'], self.outputs1, None, self._dlogits, 0, n)
+            e.bgrad(self.node_pred.vars['bias'], self._dlogits, n, self.num_classes)
+            e.wgrad(a1.vars['self_weights'], h0.rows_slice(0, n), None, self._tail_dz, 0, n)
+            e.wgrad(a1.vars['neigh_weights'], self._tail_means, None, self._tail_dz, o, n)
+            mode, agg0, rows, offsets, outs = self._tape[0]
+            agg0.backward_hops(self._tail_dh0, True, embed_sink=None)
+            e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
+                              side_jobs=wgrad_jobs,
+                              loss=(self._loss_rows, n, 1.0 / n, self.loss_dev, self._loss_accumulate) if epilogue is not None else None,
+                              step_offset=0 if self._tail_step_advanced else 1)
+            return
         if self._head_fused:
             e.wgrad(self.node_pred.vars['weights'], self.outputs1, None, self._dlogits, 0, n)
             e.bgrad(self.node_pred.vars['bias'], self._dlogits, n, self.num_classes)
@@ -172,9 +234,9 @@ class SupervisedGraphsage(SampleAndAggregate):
         def fwd_bwd():
             if prologue is not None:
                 prologue()
-            self._forward(batch_dev, labels_dev, n, train=True)
-            self._backward(n, fuse_adam=fused, epilogue=dict(step=1 if fused else 0, clock=1, cursor=cursor,
-                                                             cursor_delta=n if cursor is not None else 0))
+            ep = dict(step=1 if fused else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
+            self._forward(batch_dev, labels_dev, n, train=True, epilogue=ep)
+            self._backward(n, fuse_adam=fused, epilogue=ep)
 
         if fused:
             self._run((key, n, self._adj_version()), fwd_bwd)     # the whole step: one hipGraph
@@ -270,7 +332,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
             fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
-            self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs)
+            self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue)
             self._backward(n, fuse_adam=fused, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
 
         def body():

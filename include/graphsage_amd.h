@@ -330,9 +330,50 @@ typedef struct gs_var_desc {
                               after being read so that the next backward pass starts from 0 (needs n_slabs == 1) */
     int32_t reserved_;
 } gs_var_desc;
+/* step_offset: Adam's t = *step_dev + step_offset (1 when the counter is advanced AFTER this launch, 0 when an earlier
+ * launch of the step -- gs_sage_tail_fwd_bwd -- already advanced it).  loss_rows (nullable): the step's scalar loss
+ * loss_out[0] (+)= loss_scale * sum(loss_rows[0:loss_n]) is formed by workgroup 0 in a fixed order (replaces the
+ * gs_finalize_step launch of a training step). */
 int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
                         int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,
-                        float eps, float clip, float grad_scale, const uint64_t* step_dev, void* stream);
+                        float eps, float clip, float grad_scale, const uint64_t* step_dev, int32_t step_offset,
+                        const float* loss_rows, int64_t loss_n, float loss_scale, float* loss_out, int loss_accumulate,
+                        void* stream);
+
+/* Fused tail of the supervised two-layer GraphSAGE-mean model: layer 1 (MeanAggregator._call on the layer-0 outputs,
+ * aggregators.py:43-64, identity act: last layer, models.py:307-310), l2_normalize + Dense head + loss/preds
+ * (supervised_models.py:85-126) and their gradients down to dLoss/d(layer-0 pre-activations), ONE launch.  Every batch
+ * row is independent given the weights: a workgroup takes 16 rows through the whole chain (fp32 MFMA 16x16x4).
+ *   h0      [n + n*s, d_in]  relu outputs of layer 0: rows 0..n-1 = batch nodes, row n + i*s + j = j-th sample of node i
+ *   means   [n, d_in], z [n, 2*out_dim] (pre-normalisation), y [n, 2*out_dim] (= outputs1), logits / preds / dlogits
+ *           [n, C], loss_rows [n]: written (inputs of the weight-gradient launch and model outputs)
+ *   train != 0: dz [n, 2*out_dim] = dLoss/dz and d_h0 [n + n*s, d_in] = relu'(h0) * dLoss/dh0 are written too
+ *   c0..c2 (nullable device counters) are advanced by d0..d2 at the end of the launch.
+ * Supported: concat, no aggregator bias, d_in in {128, 256}, out_dim in {64, 128}, C <= 128 (gs_sage_tail_supported);
+ * anything else returns GS_ENOTSUP and the caller uses the per-operator entry points. */
+typedef struct gs_tail_desc {
+    const float* h0; int64_t ldh; int64_t n;
+    const float* W_self; int64_t ldws;
+    const float* W_neigh; int64_t ldwn;
+    const float* W_head; int64_t ldwh;
+    const float* b_head;
+    const float* labels; int64_t ldlab;
+    float* means; int64_t ldm;
+    float* z; int64_t ldz;
+    float* y; int64_t ldy;
+    float* logits; int64_t ldlo;
+    float* preds; int64_t ldp;
+    float* dlogits; int64_t lddl;
+    float* loss_rows;
+    float* dz; int64_t lddz;
+    float* d_h0; int64_t lddh;
+    uint64_t* c0; uint64_t d0;
+    uint64_t* c1; uint64_t d1;
+    uint64_t* c2; uint64_t d2;
+    int32_t s, d_in, out_dim, C, sigmoid, train;
+} gs_tail_desc;
+int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
+int gs_sage_tail_fwd_bwd(const gs_tail_desc* desc_host, void* stream);
 
 /* Inverted dropout tf.nn.dropout(x, keep_prob = 1 - rate) (aggregators.py:46-47,104-105; layers.py:107): kept
  * elements are scaled by 1/keep_prob.  The keep mask is a counter hash of (seed, *clock_dev, site, row0 + row,

@@ -555,9 +555,15 @@ def test_grouped_wgrad_and_flat_reduce_adam(dev):
     for i in range(3):
         vd[i].offset, vd[i].size, vd[i].slabs, vd[i].n_slabs, vd[i].decay = int(offs[i]), sizes[i], slabs[i].data_ptr(), nsl[i], int(i < 2)
     wd = 0.01
+    # the step's scalar loss is folded into the same launch (workgroup 0): loss_out = 7 + mean(loss_rows)
+    loss_rows_h = rng.random(700).astype(np.float32)
+    loss_rows = torch.from_numpy(loss_rows_h).to(dev)
+    loss_out = torch.full((1,), 7.0, device=dev)
     ops.call("gs_flat_reduce_adam", ctypes.addressof(vd), 3, ops.ptr(params), ops.ptr(grads), ops.ptr(m), ops.ptr(v), total,
-             wd, 1, 0.01, 0.9, 0.999, 1e-8, 5.0, 1.0, ops.ptr(step), ops.current_stream())
+             wd, 1, 0.01, 0.9, 0.999, 1e-8, 5.0, 1.0, ops.ptr(step), 1, ops.ptr(loss_rows), 700, 1.0 / 700, ops.ptr(loss_out), 1,
+             ops.current_stream())
     _sync()
+    np.testing.assert_allclose(float(loss_out.item()), 7.0 + loss_rows_h.astype(np.float64).mean(), rtol=1e-5)
     want = np.concatenate([(X[idx].astype(np.float64).T @ dZ[:, :out]).reshape(-1) + wd * p0[:sizes[0]],
                            (mean.astype(np.float64).T @ dZ[:, out:]).reshape(-1) + wd * p0[offs[1]:offs[2]],
                            dZ.astype(np.float64).sum(0)])
@@ -684,3 +690,52 @@ def test_sage_dense_cogather_equals_separate_calls(dev):
     assert np.array_equal(o1.numpy(), o2.numpy())
     assert np.array_equal(ma1.numpy(), ma2.numpy()) and np.array_equal(mb1.numpy(), mb2.numpy())
     np.testing.assert_allclose(ma2.numpy(), X[idx_a].reshape(700, 25, d).mean(1), **TOL)
+
+
+@pytest.mark.parametrize("n,s,D,O,C,sig,train", [(512, 10, 256, 128, 41, False, True), (37, 3, 128, 64, 7, True, True),
+                                                 (100, 10, 256, 64, 121, True, True), (48, 5, 128, 128, 64, False, True),
+                                                 (33, 4, 256, 128, 41, False, False)])
+def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
+    """gs_sage_tail_fwd_bwd (layer 1 + l2_normalize + head + loss + every input gradient, ONE launch) vs the oracle's
+    MeanAggregator / head restatements (aggregators.py:43-64, supervised_models.py:85-126) in fp64; ragged n, both
+    losses, C above and below one 64-column group, device counters."""
+    rng = np.random.default_rng(n + C)
+    rows = n + n * s
+    h0 = np.maximum(_asym(rng, (rows, D)), 0).astype(np.float32)            # relu outputs of layer 0 (zeros included)
+    Ws, Wn = _asym(rng, (D, O)) * 0.2, _asym(rng, (D, O)) * 0.2
+    Wh, bh = _asym(rng, (2 * O, C)) * 0.3, _asym(rng, (C,)) * 0.1
+    lab = (rng.random((n, C)) > 0.5).astype(np.float32) if sig else np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]
+    Z = 2 * O
+    assert ops.sage_tail_supported(D, O, C)
+    means, z, y = Mat.zeros(n, D, dev), Mat.zeros(n, Z, dev), Mat.zeros(n, Z, dev)
+    lo, pr, dl = Mat.zeros(n, C, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
+    lr = torch.zeros(n, device=dev)
+    dz, dh0 = Mat.zeros(n, Z, dev), Mat.zeros(rows, D, dev)
+    c0, c1 = torch.full((1,), 5, dtype=torch.int64, device=dev), torch.full((1,), 100, dtype=torch.int64, device=dev)
+    ops.sage_tail_fwd_bwd(Mat.from_numpy(h0, dev), n, s, Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev), O,
+                          Mat.from_numpy(Wh, dev), torch.from_numpy(bh).to(dev), Mat.from_numpy(lab, dev), C, sig, means, z, y,
+                          lo, pr, dl, lr, dz=dz if train else None, d_h0=dh0 if train else None,
+                          counters=[(c0, 1), (None, 3), (c1, n)])
+    _sync()
+    assert int(c0.item()) == 6 and int(c1.item()) == 100 + n
+    h64 = h0.astype(np.float64)
+    self_v, neigh = h64[:n], h64[n:].reshape(n, s, D)
+    zz, cache = orc.mean_aggregator_fwd(self_v, neigh, Ws.astype(np.float64), Wn.astype(np.float64), True, "id")
+    np.testing.assert_allclose(means.numpy(), neigh.mean(1), **TOL)
+    np.testing.assert_allclose(z.numpy(), zz, rtol=1e-4, atol=1e-4)
+    wy, ncache = orc.l2_normalize_fwd(zz)
+    np.testing.assert_allclose(y.numpy(), wy, **TOL)
+    logits = wy @ Wh.astype(np.float64) + bh
+    loss, dlog = orc.classification_loss(logits, lab.astype(np.float64), sig)
+    np.testing.assert_allclose(lo.numpy(), logits, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pr.numpy(), orc.sigmoid(logits) if sig else orc.softmax(logits), **TOL)
+    np.testing.assert_allclose(lr.cpu().numpy().astype(np.float64).mean(), loss, rtol=1e-4)
+    np.testing.assert_allclose(dl.numpy(), dlog, rtol=1e-4, atol=1e-7)
+    if not train:
+        assert float(dz.buf.abs().max().item()) == 0.0 and float(dh0.buf.abs().max().item()) == 0.0
+        return
+    d_z = orc.l2_normalize_bwd(dlog @ Wh.astype(np.float64).T, ncache)
+    np.testing.assert_allclose(dz.numpy(), d_z, rtol=1e-4, atol=1e-4 * np.abs(d_z).max())
+    d_self, d_neigh, _ = orc.mean_aggregator_bwd(d_z, cache, Ws.astype(np.float64), Wn.astype(np.float64), True, "id")
+    want = np.concatenate([d_self, d_neigh.reshape(n * s, D)], axis=0) * (h64 > 0)
+    np.testing.assert_allclose(dh0.numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())

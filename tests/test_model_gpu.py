@@ -65,7 +65,7 @@ def build(dev, agg_type, concat, sigmoid, K=2, csr=False, wd=0.0, feat_dim=50, d
     model = SupervisedGraphsage(G.num_classes, ph, G.padded_features() if use_features else None, adj_info, it.deg,
                                 layer_infos, concat=concat, aggregator_type=agg_type, sigmoid_loss=sigmoid,
                                 learning_rate=0.01, weight_decay=wd, identity_dim=identity_dim)
-    model.fuse_head = model.fuse_sampler = fuse
+    model.fuse_head = model.fuse_sampler = model.fuse_tail = fuse
     return G, it, ph, sampler, model, ns
 
 
