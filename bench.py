@@ -234,7 +234,9 @@ def main():
             order = gsd.shard_order(epoch, rank, world, B) if world > 1 else epoch
             model.attach_device_epoch(order, DG.label_table)
     if world > 1:
-        model.grad_hook = gsd.make_grad_hook(e)
+        model.grad_hook = gsd.make_grad_hook(e, log=log)
+        if rank == 0:
+            log("gradient all-reduce: %s" % type(model.grad_hook).__name__)
     elif os.environ.get("GS_PROBE_DP_SCHEDULE"):
         # diagnostic: run the data-parallel step schedule on one GPU with a no-op hook, to see its host-side cost
         model.grad_hook = lambda m: None

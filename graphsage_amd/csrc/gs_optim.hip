@@ -75,8 +75,8 @@ extern "C" int gs_colsum_slabs(const float* Z, int64_t ldz, int64_t n, int32_t n
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t count, float lr,
                                                    float b1, float b2, float eps, float clip, float gscale,
-                                                   const uint64_t* __restrict__ step_dev) {
-    const float t = (float)((step_dev ? *step_dev : 0ull) + 1ull);
+                                                   const uint64_t* __restrict__ step_dev, int step_offset) {
+    const float t = (float)((step_dev ? *step_dev : 0ull) + (uint64_t)step_offset);
     const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         float g = grad[i] * gscale;
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 extern "C" int gs_adam_step(float* p, const float* grad, float* m, float* v, int64_t count, float lr, float beta1,
                             float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
-                            void* stream) {
+                            int32_t step_offset, void* stream) {
     GS_REQUIRE(p && grad && m && v && count >= 0, "gs_adam_step: bad args");
     if (count == 0) return GS_OK;
     int blocks = (int)std::min<int64_t>(gs_ceil_div(count, 256), 2048);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, count, lr, beta1, beta2,
-                       eps, clip, grad_scale, step_dev);
+                       eps, clip, grad_scale, step_dev, step_offset);
     GS_LAUNCH_CHECK("adam_kernel");
     return GS_OK;
 }

@@ -48,87 +48,21 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int TT> struct VecT;
-template <> struct VecT<1> { typedef float type; };
-template <> struct VecT<2> { typedef f32x2 type; };
-template <> struct VecT<4> { typedef f32x4 type; };
-
-template <int TT>
-__device__ __forceinline__ float vec_elem(const typename VecT<TT>::type& v, int t) {
-    if constexpr (TT == 1) return v; else return v[t];
-}
-
-// acc[t] += A[16 x (k0..k1)] . B[(k0..k1) x cols(t)],  cols(t) = {n0 + TT*j + t, j = 0..15}.  (k1 - k0) % 4 == 0.
-// Lanes whose first column n0 + TT*j is >= n_lim contribute zeros (their output columns are garbage-free zeros).
-template <int TT>
-__device__ __forceinline__ void mm16_nn(const float* __restrict__ A, const int lda, const float* __restrict__ B,
-                                        const int64_t ldb, const int n0, const int n_lim, const int k0, const int k1,
-                                        f32x4 (&acc)[TT], const int lane) {
-    typedef typename VecT<TT>::type V;
-    const int j = lane & 15, q = lane >> 4;
-    const bool ok = n0 + TT * j < n_lim;
-    const float* bp = B + (int64_t)(k0 + q) * ldb + (ok ? n0 + TT * j : 0);
-    const float* ap = A + j * lda + k0 + q;
-    constexpr int U = 8;
-    int k = k0;
-    for (; k + 4 * U <= k1; k += 4 * U) {
-        V b[U];
-        float a[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            b[u] = *reinterpret_cast<const V*>(bp + (int64_t)(4 * u) * ldb);
-            a[u] = ap[4 * u];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float av = ok ? a[u] : 0.f;
-#pragma unroll
-            for (int t = 0; t < TT; ++t) acc[t] = mfma16(av, vec_elem<TT>(b[u], t), acc[t]);
-        }
-        bp += (int64_t)(4 * U) * ldb;
-        ap += 4 * U;
-    }
-    for (; k < k1; k += 4) {
-        const V b = *reinterpret_cast<const V*>(bp);
-        const float av = ok ? ap[0] : 0.f;
-#pragma unroll
-        for (int t = 0; t < TT; ++t) acc[t] = mfma16(av, vec_elem<TT>(b, t), acc[t]);
-        bp += 4 * ldb;
-        ap += 4;
-    }
-}
-
-// acc[t] += A[16 x K] . Bt,  Bt[k][col] = B[n0 + 16t + j][k]  (B row-major [n_rows x >=k_lim], k-contiguous).
-// K % 16 == 0 (A zero-padded to K in LDS); weight rows >= n_rows and k-quads starting at >= k_lim read as zeros.
-template <int TT>
-__device__ __forceinline__ void mm16_nt(const float* __restrict__ A, const int lda, const float* __restrict__ B,
-                                        const int64_t ldb, const int n0, const int n_rows, const int K, const int k_lim,
-                                        f32x4 (&acc)[TT], const int lane) {
-    const int j = lane & 15, q = lane >> 4;
-    const float* ap = A + j * lda + 4 * q;
-    const float* bp[TT];
-    bool rok[TT];
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-        const int nrow = n0 + 16 * t + j;
-        rok[t] = nrow < n_rows;
-        bp[t] = B + (int64_t)(rok[t] ? nrow : 0) * ldb + 4 * q;
-    }
-#pragma unroll 2
-    for (int kb = 0; kb < K; kb += 16) {
-        const bool kok = kb + 4 * q < k_lim;
-        f32x4 b4[TT];
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            b4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rok[t] && kok) b4[t] = *reinterpret_cast<const f32x4*>(bp[t] + kb);
-        }
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + kb);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < TT; ++t) acc[t] = mfma16(a4[e], b4[t][e], acc[t]);
-    }
+// WHAT BOUNDS THIS KERNEL: 32 workgroups, one per CU, 8 waves each -- nothing hides latency, and every global load a
+// phase waits for costs a full memory round trip (~1.5-2 us: the operands were last written by another XCD).  A first
+// version that loaded "just in time" spent ~24 dependent round trips (38-59 us for ~3 us of MFMA work).  None of the
+// global operands depends on anything computed here (h0, the weights, the labels are all inputs), so they are
+// PREFETCHED INTO REGISTERS up front, in two waves of requests, and the phases consume them from registers:
+//   S0 (kernel entry): this thread's h0 rows (self + s neighbors, 2 passes) and the wave's whole W slab of the z
+//                      contraction                                                        -> ~216 VGPRs in flight
+//   S1 (after z):      the wave's slices of W_head (both forms), labels / bias, and its two W slabs of the input-gradient
+//                      contraction                                                        -> ~200 VGPRs in flight
+// The relu mask of phase 8 is kept from S0 as bit flags, so h0 is read exactly once.  Barriers between phases are
+// LDS-only (fence on the "local" address space + s_barrier): they do not drain the outstanding global loads.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 __device__ __forceinline__ float tail_wave_sum(float v) {
@@ -142,192 +76,245 @@ __device__ __forceinline__ float tail_wave_max(float v) {
     return v;
 }
 
-// TZ = Z/128 (tiles per wave of the z / d_y contractions), TD = 2*D/128 (tiles per wave of the input gradients)
-template <int TZ, int TD>
+#define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
+
+template <int D, int O>
 __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a) {
+    constexpr int Z = 2 * O;
+    constexpr int ldh = D + 4, ldzs = Z + 4;
+    constexpr int D4 = D / 4;
+    constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;        // (row, float4 column) items per thread: D / 128
+    constexpr int ZSLABS = Z / 32;                                // 32-column slabs of z / d_y  (<= 8: one per wave)
+    constexpr int DSLABS = 2 * D / 32;                            // 32-column slabs of [d_self | d_means]
+    constexpr int DPW = DSLABS / TAIL_WAVES;                      // ... per wave (1 or 2)
+    constexpr int KZ = D / 4;                                     // k-steps (4 k each) of the z contraction
+    constexpr int M7 = O / 16;                                    // macro steps (16 k each) of the input-gradient contraction
+    constexpr int ldi = 2 * D + 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int D = a.D, O = a.O, Z = 2 * a.O, C = a.C;
-    const int ldh = D + 4, ldzs = Z + 4;
-    const int Cp4 = (C + 3) & ~3, Cp16 = (C + 15) & ~15;
-    const int groups = (C + 63) >> 6;                 // 64-column groups of the logits (1 or 2)
-    const int GC = groups * 64;
-    const int nks = TAIL_WAVES / groups;              // K-split of the logits contraction
-    const int ldc = Cp16 + 4;
+    const int C = a.C;
+    const int Cp4 = (C + 3) & ~3, Cp32 = (C + 31) & ~31;
+    constexpr int lslabs = 2, nks = 4, GC = 64;       // logits (C <= 64): 2 column slabs x 4 K-slices = the 8 waves
+    constexpr int KL = Z / nks / 4;                   // k-steps (4 k each) per K-slice
+    const int ldc = Cp32 + 4;
     float* Hs = lds;                                  // [16][ldh]   self rows of h0      (later: DIN [16][2D+8])
     float* Ms = Hs + TAIL_ROWS * ldh;                 // [16][ldh]   neighbor means
     float* Zs = Ms + TAIL_ROWS * ldh;                 // [16][ldzs]  z, then y
     float* DZs = Zs + TAIL_ROWS * ldzs;               // [16][ldzs]  dLoss/dz
     float* Ps = DZs + TAIL_ROWS * ldzs;               // [nks][16][GC] logits partials   (later: DY [16][ldzs])
     const int ps_floats = max(nks * TAIL_ROWS * GC, TAIL_ROWS * ldzs);
-    float* DLs = Ps + ps_floats;                      // [16][ldc]   dlogits, zero-padded to Cp16
+    float* DLs = Ps + ps_floats;                      // [16][ldc]   dlogits, zero-padded to Cp32
     float* invs = DLs + TAIL_ROWS * ldc;              // [16]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * TAIL_ROWS;
-    const int64_t n = a.n;
+    const int r0 = (int)blockIdx.x * TAIL_ROWS;       // (n + n*s) * ld < 2^31 is checked on the host: 32-bit offsets
+    const int n = (int)a.n;
     const int s = a.s;
+    const int ldh0 = (int)a.ldh;
+    const float inv_s = 1.0f / (float)s;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // ---------------- phase 0: self rows -> LDS; neighbor means (aggregators.py:48) -> LDS + global
-    {
-        const int d4 = D >> 2;
-        const float inv_s = 1.0f / (float)s;
-        for (int it = tid; it < TAIL_ROWS * d4; it += TAIL_THREADS) {
-            const int r = it / d4, c = (it - r * d4) * 4;
-            const int64_t i = r0 + r;
-            f32x4 hs = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
-            if (i < n) {
-                hs = *reinterpret_cast<const f32x4*>(a.h0 + i * a.ldh + c);
-                const float* nb = a.h0 + (n + i * s) * a.ldh + c;
-                int jn = 0;
-                for (; jn + 5 <= s; jn += 5) {
-                    f32x4 v[5];
+    // ================= S0: issue this thread's h0 rows and the wave's z-contraction weight slab
+    f32x4 hself[PASSES], hnb[PASSES][TAIL_NB];
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) v[u] = *reinterpret_cast<const f32x4*>(nb + (int64_t)(jn + u) * a.ldh);
+    for (int p = 0; p < PASSES; ++p) {
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it / D4, c = (it % D4) * 4;
+        const int i = min(r0 + r, n - 1);
+        hself[p] = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
+        const float* nb = a.h0 + (n + i * s) * ldh0 + c;
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) acc += v[u];
-                }
-                for (; jn < s; ++jn) acc += *reinterpret_cast<const f32x4*>(nb + (int64_t)jn * a.ldh);
-                acc *= inv_s;
-                *reinterpret_cast<f32x4*>(a.means + i * a.ldm + c) = acc;
-            }
-            *reinterpret_cast<f32x4*>(Hs + r * ldh + c) = hs;
-            *reinterpret_cast<f32x4*>(Ms + r * ldh + c) = acc;
-        }
+        for (int u = 0; u < TAIL_NB; ++u) hnb[p][u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
     }
-    __syncthreads();
+    // the z-contraction weight slab of this wave: a quarter of K now, the rest once phase 0 has freed registers
+    constexpr int KZA = KZ / 4, KZB = KZ - KZA;
+    f32x2 bzA[KZA], bzB[KZB];
+    const int zcol0 = (wave < ZSLABS ? wave : 0) * 32;
+    const int zterm = zcol0 >= O ? 1 : 0;
+    const int zldb4 = 4 * (int)(zterm ? a.ldwn : a.ldws);
+    const float* zB = (zterm ? a.Wn : a.Ws) + q * (zldb4 >> 2) + (zcol0 - zterm * O) + 2 * j;
+#pragma unroll
+    for (int u = 0; u < KZA; ++u) bzA[u] = *reinterpret_cast<const f32x2*>(zB + u * zldb4);
+
+    // ---------------- phase 0: self rows -> LDS; neighbor means (aggregators.py:48) -> LDS + global; relu mask bits
+    uint32_t mself[PASSES], mnb[PASSES][2];            // 4 bits per row: h > 0 of the float4's elements
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it / D4, c = (it % D4) * 4;
+        const bool valid = r0 + r < n;
+        f32x4 acc = zero4;
+        mnb[p][0] = mnb[p][1] = 0u;
+#pragma unroll
+        for (int u = 0; u < TAIL_NB; ++u) {
+            const f32x4 v = hnb[p][u];
+            if (u < s) acc += v;                                     // summation order j = 0..s-1, as gather_mean_wave
+            const uint32_t bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            mnb[p][u >> 3] |= bits << (4 * (u & 7));
+        }
+        const f32x4 hs = hself[p];
+        mself[p] = (hs.x > 0.f ? 1u : 0u) | (hs.y > 0.f ? 2u : 0u) | (hs.z > 0.f ? 4u : 0u) | (hs.w > 0.f ? 8u : 0u);
+        // pin the flags here: otherwise the compiler keeps the 12 float4 rows alive until phase 8 and re-derives them
+        asm volatile("" : "+v"(mself[p]), "+v"(mnb[p][0]), "+v"(mnb[p][1]));
+        acc = valid ? acc * inv_s : zero4;
+        if (valid) *reinterpret_cast<f32x4*>(a.means + (r0 + r) * (int)a.ldm + c) = acc;
+        *reinterpret_cast<f32x4*>(Hs + r * ldh + c) = valid ? hs : zero4;
+        *reinterpret_cast<f32x4*>(Ms + r * ldh + c) = acc;
+    }
+#pragma unroll
+    for (int u = 0; u < KZB; ++u) bzB[u] = *reinterpret_cast<const f32x2*>(zB + (KZA + u) * zldb4);
+    lds_barrier();
 
     // ---------------- phase 1: z = [self . W_self | means . W_neigh]   (concat, identity act: last layer)
-    {
-        const int col0 = wave * 16 * TZ;              // this wave's first output column in [0, Z)
-        const int term = col0 >= O ? 1 : 0;
-        f32x4 acc[TZ];
+    if (wave < ZSLABS) {
+        const int col0 = wave * 32;
+        const float* A = (col0 >= O ? Ms : Hs) + j * ldh + q;
+        f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
-        for (int t = 0; t < TZ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mm16_nn<TZ>(term ? Ms : Hs, ldh, term ? a.Wn : a.Ws, term ? a.ldwn : a.ldws, col0 - term * O, O, 0, D, acc, lane);
+        for (int u = 0; u < KZA; ++u) {
+            const float av = A[4 * u];
+            acc0 = mfma16(av, bzA[u].x, acc0);
+            acc1 = mfma16(av, bzA[u].y, acc1);
+        }
+#pragma unroll
+        for (int u = 0; u < KZB; ++u) {
+            const float av = A[4 * (KZA + u)];
+            acc0 = mfma16(av, bzB[u].x, acc0);
+            acc1 = mfma16(av, bzB[u].y, acc1);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 4 * q + i;
-#pragma unroll
-            for (int t = 0; t < TZ; ++t) {
-                const int col = col0 + TZ * j + t;
-                Zs[row * ldzs + col] = acc[t][i];
-                if (r0 + row < n) a.z[(r0 + row) * a.ldz + col] = acc[t][i];
-            }
+            const f32x2 v = {acc0[i], acc1[i]};
+            *reinterpret_cast<f32x2*>(Zs + row * ldzs + col0 + 2 * j) = v;
+            if (r0 + row < n) *reinterpret_cast<f32x2*>(a.z + (r0 + row) * (int)a.ldz + col0 + 2 * j) = v;
         }
     }
-    __syncthreads();
+
+    __builtin_amdgcn_sched_barrier(0);     // keep the S1 loads below the z MFMAs: hoisted, they would spill (256 VGPRs)
+    // ================= S1: issue the operands of every later phase (they land while phases 2..6 run)
+    // phase 3 (logits, NN form): column slab g3, K-slice ks3 of Z/4 k
+    const int g3 = wave % lslabs, ks3 = wave / lslabs;
+    f32x2 bl[KL];
+    {
+        const int ldw = (int)a.ldwh;
+        // lanes past the last class quad read column 0 instead (finite): their output columns are never read
+        const float* B = a.Wh + (ks3 * (4 * KL) + q) * ldw + (g3 * 32 + 2 * j < Cp4 ? g3 * 32 + 2 * j : 0);
+#pragma unroll
+        for (int u = 0; u < KL; ++u) bl[u] = *reinterpret_cast<const f32x2*>(B + (4 * u) * ldw);
+    }
+    // phase 4: bias / labels of this wave's two rows (one class per lane)
+    const int cl = min(lane, C - 1);
+    const float bias_l = a.bh ? a.bh[cl] : 0.f;
+    float lab2[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) lab2[rr] = a.labels[min(r0 + wave * 2 + rr, n - 1) * (int)a.ldlab + cl];
+    // phase 7 ([d_self | d_means], NT form): DPW slabs of 32 weight rows, K = O; slab 0 now, slab 1 after phase 3
+    f32x4 b7[DPW][M7][2];
+    auto load_b7 = [&](const int sl) {
+        const int col0 = (wave + sl * TAIL_WAVES) * 32;          // in [0, 2D)
+        const int term = col0 >= D ? 1 : 0;
+        const int ldw = (int)(term ? a.ldwn : a.ldws);
+        const float* B0 = (term ? a.Wn : a.Ws) + (col0 - term * D + j) * ldw + 4 * q;
+#pragma unroll
+        for (int m = 0; m < M7; ++m) {
+            b7[sl][m][0] = *reinterpret_cast<const f32x4*>(B0 + 16 * m);
+            b7[sl][m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + 16 * m);
+        }
+    };
+    load_b7(0);
+    lds_barrier();
 
     // ---------------- phase 2: y = l2_normalize(z)   (supervised_models.py:85); two rows per wave
+#pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = wave * 2 + rr;
+        float v[Z / 64];
         float ss = 0.f;
-        for (int c = lane; c < Z; c += 64) {
-            const float v = Zs[row * ldzs + c];
-            ss += v * v;
+#pragma unroll
+        for (int m = 0; m < Z / 64; ++m) {
+            v[m] = Zs[row * ldzs + lane + 64 * m];
+            ss += v[m] * v[m];
         }
         ss = tail_wave_sum(ss);
-        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-        for (int c = lane; c < Z; c += 64) {
-            const float v = Zs[row * ldzs + c] * inv;
-            Zs[row * ldzs + c] = v;
-            if (r0 + row < n) a.y[(r0 + row) * a.ldy + c] = v;
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-12f));      // v_rsq_f32 (1 ulp)
+#pragma unroll
+        for (int m = 0; m < Z / 64; ++m) {
+            const float y = v[m] * inv;
+            Zs[row * ldzs + lane + 64 * m] = y;
+            if (r0 + row < n) a.y[(r0 + row) * (int)a.ldy + lane + 64 * m] = y;
         }
         if (lane == 0) invs[row] = inv;
     }
-    __syncthreads();
+    lds_barrier();
 
-    // ---------------- phase 3: logits partials, K split over the waves (fixed-order sum in phase 4)
+    // ---------------- phase 3: logits partials: slab g, K-slice ks per wave (fixed-order sum in phase 4)
     {
-        const int g = wave % groups, ks = wave / groups;
-        const int kchunk = Z / nks;
-        f32x4 acc[4];
+        const float* A = Zs + j * ldzs + ks3 * (4 * KL) + q;
+        f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mm16_nn<4>(Zs, ldzs, a.Wh, a.ldwh, g * 64, Cp4, ks * kchunk, (ks + 1) * kchunk, acc, lane);
+        for (int u = 0; u < KL; ++u) {
+            const float av = A[4 * u];
+            acc0 = mfma16(av, bl[u].x, acc0);
+            acc1 = mfma16(av, bl[u].y, acc1);
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * q + i;
-            *reinterpret_cast<f32x4*>(Ps + (ks * TAIL_ROWS + row) * GC + g * 64 + 4 * j) =
-                f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x2*>(Ps + (ks3 * TAIL_ROWS + 4 * q + i) * GC + g3 * 32 + 2 * j) = f32x2{acc0[i], acc1[i]};
+    }
+    // phase 5 (d_y, NT form): rows n0 .. n0+31 of W_head, K = Cp32 <= 64 -> up to 4 macro steps x 2 tiles
+    f32x4 bh5[4][2];
+    {
+        const int ldw = (int)a.ldwh;
+        const int n0 = (wave < ZSLABS ? wave : 0) * 32;
+        const float* B0 = a.Wh + (n0 + j) * ldw;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int kq = min(16 * m + 4 * q, Cp4 - 4);     // clamped: dlogits are zero beyond C
+            bh5[m][0] = *reinterpret_cast<const f32x4*>(B0 + kq);
+            bh5[m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + kq);
         }
     }
-    __syncthreads();
+    if (DPW > 1) load_b7(DPW - 1);
+    lds_barrier();
 
-    // ---------------- phase 4: logits, loss rows, preds, dlogits   (supervised_models.py:111-126); two rows per wave
+    const float inv_n = 1.0f / (float)n, inv_c = 1.0f / (float)C, inv_nc = inv_n * inv_c;
+    // ---------------- phase 4: logits, loss rows, preds, dlogits   (supervised_models.py:111-126); two rows per wave,
+    // one class per lane (C <= 64).  __expf / __logf: v_exp_f32 / v_log_f32 based, ~1e-6 relative.
+#pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = wave * 2 + rr;
-        const int64_t i = r0 + row;
+        const int i = r0 + row;
         const bool valid = i < n;
-        float x[2], zl[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int c = lane + 64 * m;
-            x[m] = 0.f;
-            zl[m] = 0.f;
-            if (m < groups && c < C) {
-                float v = a.bh ? a.bh[c] : 0.f;
-                for (int ks = 0; ks < nks; ++ks) v += Ps[(ks * TAIL_ROWS + row) * GC + c];
-                x[m] = v;
-                if (valid) zl[m] = a.labels[i * a.ldlab + c];
-            }
-        }
-        float gl[2] = {0.f, 0.f}, pr[2] = {0.f, 0.f};
-        float loss = 0.f;
+        const bool in = lane < C;
+        float x = bias_l;
+        for (int ks = 0; ks < nks; ++ks) x += Ps[(ks * TAIL_ROWS + row) * GC + cl];
+        const float zl = (valid && in) ? lab2[rr] : 0.f;
+        if (!in) x = 0.f;
+        float gl, pr, loss;
         if (a.sigmoid) {
-            const float gscale = 1.0f / ((float)n * (float)C);
-            float acc = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int c = lane + 64 * m;
-                if (m < groups && c < C) {
-                    acc += fmaxf(x[m], 0.f) - x[m] * zl[m] + log1pf(expf(-fabsf(x[m])));
-                    pr[m] = 1.0f / (1.0f + expf(-x[m]));
-                    gl[m] = (pr[m] - zl[m]) * gscale;
-                }
-            }
-            loss = tail_wave_sum(acc) / (float)C;
+            const float e = __expf(-fabsf(x));
+            const float term = in ? fmaxf(x, 0.f) - x * zl + __logf(1.0f + e) : 0.f;
+            const float r1 = __builtin_amdgcn_rcpf(1.0f + e);               // v_rcp_f32 (1 ulp)
+            pr = x >= 0.f ? r1 : e * r1;
+            gl = (pr - zl) * inv_nc;
+            loss = tail_wave_sum(term) * inv_c;
         } else {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                if (m < groups && lane + 64 * m < C) mx = fmaxf(mx, x[m]);
-            mx = tail_wave_max(mx);
-            float se = 0.f, zs = 0.f, zx = 0.f;
-            float ex[2] = {0.f, 0.f};
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                if (m < groups && lane + 64 * m < C) {
-                    ex[m] = expf(x[m] - mx);
-                    se += ex[m];
-                    zs += zl[m];
-                    zx += zl[m] * x[m];
-                }
-            se = tail_wave_sum(se);
-            zs = tail_wave_sum(zs);
-            zx = tail_wave_sum(zx);
-            const float lse = mx + logf(se), inv_se = 1.0f / se, gscale = 1.0f / (float)n;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                if (m < groups && lane + 64 * m < C) {
-                    pr[m] = ex[m] * inv_se;
-                    gl[m] = (pr[m] * zs - zl[m]) * gscale;
-                }
-            loss = zs * lse - zx;
+            const float mx = tail_wave_max(in ? x : -INFINITY);
+            const float ex = in ? __expf(x - mx) : 0.f;
+            const float se = tail_wave_sum(ex);
+            const float zs = tail_wave_sum(zl);
+            const float zx = tail_wave_sum(zl * x);
+            pr = ex * __builtin_amdgcn_rcpf(se);
+            gl = (pr * zs - zl) * inv_n;
+            loss = zs * (mx + __logf(se)) - zx;
         }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int c = lane + 64 * m;
-            if (m < groups) {
-                const float gv = (valid && c < C) ? gl[m] : 0.f;
-                if (c < Cp16) DLs[row * ldc + c] = gv;
-                if (valid && c < Cp4) {
-                    const bool in = c < C;
-                    if (a.logits) a.logits[i * a.ldlo + c] = in ? x[m] : 0.f;
-                    if (a.preds) a.preds[i * a.ldp + c] = in ? pr[m] : 0.f;
-                    a.dlogits[i * a.lddl + c] = gv;
-                }
-            }
+        const float gv = (valid && in) ? gl : 0.f;
+        if (lane < Cp32) DLs[row * ldc + lane] = gv;
+        if (valid && lane < Cp4) {
+            if (a.logits) a.logits[i * (int)a.ldlo + lane] = in ? x : 0.f;
+            if (a.preds) a.preds[i * (int)a.ldp + lane] = in ? pr : 0.f;
+            a.dlogits[i * (int)a.lddl + lane] = gv;
         }
         if (valid && lane == 0) a.loss_rows[i] = loss;
     }
@@ -339,77 +326,113 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
         return;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---------------- phase 5: d_y = dlogits . W_head^T   -> DY (aliases the logits partials)
     float* DYs = Ps;
-    {
-        const int n0 = wave * 16 * TZ;
-        f32x4 acc[TZ];
+    if (wave < ZSLABS) {
+        const int n0 = wave * 32;
+        const float* A = DLs + j * ldc + 4 * q;
+        f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
-        for (int t = 0; t < TZ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mm16_nt<TZ>(DLs, ldc, a.Wh, a.ldwh, n0, Z, Cp16, Cp4, acc, lane);
+        for (int m = 0; m < 4; ++m) {
+            if (16 * m < Cp32) {                                   // wave-uniform
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + 16 * m);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = mfma16(a4[e], bh5[m][0][e], acc0);
+                    acc1 = mfma16(a4[e], bh5[m][1][e], acc1);
+                }
+            }
+        }
 #pragma unroll
-            for (int t = 0; t < TZ; ++t) DYs[(4 * q + i) * ldzs + n0 + 16 * t + j] = acc[t][i];
+        for (int i = 0; i < 4; ++i) {
+            DYs[(4 * q + i) * ldzs + n0 + j] = acc0[i];
+            DYs[(4 * q + i) * ldzs + n0 + 16 + j] = acc1[i];
+        }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---------------- phase 6: d_z = l2_normalize'(d_y)   (two rows per wave)
+#pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = wave * 2 + rr;
+        float dy[Z / 64], yv[Z / 64];
         float dot = 0.f;
-        for (int c = lane; c < Z; c += 64) dot += DYs[row * ldzs + c] * Zs[row * ldzs + c];
+#pragma unroll
+        for (int m = 0; m < Z / 64; ++m) {
+            dy[m] = DYs[row * ldzs + lane + 64 * m];
+            yv[m] = Zs[row * ldzs + lane + 64 * m];
+            dot += dy[m] * yv[m];
+        }
         dot = tail_wave_sum(dot);
         const float inv = invs[row];
         const bool clamped = inv >= 1.0e6f;   // sum(z^2) < 1e-12: y = z * 1e6, no normalisation term
-        for (int c = lane; c < Z; c += 64) {
-            const float dyv = DYs[row * ldzs + c];
-            const float g = clamped ? dyv * inv : inv * (dyv - Zs[row * ldzs + c] * dot);
-            DZs[row * ldzs + c] = g;
-            if (r0 + row < n) a.dz[(r0 + row) * a.lddz + c] = g;
+#pragma unroll
+        for (int m = 0; m < Z / 64; ++m) {
+            const float g = clamped ? dy[m] * inv : inv * (dy[m] - yv[m] * dot);
+            DZs[row * ldzs + lane + 64 * m] = g;
+            if (r0 + row < n) a.dz[(r0 + row) * (int)a.lddz + lane + 64 * m] = g;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---------------- phase 7: [d_self | d_means] = [d_z[:, :O] . W_self^T | d_z[:, O:] . W_neigh^T]  -> DIN
     float* DIN = Hs;                                   // [16][2D + 8]   (Hs | Ms are dead since phase 1)
-    const int ldi = 2 * D + 8;
-    {
-        const int col0 = wave * 16 * TD;               // in [0, 2D)
+#pragma unroll
+    for (int sl = 0; sl < DPW; ++sl) {
+        const int col0 = (wave + sl * TAIL_WAVES) * 32;
         const int term = col0 >= D ? 1 : 0;
-        f32x4 acc[TD];
+        const float* A = DZs + term * O + j * ldzs + 4 * q;
+        f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
-        for (int t = 0; t < TD; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mm16_nt<TD>(DZs + term * O, ldzs, term ? a.Wn : a.Ws, term ? a.ldwn : a.ldws, col0 - term * D, D, O, O, acc, lane);
+        for (int m = 0; m < M7; ++m) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + 16 * m);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 4; ++e) {
+                acc0 = mfma16(a4[e], b7[sl][m][0][e], acc0);
+                acc1 = mfma16(a4[e], b7[sl][m][1][e], acc1);
+            }
+        }
 #pragma unroll
-            for (int t = 0; t < TD; ++t) DIN[(4 * q + i) * ldi + col0 + 16 * t + j] = acc[t][i];
+        for (int i = 0; i < 4; ++i) {
+            DIN[(4 * q + i) * ldi + col0 + j] = acc0[i];
+            DIN[(4 * q + i) * ldi + col0 + 16 + j] = acc1[i];
+        }
     }
-    __syncthreads();
+    lds_barrier();
 
-    // ---------------- phase 8: d_h0 = relu'(h0) * (d_self on the self row, d_means / s on each of the s neighbor rows)
+    // ---------------- phase 8: d_h0 = relu'(h0) * (d_self on the self row, d_means / s on each of the s neighbor rows);
+    // the relu masks are the bit flags kept from phase 0 (h0 is read once).
     {
-        const int d4 = D >> 2;
-        const float inv_s = 1.0f / (float)s;
-        const int per_row = (1 + s) * d4;
-        for (int it = tid; it < TAIL_ROWS * per_row; it += TAIL_THREADS) {
-            const int r = it / per_row;
-            const int rem = it - r * per_row;
-            const int jn = rem / d4, c = (rem - jn * d4) * 4;
-            const int64_t i = r0 + r;
-            if (i >= n) continue;
-            const int64_t tgt = jn == 0 ? i : n + i * s + (jn - 1);
-            f32x4 g = *reinterpret_cast<const f32x4*>(DIN + r * ldi + (jn == 0 ? 0 : D) + c);
-            if (jn != 0) g *= inv_s;
-            const f32x4 h = *reinterpret_cast<const f32x4*>(a.h0 + tgt * a.ldh + c);
-            g.x = h.x > 0.f ? g.x : 0.f;
-            g.y = h.y > 0.f ? g.y : 0.f;
-            g.z = h.z > 0.f ? g.z : 0.f;
-            g.w = h.w > 0.f ? g.w : 0.f;
-            *reinterpret_cast<f32x4*>(a.d_h0 + tgt * a.lddh + c) = g;
+        const int lddh0 = (int)a.lddh;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int it = tid + p * TAIL_THREADS;
+            const int r = it / D4, c = (it % D4) * 4;
+            const int i = r0 + r;
+            if (i < n) {
+                const f32x4 g_self = *reinterpret_cast<const f32x4*>(DIN + r * ldi + c);
+                const f32x4 g_mean = *reinterpret_cast<const f32x4*>(DIN + r * ldi + D + c) * inv_s;
+                f32x4 o;
+                o.x = (mself[p] & 1u) ? g_self.x : 0.f;
+                o.y = (mself[p] & 2u) ? g_self.y : 0.f;
+                o.z = (mself[p] & 4u) ? g_self.z : 0.f;
+                o.w = (mself[p] & 8u) ? g_self.w : 0.f;
+                *reinterpret_cast<f32x4*>(a.d_h0 + i * lddh0 + c) = o;
+                float* dst = a.d_h0 + (n + i * s) * lddh0 + c;
+#pragma unroll
+                for (int u = 0; u < TAIL_NB; ++u) {
+                    if (u < s) {
+                        const uint32_t bits = mnb[p][u >> 3] >> (4 * (u & 7));
+                        o.x = (bits & 1u) ? g_mean.x : 0.f;
+                        o.y = (bits & 2u) ? g_mean.y : 0.f;
+                        o.z = (bits & 4u) ? g_mean.z : 0.f;
+                        o.w = (bits & 8u) ? g_mean.w : 0.f;
+                        *reinterpret_cast<f32x4*>(dst + u * lddh0) = o;
+                    }
+                }
+            }
         }
     }
     if (blockIdx.x == 0 && tid == 0) {                // device counters (sampler clock / epoch cursor / optimizer step)
@@ -421,28 +444,28 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
 
 static size_t tail_lds_bytes(int D, int O, int C) {
     const int Z = 2 * O, ldh = D + 4, ldzs = Z + 4;
-    const int Cp16 = (C + 15) & ~15, groups = (C + 63) >> 6, GC = groups * 64, nks = TAIL_WAVES / groups;
-    const int ps = std::max(nks * TAIL_ROWS * GC, TAIL_ROWS * ldzs);
-    const size_t floats = (size_t)2 * TAIL_ROWS * ldh + (size_t)2 * TAIL_ROWS * ldzs + ps + (size_t)TAIL_ROWS * (Cp16 + 4) + TAIL_ROWS;
+    const int Cp32 = (C + 31) & ~31;
+    const int ps = std::max(4 * TAIL_ROWS * 64, TAIL_ROWS * ldzs);      // logits partials [4][16][64] | DY [16][ldzs]
+    const size_t floats = (size_t)2 * TAIL_ROWS * ldh + (size_t)2 * TAIL_ROWS * ldzs + ps + (size_t)TAIL_ROWS * (Cp32 + 4) + TAIL_ROWS;
     return floats * sizeof(float);
 }
 
 extern "C" int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C) {
-    const bool ok = (d_in == 128 || d_in == 256) && (out_dim == 64 || out_dim == 128) && C >= 1 && C <= 128 &&
+    const bool ok = (d_in == 128 || d_in == 256) && (out_dim == 64 || out_dim == 128) && C >= 1 && C <= 64 &&
                     tail_lds_bytes(d_in, out_dim, C) <= 160 * 1024;
     return ok ? 1 : 0;
 }
 
-template <int TZ, int TD>
+template <int D, int O>
 static int launch_tail(const TailArgs& a, hipStream_t st) {
     const size_t lds = tail_lds_bytes(a.D, a.O, a.C);
     static bool attr_done = false;
     if (!attr_done) {
-        GS_HIP(hipFuncSetAttribute((const void*)sage_tail_kernel<TZ, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GS_HIP(hipFuncSetAttribute((const void*)sage_tail_kernel<D, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const unsigned blocks = (unsigned)gs_ceil_div(a.n, TAIL_ROWS);
-    hipLaunchKernelGGL((sage_tail_kernel<TZ, TD>), dim3(blocks), dim3(TAIL_THREADS), lds, st, a);
+    hipLaunchKernelGGL((sage_tail_kernel<D, O>), dim3(blocks), dim3(TAIL_THREADS), lds, st, a);
     GS_LAUNCH_CHECK("sage_tail_kernel");
     return GS_OK;
 }
@@ -451,8 +474,14 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, void* stream) {
     GS_REQUIRE(q, "gs_sage_tail_fwd_bwd: null descriptor");
     if (q->n == 0) return GS_OK;
     GS_REQUIRE(q->n > 0 && q->s > 0, "gs_sage_tail_fwd_bwd: bad sizes");
+    if (q->s > TAIL_NB) {
+        gs_set_error("gs_sage_tail_fwd_bwd: at most %d samples per node (got %d)", TAIL_NB, q->s);
+        return GS_ENOTSUP;
+    }
+    GS_REQUIRE((q->n + q->n * (int64_t)q->s) * std::max(q->ldh, std::max(q->lddh, (int64_t)1)) < (1ll << 31),
+               "gs_sage_tail_fwd_bwd: (n + n*s) * ld must be < 2^31 (32-bit row offsets)");
     if (!gs_sage_tail_supported(q->d_in, q->out_dim, q->C)) {
-        gs_set_error("gs_sage_tail_fwd_bwd: unsupported shape d_in=%d out_dim=%d C=%d (d_in in {128,256}, out_dim in {64,128}, C <= 128)",
+        gs_set_error("gs_sage_tail_fwd_bwd: unsupported shape d_in=%d out_dim=%d C=%d (d_in in {128,256}, out_dim in {64,128}, C <= 64)",
                      q->d_in, q->out_dim, q->C);
         return GS_ENOTSUP;
     }
@@ -485,9 +514,8 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, void* stream) {
     a.c0 = q->c0; a.d0 = q->d0; a.c1 = q->c1; a.d1 = q->d1; a.c2 = q->c2; a.d2 = q->d2;
     a.train = q->train ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    // TZ = Z/128 in {1, 2};  TD = 2*D/128 in {2, 4}
-    if (Z == 256 && D == 256) return launch_tail<2, 4>(a, st);
-    if (Z == 256 && D == 128) return launch_tail<2, 2>(a, st);
-    if (Z == 128 && D == 256) return launch_tail<1, 4>(a, st);
-    return launch_tail<1, 2>(a, st);
+    if (D == 256 && O == 128) return launch_tail<256, 128>(a, st);
+    if (D == 256 && O == 64) return launch_tail<256, 64>(a, st);
+    if (D == 128 && O == 128) return launch_tail<128, 128>(a, st);
+    return launch_tail<128, 64>(a, st);
 }

@@ -58,6 +58,97 @@ class GradAllReduce(object):
             allreduce_sum_(self.engine.grads)
 
 
-def make_grad_hook(engine):
-    """The gradient all-reduce hook of a data-parallel run (see GradAllReduce)."""
+class NativeAllReduce(object):
+    """grad_hook backed by the C ABI's RCCL binding (gs_comm_*): ONE ncclAllReduce(sum, fp32) of the flat gradient
+    buffer, enqueued on the ENGINE stream.  `capturable = True`: the model records it inside the step's hipGraph, so a
+    data-parallel step is one graph launch (backward | all-reduce | clip+Adam) and several steps replay per launch.
+    The RCCL unique id travels from rank 0 to the other ranks over torch.distributed (plumbing only)."""
+    capturable = True
+
+    def __init__(self, engine, world_size=None, rank=None):
+        import ctypes
+        import torch.distributed as dist
+        from . import _lib, ops
+        self.engine = engine
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_initialized() else 1
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world_size, self.rank = int(world_size), int(rank)
+        nbytes = 128
+        buf = (ctypes.c_uint8 * nbytes)()
+        if self.rank == 0:
+            ops.call("gs_comm_unique_id", ctypes.addressof(buf), nbytes)
+        if self.world_size > 1:
+            dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0)
+            raw = bytes(t.cpu().tolist())
+            buf = (ctypes.c_uint8 * nbytes)(*raw)
+        h = ctypes.c_void_p()
+        torch.cuda.set_device(engine.device)
+        ops.call("gs_comm_init_rank", ctypes.byref(h), self.world_size, self.rank, ctypes.addressof(buf), nbytes)
+        self._comm = h.value
+        self._lib = _lib
+
+    def all_reduce(self, flat, stream=None):
+        from . import ops
+        ops.call("gs_comm_allreduce_sum_f32", self._comm, ops.ptr(flat), flat.numel(), self.engine.stream if stream is None else stream)
+
+    def __call__(self, model):
+        self.all_reduce(self.engine.grads)
+
+    def self_test(self):
+        """The all-reduce eagerly and replayed from a captured hipGraph on a scratch buffer: sum of (rank + 1)."""
+        from . import ops
+        e = self.engine
+        x = torch.full((1024,), float(self.rank + 1), device=e.device)
+        torch.cuda.synchronize()
+        want = float(sum(range(1, self.world_size + 1)))
+        self.all_reduce(x)
+        e.sync()
+        if abs(float(x[0].item()) - want) > 1e-6 or abs(float(x[-1].item()) - want) > 1e-6:
+            raise RuntimeError("eager RCCL all-reduce gave %r, expected %r" % (float(x[0].item()), want))
+        g = ops.Graph(e.stream)
+        g.begin()
+        try:
+            self.all_reduce(x)
+        finally:
+            g.end()
+        x.fill_(float(self.rank + 1))
+        torch.cuda.synchronize()
+        g.launch()
+        e.sync()
+        if abs(float(x[5].item()) - want) > 1e-6:
+            raise RuntimeError("graph-replayed RCCL all-reduce gave %r, expected %r" % (float(x[5].item()), want))
+        return True
+
+    def close(self):
+        if self._comm:
+            self._lib.load().gs_comm_destroy(self._comm)
+            self._comm = None
+
+
+def make_grad_hook(engine, log=None):
+    """The gradient all-reduce hook of a data-parallel run: the in-graph RCCL binding of the C ABI when it initialises
+    and passes its self test on EVERY rank (the decision is collective), else the eager torch.distributed all-reduce
+    between two graphs (GradAllReduce).  GS_DP_NATIVE=0 forces the fallback."""
+    import torch.distributed as dist
+    hook, ok = None, 0
+    if os.environ.get("GS_DP_NATIVE", "1") == "1":
+        try:
+            hook = NativeAllReduce(engine)
+            hook.self_test()
+            ok = 1
+        except Exception as ex:      # RCCL missing / init or capture failure: every rank falls back together
+            if log:
+                log("native RCCL hook unavailable on rank %d: %r" % (dist.get_rank() if dist.is_initialized() else 0, ex))
+            ok = 0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=engine.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if ok:
+        return hook
+    if hook is not None:
+        hook.close()
     return GradAllReduce(engine)

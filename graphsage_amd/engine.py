@@ -276,10 +276,10 @@ class Engine(object):
         if fuse_adam:
             self._params_updated()
 
-    def adam(self, lr, clip=5.0, grad_scale=1.0):
+    def adam(self, lr, clip=5.0, grad_scale=1.0, step_offset=1):
         """Separate optimizer launch (data-parallel path: runs after the RCCL all-reduce of engine.grads)."""
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_param_floats, lr, self.step_dev,
-                      clip=clip, grad_scale=grad_scale, stream=self.stream)
+                      clip=clip, grad_scale=grad_scale, step_offset=step_offset, stream=self.stream)
         self._params_updated()
 
     def _params_updated(self):

@@ -569,6 +569,7 @@ class SampleAndAggregate(object):
     def _sample_phase(self, batch, n, parity, stage=None):
         """Batch/label staging + neighbor sampling into the parity-keyed id buffer (weight-free)."""
         self._parity = parity
+        self.reset_tapes()      # a forward-only step (eval) leaves saved activations behind: buffer keys count them
         for s in self._samplers():
             s.new_step()
         self._pending_stage = stage
@@ -607,8 +608,13 @@ class SampleAndAggregate(object):
         g.begin()
         try:
             fn()
-        finally:
-            g.end()
+        except Exception:
+            try:                      # leave the stream out of capture mode, or every later launch on it fails too
+                g.end()
+            except Exception:
+                pass
+            raise
+        g.end()
         self._graphs[key] = g
         self._graph_outputs[key] = {name: getattr(self, name) for name in self._OUT_ATTRS if hasattr(self, name)}
         g.launch()

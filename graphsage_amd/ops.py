@@ -373,9 +373,10 @@ def reduce_slabs(slabs, n_slabs, slab_stride, rows, cols, ld_slab, weight_decay,
 
 
 def adam_step(p, grad, m, v, count, lr, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, clip=5.0, grad_scale=1.0,
-              stream=None):
+              step_offset=1, stream=None):
+    """TF Adam with t = *step_dev + step_offset (0 when the step counter was already advanced this step)."""
     call("gs_adam_step", ptr(p), ptr(grad), ptr(m), ptr(v), count, lr, beta1, beta2, eps, clip, grad_scale,
-         ptr(step_dev), _s(stream))
+         ptr(step_dev), int(step_offset), _s(stream))
 
 
 def sum_scaled(x, count, scale, out, accumulate=False, stream=None):

@@ -66,6 +66,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             return False
         a1 = self.aggregators[1]
         return (self.concat and not a1.bias and self._dropout_rate() == 0 and self.embeds is None
+                and self.num_samples[-1] <= 11          # neighbor rows of a batch node are held in registers
                 and ops.sage_tail_supported(2 * self.dims[1], self.dims[2], self.num_classes))
 
     def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None, epilogue=None):
@@ -186,12 +187,18 @@ class SupervisedGraphsage(SampleAndAggregate):
         self.engine.advance(loss_rows=self._loss_rows, n=n, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
                             **counters)
 
-    def _optimize(self):
+    def _optimize(self, advanced=False):
         """Data-parallel path: clip_by_value(+-5) + Adam (:96-99) after the RCCL all-reduce.  The local gradient
-        is that of the local batch mean; the hook sums over ranks and grad_scale divides by world_size."""
+        is that of the local batch mean; the hook sums over ranks and grad_scale divides by world_size.
+        advanced: the step counter was already incremented by an earlier launch of this step."""
         e = self.engine
-        e.adam(self.learning_rate, clip=5.0, grad_scale=1.0 / self.world_size)
-        e.advance(step=1)
+        e.adam(self.learning_rate, clip=5.0, grad_scale=1.0 / self.world_size, step_offset=0 if advanced else 1)
+        if not advanced:
+            e.advance(step=1)
+
+    def _dp_in_graph(self):
+        """Data-parallel AND the all-reduce hook can be recorded inside the step's hipGraph (NativeAllReduce)."""
+        return self.grad_hook is not None and getattr(self.grad_hook, "capturable", False)
 
     # ------------------------------------------------------------------------------ feeds
     def _stage_feed(self, feed_dict):
@@ -230,16 +237,20 @@ class SupervisedGraphsage(SampleAndAggregate):
     def _train_on_device(self, batch_dev, labels_dev, n, fetch=True, prologue=None, cursor=None, key="train"):
         e = self.engine
         fused = self.grad_hook is None
+        in_graph = self._dp_in_graph()
 
         def fwd_bwd():
             if prologue is not None:
                 prologue()
-            ep = dict(step=1 if fused else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
+            ep = dict(step=1 if (fused or in_graph) else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
             self._forward(batch_dev, labels_dev, n, train=True, epilogue=ep)
             self._backward(n, fuse_adam=fused, epilogue=ep)
+            if in_graph:
+                self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
+                self._optimize(advanced=True)
 
-        if fused:
-            self._run((key, n, self._adj_version()), fwd_bwd)     # the whole step: one hipGraph
+        if fused or in_graph:
+            self._run((key if fused else key + "_dp", n, self._adj_version()), fwd_bwd)     # the whole step: one hipGraph
         else:
             self._run((key + "_fb", n, self._adj_version()), fwd_bwd)
             self.grad_hook(self)              # RCCL all-reduce of engine.grads (ordered by stream events)
@@ -294,7 +305,7 @@ class SupervisedGraphsage(SampleAndAggregate):
 
             return self._train_on_device(batch_dev, labels_dev, n, fetch, prologue=stage, cursor=self._cursor,
                                          key="dtrain")
-        fused = self.grad_hook is None
+        fused = self.grad_hook is None or self._dp_in_graph()
         data = self._data_fn(n)
         if self._primed != n:                       # fill the pipeline: data chain of the first step
             self._pipe_parity = 0
@@ -325,6 +336,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         e = self.engine
         p0 = self._pipe_parity
         mode = "streams" if self.pipeline == "streams" else "fused"
+        in_graph = self._dp_in_graph()          # `fused` is then True as well: the whole DP step is one graph
+        local_adam = self.grad_hook is None
 
         def compute(p, side_jobs=None, epilogue=None):
             batch_dev, labels_dev, pre = self._prefetched[(n, p)]
@@ -333,7 +346,10 @@ class SupervisedGraphsage(SampleAndAggregate):
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
             fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
             self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue)
-            self._backward(n, fuse_adam=fused, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
+            self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
+            if in_graph:
+                self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
+                self._optimize(advanced=True)
 
         def body():
             p = p0
@@ -355,7 +371,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                                                              cursor_delta=n))
                 p = 1 - p
 
-        key = ("ptrain" if fused else "ptrain_fb", mode, n, k, p0, self._adj_version())
+        key = ("ptrain" if local_adam else ("ptrain_dp" if in_graph else "ptrain_fb"), mode, n, k, p0, self._adj_version())
         self._run(key, body)
         if not fused:
             assert k == 1
@@ -367,7 +383,7 @@ class SupervisedGraphsage(SampleAndAggregate):
     def train_steps_device(self, n, steps, steps_per_launch=8):
         """`steps` training steps on the device-resident epoch; on a single GPU `steps_per_launch` consecutive steps
         are replayed per hipGraph launch (amortises the launch gap; the schedule and results are unchanged)."""
-        fused = self.grad_hook is None
+        fused = self.grad_hook is None or self._dp_in_graph()
         k = steps_per_launch - (steps_per_launch % 2)
         if not (getattr(self, "pipeline", True) and self._dropout_rate() == 0 and fused and self.use_graphs and k >= 2):
             for _ in range(steps):

@@ -316,7 +316,7 @@ int gs_reduce_slabs(const float* slabs, int32_t n_slabs, int64_t slab_stride, in
  *   p -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)          (epsilon OUTSIDE the sqrt) */
 int gs_adam_step(float* p, const float* grad, float* m, float* v, int64_t count,
                  float lr, float beta1, float beta2, float eps, float clip, float grad_scale,
-                 const uint64_t* step_dev, void* stream);
+                 const uint64_t* step_dev, int32_t step_offset, void* stream);
 
 /* Gradient finalisation over the whole flat parameter buffer in ONE launch:
  *   grads[i] = sum_{z < n_slabs(var)} slabs_var[z*size_var + (i - offset_var)] + (decay_var ? weight_decay*params[i] : 0)
@@ -349,7 +349,8 @@ int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* par
  *           [n, C], loss_rows [n]: written (inputs of the weight-gradient launch and model outputs)
  *   train != 0: dz [n, 2*out_dim] = dLoss/dz and d_h0 [n + n*s, d_in] = relu'(h0) * dLoss/dh0 are written too
  *   c0..c2 (nullable device counters) are advanced by d0..d2 at the end of the launch.
- * Supported: concat, no aggregator bias, d_in in {128, 256}, out_dim in {64, 128}, C <= 128 (gs_sage_tail_supported);
+ * Supported: concat, no aggregator bias, s <= 11, d_in in {128, 256}, out_dim in {64, 128}, C <= 64
+ * (gs_sage_tail_supported);
  * anything else returns GS_ENOTSUP and the caller uses the per-operator entry points. */
 typedef struct gs_tail_desc {
     const float* h0; int64_t ldh; int64_t n;
@@ -447,6 +448,21 @@ int gs_stage_batch(const int32_t* order, int64_t n_order, const uint64_t* cursor
 int gs_sum_scaled(const float* x, int64_t count, float scale, float* out, int accumulate, void* stream);
 /* out[0] (+)= scale * sum x[i]^2  -- weight_decay * tf.nn.l2_loss(var), supervised_models.py:106 */
 int gs_sumsq_scaled(const float* x, int64_t count, float scale, float* out, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * C1  gradient all-reduce over RCCL / xGMI (data-parallel training; the reference is single-device,
+ * supervised_train.py:55-59).  One process per GPU; ONE in-place sum over the flat fp32 gradient buffer per step,
+ * enqueued on `stream` and capturable into the step's hipGraph.  RCCL is bound at run time (dlopen) -- the copy
+ * already mapped in the process is reused.
+ *   gs_comm_unique_id : rank 0 fills a >= 128-byte HOST buffer which the host code ships to every rank
+ *                       (torch.distributed / MPI / a file -- not this library's business)
+ *   gs_comm_init_rank : collective over all ranks; uses the calling thread's current HIP device
+ * ------------------------------------------------------------------------------------------- */
+#define GS_COMM_ID_BYTES 128
+int gs_comm_unique_id(void* id_out_host, int32_t len);
+int gs_comm_init_rank(void** comm_out, int32_t nranks, int32_t rank, const void* id_host, int32_t len);
+int gs_comm_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);
+int gs_comm_destroy(void* comm);
 
 /* ---------------------------------------------------------------------------------------------
  * hipGraph helpers: the per-step kernel chain is captured once and replayed (no tracing compiler).

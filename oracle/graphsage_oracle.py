@@ -105,9 +105,41 @@ def glorot(shape, rng, dtype=np.float32):
 # activations
 # --------------------------------------------------------------------------
 
+# relu'(x) at a pre-activation that is zero up to fp32 summation noise is decided by that noise: TF/Eigen, this
+# oracle and the device sum in different orders, so such entries can come out > 0 on one side and == 0 on the other.
+# Like the sampler's permutations and the dropout masks, the tie is INJECTED: _RELU_TIES (set through
+# `relu_ties_from`) maps an activation to the sign pattern to follow for entries with |pre-activation| <= _TIE_EPS.
+_TIE_EPS = 2e-6
+_relu_ties = None
+
+
+class relu_ties_from(object):
+    """with relu_ties_from(fn): fn(shape) -> bool array ("positive on the other side") or None, consulted by every
+    relu in call order; only entries whose pre-activation is within _TIE_EPS of zero follow it."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _relu_ties
+        _relu_ties = self.fn
+
+    def __exit__(self, *exc):
+        global _relu_ties
+        _relu_ties = None
+
+
 def _act(x, act):
     if act == "relu":
-        return np.maximum(x, 0)
+        y = np.maximum(x, 0)
+        if _relu_ties is not None:
+            other = _relu_ties(x.shape)
+            if other is not None:
+                ties = np.abs(x) <= _TIE_EPS
+                if ties.any():
+                    # follow the other side on ties: a strictly positive marker where it is positive, exact 0 elsewhere
+                    y = np.where(ties, np.where(other, np.asarray(np.finfo(x.dtype).tiny, x.dtype), 0), y).astype(x.dtype)
+        return y
     return x
 
 

@@ -78,3 +78,31 @@ def test_two_rank_dp_matches_single_process_global_batch(dev):
     per = s2.size // (2 * B)
     assert np.array_equal(s2[: B * per], res[0][1]) and np.array_equal(s2[B * per:], res[1][1])   # same neighbor sets
     np.testing.assert_allclose(res[0][0], single, rtol=2e-4, atol=2e-6)
+
+
+def test_native_rccl_hook_in_graph_single_rank(dev):
+    """The C ABI's RCCL binding (gs_comm_*) with one rank: unique id -> ncclCommInitRank -> ncclAllReduce enqueued on the
+    engine stream, eagerly and replayed from a hipGraph; then the data-parallel step schedule with the all-reduce
+    recorded INSIDE the step graph (backward | all-reduce | clip+Adam, several steps per launch) must reproduce the
+    single-GPU fused schedule (world = 1: the sum is the identity, grad_scale = 1)."""
+    import numpy as np
+    from graphsage_amd import engine as eng
+    from graphsage_amd.distributed import NativeAllReduce
+    from test_model_gpu import build
+    outs = []
+    for dp in (False, True):
+        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+        if dp:
+            hook = NativeAllReduce(eng.get_engine(), world_size=1, rank=0)
+            assert hook.self_test()
+            model.grad_hook = hook
+            assert model._dp_in_graph()
+        model.attach_device_epoch(it.train_nodes[:320], it.label_matrix)
+        model.train_steps_device(32, 9, steps_per_launch=2)
+        loss, preds = model._fetch(32)
+        outs.append((loss, preds.copy(), eng.get_engine().params.cpu().numpy().copy()))
+        if dp:
+            assert any(k[0] == "ptrain_dp" and k[3] == 2 for k in model._graphs), list(model._graphs)   # 2-step DP graphs
+            hook.close()
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7)
