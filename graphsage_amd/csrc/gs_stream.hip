@@ -1,0 +1,443 @@
+// "Stream" form of the two big launches of a mean/GCN training step: the layer-0 contraction and the grouped weight
+// gradients, each co-scheduled with a share of the NEXT step's gather+mean (HBM-bound, needs no weights).
+//
+// Why a second GEMM form (measured, profiles/r02_a_*): in the LDS-tiled fused kernels every workgroup -- gather
+// workgroups included -- carries the GEMM's 35 KB of LDS and ~110 VGPRs, the 352 tile workgroups land 1.4 per CU, and a
+// tile workgroup stalls all four waves at a barrier per 32-k stage; the fused launches ran at 20 % MFMA utilisation and
+// stretched the gather to 48 + 45 us (49 us alone).  Here the contraction waves use NO LDS and NO barriers:
+//   * one WAVE owns one output tile and is completely independent (a workgroup is just 4 such waves, one per SIMD);
+//   * A and B fragments go straight from global memory (L2 / MALL resident: dense [self | mean] rows written by the
+//     previous step's gather, weights, dZ) into the MFMA operand registers through a 4..8-stage register ring, so each
+//     wave keeps 4-8 KB of operand loads in flight and nothing else in the CU has to wait for it;
+//   * the layer-0 A operand is DENSE: the gather jobs also copy the self rows X[ids] into a dense matrix (one more
+//     s = 1 gather job), so neither contraction re-gathers scattered 2.4 KB rows in 128-byte pieces;
+//   * the number of contraction waves is kept <= 4 per CU (<= 1 per SIMD): fp32 MFMA is so slow (64 cycles per
+//     32x32x2) that a single wave per SIMD saturates the pipe when its operands arrive, and the remaining 12+ wave
+//     slots of every CU belong to gather waves.
+// fp32 MFMA 32x32x2 (exact fp32).  Forward tile: 32 rows x 64 columns per wave, A k-contiguous (one 16-byte load per
+// lane feeds 4 MFMA k-steps), B n-contiguous (coalesced dword loads).  Weight-gradient tile: 64 x 64 per wave, both
+// operands row-contiguous over the reduction index (coalesced dword loads), split-K slabs as before (deterministic).
+#include "gs_common.h"
+#include "gs_gather_dev.h"
+#include <stdlib.h>
+
+#define GS_MAX_COJOBS_S 6
+struct CoGatherS {
+    GatherArgs job[GS_MAX_COJOBS_S];
+    int64_t wave_start[GS_MAX_COJOBS_S + 1];
+    int32_t n;
+};
+
+// XCD-aware work placement: block b runs on XCD b % 8 (each XCD has its own 4 MB L2).  Consecutive LOGICAL ids go to
+// the same XCD, so a contiguous range of work items (= a contiguous range of rows / reduction slices) shares one L2:
+// without it every XCD streams the whole A operand (13.7 MB) through its 4 MB L2 and every operand load is a MALL hit.
+__device__ __forceinline__ int stream_xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void run_gather_item(const CoGatherS& J, const int64_t w, const int lane) {
+    if (w >= J.wave_start[J.n]) return;  // wave-uniform
+    int k = 0;
+    while (k + 1 < J.n && w >= J.wave_start[k + 1]) ++k;
+    const GatherArgs& a = J.job[k];
+    if (a.s >= 8)
+        gather_mean_wave<8>(a, w - J.wave_start[k], lane);
+    else
+        gather_mean_wave<1>(a, w - J.wave_start[k], lane);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+struct FwdTerm {
+    const float* A;   // dense [M, lda]
+    const float* W;   // [K, ldw]
+    int32_t lda, ldw;
+};
+struct FwdArgs {
+    FwdTerm t[2];
+    int32_t nterms;       // 1, or 2 (concat: term i writes columns [i*N, (i+1)*N))
+    int32_t M, N, K;
+    float* C;
+    int32_t ldc;
+    const float* bias;    // indexed by output column (incl. the concat offset), nullable
+    int32_t act;
+    int32_t tiles_n;      // 64-column tiles per term
+    int32_t n_items;      // tiles_m * tiles_n * nterms
+};
+
+// One wave: C[m0 .. m0+31][col_off + n0 .. n0 + 32*TN - 1] = act(A[m0.., :K] . W[:K, n0 ..] + bias)
+template <int TN>
+__device__ __forceinline__ void stream_fwd_item(const FwdArgs& g, const int item, const int lane) {
+    constexpr int P = 4;                                   // register ring: macro steps (8 k) in flight
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int per_term = g.n_items / g.nterms;
+    const int term = item / per_term;
+    const int it = item - term * per_term;
+    const int tile_m = it / g.tiles_n, tile_n = it - tile_m * g.tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 32 * TN;
+    const FwdTerm T = g.t[term];
+    const int K = g.K, N = g.N;
+    const float* ap = T.A + min(m0 + l31, g.M - 1) * T.lda + 4 * lh;
+    const float* bp[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) bp[t] = T.W + (4 * lh) * T.ldw + min(n0 + 32 * t + l31, N - 1);
+    const int ldw = T.ldw;
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    f32x4 a[P];
+    float b[P][TN][4];
+    const int nfull = K >> 3;                              // macro steps whose 8 k are all < K
+    auto load_stage = [&](const int st, const int m) {
+        a[st] = *reinterpret_cast<const f32x4*>(ap + 8 * m);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const float* q = bp[t] + (8 * m) * ldw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[st][t][e] = q[e * ldw];
+        }
+    };
+    auto compute_stage = [&](const int st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = mfma32(a[st][e], b[st][t][e], acc[t]);
+    };
+    // Branch-free steady state (one basic block, so the compiler can count outstanding loads exactly -- a guard per
+    // stage turned every stage into its own block and each block boundary into a full s_waitcnt vmcnt(0)):
+    // stages m .. m+P-1 are in flight on entry; each is consumed and immediately refilled with stage m+st+P.
+    int m = 0;
+    if (nfull >= P) {
+#pragma unroll
+        for (int st = 0; st < P; ++st) load_stage(st, st);
+#pragma unroll 1
+        for (; m + 2 * P <= nfull; m += P) {
+#pragma unroll
+            for (int st = 0; st < P; ++st) {
+                compute_stage(st);
+                load_stage(st, m + st + P);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < P; ++st) compute_stage(st);
+        m += P;
+    }
+#pragma unroll 1
+    for (; m < nfull; ++m) {                               // < P leftover macro steps: one at a time
+        load_stage(0, m);
+        compute_stage(0);
+    }
+    if ((K & 7) != 0) {
+        // tail macro step: k = 8*nfull + 4*lh + e; elements with k >= K are zeroed on the A side, B rows are clamped
+        const int kq = 8 * nfull + 4 * lh;
+        f32x4 av = {0.f, 0.f, 0.f, 0.f};
+        if (kq < K) {
+            // stay inside the row: the last quad may start before kq (row length lda >= round_up(K, 4))
+            av = *reinterpret_cast<const f32x4*>(ap + 8 * nfull);
+            if (kq + 1 >= K) av.y = 0.f;
+            if (kq + 2 >= K) av.z = 0.f;
+            if (kq + 3 >= K) av.w = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kr = min(kq + e, K - 1) - 4 * lh;    // row offset relative to bp's (4*lh) base
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = mfma32(av[e], bp[t][kr * ldw], acc[t]);
+        }
+    }
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int col_off = term * N;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int c = n0 + 32 * t + l31;
+        const float bv = (g.bias && c < N) ? g.bias[col_off + c] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (row < g.M && c < N) {
+                float v = acc[t][e] + bv;
+                if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                g.C[row * g.ldc + col_off + c] = v;
+            }
+        }
+    }
+}
+
+// TN = 2: 32x64 tiles, 4 independent waves per workgroup (one per SIMD).  TN = 1: 32x32 tiles, 8 waves per workgroup
+// (TWO per SIMD: while one waits for its operands the other owns the MFMA pipe).
+template <int TN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sage_stream_fwd_kernel(const FwdArgs g, const int mfma_blocks, const CoGatherS J) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < mfma_blocks) {
+        const int item = stream_xcd_swizzle(blockIdx.x, mfma_blocks) * WAVES + wave;
+        if (item < g.n_items) stream_fwd_item<TN>(g, item, lane);
+        return;
+    }
+    run_gather_item(J, ((int64_t)blockIdx.x - mfma_blocks) * WAVES + wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------ weight gradients
+#define GS_MAX_SGROUP 12
+struct WgradProb {
+    const float* A;       // [*, lda]: row r of the reduction is A[a_idx ? a_idx[r] : r]
+    const int32_t* a_idx; // nullable row gather (layer 0: the self rows of the feature table)
+    const float* dZ;      // [n, ldz], already offset by col0
+    float* slabs;         // [n_slabs][d][ld_slab]
+    int32_t lda, ldz, ld_slab;
+    int32_t n, d, out_dim;
+    int32_t tiles_m, tiles_n, n_slabs, kchunk;   // kchunk: rows per slab (even)
+    int32_t item_start;   // first work item of this problem
+};
+struct WgradArgs {
+    WgradProb p[GS_MAX_SGROUP];
+    int32_t n, n_items;
+};
+
+// One wave: slab[z][f0 .. f0+63][o0 .. o0+63] = sum_{r in slice z} A[r][f] * dZ[r][o]
+__device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int item, const int lane) {
+    constexpr int P = 8;                                   // register ring: k-pairs (2 reduction rows) in flight
+    int pi = 0;
+    while (pi + 1 < G.n && item >= G.p[pi + 1].item_start) ++pi;
+    const WgradProb q = G.p[pi];
+    const int local = item - q.item_start;
+    const int tiles = q.tiles_m * q.tiles_n;
+    const int z = local / tiles;
+    const int tt = local - z * tiles;
+    const int tile_m = tt / q.tiles_n, tile_n = tt - tile_m * q.tiles_n;
+    const int f0 = tile_m * 64, o0 = tile_n * 64;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int rb = z * q.kchunk, re = min(rb + q.kchunk, q.n);
+    // per-lane column pointers (clamped: out-of-range columns are not stored)
+    const float* a0 = q.A + min(f0 + l31, q.d - 1);
+    const float* a1 = q.A + min(f0 + 32 + l31, q.d - 1);
+    const float* z0 = q.dZ + min(o0 + l31, q.out_dim - 1);
+    const float* z1 = q.dZ + min(o0 + 32 + l31, q.out_dim - 1);
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+    float av0[P], av1[P], bv0[P], bv1[P];
+    const int nfull = (re - rb) >> 1;                      // k-pairs whose two rows both exist
+    const int lda = q.lda, ldz = q.ldz;
+    // Row-gathered A (layer 0 self rows): the slice's gather indices (<= 512 rows) are loaded ONCE into registers
+    // (lane L holds idx[rb + L + 64*j]); the two rows of a k-pair come out with v_readlane, so the A loads stay
+    // single-latency (index, then row would be two dependent round trips per stage).
+    constexpr int IDXR = 8;                                // 8 * 64 = 512 rows per slice at most
+    int32_t idxr[IDXR];
+    const bool gathered = q.a_idx != nullptr;
+    if (gathered) {
+#pragma unroll
+        for (int jx = 0; jx < IDXR; ++jx) {
+            const int r = rb + lane + 64 * jx;
+            idxr[jx] = q.a_idx[min(r, re - 1)];
+        }
+    }
+    auto arow = [&](const int r) -> int {                  // source row of reduction row r (r = rb + 2*kp + lh)
+        if (!gathered) return r;
+        const int o = r - rb - lh;                         // wave-uniform, even
+        const int jx = o >> 6, l = o & 63;
+        int32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int t = 0; t < IDXR; ++t) {
+            if (t == jx) {                                 // wave-uniform select of the register holding the index
+                lo = __builtin_amdgcn_readlane(idxr[t], l);
+                hi = __builtin_amdgcn_readlane(idxr[t], l + 1);   // l is even: l + 1 <= 63 stays in the same register
+            }
+        }
+        return lh ? hi : lo;
+    };
+    auto load_stage = [&](const int st, const int kp) {    // no arithmetic on the loaded values here: a use would
+        const int r = rb + 2 * kp + lh;                    // force a wait right behind the load and empty the ring
+        const int ra = arow(r);
+        av0[st] = a0[ra * lda];
+        av1[st] = a1[ra * lda];
+        bv0[st] = z0[r * ldz];
+        bv1[st] = z1[r * ldz];
+    };
+    auto compute_stage = [&](const int st) {
+        acc00 = mfma32(av0[st], bv0[st], acc00);
+        acc01 = mfma32(av0[st], bv1[st], acc01);
+        acc10 = mfma32(av1[st], bv0[st], acc10);
+        acc11 = mfma32(av1[st], bv1[st], acc11);
+    };
+    // branch-free steady state, see stream_fwd_item
+    int kp = 0;
+    if (nfull >= P) {
+#pragma unroll
+        for (int st = 0; st < P; ++st) load_stage(st, st);
+#pragma unroll 1
+        for (; kp + 2 * P <= nfull; kp += P) {
+#pragma unroll
+            for (int st = 0; st < P; ++st) {
+                compute_stage(st);
+                // keep the refill of stage st BELOW the MFMAs that read it: hoisted above them the loads need fresh
+                // registers (the ring doubles: 132 VGPRs + 64 AGPRs = 2 waves per SIMD, and the gather waves starve)
+                __builtin_amdgcn_sched_barrier(0);
+                load_stage(st, kp + st + P);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < P; ++st) compute_stage(st);
+        kp += P;
+    }
+#pragma unroll 1
+    for (; kp < nfull; ++kp) {
+        load_stage(0, kp);
+        compute_stage(0);
+    }
+    if ((re - rb) & 1) {                                   // odd slice: its last row pairs with a zero row
+        const int r = re - 1;
+        const float mk = lh == 0 ? 1.f : 0.f;
+        const int ra = gathered ? q.a_idx[r] : r;
+        av0[0] = a0[ra * lda] * mk;
+        av1[0] = a1[ra * lda] * mk;
+        bv0[0] = z0[r * ldz];
+        bv1[0] = z1[r * ldz];
+        compute_stage(0);
+    }
+    float* S = q.slabs + (int64_t)z * q.d * q.ld_slab;
+    const int c0 = o0 + l31, c1 = o0 + 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rr = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int fa = f0 + rr, fb = f0 + 32 + rr;
+        if (fa < q.d) {
+            if (c0 < q.out_dim) S[fa * q.ld_slab + c0] = acc00[e];
+            if (c1 < q.out_dim) S[fa * q.ld_slab + c1] = acc01[e];
+        }
+        if (fb < q.d) {
+            if (c0 < q.out_dim) S[fb * q.ld_slab + c0] = acc10[e];
+            if (c1 < q.out_dim) S[fb * q.ld_slab + c1] = acc11[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void stream_wgrad_kernel(const WgradArgs G, const int mfma_blocks, const CoGatherS J) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < mfma_blocks) {
+        const int item = stream_xcd_swizzle(blockIdx.x, mfma_blocks) * 4 + wave;
+        if (item < G.n_items) stream_wgrad_item(G, item, lane);
+        return;
+    }
+    run_gather_item(J, ((int64_t)blockIdx.x - mfma_blocks) * 4 + wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static inline int rup4s(int x) { return (x + 3) & ~3; }
+
+static int build_cojobs_s(const gs_gather_desc* jobs_host, int32_t n_jobs, CoGatherS* Jout, int64_t* waves_out) {
+    GS_REQUIRE(n_jobs >= 0 && n_jobs <= GS_MAX_COJOBS_S && (n_jobs == 0 || jobs_host), "stream co-gather: 0..%d jobs", GS_MAX_COJOBS_S);
+    CoGatherS& J = *Jout;
+    J.n = n_jobs;
+    int64_t waves = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const gs_gather_desc& q = jobs_host[i];
+        GS_CHECK_MAT(q.X, q.ldx, "stream co-gather job X");
+        GS_CHECK_MAT(q.out, q.ldo, "stream co-gather job out");
+        GS_REQUIRE(q.n > 0 && q.s > 0 && q.d > 0 && q.ldx >= rup4s(q.d) && q.ldo >= rup4s(q.d), "stream co-gather: bad job %d", i);
+        if (q.self_src) GS_CHECK_MAT(q.self_src, q.ld_self, "stream co-gather job self");
+        const int chunks = ((q.d + 3) / 4 + 63) / 64;
+        J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
+                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
+                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
+        J.wave_start[i] = waves;
+        waves += q.n * (int64_t)chunks;
+    }
+    J.wave_start[n_jobs] = waves;
+    *waves_out = waves;
+    return GS_OK;
+}
+
+extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const float* agg, int64_t ld_agg, int32_t d,
+                                        int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,
+                                        int64_t ldw_neigh, int32_t out_dim, int act, const float* bias, float* out,
+                                        int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    GS_REQUIRE(n > 0 && agg && W_neigh && out && d > 0 && out_dim > 0, "gs_sage_dense_fwd_stream: bad args");
+    GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_stream agg");
+    GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_fwd_stream W_neigh");
+    GS_CHECK_MAT(out, ldo, "gs_sage_dense_fwd_stream out");
+    GS_REQUIRE(ld_agg >= rup4s(d) && ldw_neigh >= out_dim, "gs_sage_dense_fwd_stream: ld too small");
+    FwdArgs g = {};
+    if (self) {
+        GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_stream self");
+        GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd_stream W_self");
+        GS_REQUIRE(ld_self >= rup4s(d) && ldw_self >= out_dim, "gs_sage_dense_fwd_stream: self ld too small");
+        g.t[0] = FwdTerm{self, W_self, (int32_t)ld_self, (int32_t)ldw_self};
+        g.t[1] = FwdTerm{agg, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
+        g.nterms = 2;
+    } else {
+        g.t[0] = FwdTerm{agg, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
+        g.nterms = 1;
+    }
+    GS_REQUIRE(ldo >= out_dim * g.nterms, "gs_sage_dense_fwd_stream: ldo too small");
+    GS_REQUIRE(n * std::max(std::max(ld_self, ld_agg), ldo) < (1ll << 31) && (int64_t)d * std::max(ldw_self, ldw_neigh) < (1ll << 31),
+               "gs_sage_dense_fwd_stream: 32-bit offsets exceeded");
+    g.M = (int32_t)n; g.N = out_dim; g.K = d; g.C = out; g.ldc = (int32_t)ldo; g.bias = bias; g.act = act;
+    static const int variant = getenv("GS_STREAM_FWD_TN") ? atoi(getenv("GS_STREAM_FWD_TN")) : 1;   // tuning hook
+    const int TN = variant == 2 ? 2 : 1, WAVES = TN == 2 ? 4 : 8;
+    const int tiles_m = (int)gs_ceil_div(n, 32);
+    g.tiles_n = (int)gs_ceil_div(out_dim, 32 * TN);
+    g.n_items = tiles_m * g.tiles_n * g.nterms;
+    const int mfma_blocks = (int)gs_ceil_div(g.n_items, WAVES);
+    CoGatherS J = {};
+    int64_t waves = 0;
+    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
+    if (rc != GS_OK) return rc;
+    const int64_t blocks = mfma_blocks + gs_ceil_div(waves, WAVES);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_sage_dense_fwd_stream: grid too large");
+    if (TN == 2)
+        hipLaunchKernelGGL((sage_stream_fwd_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, mfma_blocks, J);
+    else
+        hipLaunchKernelGGL((sage_stream_fwd_kernel<1, 8>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, g, mfma_blocks, J);
+    GS_LAUNCH_CHECK("sage_stream_fwd_kernel");
+    return GS_OK;
+}
+
+extern "C" int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                             int32_t n_jobs, void* stream) {
+    GS_REQUIRE(descs_host && n_desc > 0 && n_desc <= GS_MAX_SGROUP, "gs_dense_wgrad_grouped_stream: 1..%d problems", GS_MAX_SGROUP);
+    WgradArgs G = {};
+    G.n = n_desc;
+    int items = 0;
+    for (int i = 0; i < n_desc; ++i) {
+        const gs_wgrad_desc& q = descs_host[i];
+        GS_CHECK_MAT(q.A, q.lda, "gs_dense_wgrad_grouped_stream A");
+        GS_CHECK_MAT(q.dZ, q.ldz, "gs_dense_wgrad_grouped_stream dZ");
+        GS_CHECK_MAT(q.slabs, q.ld_slab, "gs_dense_wgrad_grouped_stream slabs");
+        GS_REQUIRE(q.d > 0 && q.out_dim > 0 && q.n > 0 && q.n_slabs > 0 && q.col0 >= 0 && q.col0 % 4 == 0,
+                   "gs_dense_wgrad_grouped_stream: bad sizes");
+        GS_REQUIRE(q.lda >= q.d && q.ldz >= q.col0 + q.out_dim && q.ld_slab >= q.out_dim, "gs_dense_wgrad_grouped_stream: ld too small");
+        GS_REQUIRE(q.n * std::max(q.lda, q.ldz) < (1ll << 31) && (int64_t)q.d * q.ld_slab < (1ll << 31),
+                   "gs_dense_wgrad_grouped_stream: 32-bit offsets exceeded");
+        WgradProb& p = G.p[i];
+        p.A = q.A; p.a_idx = q.a_idx; p.dZ = q.dZ + q.col0; p.slabs = q.slabs;
+        p.lda = (int32_t)q.lda; p.ldz = (int32_t)q.ldz; p.ld_slab = (int32_t)q.ld_slab;
+        p.n = (int32_t)q.n; p.d = q.d; p.out_dim = q.out_dim;
+        p.tiles_m = (int)gs_ceil_div(q.d, 64);
+        p.tiles_n = (int)gs_ceil_div(q.out_dim, 64);
+        p.n_slabs = q.n_slabs;
+        p.kchunk = (int32_t)(gs_ceil_div(gs_ceil_div(q.n, q.n_slabs), 2) * 2);
+        GS_REQUIRE(!q.a_idx || p.kchunk <= 512, "gs_dense_wgrad_grouped_stream: a row-gathered problem needs slices of <= 512 rows "
+                   "(n = %lld, n_slabs = %d)", (long long)q.n, q.n_slabs);
+        p.item_start = items;
+        items += p.tiles_m * p.tiles_n * q.n_slabs;
+    }
+    G.n_items = items;
+    const int mfma_blocks = (int)gs_ceil_div(items, 4);
+    CoGatherS J = {};
+    int64_t waves = 0;
+    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
+    if (rc != GS_OK) return rc;
+    const int64_t blocks = mfma_blocks + gs_ceil_div(waves, 4);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_dense_wgrad_grouped_stream: grid too large");
+    hipLaunchKernelGGL(stream_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
+    GS_LAUNCH_CHECK("stream_wgrad_kernel");
+    return GS_OK;
+}

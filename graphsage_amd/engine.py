@@ -72,6 +72,8 @@ class Engine(object):
         self.post_update_hooks = []
         self.dropout_seed = 123
         self._n_sites = 0
+        # "stream" contraction kernels (gs_stream.hip) for the layer-0 forward and the grouped weight gradients
+        self.stream_gemm = os.environ.get("GS_STREAM_GEMM", "1") == "1"
         # second stream for the data chain (sampling + gathers of the NEXT step overlap this step's compute)
         self._stream2_obj = None
         self.stream2 = None
@@ -198,6 +200,10 @@ class Engine(object):
         t = 128 if big else 64
         tiles = ((var.rows + t - 1) // t) * ((var.cols + t - 1) // t)
         k = self.pick_slabs(n, tiles)
+        if self.stream_gemm and not big:
+            # stream kernel: one WAVE per (64x64 tile, slice); ~1 contraction wave per SIMD over the whole launch
+            # (~900 items for the Reddit step) with >= 256 reduction rows per slice
+            k = int(max(1, min(32, MAX_SLABS - var.n_slabs, round(n / float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))))))
         if var.n_slabs + k > MAX_SLABS:
             raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
         if big:
@@ -242,6 +248,13 @@ class Engine(object):
                          j.ldo, self.stream)
             return
         arr = (ops._lib.WgradDesc * len(self._pending))(*self._pending)
+        if self.stream_gemm and len(self._pending) <= 12 and all((not d.a_idx) or (d.n + d.n_slabs - 1) // d.n_slabs <= 510 for d in self._pending):
+            jobs = list(side_jobs or ())
+            jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
+            ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr), len(self._pending), ctypes.addressof(jarr),
+                     len(jobs), self.stream)
+            self._pending = []
+            return
         if side_jobs:
             jarr = (ops._lib.GatherDesc * len(side_jobs))(*side_jobs)
             ops.call("gs_dense_wgrad_grouped_cogather", ctypes.addressof(arr), len(self._pending), ctypes.addressof(jarr),

@@ -113,7 +113,9 @@ class SampleAndAggregate(object):
         self.use_graphs = True
         self.grad_hook = None
         if self.identity_dim == 0:
-            self.pipeline = True
+            # True / "fused": next-step gather co-scheduled inside this step's big launches (one stream);
+            # "streams": the data chain of the next step on a second stream (fork/join inside the step graph)
+            self.pipeline = os.environ.get("GS_PIPELINE", "fused") if os.environ.get("GS_PIPELINE") else True
         self._primed = None
         self._prefetched = {}
         self._pending_stage = None

@@ -250,6 +250,17 @@ def sage_dense_fwd_cogather(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, 
     return out
 
 
+def sage_dense_fwd_stream(self_m, agg, n, W_self, W_neigh, out_dim, act, bias, out, jobs, stream=None):
+    """gs_sage_dense_fwd_stream: LDS-free contraction waves + the gather jobs in ONE launch (dense self / agg)."""
+    import ctypes
+    jobs = list(jobs or ())
+    arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_dense_fwd_stream", self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0,
+         agg.ptr, agg.ld, agg.d, n, W_self.ptr if W_self is not None else None, W_self.ld if W_self is not None else 0,
+         W_neigh.ptr, W_neigh.ld, out_dim, act, ptr(bias), out.ptr, out.ld, ctypes.addressof(arr), len(jobs), _s(stream))
+    return out
+
+
 def dense_wgrad(A, a_idx, dZ, col0, out_dim, n, n_slabs, slabs, ld_slab, stream=None):
     """slabs: flat fp32 tensor with room for n_slabs * A.d * ld_slab floats."""
     call("gs_dense_wgrad", A.ptr, A.ld, ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, out_dim, n, n_slabs, ptr(slabs),

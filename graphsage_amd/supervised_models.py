@@ -287,6 +287,17 @@ class SupervisedGraphsage(SampleAndAggregate):
         self._primed = None
         torch.cuda.synchronize()
 
+    def _drop_prefetched(self):
+        """Forget the batch the pipeline has already staged (a different batch size follows, e.g. the short last batch
+        of an epoch): hand its ids back to the epoch cursor and its tick back to the sampler clock, so the schedule
+        draws exactly what the sequential one would."""
+        if self._primed is not None:
+            self.engine.sync()
+            self._cursor -= int(self._primed)
+            self.engine.sample_clock_dev -= 1
+            self._primed = None
+            torch.cuda.synchronize()
+
     def train_step_device(self, n, fetch=False):
         """One training step on the next n ids of the device-resident epoch order.
 
@@ -308,6 +319,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         fused = self.grad_hook is None or self._dp_in_graph()
         data = self._data_fn(n)
         if self._primed != n:                       # fill the pipeline: data chain of the first step
+            self._drop_prefetched()
             self._pipe_parity = 0
             data(0)
             e.sync()

@@ -55,23 +55,51 @@ def build_flags(argv=None):
     # additions of this engine
     p.add_argument('--synthetic', default='', help='ppi | reddit | small: generate a graph of that shape')
     p.add_argument('--sampler', default='csr', help='csr (MI355X-native) | padded (reference table semantics)')
+    p.add_argument('--feed_path', default='device',
+                   help='device: epoch order + labels resident in HBM, host fetches only printed steps (CSR sampler); '
+                        'host: the reference feed_dict path, one host round trip per step')
     return p.parse_args(argv)
 
 
 FLAGS = None
 
 
+def f1_micro_macro(y_true, y_pred, multilabel):
+    """sklearn.metrics.f1_score(average="micro") and (average="macro") in NumPy (same definitions: per-class
+    tp/fp/fn; macro averages the per-class F1 over the classes that occur in y_true or y_pred -- every column for
+    multilabel indicator input -- with F1 = 0 where tp + fp + fn == 0 ... == 0 only for absent columns, which sklearn
+    scores 0 as well).  The reference calls sklearn every print_every steps (supervised_train.py:63-70); at ~0.15 ms per
+    training step that call would dominate the loop."""
+    if multilabel:
+        t = np.asarray(y_true) > 0.5
+        p = np.asarray(y_pred) > 0.5
+        tp = (t & p).sum(axis=0).astype(np.float64)
+        fp = (~t & p).sum(axis=0).astype(np.float64)
+        fn = (t & ~p).sum(axis=0).astype(np.float64)
+    else:
+        t = np.asarray(y_true).astype(np.int64)
+        p = np.asarray(y_pred).astype(np.int64)
+        classes = np.union1d(t, p)
+        C = int(classes.max()) + 1 if classes.size else 1
+        hit = t == p
+        tp_all = np.bincount(t[hit], minlength=C).astype(np.float64)
+        fp_all = np.bincount(p[~hit], minlength=C).astype(np.float64)
+        fn_all = np.bincount(t[~hit], minlength=C).astype(np.float64)
+        tp, fp, fn = tp_all[classes], fp_all[classes], fn_all[classes]
+    den = 2 * tp + fp + fn
+    per_class = np.where(den > 0, 2 * tp / np.where(den > 0, den, 1), 0.0)
+    D = 2 * tp.sum() + fp.sum() + fn.sum()
+    micro = float(2 * tp.sum() / D) if D > 0 else 0.0
+    macro = float(per_class.mean()) if per_class.size else 0.0
+    return micro, macro
+
+
 def calc_f1(y_true, y_pred):
     """supervised_train.py:63-70"""
-    from sklearn import metrics
     y_pred = np.array(y_pred, copy=True)
     if not FLAGS.sigmoid:
-        y_true = np.argmax(y_true, axis=1)
-        y_pred = np.argmax(y_pred, axis=1)
-    else:
-        y_pred[y_pred > 0.5] = 1
-        y_pred[y_pred <= 0.5] = 0
-    return metrics.f1_score(y_true, y_pred, average="micro"), metrics.f1_score(y_true, y_pred, average="macro")
+        return f1_micro_macro(np.argmax(y_true, axis=1), np.argmax(y_pred, axis=1), False)
+    return f1_micro_macro(y_true, y_pred > 0.5, True)
 
 
 def evaluate(model, minibatch_iter, placeholders, size=None):
@@ -185,29 +213,85 @@ def train(G):
     else:
         raise Exception('Error: model name unrecognized.')
 
-    # Train model (:254-312)
+    # Train model (:254-312).  Same loop, log line and validation cadence as the reference; the difference is WHERE the
+    # batches come from: with the CSR sampler the shuffled epoch order and the label table live in HBM
+    # (attach_device_epoch), and the steps between two host-visible events (a printed line, a validation, the end of
+    # the epoch) are replayed as hipGraphs with no host round trip -- loss / preds are fetched only for the step whose
+    # statistics are printed (`--feed_path host` keeps the reference's per-step feed_dict path).
+    device_path = (FLAGS.sampler == 'csr' and FLAGS.feed_path == 'device')
     total_steps = 0
     avg_time = 0.0
     epoch_val_costs = []
     val_cost = val_f1_mic = val_f1_mac = 0.0
+    B = FLAGS.batch_size
+    if device_path:
+        model.attach_device_epoch(minibatch.train_nodes, minibatch.label_matrix)
+
+    def validate():
+        adj_info.assign(test_adj)                             # sess.run(val_adj_info.op) (:280)
+        if FLAGS.validate_batch_size == -1:
+            res = incremental_evaluate(model, minibatch, FLAGS.batch_size)
+        else:
+            res = evaluate(model, minibatch, placeholders, FLAGS.validate_batch_size)
+        adj_info.assign(train_adj)                            # sess.run(train_adj_info.op) (:285)
+        return res
+
     for epoch in range(FLAGS.epochs):
         minibatch.shuffle()
         it = 0
         print('Epoch: %04d' % (epoch + 1))
         epoch_val_costs.append(0)
+        if device_path:
+            placeholders['dropout'].value = FLAGS.dropout
+            model.set_epoch_order(minibatch.train_nodes)
+            n_train = len(minibatch.train_nodes)
+            n_iters = (n_train + B - 1) // B
+            while it < n_iters:
+                # the next iteration whose results the host looks at: a validation (it % validate_iter == 0), a printed
+                # line (total_steps % print_every == 0) or the last, possibly short, batch of the epoch
+                quiet = 0
+                while (it + quiet < n_iters - 1 and (it + quiet) % FLAGS.validate_iter != 0
+                       and (total_steps + quiet) % FLAGS.print_every != 0
+                       and total_steps + quiet + 1 <= FLAGS.max_total_steps):
+                    quiet += 1
+                t = time.time()
+                if quiet:
+                    model.train_steps_device(B, quiet)                  # no host round trip
+                it += quiet
+                total_steps += quiet
+                n = min(B, n_train - it * B)
+                train_cost, preds = model.train_step_device(n, fetch=True)      # Training step (:275)
+                batch_nodes = minibatch.train_nodes[it * B: it * B + n]
+                labels = minibatch.label_matrix[batch_nodes]
+                if it % FLAGS.validate_iter == 0:
+                    val_cost, val_f1_mic, val_f1_mac, duration = validate()
+                    epoch_val_costs[-1] += val_cost
+                dt = (time.time() - t) / (quiet + 1)
+                avg_time = (avg_time * (total_steps - quiet) + dt * (quiet + 1)) / (total_steps + 1)
+                if total_steps % FLAGS.print_every == 0:
+                    train_f1_mic, train_f1_mac = calc_f1(labels, preds)
+                    print("Iter:", '%04d' % it,
+                          "train_loss=", "{:.5f}".format(train_cost),
+                          "train_f1_mic=", "{:.5f}".format(train_f1_mic),
+                          "train_f1_mac=", "{:.5f}".format(train_f1_mac),
+                          "val_loss=", "{:.5f}".format(val_cost),
+                          "val_f1_mic=", "{:.5f}".format(val_f1_mic),
+                          "val_f1_mac=", "{:.5f}".format(val_f1_mac),
+                          "time=", "{:.5f}".format(avg_time))
+                it += 1
+                total_steps += 1
+                if total_steps > FLAGS.max_total_steps:
+                    break
+            if total_steps > FLAGS.max_total_steps:
+                break
+            continue
         while not minibatch.end():
             feed_dict, labels = minibatch.next_minibatch_feed_dict()
             feed_dict.update({placeholders['dropout']: FLAGS.dropout})
             t = time.time()
             train_cost, preds = model.train_step(feed_dict)          # Training step (:275)
             if it % FLAGS.validate_iter == 0:
-                adj_info.assign(test_adj)                             # sess.run(val_adj_info.op) (:280)
-                if FLAGS.validate_batch_size == -1:
-                    val_cost, val_f1_mic, val_f1_mac, duration = incremental_evaluate(model, minibatch, FLAGS.batch_size)
-                else:
-                    val_cost, val_f1_mic, val_f1_mac, duration = evaluate(model, minibatch, placeholders,
-                                                                          FLAGS.validate_batch_size)
-                adj_info.assign(train_adj)                            # sess.run(train_adj_info.op) (:285)
+                val_cost, val_f1_mic, val_f1_mac, duration = validate()
                 epoch_val_costs[-1] += val_cost
             avg_time = (avg_time * total_steps + time.time() - t) / (total_steps + 1)
             if total_steps % FLAGS.print_every == 0:

@@ -196,6 +196,22 @@ int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, void
 int gs_dense_wgrad_grouped_cogather(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                     int32_t n_jobs, void* stream);
 
+/* "Stream" forms of the two launches above (same maths, same co-scheduled gather jobs, up to 6 of them): the
+ * contraction waves use no LDS and no barriers -- one wave per output tile, operands straight from L2 into the MFMA
+ * registers through a register ring -- so that the gather waves sharing the launch keep their occupancy.  The forward
+ * form needs DENSE operands (the caller materialises the layer-0 self rows with one more gather job).
+ *   gs_sage_dense_fwd_stream: out[:, 0:out_dim] = act(self . W_self + bias), out[:, out_dim:2*out_dim] =
+ *     act(agg . W_neigh + bias)  (concat form of aggregators.py:51-58; self == NULL: the single GCN contraction,
+ *     aggregators.py:110).  self / agg are [n, d] dense with pad columns [d, round_up(d, 4)) readable.
+ *   gs_dense_wgrad_grouped_stream: as gs_dense_wgrad_grouped (<= 12 problems; a row-gathered problem needs
+ *     ceil(n / n_slabs) <= 512: the slice's gather indices live in registers). */
+int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const float* agg, int64_t ld_agg, int32_t d, int64_t n,
+                             const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
+                             int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+                             const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
+int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                  int32_t n_jobs, void* stream);
+
 /* Input gradient:  dX[n, d] (+)= dZ[:, col0:col0+out_dim] · W[d, out_dim]^T */
 int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,
                    const float* W, int64_t ldw, int32_t d, float* dX, int64_t ldx, int accumulate,

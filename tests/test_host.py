@@ -230,3 +230,26 @@ def test_rmat_generator_on_cpu():
     assert rp[0] == 0 and rp[-1] == 60000 and np.all(np.diff(rp) >= 0) and c.min() >= 0 and c.max() < 3000
     deg = np.diff(rp)
     assert deg.max() > 10 * deg.mean() and (deg == 0).any()       # skewed: hubs and isolated nodes
+
+
+def test_driver_f1_matches_sklearn():
+    """supervised_train.calc_f1's NumPy micro / macro F1 == sklearn.metrics.f1_score (what the reference calls)."""
+    from sklearn import metrics
+    from graphsage_amd.supervised_train import f1_micro_macro
+    rng = np.random.default_rng(4)
+    for C, n in ((41, 512), (7, 33), (121, 256)):
+        t = rng.integers(0, C, n)
+        p = np.where(rng.random(n) < 0.6, t, rng.integers(0, C, n))
+        p[p == 3] = 5                                            # a class that is never predicted, one never true
+        mic, mac = f1_micro_macro(t, p, False)
+        assert abs(mic - metrics.f1_score(t, p, average="micro")) < 1e-12
+        assert abs(mac - metrics.f1_score(t, p, average="macro")) < 1e-12
+        yt = (rng.random((n, C)) > 0.7).astype(np.float32)
+        yp = np.where(rng.random((n, C)) < 0.8, yt, 1 - yt)
+        yp[:, 0] = 0; yt[:, 1] = 0; yp[:, 1] = 0                 # never-predicted and all-absent columns
+        mic, mac = f1_micro_macro(yt, yp, True)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert abs(mic - metrics.f1_score(yt, yp, average="micro")) < 1e-12
+            assert abs(mac - metrics.f1_score(yt, yp, average="macro")) < 1e-12

@@ -739,3 +739,83 @@ def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
     d_self, d_neigh, _ = orc.mean_aggregator_bwd(d_z, cache, Ws.astype(np.float64), Wn.astype(np.float64), True, "id")
     want = np.concatenate([d_self, d_neigh.reshape(n * s, D)], axis=0) * (h64 > 0)
     np.testing.assert_allclose(dh0.numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("n,d,out,two,act,bias", [(5632, 602, 128, True, ops.ACT_RELU, False), (2500, 100, 128, True, ops.ACT_IDENTITY, True),
+                                                  (3001, 602, 256, False, ops.ACT_RELU, False), (2049, 37, 40, True, ops.ACT_RELU, True)])
+def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias):
+    """gs_sage_dense_fwd_stream (LDS-free contraction waves, dense operands, K tails, ragged rows/columns) + the
+    co-scheduled gather jobs (incl. the s = 1 dense-self copy) vs NumPy."""
+    rng = np.random.default_rng(n + d)
+    Nn = 4000
+    X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
+    self_m, mean = _asym(rng, (n, d)), _asym(rng, (n, d))
+    Ws, Wn = _asym(rng, (d, out)) * 0.1, _asym(rng, (d, out)) * 0.1
+    b = (_asym(rng, ((2 if two else 1) * out,)) * 0.1) if bias else None
+    idx = rng.integers(0, Nn + 1, size=(700, 25)).astype(np.int32)
+    ids1 = rng.integers(0, Nn + 1, size=900).astype(np.int32)
+    Xd = Mat.from_numpy(X, dev, 32)
+    # junk in the pad columns of the dense operands must not leak into the result (ld = round_up(d, 4) only)
+    sd, md = Mat.from_numpy(self_m, dev), Mat.from_numpy(mean, dev)
+    outm = Mat.zeros(n, (2 if two else 1) * out, dev)
+    g_out, c_out = Mat.zeros(700, d, dev), Mat.zeros(900, d, dev)
+    idx_d, ids1_d = _i32(idx.reshape(-1), dev), _i32(ids1, dev)        # descriptors hold raw pointers: keep the tensors
+    Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
+    bd = torch.from_numpy(b).to(dev) if bias else None
+    jobs = [ops.gather_job(Xd, idx_d, 700, 25, g_out), ops.gather_job(Xd, ids1_d, 900, 1, c_out)]
+    ops.sage_dense_fwd_stream(sd if two else None, md, n, Wsd if two else None, Wnd, out, act, bd, outm, jobs)
+    _sync()
+    want_n = mean.astype(np.float64) @ Wn
+    want = np.concatenate([self_m.astype(np.float64) @ Ws, want_n], axis=1) if two else want_n
+    if bias:
+        want = want + b
+    if act == ops.ACT_RELU:
+        want = np.maximum(want, 0)
+    np.testing.assert_allclose(outm.numpy(), want, rtol=1e-4, atol=1e-4 * np.sqrt(d))
+    np.testing.assert_allclose(g_out.numpy(), X[idx].mean(axis=1), **TOL)
+    assert np.array_equal(c_out.numpy(), X[ids1])
+
+
+def test_dense_wgrad_grouped_stream(dev):
+    """gs_dense_wgrad_grouped_stream: the weight gradients of a mean step (layer 0: 602x128 x2 over 5632 rows, layer 1:
+    256x128 x2 over 512 rows, head 256x41, bias 1x41, odd slice lengths) as split-K slabs + a co-scheduled gather job."""
+    import ctypes
+    from graphsage_amd import _lib
+    rng = np.random.default_rng(77)
+    probs = [(5631, 602, 128, 0, 22), (5631, 602, 128, 128, 22), (512, 256, 128, 0, 3), (512, 256, 128, 128, 2), (512, 256, 41, 0, 2),
+             (512, 1, 41, 0, 2)]
+    descs = (_lib.WgradDesc * len(probs))()
+    keep, want, slabs = [], [], []
+    for i, (n, d, o, col0, ns) in enumerate(probs):
+        A = np.ones((n, 1), np.float32) if d == 1 else _asym(rng, (n, d))
+        dZ = _asym(rng, (n, col0 + o)) * 0.1
+        aidx = None
+        if i == 0:          # layer-0 self term: rows gathered from a table through an index vector (cached in registers)
+            table = _asym(rng, (3000, d))
+            aidx = rng.integers(0, 3000, size=n).astype(np.int32)
+            A = table[aidx]
+            Ad, idx_dev = Mat.from_numpy(table, dev, 32), _i32(aidx, dev)
+            keep.append(idx_dev)
+        else:
+            Ad = Mat.from_numpy(A, dev)
+        Zd = Mat.from_numpy(dZ, dev)
+        ld_slab = (o + 3) & ~3
+        sl = torch.zeros(ns * d * ld_slab, device=dev)
+        keep += [Ad, Zd, sl]
+        descs[i].A, descs[i].a_idx, descs[i].dZ, descs[i].slabs = Ad.ptr, ops.ptr(idx_dev) if aidx is not None else None, Zd.ptr, sl.data_ptr()
+        descs[i].lda, descs[i].ldz, descs[i].ld_slab, descs[i].n = Ad.ld, Zd.ld, ld_slab, n
+        descs[i].d, descs[i].col0, descs[i].out_dim, descs[i].n_slabs = d, col0, o, ns
+        want.append(A.astype(np.float64).T @ dZ[:, col0:].astype(np.float64))
+        slabs.append((sl, ns, d, ld_slab, o))
+    X = _asym(rng, (1000, 602))
+    idx = rng.integers(0, 1000, size=(300, 10)).astype(np.int32)
+    g_out = Mat.zeros(300, 602, dev)
+    Xd, idx_d = Mat.from_numpy(X, dev, 32), _i32(idx.reshape(-1), dev)   # descriptors hold raw pointers: keep the tensors
+    job = ops.gather_job(Xd, idx_d, 300, 10, g_out)
+    jarr = (_lib.GatherDesc * 1)(job)
+    ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(descs), len(probs), ctypes.addressof(jarr), 1, ops.current_stream())
+    _sync()
+    for (sl, ns, d, ld_slab, o), w in zip(slabs, want):
+        got = sl.cpu().numpy().reshape(ns, d, ld_slab)[:, :, :o].astype(np.float64).sum(axis=0)
+        np.testing.assert_allclose(got, w, rtol=1e-4, atol=1e-4 * np.sqrt(5632))
+    np.testing.assert_allclose(g_out.numpy(), X[idx].mean(axis=1), **TOL)
