@@ -80,7 +80,27 @@ def main():
     torch.cuda.synchronize()
     arr_t, k1 = descs(32, 8, X, ids_self)
     res["wgrad_tiled_gathered_alone_us"] = timeit(lambda: ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr_t), 6, s), s)
-    for sl0 in (11, 22, 32):
+    arr_g, kg = descs(22, 2, X, ids_self)
+    jn0 = (_lib.GatherDesc * 1)()
+    res["wgrad_stream_GATHERED_A_alone_slices22_us"] = timeit(lambda: ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr_g), 6, ctypes.addressof(jn0), 0, s), s)
+    # cold operands: flush L2/MALL between launches by streaming a 1 GB buffer
+    big = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)
+    def cold(fn):
+        tot = 0.0
+        for _ in range(8):
+            big.add_(1.0)
+            torch.cuda.synchronize()
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record(s); fn(); e1.record(s)
+            tot += e0.elapsed_ms(e1) * 1e3
+        return tot / 8
+    arr_d, kd = descs(22, 2, selfd, None)
+    res["wgrad_stream_dense_COLD_slices22_us"] = cold(lambda: ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr_d), 6, ctypes.addressof(jn0), 0, s))
+    res["wgrad_stream_GATHERED_COLD_slices22_us"] = cold(lambda: ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr_g), 6, ctypes.addressof(jn0), 0, s))
+    res["wgrad_tiled_gathered_COLD_us"] = cold(lambda: ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr_t), 6, s))
+    res["fwd_tiled_gathered_COLD_us"] = cold(lambda: ops.sage_dense_fwd(X, ids_self, means, None, n, Ws, Wn, D, True, ops.ACT_RELU, None, out, stream=s))
+    res["fwd_tiled_dense_COLD_us"] = cold(lambda: ops.sage_dense_fwd(selfd, None, means, None, n, Ws, Wn, D, True, ops.ACT_RELU, None, out, stream=s))
+    for sl0 in (22,):
         arr_s, k2 = descs(sl0, 2, selfd, None)
         jn = (_lib.GatherDesc * 1)()
         res["wgrad_stream_alone_slices%d_us" % sl0] = timeit(lambda: ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr_s), 6, ctypes.addressof(jn), 0, s), s)

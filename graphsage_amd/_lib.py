@@ -73,8 +73,10 @@ _PROTOS = {
     "gs_sage_dense_fwd_stream": [_P, c_int64, _P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int, _P, _P,
                                  c_int64, _P, c_int32, _P],
     "gs_dense_wgrad_grouped_stream": [_P, c_int32, _P, c_int32, _P],
+    "gs_flat_reduce_adam_sample": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
+                                   c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P],
     "gs_sage_tail_supported": [c_int32, c_int32, c_int32],
-    "gs_sage_tail_fwd_bwd": [_P, _P],
+    "gs_sage_tail_fwd_bwd": [_P, _P, c_int32, _P],
     "gs_dropout_rows": [_P, c_int64, _P, c_int64, c_int32, _P, _P, c_int64, _P],
     "gs_gather_mean_dropout_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P, _P],
     "gs_scatter_add_rows": [_P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P, c_int64, _P],
@@ -139,6 +141,19 @@ class TailDesc(ctypes.Structure):
                 ("c0", c_void_p), ("d0", c_uint64), ("c1", c_void_p), ("d1", c_uint64), ("c2", c_void_p), ("d2", c_uint64),
                 ("s", c_int32), ("d_in", c_int32), ("out_dim", c_int32), ("C", c_int32), ("sigmoid", c_int32),
                 ("train", c_int32)]
+
+
+class FanoutDesc(ctypes.Structure):
+    """struct gs_fanout_desc (include/graphsage_amd.h)"""
+    _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("n_nodes", c_int64),
+                ("ids_all", c_void_p), ("B", c_int64),
+                ("seed", c_uint64), ("step", c_uint64), ("step_dev", c_void_p),
+                ("root_offset", c_int64),
+                ("order", c_void_p), ("n_order", c_int64), ("cursor_dev", c_void_p),
+                ("label_table", c_void_p), ("ld_table", c_int64),
+                ("labels_out", c_void_p), ("ld_out", c_int64),
+                ("offsets", c_int64 * 4), ("fan", c_int32 * 3),
+                ("pad_id", c_int32), ("n_hops", c_int32), ("C", c_int32), ("hop0", c_uint32)]
 
 
 class VarDesc(ctypes.Structure):

@@ -96,3 +96,52 @@ __device__ __forceinline__ void gather_mean_wave(const GatherArgs& a, const int6
         *reinterpret_cast<f32x4*>(a.out + row * a.ldo + col) = acc;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Co-scheduled gather jobs: the next step's gather+mean launches (they need no weights) ride along inside another
+// launch as extra workgroups -- every launch of a training step that leaves HBM idle can carry a share of them.
+#define GS_MAX_COJOBS_S 6
+struct CoGatherS {
+    GatherArgs job[GS_MAX_COJOBS_S];
+    int64_t wave_start[GS_MAX_COJOBS_S + 1];   // prefix sums of work items (waves) per job
+    int32_t n;
+};
+
+// U: independent 16-byte loads a wave keeps in flight.  8 suits launches whose gather waves reach >= 12 per CU; hosts
+// that give a gather wave a large register budget but few wave slots (the tail launch: 8 waves per CU) use 13.
+template <int U = 8>
+__device__ __forceinline__ void run_gather_item(const CoGatherS& J, const int64_t w, const int lane) {
+    if (w >= J.wave_start[J.n]) return;  // wave-uniform
+    int k = 0;
+    while (k + 1 < J.n && w >= J.wave_start[k + 1]) ++k;
+    const GatherArgs& a = J.job[k];
+    if (a.s >= 8)
+        gather_mean_wave<U>(a, w - J.wave_start[k], lane);
+    else
+        gather_mean_wave<1>(a, w - J.wave_start[k], lane);
+}
+
+static inline int gs_rup4(int x) { return (x + 3) & ~3; }
+
+static inline int build_cojobs_s(const gs_gather_desc* jobs_host, int32_t n_jobs, CoGatherS* Jout, int64_t* waves_out) {
+    GS_REQUIRE(n_jobs >= 0 && n_jobs <= GS_MAX_COJOBS_S && (n_jobs == 0 || jobs_host), "co-gather: 0..%d jobs", GS_MAX_COJOBS_S);
+    CoGatherS& J = *Jout;
+    J.n = n_jobs;
+    int64_t waves = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const gs_gather_desc& q = jobs_host[i];
+        GS_CHECK_MAT(q.X, q.ldx, "co-gather job X");
+        GS_CHECK_MAT(q.out, q.ldo, "co-gather job out");
+        GS_REQUIRE(q.n > 0 && q.s > 0 && q.d > 0 && q.ldx >= gs_rup4(q.d) && q.ldo >= gs_rup4(q.d), "co-gather: bad job %d", i);
+        if (q.self_src) GS_CHECK_MAT(q.self_src, q.ld_self, "co-gather job self");
+        const int chunks = ((q.d + 3) / 4 + 63) / 64;
+        J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
+                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
+                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
+        J.wave_start[i] = waves;
+        waves += q.n * (int64_t)chunks;
+    }
+    J.wave_start[n_jobs] = waves;
+    *waves_out = waves;
+    return GS_OK;
+}

@@ -1,6 +1,7 @@
 // K6: gradient finalisation and the optimizer (supervised_models.py:95-99, :104-108).
 // Weight gradients arrive as split-K slabs from gs_dense_wgrad (deterministic fixed-order sums).
 #include "gs_common.h"
+#include "gs_sample_dev.h"
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int32_t n_slabs,
                                                            int64_t slab_stride, int32_t rows, int32_t cols,
@@ -157,7 +158,15 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
                                                                const uint64_t* __restrict__ step_dev, int step_offset,
                                                                const float* __restrict__ loss_rows, int64_t loss_n,
                                                                float loss_scale, float* __restrict__ loss_out,
-                                                               int loss_accumulate) {
+                                                               int loss_accumulate, const int opt_blocks,
+                                                               const FanoutArgs F) {
+    // Workgroups beyond opt_blocks run the fan-out SAMPLER of a later mini-batch (one root each): five dependent memory
+    // round trips of almost no work, hidden under this launch instead of heading a step as its own 7 us launch.
+    __shared__ int32_t lvl[2][GS_FANOUT_LDS_SMALL];
+    if ((int)blockIdx.x >= opt_blocks) {
+        sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, (int64_t)blockIdx.x - opt_blocks, lvl);
+        return;
+    }
     float lr_t = 0.f;
     if (fuse_adam) {
         const float t = (float)((step_dev ? *step_dev : 0ull) + (uint64_t)step_offset);
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
         if (threadIdx.x == 0) loss_out[0] = loss_accumulate ? loss_out[0] + sacc * loss_scale : sacc * loss_scale;
     }
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)opt_blocks * blockDim.x) {
         const int64_t i = q * 4;  // every segment offset/size is a multiple of 4 floats
         int k = 0;
         while (k + 1 < V.n && i >= V.offset[k + 1]) ++k;
@@ -181,15 +190,16 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
             float* sp = V.slabs[k] + rel;
             const int ns = V.n_slabs[k];
             const int64_t sz = V.size[k];
-            int z = 0;
-            for (; z + 4 <= ns; z += 4) {   // 4 independent loads in flight; summation order stays z = 0, 1, 2, ...
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + (int64_t)(z + 0) * sz);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + (int64_t)(z + 1) * sz);
-                const f32x4 v2 = *reinterpret_cast<const f32x4*>(sp + (int64_t)(z + 2) * sz);
-                const f32x4 v3 = *reinterpret_cast<const f32x4*>(sp + (int64_t)(z + 3) * sz);
-                g += v0; g += v1; g += v2; g += v3;
+            // 16 slab loads in flight per thread (the launch is one float4 per thread: with 4 in flight the 22-32 slabs
+            // of a Reddit step were 6-8 dependent memory round trips); summation order stays z = 0, 1, 2, ...
+            for (int z0 = 0; z0 < ns; z0 += 16) {
+                f32x4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (z0 + u < ns) g += v[u];
             }
-            for (; z < ns; ++z) g += *reinterpret_cast<const f32x4*>(sp + (int64_t)z * sz);
             if (V.clear[k]) *reinterpret_cast<f32x4*>(sp) = f32x4{0.f, 0.f, 0.f, 0.f};   // atomic accumulator: consume
         }
         f32x4 p = *reinterpret_cast<const f32x4*>(params + i);
@@ -214,11 +224,11 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
     }
 }
 
-extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
+static int flat_reduce_adam_impl(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
                                    float* v, int64_t total, float weight_decay, int fuse_adam, float lr, float beta1,
                                    float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
                                    int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
-                                   float* loss_out, int loss_accumulate, void* stream) {
+                                   float* loss_out, int loss_accumulate, const FanoutArgs* sampler, void* stream) {
     GS_REQUIRE(!loss_rows || (loss_out && loss_n > 0), "gs_flat_reduce_adam: loss_out missing");
     GS_REQUIRE(vars_host && n_vars > 0 && n_vars <= GS_MAX_VARS, "gs_flat_reduce_adam: need 1..%d variables", GS_MAX_VARS);
     GS_REQUIRE(params && grads && total > 0 && total % 4 == 0, "gs_flat_reduce_adam: bad flat buffer");
@@ -243,9 +253,43 @@ extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars,
     GS_REQUIRE(expect <= total, "gs_flat_reduce_adam: variables exceed the flat buffer");
     const int64_t total4 = expect / 4;
     int blocks = (int)std::min<int64_t>(gs_ceil_div(total4, 64), 4096);
-    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, V, params, grads, m, v,
-                       total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev, step_offset,
-                       loss_rows, loss_n, loss_scale, loss_out, loss_accumulate);
+    FanoutArgs F = {};
+    int64_t roots = 0;
+    if (sampler) { F = *sampler; roots = F.B; }
+    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3((unsigned)(blocks + roots)), dim3(64), 0, (hipStream_t)stream, V, params,
+                       grads, m, v, total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev,
+                       step_offset, loss_rows, loss_n, loss_scale, loss_out, loss_accumulate, blocks, F);
     GS_LAUNCH_CHECK("flat_reduce_adam_kernel");
     return GS_OK;
+}
+
+extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
+                                   float* v, int64_t total, float weight_decay, int fuse_adam, float lr, float beta1,
+                                   float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
+                                   int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
+                                   float* loss_out, int loss_accumulate, void* stream) {
+    return flat_reduce_adam_impl(vars_host, n_vars, params, grads, m, v, total, weight_decay, fuse_adam, lr, beta1, beta2, eps,
+                                 clip, grad_scale, step_dev, step_offset, loss_rows, loss_n, loss_scale, loss_out,
+                                 loss_accumulate, nullptr, stream);
+}
+
+extern "C" int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
+                                          float* v, int64_t total, float weight_decay, int fuse_adam, float lr, float beta1,
+                                          float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
+                                          int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
+                                          float* loss_out, int loss_accumulate, const gs_fanout_desc* s, void* stream) {
+    GS_REQUIRE(s, "gs_flat_reduce_adam_sample: null sampler descriptor");
+    FanoutArgs F;
+    int64_t kmax = 0;
+    int rc = gs_fanout_args(s->rowptr, s->col, s->n_nodes, s->pad_id, s->n_hops, s->fan, s->offsets, s->ids_all, s->B, s->seed,
+                            s->step, s->step_dev, s->hop0, s->root_offset, s->order, s->n_order, s->cursor_dev, s->label_table,
+                            s->ld_table, s->C, s->labels_out, s->ld_out, &F, &kmax);
+    if (rc != GS_OK) return rc;
+    if (kmax > GS_FANOUT_LDS_SMALL) {
+        gs_set_error("gs_flat_reduce_adam_sample: per-root fan-out %lld of a kept hop exceeds %d", (long long)kmax, GS_FANOUT_LDS_SMALL);
+        return GS_ENOTSUP;
+    }
+    return flat_reduce_adam_impl(vars_host, n_vars, params, grads, m, v, total, weight_decay, fuse_adam, lr, beta1, beta2, eps,
+                                 clip, grad_scale, step_dev, step_offset, loss_rows, loss_n, loss_scale, loss_out,
+                                 loss_accumulate, s->B > 0 ? &F : nullptr, stream);
 }

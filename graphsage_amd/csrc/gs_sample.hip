@@ -9,6 +9,7 @@
 //                             lane then draws one neighbor with a counter-based xorshift-multiply
 //                             hash and the wave stores its 64 picks as one coalesced 256-byte line.
 #include "gs_common.h"
+#include "gs_sample_dev.h"
 
 __global__ __launch_bounds__(256) void sample_padded_kernel(const int32_t* __restrict__ adj, int32_t max_deg,
                                                             const int32_t* __restrict__ ids, int64_t n,
@@ -163,82 +164,9 @@ extern "C" int gs_stage_batch(const int32_t* order, int64_t n_order, const uint6
 // reads its parents from LDS, and every hop is written to the contiguous id buffer
 // [roots | hop-1 | hop-2 | ...] with coalesced stores.  Draws are bit-identical to gs_sample_uniform_csr
 // called hop by hop (same counter-based hash of (seed, step, hop, global row, j)).
-#define GS_MAX_HOPS 3
-#define GS_FANOUT_LDS 8192
-struct FanoutArgs {
-    const int64_t* rowptr;
-    const int32_t* col;
-    int64_t n_nodes;
-    int32_t pad_id;
-    int32_t n_hops;
-    int32_t fan[GS_MAX_HOPS];
-    int64_t offsets[GS_MAX_HOPS + 1];  // start of each hop's ids inside ids_all (offsets[0] = roots)
-    int32_t* ids_all;
-    int64_t B;
-    uint64_t seed, step;
-    const uint64_t* step_dev;
-    uint32_t hop0;
-    int64_t root_offset;  // global index of this rank's first root (data-parallel invariance)
-    // optional batch staging (order == nullptr -> roots are already in ids_all)
-    const int32_t* order;
-    int64_t n_order;
-    const uint64_t* cursor;
-    const float* label_table;
-    int64_t ldt;
-    int32_t C;
-    float* labels_out;
-    int64_t ldo;
-};
-
 __global__ __launch_bounds__(256) void sample_fanout_kernel(const FanoutArgs a) {
     __shared__ int32_t lvl[2][GS_FANOUT_LDS];
-    const int tid = threadIdx.x;
-    const int64_t i = blockIdx.x;  // root index within the batch
-    int32_t root;
-    if (a.order) {
-        const uint64_t c = a.cursor ? *a.cursor : 0ull;
-        root = a.order[(int64_t)((c + (uint64_t)i) % (uint64_t)a.n_order)];
-        if (tid == 0) a.ids_all[a.offsets[0] + i] = root;
-        if (a.label_table) {
-            const int Cp = (a.C + 3) & ~3;
-            for (int k = tid; k < Cp; k += 256)
-                a.labels_out[i * a.ldo + k] = k < a.C ? a.label_table[(int64_t)root * a.ldt + k] : 0.f;
-        }
-    } else {
-        root = a.ids_all[a.offsets[0] + i];
-    }
-    if (tid == 0) lvl[0][0] = root;
-    __syncthreads();
-    const uint64_t st = a.step + (a.step_dev ? *a.step_dev : 0ull);
-    int64_t count_prev = 1;
-    for (int h = 0; h < a.n_hops; ++h) {
-        const int s = a.fan[h];
-        const int64_t count = count_prev * s;
-        const uint64_t key = gs_mix64(a.seed ^ (st * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(a.hop0 + h) << 56));
-        const int32_t* prev = lvl[h & 1];
-        int32_t* next = lvl[(h + 1) & 1];
-        const bool keep = (h + 1 < a.n_hops);  // the last hop is only written to global memory
-        for (int64_t t = tid; t < count; t += 256) {
-            const int64_t pl = t / s;  // parent slot in the previous level
-            const uint32_t j = (uint32_t)(t - pl * s);
-            const int32_t id = prev[pl];
-            int32_t pick = a.pad_id;
-            if (id >= 0 && (int64_t)id < a.n_nodes) {
-                const int64_t b = a.rowptr[id];
-                const int32_t deg = (int32_t)(a.rowptr[id + 1] - b);
-                if (deg > 0) {
-                    const int64_t grow = (a.root_offset + i) * count_prev + pl;  // global row at this hop
-                    const uint64_t u = gs_mix64(key + (uint64_t)grow * 0xD1342543DE82EF95ull + j);
-                    const uint32_t r = (uint32_t)(u >> 32);
-                    pick = a.col[b + (int64_t)(((uint64_t)r * (uint64_t)(uint32_t)deg) >> 32)];
-                }
-            }
-            if (keep) next[t] = pick;
-            a.ids_all[a.offsets[h + 1] + i * count + t] = pick;
-        }
-        __syncthreads();
-        count_prev = count;
-    }
+    sample_fanout_root<GS_FANOUT_LDS>(a, blockIdx.x, lvl);
 }
 
 extern "C" int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,
@@ -249,29 +177,12 @@ extern "C" int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, i
                                     const float* label_table, int64_t ld_table, int32_t C, float* labels_out,
                                     int64_t ld_out, void* stream) {
     if (B == 0) return GS_OK;
-    GS_REQUIRE(rowptr && col && ids_all && fan_host && offsets_host && n_nodes > 0, "gs_sample_fanout_csr: null pointer");
-    GS_REQUIRE(n_hops >= 1 && n_hops <= GS_MAX_HOPS, "gs_sample_fanout_csr: 1..%d hops", GS_MAX_HOPS);
-    GS_REQUIRE(hop0 + n_hops <= 256, "gs_sample_fanout_csr: hop ids must be < 256");
-    GS_REQUIRE(!order || n_order > 0, "gs_sample_fanout_csr: empty order");
-    GS_REQUIRE(!label_table || (labels_out && C > 0 && ld_table >= C && ld_out >= ((C + 3) & ~3) && order),
-               "gs_sample_fanout_csr: bad label staging arguments");
-    FanoutArgs a = {};
-    a.rowptr = rowptr; a.col = col; a.n_nodes = n_nodes; a.pad_id = pad_id; a.n_hops = n_hops;
-    int64_t count = 1;
-    for (int h = 0; h < n_hops; ++h) {
-        GS_REQUIRE(fan_host[h] > 0, "gs_sample_fanout_csr: fan-out must be positive");
-        a.fan[h] = fan_host[h];
-        if (h + 1 < n_hops) {
-            count *= fan_host[h];
-            GS_REQUIRE(count <= GS_FANOUT_LDS, "gs_sample_fanout_csr: per-root fan-out %lld exceeds the LDS buffer", (long long)count);
-        }
-    }
-    for (int h = 0; h <= n_hops; ++h) a.offsets[h] = offsets_host[h];
-    a.ids_all = ids_all; a.B = B; a.seed = seed; a.step = step; a.step_dev = step_dev; a.hop0 = hop0;
-    a.root_offset = root_offset;
-    a.order = order; a.n_order = n_order; a.cursor = cursor_dev;
-    a.label_table = label_table; a.ldt = ld_table; a.C = C; a.labels_out = labels_out; a.ldo = ld_out;
-    GS_REQUIRE(B < (1ll << 31), "gs_sample_fanout_csr: batch too large");
+    FanoutArgs a;
+    int64_t kmax = 0;
+    int rc = gs_fanout_args(rowptr, col, n_nodes, pad_id, n_hops, fan_host, offsets_host, ids_all, B, seed, step, step_dev, hop0,
+                            root_offset, order, n_order, cursor_dev, label_table, ld_table, C, labels_out, ld_out, &a, &kmax);
+    if (rc != GS_OK) return rc;
+    GS_REQUIRE(kmax <= GS_FANOUT_LDS, "gs_sample_fanout_csr: per-root fan-out %lld exceeds the LDS buffer", (long long)kmax);
     hipLaunchKernelGGL(sample_fanout_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("sample_fanout_kernel");
     return GS_OK;

@@ -21,13 +21,6 @@
 #include "gs_gather_dev.h"
 #include <stdlib.h>
 
-#define GS_MAX_COJOBS_S 6
-struct CoGatherS {
-    GatherArgs job[GS_MAX_COJOBS_S];
-    int64_t wave_start[GS_MAX_COJOBS_S + 1];
-    int32_t n;
-};
-
 // XCD-aware work placement: block b runs on XCD b % 8 (each XCD has its own 4 MB L2).  Consecutive LOGICAL ids go to
 // the same XCD, so a contiguous range of work items (= a contiguous range of rows / reduction slices) shares one L2:
 // without it every XCD streams the whole A operand (13.7 MB) through its 4 MB L2 and every operand load is a MALL hit.
@@ -39,17 +32,6 @@ __device__ __forceinline__ int stream_xcd_swizzle(int bid, int nwg) {
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ void run_gather_item(const CoGatherS& J, const int64_t w, const int lane) {
-    if (w >= J.wave_start[J.n]) return;  // wave-uniform
-    int k = 0;
-    while (k + 1 < J.n && w >= J.wave_start[k + 1]) ++k;
-    const GatherArgs& a = J.job[k];
-    if (a.s >= 8)
-        gather_mean_wave<8>(a, w - J.wave_start[k], lane);
-    else
-        gather_mean_wave<1>(a, w - J.wave_start[k], lane);
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -331,29 +313,6 @@ __global__ __launch_bounds__(256) void stream_wgrad_kernel(const WgradArgs G, co
 
 // ------------------------------------------------------------------------------------------ host side
 static inline int rup4s(int x) { return (x + 3) & ~3; }
-
-static int build_cojobs_s(const gs_gather_desc* jobs_host, int32_t n_jobs, CoGatherS* Jout, int64_t* waves_out) {
-    GS_REQUIRE(n_jobs >= 0 && n_jobs <= GS_MAX_COJOBS_S && (n_jobs == 0 || jobs_host), "stream co-gather: 0..%d jobs", GS_MAX_COJOBS_S);
-    CoGatherS& J = *Jout;
-    J.n = n_jobs;
-    int64_t waves = 0;
-    for (int i = 0; i < n_jobs; ++i) {
-        const gs_gather_desc& q = jobs_host[i];
-        GS_CHECK_MAT(q.X, q.ldx, "stream co-gather job X");
-        GS_CHECK_MAT(q.out, q.ldo, "stream co-gather job out");
-        GS_REQUIRE(q.n > 0 && q.s > 0 && q.d > 0 && q.ldx >= rup4s(q.d) && q.ldo >= rup4s(q.d), "stream co-gather: bad job %d", i);
-        if (q.self_src) GS_CHECK_MAT(q.self_src, q.ld_self, "stream co-gather job self");
-        const int chunks = ((q.d + 3) / 4 + 63) / 64;
-        J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
-                              q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
-                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
-        J.wave_start[i] = waves;
-        waves += q.n * (int64_t)chunks;
-    }
-    J.wave_start[n_jobs] = waves;
-    *waves_out = waves;
-    return GS_OK;
-}
 
 extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const float* agg, int64_t ld_agg, int32_t d,
                                         int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,

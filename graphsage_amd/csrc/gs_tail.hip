@@ -23,6 +23,7 @@
 // 8 waves per workgroup; each wave owns a disjoint column slab of every contraction, except the tiny logits
 // contraction, whose K is split across the waves and summed in a fixed order through LDS (deterministic).
 #include "gs_common.h"
+#include "gs_gather_dev.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -79,7 +80,13 @@ __device__ __forceinline__ float tail_wave_max(float v) {
 #define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
 
 template <int D, int O>
-__global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a) {
+__global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
+    // Co-scheduled gather: the tail occupies n/16 CUs for ~30 us of mostly waiting; the other ~220 CUs (one 8-wave
+    // workgroup each: the launch's LDS size is uniform) stream a share of the NEXT step's gather+mean from HBM meanwhile.
+    if ((int)blockIdx.x >= tail_blocks) {
+        run_gather_item<13>(J, ((int64_t)blockIdx.x - tail_blocks) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
     constexpr int Z = 2 * O;
     constexpr int ldh = D + 4, ldzs = Z + 4;
     constexpr int D4 = D / 4;
@@ -457,20 +464,22 @@ extern "C" int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C) 
 }
 
 template <int D, int O>
-static int launch_tail(const TailArgs& a, hipStream_t st) {
+static int launch_tail(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
     const size_t lds = tail_lds_bytes(a.D, a.O, a.C);
     static bool attr_done = false;
     if (!attr_done) {
         GS_HIP(hipFuncSetAttribute((const void*)sage_tail_kernel<D, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    const unsigned blocks = (unsigned)gs_ceil_div(a.n, TAIL_ROWS);
-    hipLaunchKernelGGL((sage_tail_kernel<D, O>), dim3(blocks), dim3(TAIL_THREADS), lds, st, a);
+    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);
+    const int64_t blocks = tail_blocks + gs_ceil_div(gather_waves, TAIL_WAVES);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_fwd_bwd: grid too large");
+    hipLaunchKernelGGL((sage_tail_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
     GS_LAUNCH_CHECK("sage_tail_kernel");
     return GS_OK;
 }
 
-extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, void* stream) {
+extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
     GS_REQUIRE(q, "gs_sage_tail_fwd_bwd: null descriptor");
     if (q->n == 0) return GS_OK;
     GS_REQUIRE(q->n > 0 && q->s > 0, "gs_sage_tail_fwd_bwd: bad sizes");
@@ -514,8 +523,14 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, void* stream) {
     a.c0 = q->c0; a.d0 = q->d0; a.c1 = q->c1; a.d1 = q->d1; a.c2 = q->c2; a.d2 = q->d2;
     a.train = q->train ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (D == 256 && O == 128) return launch_tail<256, 128>(a, st);
-    if (D == 256 && O == 64) return launch_tail<256, 64>(a, st);
-    if (D == 128 && O == 128) return launch_tail<128, 128>(a, st);
-    return launch_tail<128, 64>(a, st);
+    CoGatherS J = {};
+    int64_t gw = 0;
+    {
+        int rc = build_cojobs_s(jobs_host, n_jobs, &J, &gw);
+        if (rc != GS_OK) return rc;
+    }
+    if (D == 256 && O == 128) return launch_tail<256, 128>(a, J, gw, st);
+    if (D == 256 && O == 64) return launch_tail<256, 64>(a, J, gw, st);
+    if (D == 128 && O == 128) return launch_tail<128, 128>(a, J, gw, st);
+    return launch_tail<128, 64>(a, J, gw, st);
 }

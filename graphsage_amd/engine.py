@@ -77,6 +77,8 @@ class Engine(object):
         # second stream for the data chain (sampling + gathers of the NEXT step overlap this step's compute)
         self._stream2_obj = None
         self.stream2 = None
+        self._defer_sampler = False       # neigh_samplers.fanout: hand the launch to the next optimizer launch instead
+        self._deferred_sampler = None
         self._ev_fork = self._ev_join = None
 
     # -------------------------------------------------------------------------------- variables
@@ -281,11 +283,18 @@ class Engine(object):
         self.launch_wgrads(side_jobs)
         arr = self._var_descs()
         lr_, ln, lscale, lout, lacc = loss if loss is not None else (None, 0, 0.0, None, False)
-        ops.call("gs_flat_reduce_adam", ctypes.addressof(arr), len(self.variables), ops.ptr(self.params),
-                 ops.ptr(self.grads), ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats,
-                 float(weight_decay), 1 if fuse_adam else 0, lr, 0.9, 0.999, 1e-8, clip, grad_scale,
-                 ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
-                 1 if lacc else 0, self.stream)
+        args = (ctypes.addressof(arr), len(self.variables), ops.ptr(self.params),
+                ops.ptr(self.grads), ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats,
+                float(weight_decay), 1 if fuse_adam else 0, lr, 0.9, 0.999, 1e-8, clip, grad_scale,
+                ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
+                1 if lacc else 0)
+        rider = getattr(self, "_deferred_sampler", None)
+        if rider is not None:
+            # a later mini-batch's fan-out sampler rides in this launch (neigh_samplers.fanout under _defer_sampler)
+            self._deferred_sampler = None
+            ops.call("gs_flat_reduce_adam_sample", *args, ctypes.addressof(rider), self.stream)
+        else:
+            ops.call("gs_flat_reduce_adam", *args, self.stream)
         if fuse_adam:
             self._params_updated()
 

@@ -108,7 +108,13 @@ class SampleAndAggregate(object):
         self.world_size, self.rank = int(world_size), int(rank)
         self.engine.dropout_seed = 123 + 1000003 * self.rank      # every data-parallel rank draws its own masks
         self.row_offset = 0
-        self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.7))   # share of the prefetch gather in the L0 launch
+        # share of the prefetch gather carried by the layer-0 launch (the rest rides in the weight-gradient launch):
+        # 0.7 with the LDS-tiled weight-gradient kernel, 0.6 with the stream kernel (sweeps in DESIGN.md)
+        self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.4 if self.engine.stream_gemm else 0.7))
+        # share carried by the fused tail launch (supervised mean model; 0 = none)
+        self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.3 if self.engine.stream_gemm else 0.0))
+        # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
+        self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
         self.grad_hook = None
@@ -420,6 +426,14 @@ class SampleAndAggregate(object):
             parity = getattr(self, "_parity", 0)
         buf = self.engine.ws_i32(("ids_all", tuple(sizes), parity), offsets[-1])
         return buf, offsets
+
+    def _fanout_fusable(self, layer_infos=None):
+        """Will model.sample() on the contiguous id buffer take the one-launch fan-out path?"""
+        from .neigh_samplers import CSRAdjacency
+        layer_infos = layer_infos or self.layer_infos
+        sampler0 = layer_infos[0].neigh_sampler
+        return (len(layer_infos) <= 3 and all(li.neigh_sampler is sampler0 for li in layer_infos)
+                and isinstance(sampler0.adj_info.current, CSRAdjacency) and getattr(self, "fuse_sampler", True))
 
     def sample(self, inputs, layer_infos, batch_size=None):
         """Sample neighbors to be the supportive fields for multi-layer convolutions

@@ -122,8 +122,15 @@ class UniformNeighborSampler(Layer):
         order = cursor = table = labels_out = None
         if stage is not None:
             order, cursor, table, labels_out = stage
-        ops.sample_fanout_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all, batch_size,
-                              self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,
-                              order=order, cursor_dev=cursor, label_table=table, labels_out=labels_out,
-                              stream=e.stream)
+        if getattr(e, "_defer_sampler", False):
+            # not launched here: the descriptor rides in the step's optimizer launch (engine.finish_backward)
+            e._deferred_sampler = ops.fanout_desc(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all,
+                                                  batch_size, self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index,
+                                                  root_offset=root_offset, order=order, cursor_dev=cursor,
+                                                  label_table=table, labels_out=labels_out)
+        else:
+            ops.sample_fanout_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all, batch_size,
+                                  self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,
+                                  order=order, cursor_dev=cursor, label_table=table, labels_out=labels_out,
+                                  stream=e.stream)
         self._call_index += len(fans)

@@ -111,6 +111,28 @@ def sample_fanout_csr(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, s
          labels_out.ld if labels_out is not None else 0, _s(stream))
 
 
+def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, step_dev=None, hop0=0, root_offset=0,
+                order=None, cursor_dev=None, label_table=None, labels_out=None):
+    """The arguments of sample_fanout_csr as a struct gs_fanout_desc (for gs_flat_reduce_adam_sample).  The tensors are
+    kept alive on the descriptor object."""
+    q = _lib.FanoutDesc()
+    q.rowptr, q.col, q.n_nodes, q.pad_id = ptr(rowptr), ptr(col), n_nodes, pad_id
+    q.n_hops = len(fans)
+    for k, f in enumerate(fans):
+        q.fan[k] = f
+    for k, o in enumerate(offsets[: len(fans) + 1]):
+        q.offsets[k] = o
+    q.ids_all, q.B, q.seed, q.step, q.step_dev = ptr(ids_all), B, seed & 0xFFFFFFFFFFFFFFFF, 0, ptr(step_dev)
+    q.hop0, q.root_offset = hop0, root_offset
+    q.order, q.n_order, q.cursor_dev = ptr(order), (order.numel() if order is not None else 0), ptr(cursor_dev)
+    if label_table is not None:
+        q.label_table, q.ld_table, q.C = label_table.ptr, label_table.ld, label_table.d
+    if labels_out is not None:
+        q.labels_out, q.ld_out = labels_out.ptr, labels_out.ld
+    q._keep = (rowptr, col, ids_all, step_dev, order, cursor_dev, label_table, labels_out)
+    return q
+
+
 def select_batch(order, cursor_dev, n, out, stream=None):
     call("gs_select_batch", ptr(order), order.numel(), ptr(cursor_dev), n, ptr(out), _s(stream))
     return out
@@ -354,7 +376,7 @@ def sage_tail_supported(d_in, out_dim, C):
 
 
 def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels, C, sigmoid_loss, means, z, y, logits,
-                      preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), stream=None):
+                      preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), jobs=(), stream=None):
     """gs_sage_tail_fwd_bwd: layer 1 + head (+ their input gradients when dz / d_h0 are given) in ONE launch.
     counters: up to three (device int64 tensor, delta) pairs advanced at the end of the launch."""
     q = _lib.TailDesc()
@@ -373,7 +395,9 @@ def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels
     cs += [(None, 0)] * (3 - len(cs))
     (q.c0, q.d0), (q.c1, q.d1), (q.c2, q.d2) = cs[:3]
     q.s, q.d_in, q.out_dim, q.C, q.sigmoid, q.train = s, h0.d, out_dim, C, 1 if sigmoid_loss else 0, 1 if train else 0
-    call("gs_sage_tail_fwd_bwd", ctypes.addressof(q), _s(stream))
+    jobs = list(jobs or ())
+    jarr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_tail_fwd_bwd", ctypes.addressof(q), ctypes.addressof(jarr), len(jobs), _s(stream))
 
 
 # ------------------------------------------------------------------------------------------ K6

@@ -69,7 +69,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                 and self.num_samples[-1] <= 11          # neighbor rows of a batch node are held in registers
                 and ops.sage_tail_supported(2 * self.dims[1], self.dims[2], self.num_classes))
 
-    def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None, epilogue=None):
+    def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None, epilogue=None, tail_jobs=None):
         """sample -> aggregate -> l2_normalize -> node_pred -> loss/preds  (supervised_models.py:79-92,102-126).
         `epilogue`: the step's device-counter increments; when the fused tail launch runs it advances them itself
         (and `_backward` then skips the separate epilogue launch)."""
@@ -119,7 +119,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                                   self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels, C,
                                   self.sigmoid_loss, self._tail_means, self.agg_out, self.outputs1, self.node_preds,
                                   self.preds, self._dlogits, self._loss_rows, dz=self._tail_dz, d_h0=self._tail_dh0,
-                                  counters=counters, stream=e.stream)
+                                  counters=counters, jobs=tail_jobs, stream=e.stream)
         else:
             self.agg_out = out
             self.outputs1 = e.ws_mat("outputs1", n, out.d)
@@ -356,31 +356,63 @@ class SupervisedGraphsage(SampleAndAggregate):
             self._parity = p
             # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
-            fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
-            self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue)
+            fwd_jobs, rest = ops.split_gather_jobs(side_jobs, self.cogather_split)
+            tail_jobs, wgrad_jobs = [], rest
+            if rest and self.cogather_tail > 0 and self._tail_ok():
+                # the fused tail launch keeps only n/16 CUs busy: the rest of the chip streams a share of the gather
+                tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, self.cogather_tail / max(1e-6, 1.0 - self.cogather_split)))
+            self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue,
+                          tail_jobs=tail_jobs)
             self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
             if in_graph:
                 self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
                 self._optimize(advanced=True)
 
+        def sample_into(parity):
+            batch = self.ids_buffer(n, parity=parity)[0][:n]
+            labels = e.ws_mat(("labels", parity), n, self.num_classes)
+            samples, support = self._sample_phase(batch, n, parity, stage=(self._order, self._cursor, self.label_table, labels))
+            return batch, labels, samples, support
+
+        # sampler-in-optimizer-launch: only where the fused tail launch advances the device counters BEFORE the optimizer
+        per_root = 1
+        for f in self.num_samples[:0:-1]:
+            per_root *= f
+        ride = (self.sampler_rides and mode == "fused" and local_adam and fused and k > 1 and self._tail_ok()
+                and self._fanout_fusable() and per_root <= 512)
+
         def body():
             p = p0
-            for _ in range(k):
+            staged = None
+            for j in range(k):
                 if mode == "streams":
                     def main(p=p):
                         compute(p, epilogue=dict(step=1 if fused else 0))
                     e.fork_join(main, lambda p=p: data(1 - p))
                 else:
                     q = 1 - p
-                    batch_q = self.ids_buffer(n, parity=q)[0][:n]
-                    labels_q = e.ws_mat(("labels", q), n, self.num_classes)
-                    samples, support = self._sample_phase(batch_q, n, q, stage=(self._order, self._cursor,
-                                                                                self.label_table, labels_q))
+                    if staged is None:
+                        staged = sample_into(q)                    # standalone sampler launch (first step of a graph)
+                    batch_q, labels_q, samples, support = staged
                     self_all, neighs = self._layer0_inputs(samples, support, n)
                     means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
+                    staged = None
+                    if ride and j + 1 < k:
+                        # the sampler of the step AFTER the next one rides in this step's optimizer launch: by then
+                        # this step's own id / label buffers (parity p) are free, and the tail launch has already
+                        # advanced the sampler clock and the epoch cursor -- the draws are those of the standalone launch
+                        e._defer_sampler = True
+                        try:
+                            staged = sample_into(p)
+                        finally:
+                            e._defer_sampler = False
+                        if e._deferred_sampler is None:
+                            raise ops._lib.GraphsageAmdError("sampler did not take the one-launch fan-out path")
                     self._prefetched[(n, q)] = (batch_q, labels_q, (samples, support, means_q))
                     compute(p, side_jobs=jobs, epilogue=dict(step=1 if fused else 0, clock=1, cursor=self._cursor,
                                                              cursor_delta=n))
+                    if e._deferred_sampler is not None:
+                        raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
                 p = 1 - p
 
         key = ("ptrain" if local_adam else ("ptrain_dp" if in_graph else "ptrain_fb"), mode, n, k, p0, self._adj_version())

@@ -356,6 +356,29 @@ int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* par
                         const float* loss_rows, int64_t loss_n, float loss_scale, float* loss_out, int loss_accumulate,
                         void* stream);
 
+/* gs_flat_reduce_adam + the fan-out sampler of a LATER mini-batch (arguments of gs_sample_fanout_csr in a struct) in ONE
+ * launch: the sampler is a chain of dependent memory round trips with almost no work, so it hides completely under
+ * the optimizer launch of the step before.  The per-root id count of every kept hop must be <= 512
+ * (else GS_ENOTSUP: launch gs_sample_fanout_csr on its own). */
+typedef struct gs_fanout_desc {
+    const int64_t* rowptr; const int32_t* col; int64_t n_nodes;
+    int32_t* ids_all; int64_t B;
+    uint64_t seed, step; const uint64_t* step_dev;
+    int64_t root_offset;
+    const int32_t* order; int64_t n_order; const uint64_t* cursor_dev;
+    const float* label_table; int64_t ld_table;
+    float* labels_out; int64_t ld_out;
+    int64_t offsets[4];
+    int32_t fan[3];
+    int32_t pad_id, n_hops, C;
+    uint32_t hop0;
+} gs_fanout_desc;
+int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
+                               int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,
+                               float eps, float clip, float grad_scale, const uint64_t* step_dev, int32_t step_offset,
+                               const float* loss_rows, int64_t loss_n, float loss_scale, float* loss_out, int loss_accumulate,
+                               const gs_fanout_desc* sampler_host, void* stream);
+
 /* Fused tail of the supervised two-layer GraphSAGE-mean model: layer 1 (MeanAggregator._call on the layer-0 outputs,
  * aggregators.py:43-64, identity act: last layer, models.py:307-310), l2_normalize + Dense head + loss/preds
  * (supervised_models.py:85-126) and their gradients down to dLoss/d(layer-0 pre-activations), ONE launch.  Every batch
@@ -390,7 +413,9 @@ typedef struct gs_tail_desc {
     int32_t s, d_in, out_dim, C, sigmoid, train;
 } gs_tail_desc;
 int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
-int gs_sage_tail_fwd_bwd(const gs_tail_desc* desc_host, void* stream);
+/* jobs_host / n_jobs (0..6): gather+mean jobs of the NEXT step co-scheduled in the launch (as gs_sage_dense_fwd_cogather):
+ * the tail keeps n/16 CUs busy, the rest of the chip streams the gather meanwhile. */
+int gs_sage_tail_fwd_bwd(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 
 /* Inverted dropout tf.nn.dropout(x, keep_prob = 1 - rate) (aggregators.py:46-47,104-105; layers.py:107): kept
  * elements are scaled by 1/keep_prob.  The keep mask is a counter hash of (seed, *clock_dev, site, row0 + row,
