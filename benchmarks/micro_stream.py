@@ -76,6 +76,7 @@ def main():
             arr[i].A, arr[i].a_idx, arr[i].dZ, arr[i].slabs = A.ptr, ops.ptr(ai), Z.ptr, sl.data_ptr()
             arr[i].lda, arr[i].ldz, arr[i].ld_slab, arr[i].n = A.ld, Z.ld, ld_slab, nn
             arr[i].d, arr[i].col0, arr[i].out_dim, arr[i].n_slabs = d, col0, o, ns
+            arr[i].a_rows = A.rows if ai is not None else 0
         return arr, keep
     torch.cuda.synchronize()
     arr_t, k1 = descs(32, 8, X, ids_self)

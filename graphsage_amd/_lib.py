@@ -103,7 +103,7 @@ class WgradDesc(ctypes.Structure):
     """struct gs_wgrad_desc (include/graphsage_amd.h)"""
     _fields_ = [("A", c_void_p), ("a_idx", c_void_p), ("dZ", c_void_p), ("slabs", c_void_p),
                 ("lda", c_int64), ("ldz", c_int64), ("ld_slab", c_int64), ("n", c_int64),
-                ("d", c_int32), ("col0", c_int32), ("out_dim", c_int32), ("n_slabs", c_int32)]
+                ("d", c_int32), ("col0", c_int32), ("out_dim", c_int32), ("n_slabs", c_int32), ("a_rows", c_int64)]
 
 
 class GatherDesc(ctypes.Structure):

@@ -157,7 +157,7 @@ __device__ __forceinline__ void stream_fwd_item(const FwdArgs& g, const int item
 // (TWO per SIMD: while one waits for its operands the other owns the MFMA pipe).
 template <int TN, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void sage_stream_fwd_kernel(const FwdArgs g, const int mfma_blocks, const CoGatherS J) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: per-item fields live in SGPRs
     if ((int)blockIdx.x < mfma_blocks) {
         const int item = stream_xcd_swizzle(blockIdx.x, mfma_blocks) * WAVES + wave;
         if (item < g.n_items) stream_fwd_item<TN>(g, item, lane);
@@ -184,64 +184,63 @@ struct WgradArgs {
 };
 
 // One wave: slab[z][f0 .. f0+63][o0 .. o0+63] = sum_{r in slice z} A[r][f] * dZ[r][o]
-__device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int item, const int lane) {
-    constexpr int P = 8;                                   // register ring: k-pairs (2 reduction rows) in flight
-    int pi = 0;
-    while (pi + 1 < G.n && item >= G.p[pi + 1].item_start) ++pi;
-    const WgradProb q = G.p[pi];
-    const int local = item - q.item_start;
-    const int tiles = q.tiles_m * q.tiles_n;
-    const int z = local / tiles;
-    const int tt = local - z * tiles;
-    const int tile_m = tt / q.tiles_n, tile_n = tt - tile_m * q.tiles_n;
-    const int f0 = tile_m * 64, o0 = tile_n * 64;
+//
+// The wave is alone on its SIMD (~900 items over 1024 SIMDs), so every instruction between two MFMAs that does not fit
+// in the shadow of the last MFMA of a k-pair (64 cycles) is an MFMA bubble.  The loop therefore carries 32-bit BYTE
+// offsets against wave-uniform base pointers (global_load with an SGPR base), advanced with one add per load; a
+// gathered A row costs two v_readlane (SALU) + two VALU.  (The first version -- 64-bit per-lane pointers, a register
+// select ladder for the gather index -- spent ~300 cycles per k-pair outside the 256 MFMA cycles.)
+template <int P, bool GATHERED>
+__device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int z, const int f0, const int o0, const int lane) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int rb = z * q.kchunk, re = min(rb + q.kchunk, q.n);
-    // per-lane column pointers (clamped: out-of-range columns are not stored)
-    const float* a0 = q.A + min(f0 + l31, q.d - 1);
-    const float* a1 = q.A + min(f0 + 32 + l31, q.d - 1);
-    const float* z0 = q.dZ + min(o0 + l31, q.out_dim - 1);
-    const float* z1 = q.dZ + min(o0 + 32 + l31, q.out_dim - 1);
+    const char* __restrict__ Ab = (const char*)q.A;
+    const char* __restrict__ Zb = (const char*)q.dZ;
+    // per-lane column byte offsets (clamped: out-of-range columns are loaded from a valid column and never stored)
+    const uint32_t ca0 = (uint32_t)min(f0 + l31, q.d - 1) * 4u, ca1 = (uint32_t)min(f0 + 32 + l31, q.d - 1) * 4u;
+    const uint32_t strideA = (uint32_t)q.lda * 8u, strideZ = (uint32_t)q.ldz * 8u;       // two rows, bytes
+    uint32_t zo0 = (uint32_t)(rb + lh) * (uint32_t)q.ldz * 4u + (uint32_t)min(o0 + l31, q.out_dim - 1) * 4u;
+    uint32_t zo1 = (uint32_t)(rb + lh) * (uint32_t)q.ldz * 4u + (uint32_t)min(o0 + 32 + l31, q.out_dim - 1) * 4u;
+    uint32_t ao0 = (uint32_t)(rb + lh) * (uint32_t)q.lda * 4u + ca0, ao1 = (uint32_t)(rb + lh) * (uint32_t)q.lda * 4u + ca1;
+    // Row-gathered A (layer 0 self rows): the byte offsets of the slice's source rows (<= 512) are computed ONCE
+    // (lane L of rowoff[j] holds row rb + 64 j + L); the two rows of a k-pair come out with v_readlane.  rowoff[0] is
+    // always the current 64-row chunk: the registers rotate down when the load cursor crosses a chunk.
+    constexpr int IDXR = 8;
+    uint32_t rowoff[IDXR];
+    if (GATHERED) {
+#pragma unroll
+        for (int jx = 0; jx < IDXR; ++jx)
+            rowoff[jx] = (uint32_t)q.a_idx[min(rb + lane + 64 * jx, re - 1)] * ((uint32_t)q.lda * 4u);
+    }
+    const uint32_t hi_mask = lh ? 0xFFFFFFFFu : 0u;
+    int cur = 0;                                           // load cursor: rows of the slice already requested (even)
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
     float av0[P], av1[P], bv0[P], bv1[P];
-    const int nfull = (re - rb) >> 1;                      // k-pairs whose two rows both exist
-    const int lda = q.lda, ldz = q.ldz;
-    // Row-gathered A (layer 0 self rows): the slice's gather indices (<= 512 rows) are loaded ONCE into registers
-    // (lane L holds idx[rb + L + 64*j]); the two rows of a k-pair come out with v_readlane, so the A loads stay
-    // single-latency (index, then row would be two dependent round trips per stage).
-    constexpr int IDXR = 8;                                // 8 * 64 = 512 rows per slice at most
-    int32_t idxr[IDXR];
-    const bool gathered = q.a_idx != nullptr;
-    if (gathered) {
+    auto rotate = [&]() {
 #pragma unroll
-        for (int jx = 0; jx < IDXR; ++jx) {
-            const int r = rb + lane + 64 * jx;
-            idxr[jx] = q.a_idx[min(r, re - 1)];
-        }
-    }
-    auto arow = [&](const int r) -> int {                  // source row of reduction row r (r = rb + 2*kp + lh)
-        if (!gathered) return r;
-        const int o = r - rb - lh;                         // wave-uniform, even
-        const int jx = o >> 6, l = o & 63;
-        int32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int t = 0; t < IDXR; ++t) {
-            if (t == jx) {                                 // wave-uniform select of the register holding the index
-                lo = __builtin_amdgcn_readlane(idxr[t], l);
-                hi = __builtin_amdgcn_readlane(idxr[t], l + 1);   // l is even: l + 1 <= 63 stays in the same register
-            }
-        }
-        return lh ? hi : lo;
+        for (int jx = 0; jx + 1 < IDXR; ++jx) rowoff[jx] = rowoff[jx + 1];
     };
-    auto load_stage = [&](const int st, const int kp) {    // no arithmetic on the loaded values here: a use would
-        const int r = rb + 2 * kp + lh;                    // force a wait right behind the load and empty the ring
-        const int ra = arow(r);
-        av0[st] = a0[ra * lda];
-        av1[st] = a1[ra * lda];
-        bv0[st] = z0[r * ldz];
-        bv1[st] = z1[r * ldz];
+    auto load_stage = [&](const int st) {                  // no arithmetic on the loaded values here: a use would
+        uint32_t o0a, o1a;                                 // force a wait right behind the load and empty the ring
+        if (GATHERED) {
+            const int l = cur & 63;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l + 1);   // l even: same register
+            const uint32_t t = (hi - lo) & hi_mask;
+            o0a = lo + t + ca0;
+            o1a = lo + t + ca1;
+        } else {
+            o0a = ao0; o1a = ao1;
+            ao0 += strideA; ao1 += strideA;
+        }
+        av0[st] = *(const float*)(Ab + o0a);
+        av1[st] = *(const float*)(Ab + o1a);
+        bv0[st] = *(const float*)(Zb + zo0);
+        bv1[st] = *(const float*)(Zb + zo1);
+        zo0 += strideZ; zo1 += strideZ;
+        cur += 2;
     };
     auto compute_stage = [&](const int st) {
         acc00 = mfma32(av0[st], bv0[st], acc00);
@@ -249,20 +248,24 @@ __device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int 
         acc10 = mfma32(av1[st], bv0[st], acc10);
         acc11 = mfma32(av1[st], bv1[st], acc11);
     };
-    // branch-free steady state, see stream_fwd_item
+    const int nfull = (re - rb) >> 1;                      // k-pairs whose two rows both exist
+    // branch-free steady state, see stream_fwd_item.  2 P divides 64, so the cursor crosses a 64-row chunk only between
+    // two iterations.
+    static_assert(64 % (2 * P) == 0, "ring depth");
     int kp = 0;
     if (nfull >= P) {
 #pragma unroll
-        for (int st = 0; st < P; ++st) load_stage(st, st);
+        for (int st = 0; st < P; ++st) load_stage(st);
 #pragma unroll 1
         for (; kp + 2 * P <= nfull; kp += P) {
+            if (GATHERED && (cur & 63) == 0) rotate();
 #pragma unroll
             for (int st = 0; st < P; ++st) {
                 compute_stage(st);
                 // keep the refill of stage st BELOW the MFMAs that read it: hoisted above them the loads need fresh
-                // registers (the ring doubles: 132 VGPRs + 64 AGPRs = 2 waves per SIMD, and the gather waves starve)
+                // registers (the ring doubles and the gather waves that share the launch lose their occupancy)
                 __builtin_amdgcn_sched_barrier(0);
-                load_stage(st, kp + st + P);
+                load_stage(st);
             }
         }
 #pragma unroll
@@ -271,17 +274,18 @@ __device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int 
     }
 #pragma unroll 1
     for (; kp < nfull; ++kp) {
-        load_stage(0, kp);
+        if (GATHERED && (cur & 63) == 0 && cur) rotate();
+        load_stage(0);
         compute_stage(0);
     }
     if ((re - rb) & 1) {                                   // odd slice: its last row pairs with a zero row
         const int r = re - 1;
         const float mk = lh == 0 ? 1.f : 0.f;
-        const int ra = gathered ? q.a_idx[r] : r;
-        av0[0] = a0[ra * lda] * mk;
-        av1[0] = a1[ra * lda] * mk;
-        bv0[0] = z0[r * ldz];
-        bv1[0] = z1[r * ldz];
+        const int64_t ra = GATHERED ? q.a_idx[r] : r;
+        av0[0] = *(const float*)(Ab + ra * q.lda * 4 + ca0) * mk;
+        av1[0] = *(const float*)(Ab + ra * q.lda * 4 + ca1) * mk;
+        bv0[0] = q.dZ[(int64_t)r * q.ldz + min(o0 + l31, q.out_dim - 1)];
+        bv1[0] = q.dZ[(int64_t)r * q.ldz + min(o0 + 32 + l31, q.out_dim - 1)];
         compute_stage(0);
     }
     float* S = q.slabs + (int64_t)z * q.d * q.ld_slab;
@@ -301,11 +305,26 @@ __device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int 
     }
 }
 
+template <int P>
+__device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int item, const int lane) {
+    int pi = 0;
+    while (pi + 1 < G.n && item >= G.p[pi + 1].item_start) ++pi;
+    const WgradProb& q = G.p[pi];
+    const int local = item - q.item_start;
+    const int tiles = q.tiles_m * q.tiles_n;
+    const int z = local / tiles;
+    const int tt = local - z * tiles;
+    const int tile_m = tt / q.tiles_n, tile_n = tt - tile_m * q.tiles_n;
+    if (q.a_idx) stream_wgrad_body<P, true>(q, z, tile_m * 64, tile_n * 64, lane);
+    else stream_wgrad_body<P, false>(q, z, tile_m * 64, tile_n * 64, lane);
+}
+
+template <int P>
 __global__ __launch_bounds__(256) void stream_wgrad_kernel(const WgradArgs G, const int mfma_blocks, const CoGatherS J) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: per-item fields live in SGPRs
     if ((int)blockIdx.x < mfma_blocks) {
         const int item = stream_xcd_swizzle(blockIdx.x, mfma_blocks) * 4 + wave;
-        if (item < G.n_items) stream_wgrad_item(G, item, lane);
+        if (item < G.n_items) stream_wgrad_item<P>(G, item, lane);
         return;
     }
     run_gather_item(J, ((int64_t)blockIdx.x - mfma_blocks) * 4 + wave, lane);
@@ -373,8 +392,12 @@ extern "C" int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, in
         GS_REQUIRE(q.d > 0 && q.out_dim > 0 && q.n > 0 && q.n_slabs > 0 && q.col0 >= 0 && q.col0 % 4 == 0,
                    "gs_dense_wgrad_grouped_stream: bad sizes");
         GS_REQUIRE(q.lda >= q.d && q.ldz >= q.col0 + q.out_dim && q.ld_slab >= q.out_dim, "gs_dense_wgrad_grouped_stream: ld too small");
-        GS_REQUIRE(q.n * std::max(q.lda, q.ldz) < (1ll << 31) && (int64_t)q.d * q.ld_slab < (1ll << 31),
-                   "gs_dense_wgrad_grouped_stream: 32-bit offsets exceeded");
+        // the kernel addresses A and dZ with 32-bit BYTE offsets against their base pointers
+        const int64_t a_rows = q.a_idx ? q.a_rows : q.n;
+        GS_REQUIRE(!q.a_idx || q.a_rows > 0, "gs_dense_wgrad_grouped_stream: a row-gathered problem must state a_rows");
+        GS_REQUIRE((a_rows + 1) * q.lda * 4 < (1ll << 32) && (q.n + 1) * q.ldz * 4 < (1ll << 32) && (int64_t)q.d * q.ld_slab < (1ll << 31),
+                   "gs_dense_wgrad_grouped_stream: 32-bit byte offsets exceeded (A %lld x %lld, dZ %lld x %lld)",
+                   (long long)a_rows, (long long)q.lda, (long long)q.n, (long long)q.ldz);
         WgradProb& p = G.p[i];
         p.A = q.A; p.a_idx = q.a_idx; p.dZ = q.dZ + q.col0; p.slabs = q.slabs;
         p.lda = (int32_t)q.lda; p.ldz = (int32_t)q.ldz; p.ld_slab = (int32_t)q.ld_slab;
@@ -396,7 +419,13 @@ extern "C" int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, in
     if (rc != GS_OK) return rc;
     const int64_t blocks = mfma_blocks + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_dense_wgrad_grouped_stream: grid too large");
-    hipLaunchKernelGGL(stream_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
+    static const int ring = getenv("GS_STREAM_WGRAD_P") ? atoi(getenv("GS_STREAM_WGRAD_P")) : 8;   // tuning hook
+    if (ring >= 32)
+        hipLaunchKernelGGL(stream_wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
+    else if (ring >= 16)
+        hipLaunchKernelGGL(stream_wgrad_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
+    else
+        hipLaunchKernelGGL(stream_wgrad_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
     GS_LAUNCH_CHECK("stream_wgrad_kernel");
     return GS_OK;
 }

@@ -205,7 +205,8 @@ class Engine(object):
         if self.stream_gemm and not big:
             # stream kernel: one WAVE per (64x64 tile, slice); ~1 contraction wave per SIMD over the whole launch
             # (~900 items for the Reddit step) with >= 256 reduction rows per slice
-            k = int(max(1, min(32, MAX_SLABS - var.n_slabs, round(n / float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))))))
+            k = int(max(1, min(int(os.environ.get("GS_STREAM_MAX_SLABS", 32)), MAX_SLABS - var.n_slabs,
+                           round(n / float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))))))
         if var.n_slabs + k > MAX_SLABS:
             raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
         if big:
@@ -218,6 +219,7 @@ class Engine(object):
         d.slabs = var.slab_ptr(var.n_slabs)
         d.lda, d.ldz, d.ld_slab, d.n = A.ld, dZ.ld, var.ld, n
         d.d, d.col0, d.out_dim, d.n_slabs = var.rows, col0, var.cols, k
+        d.a_rows = A.rows if a_idx is not None else 0
         self._pending.append(d)
         var.n_slabs += k
 
@@ -250,7 +252,11 @@ class Engine(object):
                          j.ldo, self.stream)
             return
         arr = (ops._lib.WgradDesc * len(self._pending))(*self._pending)
-        if self.stream_gemm and len(self._pending) <= 12 and all((not d.a_idx) or (d.n + d.n_slabs - 1) // d.n_slabs <= 510 for d in self._pending):
+        def stream_ok(d):      # slices of a gathered problem fit the register-cached row offsets; 32-bit byte offsets
+            if d.a_idx and ((d.n + d.n_slabs - 1) // d.n_slabs > 510 or (d.a_rows + 1) * d.lda * 4 >= 1 << 32):
+                return False
+            return (d.n + 1) * max(d.lda if not d.a_idx else 0, d.ldz) * 4 < 1 << 32
+        if self.stream_gemm and len(self._pending) <= 12 and all(stream_ok(d) for d in self._pending):
             jobs = list(side_jobs or ())
             jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
             ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr), len(self._pending), ctypes.addressof(jarr),

@@ -188,6 +188,7 @@ typedef struct gs_wgrad_desc {
     float* slabs;          /* [n_slabs, d, ld_slab] */
     int64_t lda, ldz, ld_slab, n;
     int32_t d, col0, out_dim, n_slabs;
+    int64_t a_rows;        /* rows of the A table when a_idx != NULL (0 = not stated; gs_dense_wgrad_grouped_stream needs it) */
 } gs_wgrad_desc;
 int gs_dense_wgrad_grouped(const gs_wgrad_desc* descs_host, int32_t n_desc, void* stream);
 /* The grouped weight-gradient launch + up to 4 gather+mean jobs (see gs_sage_dense_fwd_cogather) in ONE horizontally

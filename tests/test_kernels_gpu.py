@@ -776,13 +776,14 @@ def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias):
     assert np.array_equal(c_out.numpy(), X[ids1])
 
 
-def test_dense_wgrad_grouped_stream(dev):
+@pytest.mark.parametrize("slices0", [22, 11, 45])
+def test_dense_wgrad_grouped_stream(dev, slices0):
     """gs_dense_wgrad_grouped_stream: the weight gradients of a mean step (layer 0: 602x128 x2 over 5632 rows, layer 1:
     256x128 x2 over 512 rows, head 256x41, bias 1x41, odd slice lengths) as split-K slabs + a co-scheduled gather job."""
     import ctypes
     from graphsage_amd import _lib
     rng = np.random.default_rng(77)
-    probs = [(5631, 602, 128, 0, 22), (5631, 602, 128, 128, 22), (512, 256, 128, 0, 3), (512, 256, 128, 128, 2), (512, 256, 41, 0, 2),
+    probs = [(5631, 602, 128, 0, slices0), (5631, 602, 128, 128, slices0), (512, 256, 128, 0, 3), (512, 256, 128, 128, 2), (512, 256, 41, 0, 2),
              (512, 1, 41, 0, 2)]
     descs = (_lib.WgradDesc * len(probs))()
     keep, want, slabs = [], [], []
@@ -805,6 +806,7 @@ def test_dense_wgrad_grouped_stream(dev):
         descs[i].A, descs[i].a_idx, descs[i].dZ, descs[i].slabs = Ad.ptr, ops.ptr(idx_dev) if aidx is not None else None, Zd.ptr, sl.data_ptr()
         descs[i].lda, descs[i].ldz, descs[i].ld_slab, descs[i].n = Ad.ld, Zd.ld, ld_slab, n
         descs[i].d, descs[i].col0, descs[i].out_dim, descs[i].n_slabs = d, col0, o, ns
+        descs[i].a_rows = 3000 if aidx is not None else 0
         want.append(A.astype(np.float64).T @ dZ[:, col0:].astype(np.float64))
         slabs.append((sl, ns, d, ld_slab, o))
     X = _asym(rng, (1000, 602))
