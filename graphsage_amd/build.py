@@ -17,7 +17,7 @@ STAMP = os.path.join(OUT_DIR, "build.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-ffp-contract=fast", "-fno-finite-math-only"]
+         "-ffp-contract=fast", "-fno-finite-math-only"] + os.environ.get("HIPCC_EXTRA", "").split()
 
 
 def _sources():

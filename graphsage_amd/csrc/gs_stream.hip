@@ -190,8 +190,21 @@ struct WgradArgs {
 // offsets against wave-uniform base pointers (global_load with an SGPR base), advanced with one add per load; a
 // gathered A row costs two v_readlane (SALU) + two VALU.  (The first version -- 64-bit per-lane pointers, a register
 // select ladder for the gather index -- spent ~300 cycles per k-pair outside the 256 MFMA cycles.)
+#ifdef GS_TIMELINE
+// Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_wgrad.py): per-wave wall-clock stamps (100 MHz).
+__device__ unsigned long long g_timeline[8192 * 8];
+extern "C" int gs_debug_timeline(unsigned long long* out_host, int n) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define GS_STAMP(slot) do { if (lane == 0 && tl_item < 8192) { g_timeline[tl_item * 8 + (slot)] = wall_clock64(); g_timeline[tl_item * 8 + 4 + (slot)] = clock64(); } } while (0)
+#else
+#define GS_STAMP(slot) do { } while (0)
+#endif
+
 template <int P, bool GATHERED>
-__device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int z, const int f0, const int o0, const int lane) {
+__device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int z, const int f0, const int o0, const int lane,
+                                                  const int tl_item) {
+    GS_STAMP(0);
     const int l31 = lane & 31, lh = lane >> 5;
     const int rb = z * q.kchunk, re = min(rb + q.kchunk, q.n);
     const char* __restrict__ Ab = (const char*)q.A;
@@ -212,7 +225,8 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
         for (int jx = 0; jx < IDXR; ++jx)
             rowoff[jx] = (uint32_t)q.a_idx[min(rb + lane + 64 * jx, re - 1)] * ((uint32_t)q.lda * 4u);
     }
-    const uint32_t hi_mask = lh ? 0xFFFFFFFFu : 0u;
+    uint32_t hi_mask = lh ? 0xFFFFFFFFu : 0u;
+    asm volatile("" : "+v"(hi_mask));                      // opaque: keeps `& hi_mask` an AND
     int cur = 0;                                           // load cursor: rows of the slice already requested (even)
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -228,17 +242,21 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
             const int l = cur & 63;
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l + 1);   // l even: same register
-            const uint32_t t = (hi - lo) & hi_mask;
+            const uint32_t t = (hi - lo) & hi_mask;        // (not a select: two SGPR sources would cost two v_mov first)
             o0a = lo + t + ca0;
             o1a = lo + t + ca1;
         } else {
             o0a = ao0; o1a = ao1;
             ao0 += strideA; ao1 += strideA;
         }
+#ifdef GS_TIMELINE_NOLOAD
+        av0[st] = __int_as_float(o0a); av1[st] = __int_as_float(o1a); bv0[st] = __int_as_float(zo0); bv1[st] = __int_as_float(zo1);
+#else
         av0[st] = *(const float*)(Ab + o0a);
         av1[st] = *(const float*)(Ab + o1a);
         bv0[st] = *(const float*)(Zb + zo0);
         bv1[st] = *(const float*)(Zb + zo1);
+#endif
         zo0 += strideZ; zo1 += strideZ;
         cur += 2;
     };
@@ -248,6 +266,43 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
         acc10 = mfma32(av1[st], bv0[st], acc10);
         acc11 = mfma32(av1[st], bv1[st], acc11);
     };
+    // Steady state: consume stage st and refill it, in a pinned issue order.  The wave issues in order and an MFMA holds
+    // the matrix pipe for 64 cycles, so whatever sits between two MFMAs is free as long as it issues in < 64 cycles --
+    // and an MFMA bubble if a stage's address arithmetic and its four loads are lumped behind its last MFMA (measured
+    // with the loads removed altogether: 299 / 350 cycles per k-pair dense / gathered instead of 256).  Each operand
+    // register is refilled right behind the last MFMA that reads it.
+    auto fused_stage = [&](const int st) {
+        acc00 = mfma32(av0[st], bv0[st], acc00);
+        uint32_t o0a, o1a;
+        if (GATHERED) {
+            const int l = cur & 63;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l + 1);
+            const uint32_t t = (hi - lo) & hi_mask;
+            o0a = lo + t + ca0;
+            o1a = lo + t + ca1;
+        } else {
+            o0a = ao0; o1a = ao1;
+            ao0 += strideA; ao1 += strideA;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc01 = mfma32(av0[st], bv1[st], acc01);
+        __builtin_amdgcn_sched_barrier(0);
+        av0[st] = *(const float*)(Ab + o0a);
+        __builtin_amdgcn_sched_barrier(0);
+        acc10 = mfma32(av1[st], bv0[st], acc10);
+        __builtin_amdgcn_sched_barrier(0);
+        bv0[st] = *(const float*)(Zb + zo0);
+        zo0 += strideZ;
+        __builtin_amdgcn_sched_barrier(0);
+        acc11 = mfma32(av1[st], bv1[st], acc11);
+        __builtin_amdgcn_sched_barrier(0);
+        av1[st] = *(const float*)(Ab + o1a);
+        bv1[st] = *(const float*)(Zb + zo1);
+        zo1 += strideZ;
+        cur += 2;
+        __builtin_amdgcn_sched_barrier(0);
+    };
     const int nfull = (re - rb) >> 1;                      // k-pairs whose two rows both exist
     // branch-free steady state, see stream_fwd_item.  2 P divides 64, so the cursor crosses a 64-row chunk only between
     // two iterations.
@@ -256,17 +311,12 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
     if (nfull >= P) {
 #pragma unroll
         for (int st = 0; st < P; ++st) load_stage(st);
+        GS_STAMP(1);
 #pragma unroll 1
         for (; kp + 2 * P <= nfull; kp += P) {
             if (GATHERED && (cur & 63) == 0) rotate();
 #pragma unroll
-            for (int st = 0; st < P; ++st) {
-                compute_stage(st);
-                // keep the refill of stage st BELOW the MFMAs that read it: hoisted above them the loads need fresh
-                // registers (the ring doubles and the gather waves that share the launch lose their occupancy)
-                __builtin_amdgcn_sched_barrier(0);
-                load_stage(st);
-            }
+            for (int st = 0; st < P; ++st) fused_stage(st);
         }
 #pragma unroll
         for (int st = 0; st < P; ++st) compute_stage(st);
@@ -288,6 +338,7 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
         bv1[0] = q.dZ[(int64_t)r * q.ldz + min(o0 + 32 + l31, q.out_dim - 1)];
         compute_stage(0);
     }
+    GS_STAMP(2);
     float* S = q.slabs + (int64_t)z * q.d * q.ld_slab;
     const int c0 = o0 + l31, c1 = o0 + 32 + l31;
 #pragma unroll
@@ -303,6 +354,7 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
             if (c1 < q.out_dim) S[fb * q.ld_slab + c1] = acc11[e];
         }
     }
+    GS_STAMP(3);
 }
 
 template <int P>
@@ -315,8 +367,8 @@ __device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int 
     const int z = local / tiles;
     const int tt = local - z * tiles;
     const int tile_m = tt / q.tiles_n, tile_n = tt - tile_m * q.tiles_n;
-    if (q.a_idx) stream_wgrad_body<P, true>(q, z, tile_m * 64, tile_n * 64, lane);
-    else stream_wgrad_body<P, false>(q, z, tile_m * 64, tile_n * 64, lane);
+    if (q.a_idx) stream_wgrad_body<P, true>(q, z, tile_m * 64, tile_n * 64, lane, item);
+    else stream_wgrad_body<P, false>(q, z, tile_m * 64, tile_n * 64, lane, item);
 }
 
 template <int P>
@@ -420,7 +472,9 @@ extern "C" int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, in
     const int64_t blocks = mfma_blocks + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_dense_wgrad_grouped_stream: grid too large");
     static const int ring = getenv("GS_STREAM_WGRAD_P") ? atoi(getenv("GS_STREAM_WGRAD_P")) : 8;   // tuning hook
-    if (ring >= 32)
+    if (ring == 4)
+        hipLaunchKernelGGL(stream_wgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
+    else if (ring >= 32)
         hipLaunchKernelGGL(stream_wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
     else if (ring >= 16)
         hipLaunchKernelGGL(stream_wgrad_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, mfma_blocks, J);
