@@ -50,10 +50,10 @@ def main():
                                              ops.gather_rows(X, ids_self, out=sd2, stream=s)], s)
     res["fwd_tiled_dense_alone_us"] = timeit(lambda: ops.sage_dense_fwd(selfd, None, means, None, n, Ws, Wn, D, True, ops.ACT_RELU, None, out, stream=s), s)
     res["fwd_tiled_gathered_alone_us"] = timeit(lambda: ops.sage_dense_fwd(X, ids_self, means, None, n, Ws, Wn, D, True, ops.ACT_RELU, None, out, stream=s), s)
-    res["fwd_stream_alone_us"] = timeit(lambda: ops.sage_dense_fwd_stream(selfd, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s), s)
+    res["fwd_stream_alone_us"] = timeit(lambda: ops.sage_dense_fwd_stream(selfd, None, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s), s)
     for frac in (1.0, 0.7, 0.5, 0.3):
         head, tail = ops.split_gather_jobs(jobs_all, frac)
-        res["fwd_stream_cogather_%.1f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_stream(selfd, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, head, stream=s), s)
+        res["fwd_stream_cogather_%.1f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_stream(selfd, None, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, head, stream=s), s)
         res["fwd_tiled_cogather_%.1f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_cogather(X, ids_self, means, None, n, Ws, Wn, D, True, ops.ACT_RELU, None, out, head[:4], stream=s), s)
     # weight gradients of the step
     dz0 = Mat.zeros(n, 2 * D, dev); dz0.buf.normal_()

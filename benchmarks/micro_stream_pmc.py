@@ -24,7 +24,7 @@ for i, (A, Z, col0) in enumerate(probs):
     arr[i].d, arr[i].col0, arr[i].out_dim, arr[i].n_slabs = F, col0, D, 22
 jn = (_lib.GatherDesc * 1)()
 for _ in range(10):
-    ops.sage_dense_fwd_stream(selfd, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s)
+    ops.sage_dense_fwd_stream(selfd, None, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s)
     ops.sage_dense_fwd(selfd, None, means, None, n, Ws, Wn, D, True, ops.ACT_RELU, None, out, stream=s)
     ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr), 2, ctypes.addressof(jn), 0, s)
     ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr), 2, s)

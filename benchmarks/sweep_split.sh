@@ -1,10 +1,10 @@
 #!/bin/bash
 # A/B of the per-step schedule knobs on the bench workload (env overrides; one JSON line each, steps short).
 run() { echo -n "$* : "; env "$@" python bench.py --steps 96 --no-cpu-baseline --no-aux 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.2f us/step  loss %.4f' % (d['ms_per_step']*1e3, d['config']['loss_after']))"; }
-run GS_STREAM_WGRAD_P=8
-run GS_STREAM_WGRAD_P=16
-run GS_STREAM_WGRAD_P=8 GS_COGATHER_SPLIT=0.4 GS_COGATHER_TAIL=0.25
-run GS_STREAM_WGRAD_P=8 GS_COGATHER_SPLIT=0.35 GS_COGATHER_TAIL=0.3
-run GS_STREAM_WGRAD_P=8 GS_COGATHER_SPLIT=0.45 GS_COGATHER_TAIL=0.3
-run GS_STREAM_WGRAD_P=8 GS_STREAM_MAX_SLABS=48 GS_STREAM_SLICE_ROWS=128
-run GS_STREAM_WGRAD_P=8
+run GS_COGATHER_OPT=0.0
+run GS_COGATHER_OPT=0.05
+run GS_COGATHER_OPT=0.1
+run GS_COGATHER_OPT=0.15
+run GS_COGATHER_OPT=0.1 GS_COGATHER_SPLIT3=0.1
+run GS_COGATHER_OPT=0.1 GS_COGATHER_TAIL=0.55
+run GS_COGATHER_OPT=0.0

@@ -70,11 +70,11 @@ _PROTOS = {
     "gs_sage_dense_dgrad": [_P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
     "gs_flat_reduce_adam": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P],
-    "gs_sage_dense_fwd_stream": [_P, c_int64, _P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int, _P, _P,
+    "gs_sage_dense_fwd_stream": [_P, c_int64, _P, _P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int, _P, _P,
                                  c_int64, _P, c_int32, _P],
     "gs_dense_wgrad_grouped_stream": [_P, c_int32, _P, c_int32, _P],
     "gs_flat_reduce_adam_sample": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
-                                   c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P],
+                                   c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P, c_int32, _P],
     "gs_sage_tail_supported": [c_int32, c_int32, c_int32],
     "gs_sage_tail_fwd_bwd": [_P, _P, c_int32, _P],
     "gs_dropout_rows": [_P, c_int64, _P, c_int64, c_int32, _P, _P, c_int64, _P],

@@ -160,7 +160,6 @@ class MeanAggregator(_SageBase):
         self.output_dim = output_dim
         self.neigh_input_dim = neigh_input_dim
         self._saved = []
-        self._dense_self = {}      # means buffer -> dense copy of the matching self rows (stream kernels)
 
     def prefetch(self, self_all, neighs, tag=0):
         """The weight-free half of the call: reduce_mean(neigh_vecs, axis=1) (aggregators.py:48) fused with the row
@@ -179,17 +178,7 @@ class MeanAggregator(_SageBase):
             r += n
             row0 += n * s
         assert r == n_total
-        if self._wants_dense_self(self_all, rate):
-            sd = e.ws_mat((self.name, "selfd", k, tag), n_total, d)
-            ops.gather_rows(self_all.src, self_all.ids, out=sd, stream=e.stream)
-            self._dense_self[means.ptr] = sd
         return means
-
-    def _wants_dense_self(self, self_all, rate=0.0):
-        """Stream contraction kernels read DENSE operands: when the self rows are a row gather of the feature table
-        (layer 0), the gather jobs also copy them into a dense matrix (the same rows, one more s = 1 job)."""
-        return (os.environ.get("GS_STREAM_FWD", "0") == "1" and self.engine.stream_gemm and self.concat
-                and self_all.ids is not None and rate == 0)
 
     def prefetch_jobs(self, self_all, neighs, tag=0):
         """Like prefetch(), but only DESCRIBES the gather+mean launches (one per hop) so that they can be issued
@@ -204,10 +193,6 @@ class MeanAggregator(_SageBase):
             n, s, _ = nv.shape3
             jobs.append(ops.gather_job(nv.src, nv.ids, n, s, means.rows_slice(r, r + n)))
             r += n
-        if self._wants_dense_self(self_all):
-            sd = e.ws_mat((self.name, "selfd", len(self._saved), tag), n_total, d)
-            jobs.append(ops.gather_job(self_all.src, self_all.ids, n_total, 1, sd))
-            self._dense_self[means.ptr] = sd
         return means, jobs
 
     def call_hops(self, self_all, neighs, means=None, side_jobs=None):
@@ -218,64 +203,36 @@ class MeanAggregator(_SageBase):
         if means is None:
             means = self.prefetch(self_all, neighs)
         self_in = self._drop_self(self_all, rate, k) if rate > 0 else self_all           # dropout(self_vecs) (:47)
-        dense_self = self._dense_self.get(means.ptr) if rate == 0 else None
-        if dense_self is not None and self.engine.stream_gemm and self.concat and n_total > 2048:
-            # dense [self | mean] operands (the self rows were copied by a gather job): the weight gradients then run as
-            # LDS-free stream waves (gs_dense_wgrad_grouped_stream).  The forward contraction itself measured no faster
-            # in stream form (32.9 vs 32.8 us: the per-lane row-strided A loads are bound by L1 tag lookups), so it stays
-            # on the LDS-tiled kernel unless GS_STREAM_FWD=1.
-            n_out = self.output_dim * 2
-            out = e.ws_mat((self.name, "out", k), n_total, n_out)
-            b = self.vars['bias'].value.buf if self.bias else None
-            jobs = list(side_jobs or ())
-            stream_fwd = os.environ.get("GS_STREAM_FWD", "0") == "1"
-
-            def launch(jobs=jobs):
-                if stream_fwd:
-                    ops.sage_dense_fwd_stream(dense_self, means, n_total, self.vars['self_weights'].value,
-                                              self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, jobs,
-                                              stream=e.stream)
-                elif jobs:
-                    ops.sage_dense_fwd_cogather(dense_self, None, means, None, n_total, self.vars['self_weights'].value,
-                                                self.vars['neigh_weights'].value, self.output_dim, True, self.act_code, b,
-                                                out, jobs, stream=e.stream)
-                else:
-                    ops.sage_dense_fwd(dense_self, None, means, None, n_total, self.vars['self_weights'].value,
-                                       self.vars['neigh_weights'].value, self.output_dim, True, self.act_code, b, out,
-                                       stream=e.stream)
-            launch()
-            d_in = means.d
-            self.last_fused_launch = (launch, {
-                "kernel": "%s: [%d x %d|%d] . [%d x %d] x2 (fp32 MFMA) + %d co-scheduled gather jobs of the next step" % (
-                    "sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel", n_total, d_in, d_in, d_in,
-                    self.output_dim, len(jobs)),
-                "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in jobs),
-                "gemm_bytes": n_total * 2 * d_in * 4 + 2 * d_in * self.output_dim * 4 + n_total * n_out * 4,
-                "flops": 2.0 * n_total * 2 * d_in * self.output_dim,
-                "gather_share": sum(j.n * j.s for j in jobs) / float(max(1, n_total + sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)))})
-            self_dense_rows = Rows(dense_self, None, n_total, False)
-            self._push((self_all, neighs, means, out, rate, self_dense_rows))
-            return out
         # from_neighs / from_self matmuls + concat|add + bias + act   (:51-64): ONE launch for all hops
         n_out = self.output_dim * (2 if self.concat else 1)
         out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
-        if side_jobs:
-            # horizontally fused launch: these GEMM tiles + the NEXT step's gather-mean waves share the CUs
-            def launch(jobs=list(side_jobs)):
-                ops.sage_dense_fwd_cogather(self_all.src, self_all.ids, means, None, n_total,
-                                            self.vars['self_weights'].value, self.vars['neigh_weights'].value,
-                                            self.output_dim, self.concat, self.act_code, b, out, jobs, stream=e.stream)
+        stream_fwd = (e.stream_gemm and self.concat and rate == 0 and n_total > 2048 and self.output_dim % 2 == 0
+                      and os.environ.get("GS_STREAM_FWD", "1") == "1")
+        if side_jobs or stream_fwd:
+            # horizontally fused launch: the contraction workgroups + the NEXT step's gather-mean waves share the CUs.
+            # Stream form (gs_stream.hip): split-K workgroups without LDS staging, the self rows gathered in the A loads.
+            def launch(jobs=list(side_jobs or ())):
+                if stream_fwd:
+                    ops.sage_dense_fwd_stream(self_all.src, self_all.ids, means, n_total, self.vars['self_weights'].value,
+                                              self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, jobs,
+                                              stream=e.stream)
+                else:
+                    ops.sage_dense_fwd_cogather(self_all.src, self_all.ids, means, None, n_total,
+                                                self.vars['self_weights'].value, self.vars['neigh_weights'].value,
+                                                self.output_dim, self.concat, self.act_code, b, out, jobs, stream=e.stream)
             launch()
             # bench.py re-issues exactly this launch between HIP events (roofline of the step's dominant kernel)
             d_in = self_all.src.d
+            jobs_ = list(side_jobs or ())
             self.last_fused_launch = (launch, {
-                "kernel": "sage_dense_cogather_kernel: [%d x %d|%d] . [%d x %d] x2 (fp32 MFMA) + %d co-scheduled "
-                          "gather+mean jobs of the next step" % (n_total, d_in, means.d, d_in, self.output_dim, len(side_jobs)),
-                "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in side_jobs),
+                "kernel": "%s: [%d x %d|%d] . [%d x %d] x2 (fp32 MFMA) + %d co-scheduled "
+                          "gather+mean jobs of the next step" % ("sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
+                                                                 n_total, d_in, means.d, d_in, self.output_dim, len(jobs_)),
+                "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in jobs_),
                 "gemm_bytes": n_total * (d_in + means.d) * 4 + (d_in + means.d) * self.output_dim * 4 + n_total * n_out * 4,
                 "flops": 2.0 * n_total * (d_in + means.d) * self.output_dim,
-                "gather_share": sum(j.n * j.s for j in side_jobs) / float(max(1, sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)))})
+                "gather_share": sum(j.n * j.s for j in jobs_) / float(max(1, sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)))})
         else:
             ops.sage_dense_fwd(self_in.src, self_in.ids, means, None, n_total, self.vars['self_weights'].value,
                                self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
@@ -413,9 +370,9 @@ class GCNAggregator(_SageBase):
             means = self.prefetch(self_all, neighs)
         out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
-        if e.stream_gemm and n_total > 2048 and rate == 0:
+        if e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
             # stream form: LDS-free contraction waves (+ the next step's gather jobs) in one launch
-            ops.sage_dense_fwd_stream(None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
+            ops.sage_dense_fwd_stream(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
                                       b, out, side_jobs, stream=e.stream)
         elif side_jobs:
             # horizontally fused launch: these GEMM tiles + the NEXT step's gather-mean waves share the CUs

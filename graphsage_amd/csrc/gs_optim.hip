@@ -2,6 +2,7 @@
 // Weight gradients arrive as split-K slabs from gs_dense_wgrad (deterministic fixed-order sums).
 #include "gs_common.h"
 #include "gs_sample_dev.h"
+#include "gs_gather_dev.h"
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int32_t n_slabs,
                                                            int64_t slab_stride, int32_t rows, int32_t cols,
@@ -159,12 +160,14 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
                                                                const float* __restrict__ loss_rows, int64_t loss_n,
                                                                float loss_scale, float* __restrict__ loss_out,
                                                                int loss_accumulate, const int opt_blocks,
-                                                               const FanoutArgs F) {
+                                                               const FanoutArgs F, const CoGatherS J) {
     // Workgroups beyond opt_blocks run the fan-out SAMPLER of a later mini-batch (one root each): five dependent memory
     // round trips of almost no work, hidden under this launch instead of heading a step as its own 7 us launch.
     __shared__ int32_t lvl[2][GS_FANOUT_LDS_SMALL];
     if ((int)blockIdx.x >= opt_blocks) {
-        sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, (int64_t)blockIdx.x - opt_blocks, lvl);
+        const int64_t r = (int64_t)blockIdx.x - opt_blocks;
+        if (r < F.B) sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, lvl);
+        else run_gather_item(J, r - F.B, threadIdx.x);     // ... and gather+mean waves of the next mini-batch (one per block)
         return;
     }
     float lr_t = 0.f;
@@ -228,7 +231,8 @@ static int flat_reduce_adam_impl(const gs_var_desc* vars_host, int32_t n_vars, f
                                    float* v, int64_t total, float weight_decay, int fuse_adam, float lr, float beta1,
                                    float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
                                    int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
-                                   float* loss_out, int loss_accumulate, const FanoutArgs* sampler, void* stream) {
+                                   float* loss_out, int loss_accumulate, const FanoutArgs* sampler, const gs_gather_desc* jobs_host,
+                                 int32_t n_jobs, void* stream) {
     GS_REQUIRE(!loss_rows || (loss_out && loss_n > 0), "gs_flat_reduce_adam: loss_out missing");
     GS_REQUIRE(vars_host && n_vars > 0 && n_vars <= GS_MAX_VARS, "gs_flat_reduce_adam: need 1..%d variables", GS_MAX_VARS);
     GS_REQUIRE(params && grads && total > 0 && total % 4 == 0, "gs_flat_reduce_adam: bad flat buffer");
@@ -256,9 +260,14 @@ static int flat_reduce_adam_impl(const gs_var_desc* vars_host, int32_t n_vars, f
     FanoutArgs F = {};
     int64_t roots = 0;
     if (sampler) { F = *sampler; roots = F.B; }
-    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3((unsigned)(blocks + roots)), dim3(64), 0, (hipStream_t)stream, V, params,
-                       grads, m, v, total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev,
-                       step_offset, loss_rows, loss_n, loss_scale, loss_out, loss_accumulate, blocks, F);
+    CoGatherS J = {};
+    int64_t waves = 0;
+    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
+    if (rc != GS_OK) return rc;
+    GS_REQUIRE(blocks + roots + waves < (1ll << 31), "gs_flat_reduce_adam: grid too large");
+    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3((unsigned)(blocks + roots + waves)), dim3(64), 0, (hipStream_t)stream, V,
+                       params, grads, m, v, total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev,
+                       step_offset, loss_rows, loss_n, loss_scale, loss_out, loss_accumulate, blocks, F, J);
     GS_LAUNCH_CHECK("flat_reduce_adam_kernel");
     return GS_OK;
 }
@@ -270,15 +279,19 @@ extern "C" int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars,
                                    float* loss_out, int loss_accumulate, void* stream) {
     return flat_reduce_adam_impl(vars_host, n_vars, params, grads, m, v, total, weight_decay, fuse_adam, lr, beta1, beta2, eps,
                                  clip, grad_scale, step_dev, step_offset, loss_rows, loss_n, loss_scale, loss_out,
-                                 loss_accumulate, nullptr, stream);
+                                 loss_accumulate, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
                                           float* v, int64_t total, float weight_decay, int fuse_adam, float lr, float beta1,
                                           float beta2, float eps, float clip, float grad_scale, const uint64_t* step_dev,
                                           int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
-                                          float* loss_out, int loss_accumulate, const gs_fanout_desc* s, void* stream) {
-    GS_REQUIRE(s, "gs_flat_reduce_adam_sample: null sampler descriptor");
+                                          float* loss_out, int loss_accumulate, const gs_fanout_desc* s,
+                                          const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    if (!s)
+        return flat_reduce_adam_impl(vars_host, n_vars, params, grads, m, v, total, weight_decay, fuse_adam, lr, beta1, beta2,
+                                     eps, clip, grad_scale, step_dev, step_offset, loss_rows, loss_n, loss_scale, loss_out,
+                                     loss_accumulate, nullptr, jobs_host, n_jobs, stream);
     FanoutArgs F;
     int64_t kmax = 0;
     int rc = gs_fanout_args(s->rowptr, s->col, s->n_nodes, s->pad_id, s->n_hops, s->fan, s->offsets, s->ids_all, s->B, s->seed,
@@ -291,5 +304,5 @@ extern "C" int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t 
     }
     return flat_reduce_adam_impl(vars_host, n_vars, params, grads, m, v, total, weight_decay, fuse_adam, lr, beta1, beta2, eps,
                                  clip, grad_scale, step_dev, step_offset, loss_rows, loss_n, loss_scale, loss_out,
-                                 loss_accumulate, s->B > 0 ? &F : nullptr, stream);
+                                 loss_accumulate, s->B > 0 ? &F : nullptr, jobs_host, n_jobs, stream);
 }

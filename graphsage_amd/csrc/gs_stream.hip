@@ -1,22 +1,22 @@
 // "Stream" form of the two big launches of a mean/GCN training step: the layer-0 contraction and the grouped weight
 // gradients, each co-scheduled with a share of the NEXT step's gather+mean (HBM-bound, needs no weights).
 //
-// Why a second GEMM form (measured, profiles/r02_a_*): in the LDS-tiled fused kernels every workgroup -- gather
+// Why a second GEMM form (measured, profiles/r02_*): in the LDS-tiled fused kernels every workgroup -- gather
 // workgroups included -- carries the GEMM's 35 KB of LDS and ~110 VGPRs, the 352 tile workgroups land 1.4 per CU, and a
-// tile workgroup stalls all four waves at a barrier per 32-k stage; the fused launches ran at 20 % MFMA utilisation and
-// stretched the gather to 48 + 45 us (49 us alone).  Here the contraction waves use NO LDS and NO barriers:
-//   * one WAVE owns one output tile and is completely independent (a workgroup is just 4 such waves, one per SIMD);
-//   * A and B fragments go straight from global memory (L2 / MALL resident: dense [self | mean] rows written by the
-//     previous step's gather, weights, dZ) into the MFMA operand registers through a 4..8-stage register ring, so each
-//     wave keeps 4-8 KB of operand loads in flight and nothing else in the CU has to wait for it;
-//   * the layer-0 A operand is DENSE: the gather jobs also copy the self rows X[ids] into a dense matrix (one more
-//     s = 1 gather job), so neither contraction re-gathers scattered 2.4 KB rows in 128-byte pieces;
-//   * the number of contraction waves is kept <= 4 per CU (<= 1 per SIMD): fp32 MFMA is so slow (64 cycles per
-//     32x32x2) that a single wave per SIMD saturates the pipe when its operands arrive, and the remaining 12+ wave
-//     slots of every CU belong to gather waves.
-// fp32 MFMA 32x32x2 (exact fp32).  Forward tile: 32 rows x 64 columns per wave, A k-contiguous (one 16-byte load per
-// lane feeds 4 MFMA k-steps), B n-contiguous (coalesced dword loads).  Weight-gradient tile: 64 x 64 per wave, both
-// operands row-contiguous over the reduction index (coalesced dword loads), split-K slabs as before (deterministic).
+// tile workgroup stalls all four waves at a barrier per 32-k stage; the fused launches ran at 20 % MFMA utilisation.
+// Here the contraction waves stage nothing through LDS and meet no barrier inside the K loop:
+//   * A and B fragments go straight from global memory (L2 / MALL resident rows, weights, dZ) into the MFMA operand
+//     registers through a 4..8-stage register ring, addressed as 32-bit offsets against SGPR base pointers: every
+//     instruction between two MFMAs costs matrix-pipe time (benchmarks/probes/mfma_issue.hip: 64 cycles per MFMA alone,
+//     72-80 with one or two VALU instructions per MFMA, at 1, 2 or 3 waves per SIMD alike), so the loops carry one
+//     integer add per load and nothing else;
+//   * row-gathered A operands (layer 0: the self rows X[ids]) are gathered inside the A loads -- forward: the row
+//     pointer is per lane and fixed for the whole K loop; weight gradient: the slice's row offsets sit in registers
+//     and reach the loads through v_readlane;
+//   * forward: one WORKGROUP per 32 x 64 output tile, its four waves contracting a quarter of K each (2816 waves for
+//     1024 SIMDs instead of 704), partial tiles summed in a fixed order through LDS;
+//   * weight gradient: one WAVE per (64 x 64 tile, reduction slice), ~900 of them, split-K slabs as before.
+// fp32 MFMA 32x32x2 (exact fp32), deterministic summation order (no atomics).
 #include "gs_common.h"
 #include "gs_gather_dev.h"
 #include <stdlib.h>
@@ -34,10 +34,26 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+#ifdef GS_TIMELINE
+// Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_wgrad.py): per-wave wall-clock stamps (100 MHz).
+__device__ unsigned long long g_timeline[8192 * 8];
+extern "C" int gs_debug_timeline(unsigned long long* out_host, int n) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define GS_STAMP(slot) do { if (lane == 0 && tl_item < 8192) { g_timeline[tl_item * 8 + (slot)] = wall_clock64(); \
+    g_timeline[tl_item * 8 + 4 + (slot)] = (slot) == 0 ? (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | \
+        (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4)) : clock64(); } } while (0)
+#else
+#define GS_STAMP(slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------ forward
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct FwdTerm {
-    const float* A;   // dense [M, lda]
-    const float* W;   // [K, ldw]
+    const float* A;        // [*, lda]; row i of the term is A[a_idx ? a_idx[i] : i]
+    const int32_t* a_idx;  // nullable row gather (layer 0: the self rows of the feature table)
+    const float* W;        // [K, ldw]
     int32_t lda, ldw;
 };
 struct FwdArgs {
@@ -49,63 +65,87 @@ struct FwdArgs {
     const float* bias;    // indexed by output column (incl. the concat offset), nullable
     int32_t act;
     int32_t tiles_n;      // 64-column tiles per term
-    int32_t n_items;      // tiles_m * tiles_n * nterms
+    int32_t n_tiles;      // tiles_m * tiles_n * nterms = contraction workgroups
 };
 
-// One wave: C[m0 .. m0+31][col_off + n0 .. n0 + 32*TN - 1] = act(A[m0.., :K] . W[:K, n0 ..] + bias)
-template <int TN>
-__device__ __forceinline__ void stream_fwd_item(const FwdArgs& g, const int item, const int lane) {
-    constexpr int P = 4;                                   // register ring: macro steps (8 k) in flight
+// One WORKGROUP (4 waves) owns one 32 x 64 output tile; wave w contracts a QUARTER of K (split-K inside the workgroup,
+// summed in a fixed order through LDS, so the result does not depend on scheduling).
+//   * Why split K: 5632 x 128 x 2 terms are only 704 32x64 tiles for 1024 SIMDs, and a whole-K tile holds a SIMD for
+//     17.6 us of MFMA time (75 macro steps of 8 k x 8 MFMAs x 64 cycles) while the chip-wide average is 12.1 us.
+//     Quarter-K waves (2816 of them, 2.75 per SIMD) bring the makespan to 3 x 4.4 us and give every SIMD a second and
+//     third wave whose loads are in flight while the first one owns the matrix pipe.
+//   * Fewer non-MFMA instructions (measured on the weight-gradient kernel: every instruction between two MFMAs is
+//     paid in full): per macro step of 8 k a lane issues ONE 16-byte A load (its row, 4 consecutive k) and FOUR 8-byte
+//     B loads (two adjacent columns of 4 k rows) for 8 MFMAs; B is addressed with four SGPR bases (W + e ldw) and one
+//     32-bit offset.  The two n-tiles of the wave interleave their columns (col = n0 + 2 (lane & 31) + j), so a lane
+//     ends up with two adjacent columns of a row: 8-byte loads, 8-byte stores.
+//   * A rows may be gathered (a_idx): the row pointer is per lane and fixed for the whole K loop.
+template <int P>
+__device__ __forceinline__ void stream_fwd_tile(const FwdArgs& g, const int tile, const int wave, const int lane,
+                                                float (*red)[32][64]) {
+    const int tl_item = tile * 4 + wave;
+    GS_STAMP(0);
+    // (Issue priorities -- s_setprio 3 outside the MFMA loop, 0 inside, 2 for the gather waves -- were measured: a SIMD
+    // serves its oldest wave first, so its three contraction waves run one after the other; with priorities they
+    // interleave instead, at the same 24-26 us for the launch.  Left out.)
     const int l31 = lane & 31, lh = lane >> 5;
-    const int per_term = g.n_items / g.nterms;
-    const int term = item / per_term;
-    const int it = item - term * per_term;
+    const int per_term = g.n_tiles / g.nterms;
+    const int term = tile / per_term;
+    const int it = tile - term * per_term;
     const int tile_m = it / g.tiles_n, tile_n = it - tile_m * g.tiles_n;
-    const int m0 = tile_m * 32, n0 = tile_n * 32 * TN;
-    const FwdTerm T = g.t[term];
+    const int m0 = tile_m * 32, n0 = tile_n * 64;
+    const FwdTerm& T = g.t[term];
     const int K = g.K, N = g.N;
-    const float* ap = T.A + min(m0 + l31, g.M - 1) * T.lda + 4 * lh;
-    const float* bp[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t) bp[t] = T.W + (4 * lh) * T.ldw + min(n0 + 32 * t + l31, N - 1);
-    const int ldw = T.ldw;
-    f32x16 acc[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    f32x4 a[P];
-    float b[P][TN][4];
     const int nfull = K >> 3;                              // macro steps whose 8 k are all < K
-    auto load_stage = [&](const int st, const int m) {
-        a[st] = *reinterpret_cast<const f32x4*>(ap + 8 * m);
+    const int mb = (nfull * wave) >> 2, me = (nfull * (wave + 1)) >> 2;   // this wave's macro steps
+    const int arow = min(m0 + l31, g.M - 1);
+    const int64_t srow = T.a_idx ? (int64_t)T.a_idx[arow] : (int64_t)arow;
+    const float* ap = T.A + srow * T.lda + 4 * lh + 8 * mb;
+    const int cl = min(n0 + 2 * l31, N - 2);               // the lane's column pair (clamped: never stored if >= N)
+    const char* __restrict__ Wb = (const char*)T.W;
+    const uint32_t ldw4 = (uint32_t)T.ldw * 4u;
+    const char* __restrict__ W0 = Wb;                      // four uniform bases: rows 8 m + 4 lh + e, e = 0..3
+    const char* __restrict__ W1 = Wb + ldw4;
+    const char* __restrict__ W2 = Wb + 2 * ldw4;
+    const char* __restrict__ W3 = Wb + 3 * ldw4;
+    uint32_t wo = (uint32_t)(8 * mb + 4 * lh) * ldw4 + (uint32_t)cl * 4u;
+    const uint32_t wstride = 8u * ldw4;
+    f32x16 acc0, acc1;
 #pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const float* q = bp[t] + (8 * m) * ldw;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b[st][t][e] = q[e * ldw];
-        }
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    f32x4 a[P];
+    f32x2 b[P][4];
+    auto load_stage = [&](const int st) {
+        a[st] = *reinterpret_cast<const f32x4*>(ap);
+        ap += 8;
+        b[st][0] = *reinterpret_cast<const f32x2*>(W0 + wo);
+        b[st][1] = *reinterpret_cast<const f32x2*>(W1 + wo);
+        b[st][2] = *reinterpret_cast<const f32x2*>(W2 + wo);
+        b[st][3] = *reinterpret_cast<const f32x2*>(W3 + wo);
+        wo += wstride;
     };
     auto compute_stage = [&](const int st) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < TN; ++t) acc[t] = mfma32(a[st][e], b[st][t][e], acc[t]);
+        for (int e = 0; e < 4; ++e) {
+            acc0 = mfma32(a[st][e], b[st][e].x, acc0);
+            acc1 = mfma32(a[st][e], b[st][e].y, acc1);
+        }
     };
-    // Branch-free steady state (one basic block, so the compiler can count outstanding loads exactly -- a guard per
-    // stage turned every stage into its own block and each block boundary into a full s_waitcnt vmcnt(0)):
-    // stages m .. m+P-1 are in flight on entry; each is consumed and immediately refilled with stage m+st+P.
-    int m = 0;
-    if (nfull >= P) {
+    // branch-free steady state: stages m .. m+P-1 are in flight on entry; each is consumed and refilled with m+st+P.
+    // (A ring of 32-k super stages -- a lane's four 16-byte A pieces of a 128-byte line loaded back to back -- measured
+    // SLOWER: 36.5 vs 24.3 us alone.)
+    int m = mb;
+    if (me - mb >= P) {
 #pragma unroll
-        for (int st = 0; st < P; ++st) load_stage(st, st);
+        for (int st = 0; st < P; ++st) load_stage(st);
+        GS_STAMP(1);
 #pragma unroll 1
-        for (; m + 2 * P <= nfull; m += P) {
+        for (; m + 2 * P <= me; m += P) {
 #pragma unroll
             for (int st = 0; st < P; ++st) {
                 compute_stage(st);
-                load_stage(st, m + st + P);
+                __builtin_amdgcn_sched_barrier(0);         // the refill stays below the MFMAs that free its registers
+                load_stage(st);
             }
         }
 #pragma unroll
@@ -113,57 +153,61 @@ __device__ __forceinline__ void stream_fwd_item(const FwdArgs& g, const int item
         m += P;
     }
 #pragma unroll 1
-    for (; m < nfull; ++m) {                               // < P leftover macro steps: one at a time
-        load_stage(0, m);
+    for (; m < me; ++m) {                                  // < P leftover macro steps: one at a time
+        load_stage(0);
         compute_stage(0);
     }
-    if ((K & 7) != 0) {
+    if (wave == 3 && (K & 7) != 0) {
         // tail macro step: k = 8*nfull + 4*lh + e; elements with k >= K are zeroed on the A side, B rows are clamped
         const int kq = 8 * nfull + 4 * lh;
         f32x4 av = {0.f, 0.f, 0.f, 0.f};
-        if (kq < K) {
-            // stay inside the row: the last quad may start before kq (row length lda >= round_up(K, 4))
-            av = *reinterpret_cast<const f32x4*>(ap + 8 * nfull);
+        if (kq < K) {                                      // the row's pad columns [K, round_up(K, 4)) are readable
+            av = *reinterpret_cast<const f32x4*>(T.A + srow * T.lda + kq);
             if (kq + 1 >= K) av.y = 0.f;
             if (kq + 2 >= K) av.z = 0.f;
             if (kq + 3 >= K) av.w = 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int kr = min(kq + e, K - 1) - 4 * lh;    // row offset relative to bp's (4*lh) base
-#pragma unroll
-            for (int t = 0; t < TN; ++t) acc[t] = mfma32(av[e], bp[t][kr * ldw], acc[t]);
+            const f32x2 bv = *reinterpret_cast<const f32x2*>(T.W + (int64_t)min(kq + e, K - 1) * T.ldw + cl);
+            acc0 = mfma32(av[e], bv.x, acc0);
+            acc1 = mfma32(av[e], bv.y, acc1);
         }
     }
-    // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    GS_STAMP(2);
+    // split-K sum in a fixed order + bias + activation + store: wave w finishes elements e = 4w .. 4w+3 of both n-tiles
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        red[wave][e][lane] = acc0[e];
+        red[wave][16 + e][lane] = acc1[e];
+    }
+    __syncthreads();
     const int col_off = term * N;
+    const int c = n0 + 2 * l31;
+    f32x2 bv = {0.f, 0.f};
+    if (g.bias && c < N) bv = *reinterpret_cast<const f32x2*>(g.bias + col_off + c);
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int c = n0 + 32 * t + l31;
-        const float bv = (g.bias && c < N) ? g.bias[col_off + c] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (row < g.M && c < N) {
-                float v = acc[t][e] + bv;
-                if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
-                g.C[row * g.ldc + col_off + c] = v;
-            }
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int e = 4 * wave + q;
+        f32x2 v;
+        v.x = ((red[0][e][lane] + red[1][e][lane]) + red[2][e][lane]) + red[3][e][lane] + bv.x;
+        v.y = ((red[0][16 + e][lane] + red[1][16 + e][lane]) + red[2][16 + e][lane]) + red[3][16 + e][lane] + bv.y;
+        if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+        // C/D layout of the 32x32 MFMA: row = (e&3) + 8*(e>>2) + 4*(lane>>5); this lane's columns are c, c+1
+        const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row < g.M && c < N) *reinterpret_cast<f32x2*>(g.C + (int64_t)row * g.ldc + col_off + c) = v;
     }
+    GS_STAMP(3);
 }
 
-// TN = 2: 32x64 tiles, 4 independent waves per workgroup (one per SIMD).  TN = 1: 32x32 tiles, 8 waves per workgroup
-// (TWO per SIMD: while one waits for its operands the other owns the MFMA pipe).
-template <int TN, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void sage_stream_fwd_kernel(const FwdArgs g, const int mfma_blocks, const CoGatherS J) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: per-item fields live in SGPRs
-    if ((int)blockIdx.x < mfma_blocks) {
-        const int item = stream_xcd_swizzle(blockIdx.x, mfma_blocks) * WAVES + wave;
-        if (item < g.n_items) stream_fwd_item<TN>(g, item, lane);
+__global__ __launch_bounds__(256) void sage_stream_fwd_kernel(const FwdArgs g, const CoGatherS J) {
+    __shared__ float red[4][32][64];                       // split-K partial tiles of the workgroup's four waves
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: SGPR fields
+    if ((int)blockIdx.x < g.n_tiles) {
+        stream_fwd_tile<4>(g, stream_xcd_swizzle(blockIdx.x, g.n_tiles), wave, lane, red);
         return;
     }
-    run_gather_item(J, ((int64_t)blockIdx.x - mfma_blocks) * WAVES + wave, lane);
+    run_gather_item(J, ((int64_t)blockIdx.x - g.n_tiles) * 4 + wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradients
@@ -190,17 +234,6 @@ struct WgradArgs {
 // offsets against wave-uniform base pointers (global_load with an SGPR base), advanced with one add per load; a
 // gathered A row costs two v_readlane (SALU) + two VALU.  (The first version -- 64-bit per-lane pointers, a register
 // select ladder for the gather index -- spent ~300 cycles per k-pair outside the 256 MFMA cycles.)
-#ifdef GS_TIMELINE
-// Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_wgrad.py): per-wave wall-clock stamps (100 MHz).
-__device__ unsigned long long g_timeline[8192 * 8];
-extern "C" int gs_debug_timeline(unsigned long long* out_host, int n) {
-    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
-}
-#define GS_STAMP(slot) do { if (lane == 0 && tl_item < 8192) { g_timeline[tl_item * 8 + (slot)] = wall_clock64(); g_timeline[tl_item * 8 + 4 + (slot)] = clock64(); } } while (0)
-#else
-#define GS_STAMP(slot) do { } while (0)
-#endif
-
 template <int P, bool GATHERED>
 __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int z, const int f0, const int o0, const int lane,
                                                   const int tl_item) {
@@ -385,11 +418,12 @@ __global__ __launch_bounds__(256) void stream_wgrad_kernel(const WgradArgs G, co
 // ------------------------------------------------------------------------------------------ host side
 static inline int rup4s(int x) { return (x + 3) & ~3; }
 
-extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const float* agg, int64_t ld_agg, int32_t d,
-                                        int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,
-                                        int64_t ldw_neigh, int32_t out_dim, int act, const float* bias, float* out,
-                                        int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg,
+                                        int64_t ld_agg, int32_t d, int64_t n, const float* W_self, int64_t ldw_self,
+                                        const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias,
+                                        float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
     GS_REQUIRE(n > 0 && agg && W_neigh && out && d > 0 && out_dim > 0, "gs_sage_dense_fwd_stream: bad args");
+    GS_REQUIRE(out_dim % 2 == 0 && ldo % 2 == 0, "gs_sage_dense_fwd_stream: out_dim and ldo must be even (8-byte column pairs)");
     GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_stream agg");
     GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_fwd_stream W_neigh");
     GS_CHECK_MAT(out, ldo, "gs_sage_dense_fwd_stream out");
@@ -399,33 +433,28 @@ extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, cons
         GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_stream self");
         GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd_stream W_self");
         GS_REQUIRE(ld_self >= rup4s(d) && ldw_self >= out_dim, "gs_sage_dense_fwd_stream: self ld too small");
-        g.t[0] = FwdTerm{self, W_self, (int32_t)ld_self, (int32_t)ldw_self};
-        g.t[1] = FwdTerm{agg, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
+        g.t[0] = FwdTerm{self, self_idx, W_self, (int32_t)ld_self, (int32_t)ldw_self};
+        g.t[1] = FwdTerm{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
         g.nterms = 2;
     } else {
-        g.t[0] = FwdTerm{agg, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
+        g.t[0] = FwdTerm{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
         g.nterms = 1;
     }
     GS_REQUIRE(ldo >= out_dim * g.nterms, "gs_sage_dense_fwd_stream: ldo too small");
-    GS_REQUIRE(n * std::max(std::max(ld_self, ld_agg), ldo) < (1ll << 31) && (int64_t)d * std::max(ldw_self, ldw_neigh) < (1ll << 31),
+    GS_REQUIRE(std::max(ld_self, ld_agg) < (1ll << 31) && ((int64_t)d + 8) * std::max(ldw_self, ldw_neigh) * 4 < (1ll << 32),
                "gs_sage_dense_fwd_stream: 32-bit offsets exceeded");
     g.M = (int32_t)n; g.N = out_dim; g.K = d; g.C = out; g.ldc = (int32_t)ldo; g.bias = bias; g.act = act;
-    static const int variant = getenv("GS_STREAM_FWD_TN") ? atoi(getenv("GS_STREAM_FWD_TN")) : 1;   // tuning hook
-    const int TN = variant == 2 ? 2 : 1, WAVES = TN == 2 ? 4 : 8;
+    GS_REQUIRE(n < (1ll << 31) - 64, "gs_sage_dense_fwd_stream: too many rows");
     const int tiles_m = (int)gs_ceil_div(n, 32);
-    g.tiles_n = (int)gs_ceil_div(out_dim, 32 * TN);
-    g.n_items = tiles_m * g.tiles_n * g.nterms;
-    const int mfma_blocks = (int)gs_ceil_div(g.n_items, WAVES);
+    g.tiles_n = (int)gs_ceil_div(out_dim, 64);
+    g.n_tiles = tiles_m * g.tiles_n * g.nterms;
     CoGatherS J = {};
     int64_t waves = 0;
     int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
     if (rc != GS_OK) return rc;
-    const int64_t blocks = mfma_blocks + gs_ceil_div(waves, WAVES);
+    const int64_t blocks = g.n_tiles + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_dense_fwd_stream: grid too large");
-    if (TN == 2)
-        hipLaunchKernelGGL((sage_stream_fwd_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, mfma_blocks, J);
-    else
-        hipLaunchKernelGGL((sage_stream_fwd_kernel<1, 8>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, g, mfma_blocks, J);
+    hipLaunchKernelGGL(sage_stream_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
     GS_LAUNCH_CHECK("sage_stream_fwd_kernel");
     return GS_OK;
 }

@@ -281,11 +281,12 @@ class Engine(object):
         return arr
 
     def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0, side_jobs=None,
-                        loss=None, step_offset=1):
+                        loss=None, step_offset=1, opt_jobs=None):
         """One grouped launch for every queued weight gradient, then ONE launch that sums the slabs into the
         flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass.
         loss = (loss_rows, n, scale, loss_out, accumulate): the step's scalar loss is formed by that launch too;
-        step_offset = 0 when an earlier launch of the step has already advanced the optimizer step counter."""
+        step_offset = 0 when an earlier launch of the step has already advanced the optimizer step counter.
+        side_jobs / opt_jobs: gather+mean descriptors of the next step riding in the weight-gradient / optimizer launch."""
         self.launch_wgrads(side_jobs)
         arr = self._var_descs()
         lr_, ln, lscale, lout, lacc = loss if loss is not None else (None, 0, 0.0, None, False)
@@ -295,10 +296,13 @@ class Engine(object):
                 ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
                 1 if lacc else 0)
         rider = getattr(self, "_deferred_sampler", None)
-        if rider is not None:
+        if rider is not None or opt_jobs:
             # a later mini-batch's fan-out sampler rides in this launch (neigh_samplers.fanout under _defer_sampler)
             self._deferred_sampler = None
-            ops.call("gs_flat_reduce_adam_sample", *args, ctypes.addressof(rider), self.stream)
+            jobs = list(opt_jobs or ())
+            jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
+            ops.call("gs_flat_reduce_adam_sample", *args, ctypes.addressof(rider) if rider is not None else None,
+                     ctypes.addressof(jarr), len(jobs), self.stream)
         else:
             ops.call("gs_flat_reduce_adam", *args, self.stream)
         if fuse_adam:

@@ -108,11 +108,14 @@ class SampleAndAggregate(object):
         self.world_size, self.rank = int(world_size), int(rank)
         self.engine.dropout_seed = 123 + 1000003 * self.rank      # every data-parallel rank draws its own masks
         self.row_offset = 0
-        # share of the prefetch gather carried by the layer-0 launch (the rest rides in the weight-gradient launch):
-        # 0.7 with the LDS-tiled weight-gradient kernel, 0.6 with the stream kernel (sweeps in DESIGN.md)
-        self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.4 if self.engine.stream_gemm else 0.7))
-        # share carried by the fused tail launch (supervised mean model; 0 = none)
-        self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.3 if self.engine.stream_gemm else 0.0))
+        # shares of the prefetch gather carried by the step's launches (sweeps in DESIGN.md).  Two-launch form (layer-0
+        # forward | weight gradients): 0.7 | 0.3 with the LDS-tiled kernels, 0.5 | 0.5 with the stream kernels.
+        # Three-launch form of the supervised mean model (layer-0 forward | fused tail | weight gradients): 0.15 | 0.5 |
+        # 0.35 -- the tail keeps only 32 CUs busy, the rest of the chip streams the gather.
+        self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.5 if self.engine.stream_gemm else 0.7))
+        self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
+        self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
+        self.cogather_opt = float(os.environ.get("GS_COGATHER_OPT", 0.0))      # share riding in the optimizer launch
         # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
         self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()

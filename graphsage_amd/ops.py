@@ -272,14 +272,16 @@ def sage_dense_fwd_cogather(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, 
     return out
 
 
-def sage_dense_fwd_stream(self_m, agg, n, W_self, W_neigh, out_dim, act, bias, out, jobs, stream=None):
-    """gs_sage_dense_fwd_stream: LDS-free contraction waves + the gather jobs in ONE launch (dense self / agg)."""
+def sage_dense_fwd_stream(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, act, bias, out, jobs, stream=None):
+    """gs_sage_dense_fwd_stream: split-K stream contraction workgroups + the gather jobs in ONE launch (self rows
+    optionally gathered through self_idx; agg dense)."""
     import ctypes
     jobs = list(jobs or ())
     arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
     call("gs_sage_dense_fwd_stream", self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0,
-         agg.ptr, agg.ld, agg.d, n, W_self.ptr if W_self is not None else None, W_self.ld if W_self is not None else 0,
-         W_neigh.ptr, W_neigh.ld, out_dim, act, ptr(bias), out.ptr, out.ld, ctypes.addressof(arr), len(jobs), _s(stream))
+         ptr(self_idx), agg.ptr, agg.ld, agg.d, n, W_self.ptr if W_self is not None else None,
+         W_self.ld if W_self is not None else 0, W_neigh.ptr, W_neigh.ld, out_dim, act, ptr(bias), out.ptr, out.ld,
+         ctypes.addressof(arr), len(jobs), _s(stream))
     return out
 
 

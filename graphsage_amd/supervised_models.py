@@ -148,7 +148,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                     first = False
             self._loss_accumulate = not first
 
-    def _backward(self, n, fuse_adam, wgrad_jobs=None, epilogue=None):
+    def _backward(self, n, fuse_adam, wgrad_jobs=None, epilogue=None, opt_jobs=None):
         """Reverse of _forward.  Every weight gradient of the pass is ONE grouped launch; the slab reduction
         (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
@@ -167,8 +167,9 @@ class SupervisedGraphsage(SampleAndAggregate):
             e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
                               side_jobs=wgrad_jobs,
                               loss=(self._loss_rows, n, 1.0 / n, self.loss_dev, self._loss_accumulate) if epilogue is not None else None,
-                              step_offset=0 if self._tail_step_advanced else 1)
+                              step_offset=0 if self._tail_step_advanced else 1, opt_jobs=opt_jobs)
             return
+        assert not opt_jobs, "optimizer-launch gather riders need the fused-tail schedule"
         if self._head_fused:
             e.wgrad(self.node_pred.vars['weights'], self.outputs1, None, self._dlogits, 0, n)
             e.bgrad(self.node_pred.vars['bias'], self._dlogits, n, self.num_classes)
@@ -356,14 +357,20 @@ class SupervisedGraphsage(SampleAndAggregate):
             self._parity = p
             # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
-            fwd_jobs, rest = ops.split_gather_jobs(side_jobs, self.cogather_split)
-            tail_jobs, wgrad_jobs = [], rest
-            if rest and self.cogather_tail > 0 and self._tail_ok():
+            opt_jobs = []
+            if side_jobs and self.cogather_tail > 0 and self._tail_ok():
                 # the fused tail launch keeps only n/16 CUs busy: the rest of the chip streams a share of the gather
-                tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, self.cogather_tail / max(1e-6, 1.0 - self.cogather_split)))
+                fwd_jobs, rest = ops.split_gather_jobs(side_jobs, self.cogather_split3)
+                tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, self.cogather_tail / max(1e-6, 1.0 - self.cogather_split3)))
+                if self.cogather_opt > 0 and local_adam:
+                    left = max(1e-6, 1.0 - self.cogather_split3 - self.cogather_tail)
+                    wgrad_jobs, opt_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_opt / left))
+            else:
+                fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
+                tail_jobs = []
             self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue,
                           tail_jobs=tail_jobs)
-            self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
+            self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue, opt_jobs=opt_jobs)
             if in_graph:
                 self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
                 self._optimize(advanced=True)

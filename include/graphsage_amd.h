@@ -198,17 +198,18 @@ int gs_dense_wgrad_grouped_cogather(const gs_wgrad_desc* descs_host, int32_t n_d
                                     int32_t n_jobs, void* stream);
 
 /* "Stream" forms of the two launches above (same maths, same co-scheduled gather jobs, up to 6 of them): the
- * contraction waves use no LDS and no barriers -- one wave per output tile, operands straight from L2 into the MFMA
- * registers through a register ring -- so that the gather waves sharing the launch keep their occupancy.  The forward
- * form needs DENSE operands (the caller materialises the layer-0 self rows with one more gather job).
- *   gs_sage_dense_fwd_stream: out[:, 0:out_dim] = act(self . W_self + bias), out[:, out_dim:2*out_dim] =
+ * contraction waves stage no operand through LDS and meet no barrier inside the K loop -- operands go from L2 into the
+ * MFMA registers through a register ring -- so that the gather waves sharing the launch keep their occupancy.
+ *   gs_sage_dense_fwd_stream: out[:, 0:out_dim] = act(self[self_idx] . W_self + bias), out[:, out_dim:2*out_dim] =
  *     act(agg . W_neigh + bias)  (concat form of aggregators.py:51-58; self == NULL: the single GCN contraction,
- *     aggregators.py:110).  self / agg are [n, d] dense with pad columns [d, round_up(d, 4)) readable.
+ *     aggregators.py:110).  self_idx (nullable) gathers the self rows inside the A loads; agg is [n, d] dense; pad
+ *     columns [d, round_up(d, 4)) must be readable.  out_dim and ldo even.  One workgroup per 32 x 64 output tile,
+ *     K split over its four waves and summed in a fixed order (deterministic).
  *   gs_dense_wgrad_grouped_stream: as gs_dense_wgrad_grouped (<= 12 problems; a row-gathered problem needs
- *     ceil(n / n_slabs) <= 512: the slice's gather indices live in registers). */
-int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const float* agg, int64_t ld_agg, int32_t d, int64_t n,
-                             const float* W_self, int64_t ldw_self, const float* W_neigh, int64_t ldw_neigh,
-                             int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+ *     ceil(n / n_slabs) <= 512 -- the slice's row offsets live in registers -- and a_rows). */
+int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg, int64_t ld_agg,
+                             int32_t d, int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,
+                             int64_t ldw_neigh, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
                              const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);
@@ -357,10 +358,12 @@ int gs_flat_reduce_adam(const gs_var_desc* vars_host, int32_t n_vars, float* par
                         const float* loss_rows, int64_t loss_n, float loss_scale, float* loss_out, int loss_accumulate,
                         void* stream);
 
-/* gs_flat_reduce_adam + the fan-out sampler of a LATER mini-batch (arguments of gs_sample_fanout_csr in a struct) in ONE
- * launch: the sampler is a chain of dependent memory round trips with almost no work, so it hides completely under
- * the optimizer launch of the step before.  The per-root id count of every kept hop must be <= 512
- * (else GS_ENOTSUP: launch gs_sample_fanout_csr on its own). */
+/* gs_flat_reduce_adam + riders in ONE launch: the fan-out sampler of a LATER mini-batch (sampler_host, nullable: the
+ * arguments of gs_sample_fanout_csr in a struct) and up to 6 gather+mean jobs of the NEXT mini-batch (as
+ * gs_sage_dense_fwd_cogather).  The optimizer launch is a short latency-bound pass over ~1 MB of parameters; the
+ * sampler (a chain of dependent round trips with almost no work) hides completely under it and the gather waves use
+ * the idle wave slots.  The per-root id count of every kept hop must be <= 512 (else GS_ENOTSUP: launch
+ * gs_sample_fanout_csr on its own). */
 typedef struct gs_fanout_desc {
     const int64_t* rowptr; const int32_t* col; int64_t n_nodes;
     int32_t* ids_all; int64_t B;
@@ -378,7 +381,7 @@ int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, flo
                                int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,
                                float eps, float clip, float grad_scale, const uint64_t* step_dev, int32_t step_offset,
                                const float* loss_rows, int64_t loss_n, float loss_scale, float* loss_out, int loss_accumulate,
-                               const gs_fanout_desc* sampler_host, void* stream);
+                               const gs_fanout_desc* sampler_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 
 /* Fused tail of the supervised two-layer GraphSAGE-mean model: layer 1 (MeanAggregator._call on the layer-0 outputs,
  * aggregators.py:43-64, identity act: last layer, models.py:307-310), l2_normalize + Dense head + loss/preds

@@ -741,15 +741,20 @@ def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
     np.testing.assert_allclose(dh0.numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
-@pytest.mark.parametrize("n,d,out,two,act,bias", [(5632, 602, 128, True, ops.ACT_RELU, False), (2500, 100, 128, True, ops.ACT_IDENTITY, True),
-                                                  (3001, 602, 256, False, ops.ACT_RELU, False), (2049, 37, 40, True, ops.ACT_RELU, True)])
-def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias):
-    """gs_sage_dense_fwd_stream (LDS-free contraction waves, dense operands, K tails, ragged rows/columns) + the
-    co-scheduled gather jobs (incl. the s = 1 dense-self copy) vs NumPy."""
+@pytest.mark.parametrize("n,d,out,two,act,bias,gathered", [
+    (5632, 602, 128, True, ops.ACT_RELU, False, True), (2500, 100, 128, True, ops.ACT_IDENTITY, True, False),
+    (3001, 602, 256, False, ops.ACT_RELU, False, False), (2049, 37, 40, True, ops.ACT_RELU, True, True),
+    (70, 20, 6, True, ops.ACT_RELU, True, True), (33, 8, 64, False, ops.ACT_IDENTITY, False, False)])
+def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias, gathered):
+    """gs_sage_dense_fwd_stream (split-K contraction workgroups; gathered or dense self rows, K tails and K too short
+    for some of the four K quarters, ragged rows/columns) + the co-scheduled gather jobs vs NumPy."""
     rng = np.random.default_rng(n + d)
     Nn = 4000
     X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
     self_m, mean = _asym(rng, (n, d)), _asym(rng, (n, d))
+    self_ids = rng.integers(0, Nn + 1, size=n).astype(np.int32)
+    if gathered:
+        self_m = X[self_ids]
     Ws, Wn = _asym(rng, (d, out)) * 0.1, _asym(rng, (d, out)) * 0.1
     b = (_asym(rng, ((2 if two else 1) * out,)) * 0.1) if bias else None
     idx = rng.integers(0, Nn + 1, size=(700, 25)).astype(np.int32)
@@ -763,7 +768,11 @@ def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias):
     Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
     bd = torch.from_numpy(b).to(dev) if bias else None
     jobs = [ops.gather_job(Xd, idx_d, 700, 25, g_out), ops.gather_job(Xd, ids1_d, 900, 1, c_out)]
-    ops.sage_dense_fwd_stream(sd if two else None, md, n, Wsd if two else None, Wnd, out, act, bd, outm, jobs)
+    sid_d = _i32(self_ids, dev)
+    if gathered:
+        ops.sage_dense_fwd_stream(Xd, sid_d, md, n, Wsd, Wnd, out, act, bd, outm, jobs)
+    else:
+        ops.sage_dense_fwd_stream(sd if two else None, None, md, n, Wsd if two else None, Wnd, out, act, bd, outm, jobs)
     _sync()
     want_n = mean.astype(np.float64) @ Wn
     want = np.concatenate([self_m.astype(np.float64) @ Ws, want_n], axis=1) if two else want_n
