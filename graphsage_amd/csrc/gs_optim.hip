@@ -189,29 +189,33 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
         while (k + 1 < V.n && i >= V.offset[k + 1]) ++k;
         const int64_t rel = i - V.offset[k];
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // parameter and Adam state first: their loads share the round trip of the slab loads below
+        f32x4 p = *reinterpret_cast<const f32x4*>(params + i);
+        f32x4 mi = {0.f, 0.f, 0.f, 0.f}, vi = {0.f, 0.f, 0.f, 0.f};
+        if (fuse_adam) {
+            mi = *reinterpret_cast<const f32x4*>(m + i);
+            vi = *reinterpret_cast<const f32x4*>(v + i);
+        }
         if (rel < V.size[k]) {
             float* sp = V.slabs[k] + rel;
             const int ns = V.n_slabs[k];
             const int64_t sz = V.size[k];
-            // 16 slab loads in flight per thread (the launch is one float4 per thread: with 4 in flight the 22-32 slabs
-            // of a Reddit step were 6-8 dependent memory round trips); summation order stays z = 0, 1, 2, ...
-            for (int z0 = 0; z0 < ns; z0 += 16) {
-                f32x4 v[16];
+            // 24 slab loads in flight per thread (the launch is one float4 per thread and latency-bound: the 22 slabs of
+            // a Reddit step are ONE memory round trip; with 4 in flight they were 6-8); summation order stays z = 0, 1, ...
+            for (int z0 = 0; z0 < ns; z0 += 24) {
+                f32x4 sv[24];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
+                for (int u = 0; u < 24; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (z0 + u < ns) g += v[u];
+                for (int u = 0; u < 24; ++u)
+                    if (z0 + u < ns) g += sv[u];
             }
             if (V.clear[k]) *reinterpret_cast<f32x4*>(sp) = f32x4{0.f, 0.f, 0.f, 0.f};   // atomic accumulator: consume
         }
-        f32x4 p = *reinterpret_cast<const f32x4*>(params + i);
         if (V.decay[k] && wd != 0.f) g += p * wd;
         *reinterpret_cast<f32x4*>(grads + i) = g;
         if (fuse_adam) {
             g *= gscale;
-            f32x4 mi = *reinterpret_cast<const f32x4*>(m + i);
-            f32x4 vi = *reinterpret_cast<const f32x4*>(v + i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float ge = g[e];
