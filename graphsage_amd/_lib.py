@@ -39,6 +39,7 @@ _PROTOS = {
     "gs_act_bwd": [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P],
     "gs_colsum_slabs": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P],
     "gs_gemm_f32": [c_int, c_int, c_int64, c_int32, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int, _P, c_int64, _P],
+    "gs_dense_pool_max_fwd": [_P, c_int64, _P, c_int32, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, c_int64, _P, c_int64, _P],
     "gs_segment_max_fwd": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P],
     "gs_segment_max_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P],
     "gs_l2norm_fwd": [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P],

@@ -493,53 +493,66 @@ class _PoolingAggregator(_SageBase):
         rate = _rate(self.dropout)
         mlp = self.mlp_layers[0]
         rows_total = sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)
-        # h_reshaped = Dense(reshape(neigh, [n*s, d]))   (aggregators.py:176-179): one GEMM over every neighbor row
-        H = e.ws_mat((self.name, "H", k), rows_total, self.hidden_dim)
         flat = [Rows(nv.src, nv.ids, nv.shape3[0] * nv.shape3[1], nv.requires_grad) for nv in neighs]
         x_all = _contiguous(flat)
         pieces = [x_all] if x_all is not None else flat
-        if rate > 0:
-            # the Dense's x = tf.nn.dropout(x, 1 - dropout) (layers.py:107) over every gathered neighbor row: the
-            # dropped rows are materialised ([n*s, d]) and feed the MLP GEMM and its weight gradient as a dense operand
-            dropped, r = [], 0
-            for i, x in enumerate(pieces):
-                xd = e.ws_mat((self.name, "x_drop", k, i), x.n, x.src.d)
-                ops.dropout_rows(x.src, x.ids, x.n, self._drop(rate, SITE_MLP, k, r), xd, stream=e.stream)
-                dropped.append(Rows(xd, None, x.n, x.requires_grad))
-                r += x.n
-            pieces = dropped
-        r = 0
-        for x in pieces:
-            ops.sage_dense_fwd(None, None, x.src, x.ids, x.n, None, mlp.vars['weights'].value, self.hidden_dim, False,
-                               ACT_RELU, mlp.vars['bias'].value.buf, H.rows_slice(r, r + x.n), stream=e.stream)
-            r += x.n
         pooled = e.ws_mat((self.name, "pooled", k), n_total, self.hidden_dim)
         argmax = None
         if self.POOL == "max":
             argmax = e.ws_i32((self.name, "argmax", k), n_total * self.hidden_dim).view(n_total, self.hidden_dim)
-        r = hr = 0
-        for nv in neighs:
-            n, s, _ = nv.shape3
-            if self.POOL == "max":
-                ops.segment_max_fwd(H.rows_slice(hr, hr + n * s), n, s, pooled.rows_slice(r, r + n), argmax[r:r + n],
-                                    stream=e.stream)                                             # reduce_max (:181)
-            else:
-                ops.gather_mean_fwd(H.rows_slice(hr, hr + n * s), None, n, s, out=pooled.rows_slice(r, r + n),
-                                    stream=e.stream)                                             # reduce_mean (:259)
-            r += n
-            hr += n * s
+        fused_pool = (self.POOL == "max" and rate == 0 and getattr(self, "fuse_pool", True)
+                      and all(nv.shape3[1] <= 64 for nv in neighs))
+        H = None
+        if fused_pool:
+            # Dense (:176-179) + reduce_max (:181) in ONE launch per hop: the GEMM tiles hold whole neighbor groups and
+            # reduce them in the epilogue, so the [n*s, hidden] activations never exist in HBM
+            r = 0
+            for nv, x in zip(neighs, flat):
+                n, s, _ = nv.shape3
+                ops.dense_pool_max_fwd(x.src, x.ids, n, s, mlp.vars['weights'].value, mlp.vars['bias'].value.buf,
+                                       pooled.rows_slice(r, r + n), argmax[r:r + n], stream=e.stream)
+                r += n
+        else:
+            # h_reshaped = Dense(reshape(neigh, [n*s, d]))   (aggregators.py:176-179): one GEMM over every neighbor row
+            H = e.ws_mat((self.name, "H", k), rows_total, self.hidden_dim)
+            if rate > 0:
+                # the Dense's x = tf.nn.dropout(x, 1 - dropout) (layers.py:107) over every gathered neighbor row: the
+                # dropped rows are materialised ([n*s, d]) and feed the MLP GEMM and its weight gradient as a dense operand
+                dropped, r = [], 0
+                for i, x in enumerate(pieces):
+                    xd = e.ws_mat((self.name, "x_drop", k, i), x.n, x.src.d)
+                    ops.dropout_rows(x.src, x.ids, x.n, self._drop(rate, SITE_MLP, k, r), xd, stream=e.stream)
+                    dropped.append(Rows(xd, None, x.n, x.requires_grad))
+                    r += x.n
+                pieces = dropped
+            r = 0
+            for x in pieces:
+                ops.sage_dense_fwd(None, None, x.src, x.ids, x.n, None, mlp.vars['weights'].value, self.hidden_dim, False,
+                                   ACT_RELU, mlp.vars['bias'].value.buf, H.rows_slice(r, r + x.n), stream=e.stream)
+                r += x.n
+            r = hr = 0
+            for nv in neighs:
+                n, s, _ = nv.shape3
+                if self.POOL == "max":
+                    ops.segment_max_fwd(H.rows_slice(hr, hr + n * s), n, s, pooled.rows_slice(r, r + n), argmax[r:r + n],
+                                        stream=e.stream)                                             # reduce_max (:181)
+                else:
+                    ops.gather_mean_fwd(H.rows_slice(hr, hr + n * s), None, n, s, out=pooled.rows_slice(r, r + n),
+                                        stream=e.stream)                                             # reduce_mean (:259)
+                r += n
+                hr += n * s
         n_out = self.output_dim * (2 if self.concat else 1)
         out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
         ops.sage_dense_fwd(self_all.src, self_all.ids, pooled, None, n_total, self.vars['self_weights'].value,
                            self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
                            stream=e.stream)
-        self._push((self_all, neighs, pieces, H, pooled, argmax, out, rate))
+        self._push((self_all, neighs, pieces, (H, rows_total), pooled, argmax, out, rate))
         return out
 
     def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
-        self_all, neighs, pieces, H, pooled, argmax, out, rate = self._saved.pop()
+        self_all, neighs, pieces, (H, rows_total), pooled, argmax, out, rate = self._saved.pop()
         n_total = self_all.n
         k = len(self._saved)
 
@@ -575,7 +588,7 @@ class _PoolingAggregator(_SageBase):
                 e.sparse_pool_wgrad(mlp.vars['weights'], nv.src, nv.ids, n, s, argmax[r:r + n], dpm.rows_slice(r, r + n))
                 r += n
             return
-        dH = e.ws_mat((self.name, "dH", k), H.rows, self.hidden_dim)
+        dH = e.ws_mat((self.name, "dH", k), rows_total, self.hidden_dim)
         r = hr = 0
         for nv in neighs:
             n, s, _ = nv.shape3
@@ -588,7 +601,7 @@ class _PoolingAggregator(_SageBase):
             r += n
             hr += n * s
         if self.POOL != "max":
-            e.bgrad(mlp.vars['bias'], dH, H.rows, self.hidden_dim)
+            e.bgrad(mlp.vars['bias'], dH, rows_total, self.hidden_dim)
         r = 0
         for x in pieces:
             e.wgrad(mlp.vars['weights'], x.src, x.ids, dH.rows_slice(r, r + x.n), 0, x.n)
@@ -598,11 +611,11 @@ class _PoolingAggregator(_SageBase):
             d_self_e = e.ws_mat((self.name, "d_self_e", k), n_total, c)
             ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value.rows_slice(0, c), d_self_e, stream=e.stream)
             e.scatter_grad(var, d_self_e, self_all.ids, n_total, 1, 1.0)      # the pooling aggregators do not drop self
-            d_neigh_e = e.ws_mat((self.name, "d_neigh_e", k), H.rows, c)
-            ops.dense_dgrad(dH, 0, self.hidden_dim, H.rows, mlp.vars['weights'].value.rows_slice(0, c), d_neigh_e,
+            d_neigh_e = e.ws_mat((self.name, "d_neigh_e", k), rows_total, c)
+            ops.dense_dgrad(dH, 0, self.hidden_dim, rows_total, mlp.vars['weights'].value.rows_slice(0, c), d_neigh_e,
                             stream=e.stream)
             if rate > 0:
-                ops.dropout_rows(d_neigh_e, None, H.rows, self._drop(rate, SITE_MLP, k), d_neigh_e, stream=e.stream)
+                ops.dropout_rows(d_neigh_e, None, rows_total, self._drop(rate, SITE_MLP, k), d_neigh_e, stream=e.stream)
             hr = 0
             for nv in neighs:
                 n, s, _ = nv.shape3
@@ -612,10 +625,10 @@ class _PoolingAggregator(_SageBase):
             return
         d_self_all = e.ws_mat((self.name, "d_self", k), n_total, self.input_dim)
         ops.dense_dgrad(dz, 0, o, n_total, self.vars['self_weights'].value, d_self_all, stream=e.stream)
-        d_neigh = e.ws_mat((self.name, "d_neigh", k), H.rows, self.neigh_input_dim)
-        ops.dense_dgrad(dH, 0, self.hidden_dim, H.rows, mlp.vars['weights'].value, d_neigh, stream=e.stream)
+        d_neigh = e.ws_mat((self.name, "d_neigh", k), rows_total, self.neigh_input_dim)
+        ops.dense_dgrad(dH, 0, self.hidden_dim, rows_total, mlp.vars['weights'].value, d_neigh, stream=e.stream)
         if rate > 0:
-            ops.dropout_rows(d_neigh, None, H.rows, self._drop(rate, SITE_MLP, k), d_neigh, stream=e.stream)
+            ops.dropout_rows(d_neigh, None, rows_total, self._drop(rate, SITE_MLP, k), d_neigh, stream=e.stream)
         segs, hr = [], 0
         for h, nv in enumerate(neighs):         # every neighbor row has its own gradient row (s = 1)
             n, s, _ = nv.shape3

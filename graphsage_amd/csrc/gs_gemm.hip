@@ -41,6 +41,14 @@ struct GemmArgs {
     int32_t act;
     int32_t accumulate;  // C += result (before act; only with act == identity)
     int32_t tiles_m, tiles_n;  // tiles_n is per term
+    // max-pool epilogue (pool_s > 0): the rows are groups of pool_s consecutive rows; a tile holds floor(BM / pool_s)
+    // WHOLE groups (its row origin advances by pool_rows = that many rows), and instead of C the epilogue writes
+    // pool_out[group, col] = max_j act(row j of the group) and pool_arg = the first j that attains it.
+    int32_t pool_s, pool_rows;
+    float* pool_out;
+    int64_t pool_ld;
+    int32_t* pool_arg;
+    int64_t pool_lda;
 };
 
 #define GS_IDXCAP 1024  // gather indices cached in LDS per k-chunk (row-gathered TN operand)
@@ -86,7 +94,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
         tile_n -= term0 * g.tiles_n;
         col_off = term0 * g.N;
     }
-    const int64_t m0 = (int64_t)tile_m * BM;
+    const int64_t m0 = (int64_t)tile_m * (g.pool_s > 0 ? g.pool_rows : BM);
     const int n0 = tile_n * BN;
 
     f32x16 acc[TM][TN];
@@ -311,6 +319,45 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    if (g.pool_s > 0) {
+        // max-pool over groups of pool_s rows (aggregators.py:176-181: Dense(relu) then reduce_max over the neighbor
+        // axis) without writing the [rows, hidden] activations: the activated tile goes to LDS (the K loop's buffers
+        // are free after its last barrier), then one thread per (group, column) scans its pool_s rows.
+        static_assert(2 * STAGE_FLOATS >= BM * BN, "pool epilogue needs the tile in LDS");
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int lc = wn * (BN / 2) + tn * 32 + l31;
+                const float bv = (g.bias && n0 + lc < g.N) ? g.bias[n0 + lc] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = wm * (BM / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float v = acc[tm][tn][e] + bv;
+                    if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                    smem[lr * BN + lc] = v;
+                }
+            }
+        __syncthreads();
+        const int s = g.pool_s;
+        const int groups = g.pool_rows / s;
+        const int64_t n_groups = g.M / s;
+        for (int item = tid; item < groups * BN; item += 256) {
+            const int gi = item / BN, lc = item - gi * BN;
+            const int64_t node = (int64_t)tile_m * groups + gi;
+            if (node >= n_groups || n0 + lc >= g.N) continue;
+            const float* col = smem + (gi * s) * BN + lc;
+            float best = col[0];
+            int arg = 0;
+            for (int j = 1; j < s; ++j) {
+                const float v = col[j * BN];
+                if (v > best) { best = v; arg = j; }
+            }
+            g.pool_out[node * g.pool_ld + n0 + lc] = best;
+            g.pool_arg[node * g.pool_lda + n0 + lc] = arg;
+        }
+        return;
+    }
     float* C = g.C + (g.kchunk > 0 ? (int64_t)zslice * g.slab_stride : 0);
     const int n_total = g.N * ((g.nterms == 2 && g.concat) ? 2 : 1);
     const int n_pad = (n_total + 3) & ~3;
@@ -608,6 +655,10 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_cogather_kernel(const Gro
 template <int BM, int BN, bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs& g, int nz, hipStream_t st) {
     g.tiles_m = (int)gs_ceil_div(g.M, BM);
+    if (g.pool_s > 0) {
+        g.pool_rows = (BM / g.pool_s) * g.pool_s;
+        g.tiles_m = (int)gs_ceil_div(g.M, g.pool_rows);
+    }
     g.tiles_n = (int)gs_ceil_div(g.N, BN);
     const int64_t nblk = (int64_t)g.tiles_m * g.tiles_n * ((g.nterms == 2 && g.concat) ? 2 : 1);
     GS_REQUIRE(nblk > 0 && nblk < (1ll << 31), "gemm: bad grid (%lld tiles)", (long long)nblk);
@@ -721,6 +772,25 @@ extern "C" int gs_sage_dense_fwd(const float* self, int64_t ld_self, const int32
     }
     g.M = n; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
     return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int gs_dense_pool_max_fwd(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_groups, int32_t s,
+                                     const float* W, int64_t ldw, int32_t hidden, const float* bias, float* pooled,
+                                     int64_t ldp, int32_t* argmax, int64_t lda, void* stream) {
+    if (n_groups == 0) return GS_OK;
+    GS_CHECK_MAT(X, ldx, "gs_dense_pool_max_fwd X");
+    GS_CHECK_MAT(W, ldw, "gs_dense_pool_max_fwd W");
+    GS_REQUIRE(pooled && argmax && n_groups > 0 && s > 0 && s <= 64 && d > 0 && hidden > 0, "gs_dense_pool_max_fwd: bad args (1 <= s <= 64)");
+    GS_REQUIRE(ldx >= rup4(d) && ldw >= rup4(hidden) && ldp >= hidden && lda >= hidden, "gs_dense_pool_max_fwd: ld too small");
+    GemmArgs g = {};
+    g.t[0] = GemmTerm{X, idx, W, ldx, ldw, d};
+    g.nterms = 1;
+    g.M = n_groups * s; g.N = hidden; g.bias = bias; g.act = GS_ACT_RELU;
+    g.pool_s = s; g.pool_out = pooled; g.pool_ld = ldp; g.pool_arg = argmax; g.pool_lda = lda;
+    // 128-row tiles hold floor(128 / s) whole groups (125 of 128 rows at s = 25); small problems take 64-row tiles
+    const int64_t big_tiles = gs_ceil_div(g.M, (128 / s) * s) * gs_ceil_div(hidden, 128);
+    if (big_tiles >= 512) return launch_gemm<128, 128, true, false>(g, 1, (hipStream_t)stream);
+    return launch_gemm<64, 64, true, false>(g, 1, (hipStream_t)stream);
 }
 
 extern "C" int gs_sage_dense_fwd_cogather(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self,

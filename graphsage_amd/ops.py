@@ -325,6 +325,12 @@ def gemm(transA, transB, M, N, K, A, B, C, a_row_idx=None, bias=None, act=ACT_ID
 
 
 # ------------------------------------------------------------------------------------------ K4
+def dense_pool_max_fwd(X, idx, n, s, W, bias, pooled, argmax, stream=None):
+    """gs_dense_pool_max_fwd: pooled = max over each group's s rows of relu(X[idx] . W + bias), + arg-max."""
+    call("gs_dense_pool_max_fwd", X.ptr, X.ld, ptr(idx), X.d, n, s, W.ptr, W.ld, W.d, ptr(bias), pooled.ptr, pooled.ld,
+         ptr(argmax), argmax.stride(0), _s(stream))
+
+
 def segment_max_fwd(H, n, s, pooled, argmax, stream=None):
     call("gs_segment_max_fwd", H.ptr, H.ld, n, s, H.d, pooled.ptr, pooled.ld, ptr(argmax), argmax.stride(0),
          _s(stream))

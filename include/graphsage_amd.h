@@ -239,6 +239,14 @@ int gs_gemm_f32(int transA, int transB, int64_t M, int32_t N, int64_t K,
  * K4  pooling aggregators     replaces aggregators.py:176-181 (MaxPool) / :254-259 (MeanPool)
  * ------------------------------------------------------------------------------------------- */
 
+/* Pooling MLP + reduce_max in ONE launch (aggregators.py:176-181):
+ *   pooled[i, c] = max_j relu( X[idx[i*s + j]] . W[:, c] + bias[c] ),   argmax[i, c] = first j attaining it
+ * The [n*s, hidden] activations are never written: a GEMM tile holds whole groups of s rows (s <= 64) and reduces them
+ * in its epilogue.  Same results as gs_sage_dense_fwd(self = NULL) followed by gs_segment_max_fwd. */
+int gs_dense_pool_max_fwd(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_groups, int32_t s,
+                          const float* W, int64_t ldw, int32_t hidden, const float* bias, float* pooled, int64_t ldp,
+                          int32_t* argmax, int64_t lda, void* stream);
+
 /* H[n*s, hidden] = relu(X[idx] · W_mlp + b_mlp)  (Dense, layers.py:104-116) is produced by
  * gs_sage_dense_fwd(self=NULL, agg=X, agg_idx=idx, ...).  This reduces it:
  *   pooled[i, c] = max_j H[i*s+j, c];  argmax[i, c] = first j attaining it   (reduce_max, :181) */

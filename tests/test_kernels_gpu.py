@@ -305,6 +305,38 @@ def test_segment_max(dev):
     assert np.array_equal(dH.numpy(), want.reshape(n * s, hid))
 
 
+@pytest.mark.parametrize("n,s,d,hid,gathered", [(5120, 25, 602, 512, True), (512, 10, 602, 512, True), (203, 25, 50, 130, False),
+                                                 (37, 7, 33, 64, True), (3, 64, 20, 40, False), (1, 1, 9, 12, True)])
+def test_dense_pool_max_fwd(dev, n, s, d, hid, gathered):
+    """gs_dense_pool_max_fwd == gs_sage_dense_fwd(relu) + gs_segment_max_fwd (pooled values within GEMM tolerance, the
+    arg-max equal wherever the top two activations of a group are not a near tie), 128- and 64-row tile forms, groups that
+    do not divide the tile, ragged columns, last partial tile."""
+    rng = np.random.default_rng(n + s)
+    Nn = 3000
+    X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
+    idx = rng.integers(0, Nn + 1, size=n * s).astype(np.int32)
+    W, b = _asym(rng, (d, hid)) * 0.2, _asym(rng, (hid,)) * 0.1
+    Xd = Mat.from_numpy(X, dev, 32) if gathered else Mat.from_numpy(X[idx], dev)
+    idx_d = _i32(idx, dev) if gathered else None
+    Wd, bd = Mat.from_numpy(W, dev), torch.from_numpy(b).to(dev)
+    pooled, arg = Mat.zeros(n, hid, dev), torch.full((n, hid), -1, dtype=torch.int32, device=dev)
+    ops.dense_pool_max_fwd(Xd, idx_d, n, s, Wd, bd, pooled, arg)
+    _sync()
+    H = np.maximum(X[idx].astype(np.float64) @ W + b, 0).reshape(n, s, hid)
+    np.testing.assert_allclose(pooled.numpy(), H.max(axis=1), rtol=1e-4, atol=1e-4 * np.sqrt(d))
+    got = arg.cpu().numpy()
+    assert got.min() >= 0 and got.max() < s
+    # the device's choice attains the maximum (up to fp32 summation noise) ...
+    picked = np.take_along_axis(H, got[:, None, :].astype(np.int64), axis=1)[:, 0, :]
+    np.testing.assert_allclose(picked, H.max(axis=1), rtol=1e-4, atol=1e-4 * np.sqrt(d))
+    # ... and is the FIRST such row wherever the runner-up is clearly smaller (or everything is clamped to 0 -> row 0)
+    srt = np.sort(H, axis=1)
+    clear = (srt[:, -1, :] - (srt[:, -2, :] if s > 1 else -1.0)) > 1e-3
+    assert np.array_equal(got[clear], H.argmax(axis=1)[clear])
+    allzero = H.max(axis=1) == 0
+    assert not got[allzero].any()
+
+
 @pytest.mark.parametrize("n,s,d,hid,k", [(203, 25, 602, 512, 7), (37, 10, 50, 128, 5), (9, 3, 70, 100, 2),
                                           (64, 16, 33, 64, 3), (21, 25, 40, 1100, 2)])
 def test_maxpool_sparse_wgrad(dev, n, s, d, hid, k):
