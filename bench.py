@@ -83,8 +83,9 @@ def describe(args, F, s1, s2, B, world):
             args.nodes, F, args.classes, args.avg_degree, args.feat_signal)
         shape = "Reddit-shaped"
     fmt = ("%s, " + mode + " %s, fan-out %dx%d, batch %d "
-           "per GPU, dims %d/%d, full training step (sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, next-step "
-           "gather co-scheduled with the layer-0 contraction and the weight-gradient launch (horizontal fusion)")
+           "per GPU, dims %d/%d, full training step (sample+gather+fwd+bwd%s+clip+Adam), hipGraph replay, the next step's "
+           "gather+mean and the sampler of the step after ride as extra workgroups in the step's own launches "
+           "(layer-0 contraction / fused tail / weight gradients / optimizer: horizontal fusion)")
     workload = fmt % (graph, args.model, s1, s2, B, args.dim_1, args.dim_2, "+RCCL all-reduce" if world > 1 else "")
     metric = "sampled-edges/sec, %s %s %s fan-out %dx%d" % (shape, mode, args.model, s1, s2)
     return metric, workload
