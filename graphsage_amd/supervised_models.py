@@ -385,7 +385,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         per_root = 1
         for f in self.num_samples[:0:-1]:
             per_root *= f
-        ride = (self.sampler_rides and mode == "fused" and local_adam and fused and k > 1 and self._tail_ok()
+        ride = (self.sampler_rides and mode == "fused" and (local_adam or in_graph) and fused and k > 1 and self._tail_ok()
                 and self._fanout_fusable() and per_root <= 512)
 
         def body():
