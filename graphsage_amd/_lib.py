@@ -141,7 +141,7 @@ class TailDesc(ctypes.Structure):
                 ("dz", c_void_p), ("lddz", c_int64), ("d_h0", c_void_p), ("lddh", c_int64),
                 ("c0", c_void_p), ("d0", c_uint64), ("c1", c_void_p), ("d1", c_uint64), ("c2", c_void_p), ("d2", c_uint64),
                 ("s", c_int32), ("d_in", c_int32), ("out_dim", c_int32), ("C", c_int32), ("sigmoid", c_int32),
-                ("train", c_int32)]
+                ("train", c_int32), ("sync", c_void_p)]
 
 
 class FanoutDesc(ctypes.Structure):

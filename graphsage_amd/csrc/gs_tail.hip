@@ -43,6 +43,7 @@ struct TailArgs {
     float* d_h0; int64_t lddh;
     uint64_t* c0; uint64_t d0; uint64_t* c1; uint64_t d1; uint64_t* c2; uint64_t d2;
     int32_t train;
+    uint32_t* sync;       // [groups] arrival counters of the z helpers (zero outside the kernel)
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -60,6 +61,17 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //                      contraction                                                        -> ~200 VGPRs in flight
 // The relu mask of phase 8 is kept from S0 as bit flags, so h0 is read exactly once.  Barriers between phases are
 // LDS-only (fence on the "local" address space + s_barrier): they do not drain the outstanding global loads.
+#ifdef GS_TIMELINE
+// Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_tail.py): wall-clock stamp (100 MHz) per phase boundary.
+__device__ unsigned long long g_tail_timeline[64 * 16];
+extern "C" int gs_debug_tail_timeline(unsigned long long* out_host, int n) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_tail_timeline), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define TAIL_STAMP(k) do { if (threadIdx.x == 0 && grp < 64) g_tail_timeline[grp * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
@@ -79,14 +91,123 @@ __device__ __forceinline__ float tail_wave_max(float v) {
 
 #define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
 
+// z helper (see the role comment in sage_tail_kernel): z[16 rows of group g][64 columns part*64 ..] of
+//   z = [h_self . W_self | mean_j(h_neigh_j) . W_neigh]      (aggregators.py:48-58, concat, identity act)
+// 8 waves = 8 K-slices of the slab's term (a 64-column slab lies in ONE term: 64 divides O), partial 16 x 64 tiles
+// summed in wave order through LDS, then published: stores -> device-scope release fence -> arrival counter.
+// The helper whose slab starts the neighbor term also writes the neighbor means (an input of the weight gradients).
+template <int D, int O>
+__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part) {
+    constexpr int ldh = D + 4;
+    constexpr int D4 = D / 4;
+    constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
+    constexpr int KW = D / 4 / TAIL_WAVES;                       // k-steps (4 k each) per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                                             // [16][ldh]  the term's A rows
+    float* Pz = lds + TAIL_ROWS * ldh;                           // [8 waves][16][64] partial tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int r0 = g * TAIL_ROWS, n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
+    const int col_base = part * 64;
+    const int term = col_base >= O ? 1 : 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // this wave's weight slice: rows 4 (wave KW + u) + q, columns col_base + 32 t + 2 j (+1)
+    const int ldw = (int)(term ? a.ldwn : a.ldws);
+    const float* Wp = (term ? a.Wn : a.Ws) + (4 * wave * KW + q) * ldw + (col_base - term * O) + 2 * j;
+    f32x2 bz[2][KW];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < KW; ++u) bz[t][u] = *reinterpret_cast<const f32x2*>(Wp + (4 * u) * ldw + 32 * t);
+    const float inv_s = 1.0f / (float)s;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it / D4, c = (it % D4) * 4;
+        const bool valid = r0 + r < n;
+        const int i = min(r0 + r, n - 1);
+        f32x4 v;
+        if (!term) {
+            v = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
+        } else {
+            const float* nb = a.h0 + (n + i * s) * ldh0 + c;
+            f32x4 hv[TAIL_NB];
+#pragma unroll
+            for (int u = 0; u < TAIL_NB; ++u) hv[u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
+            v = zero4;
+#pragma unroll
+            for (int u = 0; u < TAIL_NB; ++u)
+                if (u < s) v += hv[u];                               // summation order j = 0..s-1, as gather_mean_wave
+            v *= inv_s;
+            if (valid && col_base == O) *reinterpret_cast<f32x4*>(a.means + (r0 + r) * (int)a.ldm + c) = v;
+        }
+        *reinterpret_cast<f32x4*>(As + r * ldh + c) = valid ? v : zero4;
+    }
+    lds_barrier();
+    {
+        const float* A = As + j * ldh + 4 * wave * KW + q;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+            for (int u = 0; u < KW; ++u) {
+                const float av = A[4 * u];
+                acc0 = mfma16(av, bz[t][u].x, acc0);
+                acc1 = mfma16(av, bz[t][u].y, acc1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f32x2*>(Pz + (wave * TAIL_ROWS + 4 * q + i) * 64 + 32 * t + 2 * j) = f32x2{acc0[i], acc1[i]};
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int p = 0; p < TAIL_ROWS * 32 / TAIL_THREADS; ++p) {     // (row, column pair) items: 16 x 32
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it >> 5, c2 = (it & 31) * 2;
+        f32x2 v = *reinterpret_cast<const f32x2*>(Pz + r * 64 + c2);
+#pragma unroll
+        for (int w = 1; w < TAIL_WAVES; ++w) v += *reinterpret_cast<const f32x2*>(Pz + (w * TAIL_ROWS + r) * 64 + c2);
+        // published with device-scope (write-through) stores: a release FENCE would write back the XCD's whole L2,
+        // dirty gather output of the riders included (measured: z arrived 17 us late)
+        if (r0 + r < n) {
+            union { f32x2 f; unsigned long long u; } cv;
+            cv.f = v;
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.z + (r0 + r) * (int)a.ldz + col_base + c2), cv.u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores are acknowledged ...
+    __syncthreads();                                             // ... and everybody else's
+    if (tid == 0) __hip_atomic_fetch_add(a.sync + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int D, int O>
 __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
     // Co-scheduled gather: the tail occupies n/16 CUs for ~30 us of mostly waiting; the other ~220 CUs (one 8-wave
     // workgroup each: the launch's LDS size is uniform) stream a share of the NEXT step's gather+mean from HBM meanwhile.
-    if ((int)blockIdx.x >= tail_blocks) {
-        run_gather_item<13>(J, ((int64_t)blockIdx.x - tail_blocks) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+    // Roles by block index: [0, HP G) z HELPERS, [HP G, (HP + 1) G) the G = n/16 MAIN workgroups, then gather riders.
+    // The layer-1 contraction z = [h_self . W_self | mean(h_neigh) . W_neigh] is MFMA-bound when only the G = 32 main
+    // workgroups (32 CUs, 128 SIMDs) compute it (7.8 us of matrix-pipe time, plus 7 us to pull its operands through
+    // 32 L2->CU ports); HP = Z / 64 helper workgroups per group compute a 16 x 64 slab of it each on their own CUs
+    // (K split over the 8 waves, fixed-order sum), publish it to global memory and leave; the main workgroup meanwhile
+    // prefetches every later phase's operands and then picks z up.  Helpers never wait for anything and have the lower
+    // block indices (dispatched first), so a waiting main workgroup never keeps a helper off the chip for good; all
+    // (HP + 1) G workgroups are resident at once for n <= 816 (one 8-wave workgroup per CU).
+    constexpr int HP = 2 * O / 64;
+    const int G = tail_blocks;
+    if ((int)blockIdx.x >= (HP + 1) * G) {
+        // (a rider wave walking 4 consecutive items with prefetched ids, and 25 loads in flight per lane, were measured:
+        // 46 us / no change against 35 us -- with one 8-wave workgroup per CU the riders stream at ~4.6 TB/s either way)
+        run_gather_item<13>(J, ((int64_t)blockIdx.x - (HP + 1) * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
+    if ((int)blockIdx.x < HP * G) {
+        tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP);
+        return;
+    }
+    const int grp = (int)blockIdx.x - HP * G;
+    TAIL_STAMP(0);
     constexpr int Z = 2 * O;
     constexpr int ldh = D + 4, ldzs = Z + 4;
     constexpr int D4 = D / 4;
@@ -114,7 +235,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int r0 = (int)blockIdx.x * TAIL_ROWS;       // (n + n*s) * ld < 2^31 is checked on the host: 32-bit offsets
+    const int r0 = grp * TAIL_ROWS;                   // (n + n*s) * ld < 2^31 is checked on the host: 32-bit offsets
     const int n = (int)a.n;
     const int s = a.s;
     const int ldh0 = (int)a.ldh;
@@ -133,29 +254,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
 #pragma unroll
         for (int u = 0; u < TAIL_NB; ++u) hnb[p][u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
     }
-    // the z-contraction weight slab of this wave: a quarter of K now, the rest once phase 0 has freed registers
-    constexpr int KZA = KZ / 4, KZB = KZ - KZA;
-    f32x2 bzA[KZA], bzB[KZB];
-    const int zcol0 = (wave < ZSLABS ? wave : 0) * 32;
-    const int zterm = zcol0 >= O ? 1 : 0;
-    const int zldb4 = 4 * (int)(zterm ? a.ldwn : a.ldws);
-    const float* zB = (zterm ? a.Wn : a.Ws) + q * (zldb4 >> 2) + (zcol0 - zterm * O) + 2 * j;
-#pragma unroll
-    for (int u = 0; u < KZA; ++u) bzA[u] = *reinterpret_cast<const f32x2*>(zB + u * zldb4);
-
-    // ---------------- phase 0: self rows -> LDS; neighbor means (aggregators.py:48) -> LDS + global; relu mask bits
+    // ---------------- phase 0: the relu mask bits of this thread's h0 rows (for phase 8); the rows themselves are only
+    // needed by the z helpers
     uint32_t mself[PASSES], mnb[PASSES][2];            // 4 bits per row: h > 0 of the float4's elements
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-        const int it = tid + p * TAIL_THREADS;
-        const int r = it / D4, c = (it % D4) * 4;
-        const bool valid = r0 + r < n;
-        f32x4 acc = zero4;
         mnb[p][0] = mnb[p][1] = 0u;
 #pragma unroll
         for (int u = 0; u < TAIL_NB; ++u) {
             const f32x4 v = hnb[p][u];
-            if (u < s) acc += v;                                     // summation order j = 0..s-1, as gather_mean_wave
             const uint32_t bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
             mnb[p][u >> 3] |= bits << (4 * (u & 7));
         }
@@ -163,43 +270,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         mself[p] = (hs.x > 0.f ? 1u : 0u) | (hs.y > 0.f ? 2u : 0u) | (hs.z > 0.f ? 4u : 0u) | (hs.w > 0.f ? 8u : 0u);
         // pin the flags here: otherwise the compiler keeps the 12 float4 rows alive until phase 8 and re-derives them
         asm volatile("" : "+v"(mself[p]), "+v"(mnb[p][0]), "+v"(mnb[p][1]));
-        acc = valid ? acc * inv_s : zero4;
-        if (valid) *reinterpret_cast<f32x4*>(a.means + (r0 + r) * (int)a.ldm + c) = acc;
-        *reinterpret_cast<f32x4*>(Hs + r * ldh + c) = valid ? hs : zero4;
-        *reinterpret_cast<f32x4*>(Ms + r * ldh + c) = acc;
     }
-#pragma unroll
-    for (int u = 0; u < KZB; ++u) bzB[u] = *reinterpret_cast<const f32x2*>(zB + (KZA + u) * zldb4);
-    lds_barrier();
+    TAIL_STAMP(1);
 
-    // ---------------- phase 1: z = [self . W_self | means . W_neigh]   (concat, identity act: last layer)
-    if (wave < ZSLABS) {
-        const int col0 = wave * 32;
-        const float* A = (col0 >= O ? Ms : Hs) + j * ldh + q;
-        f32x4 acc0 = zero4, acc1 = zero4;
-#pragma unroll
-        for (int u = 0; u < KZA; ++u) {
-            const float av = A[4 * u];
-            acc0 = mfma16(av, bzA[u].x, acc0);
-            acc1 = mfma16(av, bzA[u].y, acc1);
-        }
-#pragma unroll
-        for (int u = 0; u < KZB; ++u) {
-            const float av = A[4 * (KZA + u)];
-            acc0 = mfma16(av, bzB[u].x, acc0);
-            acc1 = mfma16(av, bzB[u].y, acc1);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * q + i;
-            const f32x2 v = {acc0[i], acc1[i]};
-            *reinterpret_cast<f32x2*>(Zs + row * ldzs + col0 + 2 * j) = v;
-            if (r0 + row < n) *reinterpret_cast<f32x2*>(a.z + (r0 + row) * (int)a.ldz + col0 + 2 * j) = v;
-        }
-    }
-
-    __builtin_amdgcn_sched_barrier(0);     // keep the S1 loads below the z MFMAs: hoisted, they would spill (256 VGPRs)
-    // ================= S1: issue the operands of every later phase (they land while phases 2..6 run)
+    // ================= S1: issue the operands of every later phase (they land while the helpers compute z)
     // phase 3 (logits, NN form): column slab g3, K-slice ks3 of Z/4 k
     const int g3 = wave % lslabs, ks3 = wave / lslabs;
     f32x2 bl[KL];
@@ -216,7 +290,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     float lab2[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) lab2[rr] = a.labels[min(r0 + wave * 2 + rr, n - 1) * (int)a.ldlab + cl];
-    // phase 7 ([d_self | d_means], NT form): DPW slabs of 32 weight rows, K = O; slab 0 now, slab 1 after phase 3
+    // phase 7 ([d_self | d_means], NT form): DPW slabs of 32 weight rows, K = O
     f32x4 b7[DPW][M7][2];
     auto load_b7 = [&](const int sl) {
         const int col0 = (wave + sl * TAIL_WAVES) * 32;          // in [0, 2D)
@@ -230,7 +304,43 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     };
     load_b7(0);
+    // phase 5 (d_y, NT form): rows n0 .. n0+31 of W_head, K = Cp32 <= 64 -> up to 4 macro steps x 2 tiles
+    f32x4 bh5[4][2];
+    {
+        const int ldw = (int)a.ldwh;
+        const int n0 = (wave < ZSLABS ? wave : 0) * 32;
+        const float* B0 = a.Wh + (n0 + j) * ldw;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int kq = min(16 * m + 4 * q, Cp4 - 4);     // clamped: dlogits are zero beyond C
+            bh5[m][0] = *reinterpret_cast<const f32x4*>(B0 + kq);
+            bh5[m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + kq);
+        }
+    }
+    if (DPW > 1) load_b7(DPW - 1);
+    TAIL_STAMP(2);
+
+    // ---------------- phase 1: pick up z from the helpers
+    if (tid == 0) {
+        while (__hip_atomic_load(a.sync + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)HP) __builtin_amdgcn_s_sleep(2);
+        __hip_atomic_store(a.sync + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    {
+        // device-scope loads (they bypass this XCD's possibly stale L2 lines of z; no cache invalidation needed)
+        constexpr int Z2 = (2 * O) / 2;
+#pragma unroll
+        for (int p = 0; p < TAIL_ROWS * Z2 / TAIL_THREADS; ++p) {
+            const int it = tid + p * TAIL_THREADS;
+            const int r = it / Z2, c = (it % Z2) * 2;
+            union { f32x2 f; unsigned long long u; } cv;
+            cv.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.z + min(r0 + r, n - 1) * (int)a.ldz + c),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<f32x2*>(Zs + r * (2 * O + 4) + c) = cv.f;
+        }
+    }
     lds_barrier();
+    TAIL_STAMP(3);
 
     // ---------------- phase 2: y = l2_normalize(z)   (supervised_models.py:85); two rows per wave
 #pragma unroll
@@ -254,6 +364,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         if (lane == 0) invs[row] = inv;
     }
     lds_barrier();
+    TAIL_STAMP(4);
 
     // ---------------- phase 3: logits partials: slab g, K-slice ks per wave (fixed-order sum in phase 4)
     {
@@ -269,21 +380,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<f32x2*>(Ps + (ks3 * TAIL_ROWS + 4 * q + i) * GC + g3 * 32 + 2 * j) = f32x2{acc0[i], acc1[i]};
     }
-    // phase 5 (d_y, NT form): rows n0 .. n0+31 of W_head, K = Cp32 <= 64 -> up to 4 macro steps x 2 tiles
-    f32x4 bh5[4][2];
-    {
-        const int ldw = (int)a.ldwh;
-        const int n0 = (wave < ZSLABS ? wave : 0) * 32;
-        const float* B0 = a.Wh + (n0 + j) * ldw;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int kq = min(16 * m + 4 * q, Cp4 - 4);     // clamped: dlogits are zero beyond C
-            bh5[m][0] = *reinterpret_cast<const f32x4*>(B0 + kq);
-            bh5[m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + kq);
-        }
-    }
-    if (DPW > 1) load_b7(DPW - 1);
     lds_barrier();
+    TAIL_STAMP(5);
 
     const float inv_n = 1.0f / (float)n, inv_c = 1.0f / (float)C, inv_nc = inv_n * inv_c;
     // ---------------- phase 4: logits, loss rows, preds, dlogits   (supervised_models.py:111-126); two rows per wave,
@@ -326,7 +424,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         if (valid && lane == 0) a.loss_rows[i] = loss;
     }
     if (!a.train) {
-        if (blockIdx.x == 0 && tid == 0) {
+        if (grp == 0 && tid == 0) {
             if (a.c0) *a.c0 += a.d0;
             if (a.c1) *a.c1 += a.d1;
             if (a.c2) *a.c2 += a.d2;
@@ -334,6 +432,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         return;
     }
     lds_barrier();
+    TAIL_STAMP(6);
 
     // ---------------- phase 5: d_y = dlogits . W_head^T   -> DY (aliases the logits partials)
     float* DYs = Ps;
@@ -359,6 +458,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     }
     lds_barrier();
+    TAIL_STAMP(7);
 
     // ---------------- phase 6: d_z = l2_normalize'(d_y)   (two rows per wave)
 #pragma unroll
@@ -383,6 +483,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     }
     lds_barrier();
+    TAIL_STAMP(8);
 
     // ---------------- phase 7: [d_self | d_means] = [d_z[:, :O] . W_self^T | d_z[:, O:] . W_neigh^T]  -> DIN
     float* DIN = Hs;                                   // [16][2D + 8]   (Hs | Ms are dead since phase 1)
@@ -408,6 +509,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     }
     lds_barrier();
+    TAIL_STAMP(9);
 
     // ---------------- phase 8: d_h0 = relu'(h0) * (d_self on the self row, d_means / s on each of the s neighbor rows);
     // the relu masks are the bit flags kept from phase 0 (h0 is read once).
@@ -442,7 +544,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
             }
         }
     }
-    if (blockIdx.x == 0 && tid == 0) {                // device counters (sampler clock / epoch cursor / optimizer step)
+    TAIL_STAMP(10);
+    if (grp == 0 && tid == 0) {                       // device counters (sampler clock / epoch cursor / optimizer step)
         if (a.c0) *a.c0 += a.d0;
         if (a.c1) *a.c1 += a.d1;
         if (a.c2) *a.c2 += a.d2;
@@ -471,8 +574,8 @@ static int launch_tail(const TailArgs& a, const CoGatherS& J, int64_t gather_wav
         GS_HIP(hipFuncSetAttribute((const void*)sage_tail_kernel<D, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);
-    const int64_t blocks = tail_blocks + gs_ceil_div(gather_waves, TAIL_WAVES);
+    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + 1 main workgroup each
+    const int64_t blocks = (int64_t)tail_blocks * (2 * O / 64 + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_fwd_bwd: grid too large");
     hipLaunchKernelGGL((sage_tail_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
     GS_LAUNCH_CHECK("sage_tail_kernel");
@@ -522,6 +625,8 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     a.loss_rows = q->loss_rows; a.dz = q->dz; a.lddz = q->lddz; a.d_h0 = q->d_h0; a.lddh = q->lddh;
     a.c0 = q->c0; a.d0 = q->d0; a.c1 = q->c1; a.d1 = q->d1; a.c2 = q->c2; a.d2 = q->d2;
     a.train = q->train ? 1 : 0;
+    GS_REQUIRE(q->sync, "gs_sage_tail_fwd_bwd: sync (ceil(n / 16) zero-initialised uint32 counters) missing");
+    a.sync = q->sync;
     hipStream_t st = (hipStream_t)stream;
     CoGatherS J = {};
     int64_t gw = 0;

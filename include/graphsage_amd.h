@@ -423,6 +423,8 @@ typedef struct gs_tail_desc {
     uint64_t* c1; uint64_t d1;
     uint64_t* c2; uint64_t d2;
     int32_t s, d_in, out_dim, C, sigmoid, train;
+    uint32_t* sync;        /* [ceil(n / 16)] device counters, zero on entry and left zero (in-kernel hand-over of the layer-1
+                              pre-activations from the helper workgroups to the row-group workgroups) */
 } gs_tail_desc;
 int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
 /* jobs_host / n_jobs (0..6): gather+mean jobs of the NEXT step co-scheduled in the launch (as gs_sage_dense_fwd_cogather):

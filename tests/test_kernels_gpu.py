@@ -726,7 +726,8 @@ def test_sage_dense_cogather_equals_separate_calls(dev):
 
 @pytest.mark.parametrize("n,s,D,O,C,sig,train", [(512, 10, 256, 128, 41, False, True), (37, 3, 128, 64, 7, True, True),
                                                  (100, 10, 256, 64, 33, True, True), (48, 5, 128, 128, 64, False, True),
-                                                 (33, 4, 256, 128, 41, False, False)])
+                                                 (33, 4, 256, 128, 41, False, False),
+                                                 (3000, 10, 256, 128, 41, False, True)])     # 940 workgroups > 256 CUs
 def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
     """gs_sage_tail_fwd_bwd (layer 1 + l2_normalize + head + loss + every input gradient, ONE launch) vs the oracle's
     MeanAggregator / head restatements (aggregators.py:43-64, supervised_models.py:85-126) in fp64; ragged n, both
