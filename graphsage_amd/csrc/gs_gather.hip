@@ -8,6 +8,8 @@
 // >= 32 waves per CU), the [n*s, d] gathered tensor of models.py:299 never exists.
 // Summation order is j = 0..s-1, fixed => results are deterministic run to run.
 #include "gs_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include "gs_gather_dev.h"
 
 template <int U, bool DROP = false>
@@ -35,6 +37,23 @@ static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, i
         else
             hipLaunchKernelGGL((gather_mean_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         GS_LAUNCH_CHECK("gather_mean_kernel<dropout>");
+        return GS_OK;
+    }
+    // diagnostics (benchmarks/probe_gather_occupancy.py): GS_GATHER_PROBE="U,lds_bytes" picks the loads in flight per lane
+    // and pads the launch with dynamic LDS to cap the resident waves per CU
+    static const char* probe = getenv("GS_GATHER_PROBE");
+    if (probe && s >= 8) {
+        int pu = 8, pl = 0;
+        sscanf(probe, "%d,%d", &pu, &pl);
+        if (pl > 64 * 1024) {
+            GS_HIP(hipFuncSetAttribute((const void*)gather_mean_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GS_HIP(hipFuncSetAttribute((const void*)gather_mean_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GS_HIP(hipFuncSetAttribute((const void*)gather_mean_kernel<25>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        if (pu >= 25) hipLaunchKernelGGL(gather_mean_kernel<25>, dim3((unsigned)blocks), dim3(256), (size_t)pl, st, a);
+        else if (pu >= 13) hipLaunchKernelGGL(gather_mean_kernel<13>, dim3((unsigned)blocks), dim3(256), (size_t)pl, st, a);
+        else hipLaunchKernelGGL(gather_mean_kernel<8>, dim3((unsigned)blocks), dim3(256), (size_t)pl, st, a);
+        GS_LAUNCH_CHECK("gather_mean_kernel<probe>");
         return GS_OK;
     }
     if (s >= 8)

@@ -200,11 +200,12 @@ __device__ __forceinline__ void stream_fwd_tile(const FwdArgs& g, const int tile
     GS_STAMP(3);
 }
 
+template <int P>
 __global__ __launch_bounds__(256) void sage_stream_fwd_kernel(const FwdArgs g, const CoGatherS J) {
     __shared__ float red[4][32][64];                       // split-K partial tiles of the workgroup's four waves
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: SGPR fields
     if ((int)blockIdx.x < g.n_tiles) {
-        stream_fwd_tile<4>(g, stream_xcd_swizzle(blockIdx.x, g.n_tiles), wave, lane, red);
+        stream_fwd_tile<P>(g, stream_xcd_swizzle(blockIdx.x, g.n_tiles), wave, lane, red);
         return;
     }
     run_gather_item(J, ((int64_t)blockIdx.x - g.n_tiles) * 4 + wave, lane);
@@ -454,7 +455,10 @@ extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, cons
     if (rc != GS_OK) return rc;
     const int64_t blocks = g.n_tiles + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_dense_fwd_stream: grid too large");
-    hipLaunchKernelGGL(sage_stream_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
+    static const int ring = getenv("GS_STREAM_FWD_P") ? atoi(getenv("GS_STREAM_FWD_P")) : 4;   // tuning hook
+    if (ring >= 8) hipLaunchKernelGGL(sage_stream_fwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
+    else if (ring >= 6) hipLaunchKernelGGL(sage_stream_fwd_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
+    else hipLaunchKernelGGL(sage_stream_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
     GS_LAUNCH_CHECK("sage_stream_fwd_kernel");
     return GS_OK;
 }
