@@ -76,14 +76,21 @@ class NativeAllReduce(object):
         self.world_size, self.rank = int(world_size), int(rank)
         nbytes = 128
         buf = (ctypes.c_uint8 * nbytes)()
+        id_error = None
         if self.rank == 0:
-            ops.call("gs_comm_unique_id", ctypes.addressof(buf), nbytes)
+            try:
+                ops.call("gs_comm_unique_id", ctypes.addressof(buf), nbytes)
+            except Exception as ex:      # still take part in the broadcast below (an all-zero id): the other ranks must not hang
+                id_error = ex
+                buf = (ctypes.c_uint8 * nbytes)()
         if self.world_size > 1:
             dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
             t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=0)
             raw = bytes(t.cpu().tolist())
             buf = (ctypes.c_uint8 * nbytes)(*raw)
+        if id_error is not None or not any(bytes(buf)):
+            raise RuntimeError("RCCL unique id unavailable on rank 0: %r" % (id_error,))
         h = ctypes.c_void_p()
         torch.cuda.set_device(engine.device)
         ops.call("gs_comm_init_rank", ctypes.byref(h), self.world_size, self.rank, ctypes.addressof(buf), nbytes)
