@@ -115,14 +115,19 @@ __device__ __forceinline__ void stream_fwd_tile(const FwdArgs& g, const int tile
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
     f32x4 a[P];
     f32x2 b[P][4];
+    // `left`: pointer advances still allowed -- a refill past the wave's last macro step re-reads the last one (always a
+    // valid address; the value is never consumed), so the pipeline needs no one-at-a-time remainder.
+    int left = me - mb - 1;
     auto load_stage = [&](const int st) {
         a[st] = *reinterpret_cast<const f32x4*>(ap);
-        ap += 8;
         b[st][0] = *reinterpret_cast<const f32x2*>(W0 + wo);
         b[st][1] = *reinterpret_cast<const f32x2*>(W1 + wo);
         b[st][2] = *reinterpret_cast<const f32x2*>(W2 + wo);
         b[st][3] = *reinterpret_cast<const f32x2*>(W3 + wo);
-        wo += wstride;
+        const int adv = left > 0 ? 1 : 0;                  // wave-uniform
+        ap += 8 * adv;
+        wo += wstride * (uint32_t)adv;
+        --left;
     };
     auto compute_stage = [&](const int st) {
 #pragma unroll
@@ -132,15 +137,18 @@ __device__ __forceinline__ void stream_fwd_tile(const FwdArgs& g, const int tile
         }
     };
     // branch-free steady state: stages m .. m+P-1 are in flight on entry; each is consumed and refilled with m+st+P.
-    // (A ring of 32-k super stages -- a lane's four 16-byte A pieces of a 128-byte line loaded back to back -- measured
-    // SLOWER: 36.5 vs 24.3 us alone.)
-    int m = mb;
-    if (me - mb >= P) {
+    // The last (possibly partial) group is consumed under wave-uniform guards -- no loads there.  (A first version ran
+    // the count % P leftover macro steps one at a time, each with its whole load latency exposed: 2-3 round trips of the
+    // 8.8 us a quarter-K wave took.  Also measured and dropped: a ring of 32-k super stages that consumes whole 128-byte
+    // A lines back to back, 36.5 vs 24.3 us; ring depths 6 and 8, 28 us.)
+    const int cnt = me - mb;
+    if (cnt > 0) {
 #pragma unroll
         for (int st = 0; st < P; ++st) load_stage(st);
         GS_STAMP(1);
+        int m = 0;
 #pragma unroll 1
-        for (; m + 2 * P <= me; m += P) {
+        for (; m + P < cnt; m += P) {
 #pragma unroll
             for (int st = 0; st < P; ++st) {
                 compute_stage(st);
@@ -149,13 +157,8 @@ __device__ __forceinline__ void stream_fwd_tile(const FwdArgs& g, const int tile
             }
         }
 #pragma unroll
-        for (int st = 0; st < P; ++st) compute_stage(st);
-        m += P;
-    }
-#pragma unroll 1
-    for (; m < me; ++m) {                                  // < P leftover macro steps: one at a time
-        load_stage(0);
-        compute_stage(0);
+        for (int st = 0; st < P; ++st)
+            if (m + st < cnt) compute_stage(st);
     }
     if (wave == 3 && (K & 7) != 0) {
         // tail macro step: k = 8*nfull + 4*lh + e; elements with k >= K are zeroed on the A side, B rows are clamped
