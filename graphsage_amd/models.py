@@ -357,10 +357,13 @@ class SampleAndAggregate(object):
             return
         done = 0
         while done < steps:
-            # k-step graphs always start at buffer parity 0 (one captured graph); single steps realign the parity
-            if self._primed == B and self._pipe_parity == 0 and steps - done >= k:
-                self._pipelined_steps_unsup(B, k)
-                done += k
+            # multi-step graphs always start at buffer parity 0 (one captured graph per length); single steps realign the
+            # parity; a shorter tail takes the largest even length that fits
+            rem = steps - done
+            kk = min(k, rem - (rem % 2))
+            if self._primed == B and self._pipe_parity == 0 and kk >= 2:
+                self._pipelined_steps_unsup(B, kk)
+                done += kk
             else:
                 self._pipelined_steps_unsup(B, 1)
                 done += 1

@@ -443,10 +443,14 @@ class SupervisedGraphsage(SampleAndAggregate):
         done = 0
         data = self._data_fn(n)
         while done < steps:
-            # k-step graphs always start at buffer parity 0 (one captured graph); single steps realign the parity
-            if self._primed == n and self._pipe_parity == 0 and steps - done >= k:
-                self._pipelined_steps(n, k, data, fused)
-                done += k
+            # multi-step graphs always start at buffer parity 0 (one captured graph per length); single steps realign the
+            # parity.  A shorter tail (the drivers replay print_every - 1 steps between two printed iterations) takes the
+            # largest even length that fits, so it still is one launch with the sampler riding in the optimizer launches.
+            rem = steps - done
+            kk = min(k, rem - (rem % 2))
+            if self._primed == n and self._pipe_parity == 0 and kk >= 2:
+                self._pipelined_steps(n, kk, data, fused)
+                done += kk
             else:
                 self.train_step_device(n)
                 done += 1
