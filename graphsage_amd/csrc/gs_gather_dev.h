@@ -109,13 +109,18 @@ struct CoGatherS {
 
 // U: independent 16-byte loads a wave keeps in flight.  8 suits launches whose gather waves reach >= 12 per CU; hosts
 // that give a gather wave a large register budget but few wave slots (the tail launch: 8 waves per CU) use 13.
-template <int U = 8>
+// UBIG: loads in flight for jobs with s >= UBIG rows per group.  A wave sums its rows batch by batch (U loads, wait, add),
+// so an item is 1 + ceil(s / U) dependent memory round trips: ~10 us for s = 25 at U = 8, which only matters where the
+// host launch is shorter than that (the 9 us optimizer launch: UBIG = 25 makes the item 2 round trips).
+template <int U = 8, int UBIG = U>
 __device__ __forceinline__ void run_gather_item(const CoGatherS& J, const int64_t w, const int lane) {
     if (w >= J.wave_start[J.n]) return;  // wave-uniform
     int k = 0;
     while (k + 1 < J.n && w >= J.wave_start[k + 1]) ++k;
     const GatherArgs& a = J.job[k];
-    if (a.s >= 8)
+    if (UBIG != U && a.s >= UBIG)
+        gather_mean_wave<UBIG>(a, w - J.wave_start[k], lane);
+    else if (a.s >= 8)
         gather_mean_wave<U>(a, w - J.wave_start[k], lane);
     else
         gather_mean_wave<1>(a, w - J.wave_start[k], lane);

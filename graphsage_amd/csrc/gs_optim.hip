@@ -4,6 +4,8 @@
 #include "gs_sample_dev.h"
 #include "gs_gather_dev.h"
 
+#define GS_OPT_THREADS 256   // workgroup size of the fused reduce + Adam launch (and of its sampler / gather riders)
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int32_t n_slabs,
                                                            int64_t slab_stride, int32_t rows, int32_t cols,
                                                            int64_t ld_slab, float wd, const float* __restrict__ w,
@@ -151,7 +153,7 @@ struct FlatVars {
     int32_t n;
 };
 
-__global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, float* __restrict__ params,
+__global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const FlatVars V, float* __restrict__ params,
                                                                float* __restrict__ grads, float* __restrict__ m,
                                                                float* __restrict__ v, int64_t total4, float wd,
                                                                int fuse_adam, float lr, float b1, float b2, float eps,
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
     if ((int)blockIdx.x >= opt_blocks) {
         const int64_t r = (int64_t)blockIdx.x - opt_blocks;
         if (r < F.B) sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, lvl);
-        else run_gather_item(J, r - F.B, threadIdx.x);     // ... and gather+mean waves of the next mini-batch (one per block)
+        else run_gather_item<8, 25>(J, (r - F.B) * (GS_OPT_THREADS / 64) + (threadIdx.x >> 6), threadIdx.x & 63);   // ... and gather+mean waves of the next mini-batch
         return;
     }
     float lr_t = 0.f;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64) void flat_reduce_adam_kernel(const FlatVars V, 
         const float t = (float)((step_dev ? *step_dev : 0ull) + (uint64_t)step_offset);
         lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
     }
-    if (loss_rows && blockIdx.x == 0) {
+    if (loss_rows && blockIdx.x == 0 && threadIdx.x < 64) {
         // the step's scalar loss (supervised_models.py:111-118 reduce_mean): one wave, fixed order
         float sacc = 0.f;
         for (int64_t i = threadIdx.x; i < loss_n; i += 64) sacc += loss_rows[i];
@@ -260,7 +262,7 @@ static int flat_reduce_adam_impl(const gs_var_desc* vars_host, int32_t n_vars, f
     }
     GS_REQUIRE(expect <= total, "gs_flat_reduce_adam: variables exceed the flat buffer");
     const int64_t total4 = expect / 4;
-    int blocks = (int)std::min<int64_t>(gs_ceil_div(total4, 64), 4096);
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total4, GS_OPT_THREADS), 4096);
     FanoutArgs F = {};
     int64_t roots = 0;
     if (sampler) { F = *sampler; roots = F.B; }
@@ -268,8 +270,9 @@ static int flat_reduce_adam_impl(const gs_var_desc* vars_host, int32_t n_vars, f
     int64_t waves = 0;
     int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
     if (rc != GS_OK) return rc;
-    GS_REQUIRE(blocks + roots + waves < (1ll << 31), "gs_flat_reduce_adam: grid too large");
-    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3((unsigned)(blocks + roots + waves)), dim3(64), 0, (hipStream_t)stream, V,
+    const int64_t rider_blocks = gs_ceil_div(waves, GS_OPT_THREADS / 64);
+    GS_REQUIRE(blocks + roots + rider_blocks < (1ll << 31), "gs_flat_reduce_adam: grid too large");
+    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3((unsigned)(blocks + roots + rider_blocks)), dim3(GS_OPT_THREADS), 0, (hipStream_t)stream, V,
                        params, grads, m, v, total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev,
                        step_offset, loss_rows, loss_n, loss_scale, loss_out, loss_accumulate, blocks, F, J);
     GS_LAUNCH_CHECK("flat_reduce_adam_kernel");
