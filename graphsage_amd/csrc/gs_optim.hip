@@ -6,21 +6,45 @@
 
 #define GS_OPT_THREADS 256   // workgroup size of the fused reduce + Adam launch (and of its sampler / gather riders)
 
+// 32 consecutive outputs x 8 slab groups per workgroup: thread (o, g) sums the slabs z = g, g + 8, ... with 16
+// independent loads in flight (one memory round trip for 128 slabs), the 8 partials are added in group order through
+// LDS.  Fixed order => deterministic.  (One thread per output walking all slabs in turn took 32 us for the 128 slabs of
+// the link-prediction negatives' gradient.)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int32_t n_slabs,
                                                            int64_t slab_stride, int32_t rows, int32_t cols,
                                                            int64_t ld_slab, float wd, const float* __restrict__ w,
                                                            int64_t ldw, float* __restrict__ grad, int64_t ldg,
                                                            int accumulate) {
+    __shared__ float part[8][32];
     const int64_t total = (int64_t)rows * cols;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(t / cols);
-        const int c = (int)(t - (int64_t)r * cols);
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (int64_t base = (int64_t)blockIdx.x * 32; base < total; base += (int64_t)gridDim.x * 32) {
+        const int64_t t = base + o;
+        const bool valid = t < total;
+        const int64_t tc = valid ? t : total - 1;
+        const int r = (int)(tc / cols);
+        const int c = (int)(tc - (int64_t)r * cols);
         const float* p = slabs + (int64_t)r * ld_slab + c;
         float s = 0.f;
-        for (int z = 0; z < n_slabs; ++z) s += p[(int64_t)z * slab_stride];
-        if (w && wd != 0.f) s += wd * w[(int64_t)r * ldw + c];
-        float* dst = grad + (int64_t)r * ldg + c;
-        *dst = accumulate ? *dst + s : s;
+        for (int z0 = g; z0 < n_slabs; z0 += 8 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)min(z0 + 8 * u, n_slabs - 1) * slab_stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z0 + 8 * u < n_slabs) s += v[u];
+        }
+        part[g][o] = s;
+        __syncthreads();
+        if (g == 0 && valid) {
+            float acc = part[0][o];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) acc += part[k][o];
+            if (w && wd != 0.f) acc += wd * w[(int64_t)r * ldw + c];
+            float* dst = grad + (int64_t)r * ldg + c;
+            *dst = accumulate ? *dst + acc : acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -29,7 +53,7 @@ extern "C" int gs_reduce_slabs(const float* slabs, int32_t n_slabs, int64_t slab
                                int64_t ldg, int accumulate, void* stream) {
     GS_REQUIRE(slabs && grad && n_slabs > 0 && rows > 0 && cols > 0, "gs_reduce_slabs: bad args");
     const int64_t total = (int64_t)rows * cols;
-    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 2048);
+    int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 32), 4096);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, slab_stride,
                        rows, cols, ld_slab, weight_decay, w, ldw, grad, ldg, accumulate);
     GS_LAUNCH_CHECK("reduce_slabs_kernel");
