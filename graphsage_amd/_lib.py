@@ -39,6 +39,7 @@ _PROTOS = {
     "gs_act_bwd": [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int, _P, c_int64, _P],
     "gs_colsum_slabs": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P],
     "gs_gemm_f32": [c_int, c_int, c_int64, c_int32, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int, _P, c_int64, _P],
+    "gs_abi_struct_sizes": [_P, c_int32],
     "gs_dense_pool_max_fwd": [_P, c_int64, _P, c_int32, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, c_int64, _P, c_int64, _P],
     "gs_segment_max_fwd": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P],
     "gs_segment_max_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P],
@@ -200,6 +201,16 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
+    # struct layouts: the library's sizeof() of every descriptor must equal the ctypes mirror's
+    mirrors = [GatherDesc, WgradDesc, VarDesc, FanoutDesc, TailDesc, Dropout, PullDesc]
+    sizes = (c_int32 * 16)()
+    n = lib.gs_abi_struct_sizes(sizes, 16)
+    if n != len(mirrors):
+        raise GraphsageAmdError("%s exports %d descriptor structs, this package mirrors %d" % (LIB_PATH, n, len(mirrors)))
+    for cls, size in zip(mirrors, sizes):
+        if ctypes.sizeof(cls) != size:
+            raise GraphsageAmdError("struct layout mismatch: sizeof(%s) is %d in %s but %d in graphsage_amd/_lib.py"
+                                    % (cls.__doc__.split()[1], size, LIB_PATH, ctypes.sizeof(cls)))
     _lib = lib
     return lib
 

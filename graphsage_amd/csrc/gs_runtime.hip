@@ -19,6 +19,17 @@ void gs_set_error(const char* fmt, ...) {
 extern "C" const char* gs_last_error(void) { return g_err; }
 extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
 
+// sizeof() of the descriptor structs of include/graphsage_amd.h, in declaration order: a binding checks its own struct
+// definitions against these at load time instead of corrupting memory on a layout mismatch.
+extern "C" int gs_abi_struct_sizes(int32_t* sizes_out_host, int32_t capacity) {
+    const int32_t sizes[] = {(int32_t)sizeof(gs_gather_desc), (int32_t)sizeof(gs_wgrad_desc), (int32_t)sizeof(gs_var_desc),
+                             (int32_t)sizeof(gs_fanout_desc), (int32_t)sizeof(gs_tail_desc), (int32_t)sizeof(gs_dropout),
+                             (int32_t)sizeof(gs_pull_desc)};
+    const int32_t n = (int32_t)(sizeof(sizes) / sizeof(sizes[0]));
+    for (int32_t i = 0; i < n && i < capacity; ++i) sizes_out_host[i] = sizes[i];
+    return n;
+}
+
 extern "C" int gs_device_info(int* cu_count, int* xcd_count, char* arch_name_host, int arch_name_len) {
     int dev = 0;
     GS_HIP(hipGetDevice(&dev));

@@ -42,6 +42,10 @@ extern "C" {
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
+/* sizeof() of the descriptor structs below, in declaration order (gs_gather_desc, gs_wgrad_desc, gs_var_desc,
+ * gs_fanout_desc, gs_tail_desc, gs_dropout, gs_pull_desc): writes min(count, capacity) values, returns the count.  A
+ * binding compares them with its own struct definitions at load time. */
+int gs_abi_struct_sizes(int32_t* sizes_out_host, int32_t capacity);
 /* Fills CU count, XCD count (8 on MI355X), gcnArchName (>= 64 bytes) of the current device. */
 int gs_device_info(int* cu_count, int* xcd_count, char* arch_name_host, int arch_name_len);
 

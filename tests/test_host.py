@@ -253,3 +253,29 @@ def test_driver_f1_matches_sklearn():
             warnings.simplefilter("ignore")
             assert abs(mic - metrics.f1_score(yt, yp, average="micro")) < 1e-12
             assert abs(mac - metrics.f1_score(yt, yp, average="macro")) < 1e-12
+
+
+def test_descriptor_struct_layouts_match_the_library():
+    """Every ctypes mirror of a descriptor struct of include/graphsage_amd.h has the library's sizeof() (checked at load
+    time too: _lib.load() raises on a mismatch instead of letting a kernel read a shifted struct)."""
+    import ctypes
+    from graphsage_amd import _lib
+    lib = _lib.load()
+    sizes = (ctypes.c_int32 * 16)()
+    n = lib.gs_abi_struct_sizes(sizes, 16)
+    mirrors = [_lib.GatherDesc, _lib.WgradDesc, _lib.VarDesc, _lib.FanoutDesc, _lib.TailDesc, _lib.Dropout, _lib.PullDesc]
+    assert n == len(mirrors)
+    assert [ctypes.sizeof(c) for c in mirrors] == list(sizes[:n])
+    # a drifted mirror is caught by load()
+    saved, _lib._lib = _lib._lib, None
+    fields = _lib.WgradDesc
+    try:
+        class Drifted(ctypes.Structure):
+            """struct gs_wgrad_desc (drifted)"""
+            _fields_ = fields._fields_[:-1]
+        _lib.WgradDesc = Drifted
+        with pytest.raises(_lib.GraphsageAmdError, match="struct layout mismatch"):
+            _lib.load()
+    finally:
+        _lib.WgradDesc = fields
+        _lib._lib = saved
