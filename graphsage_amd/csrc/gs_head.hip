@@ -1,6 +1,7 @@
 // K4 (segment max) and K5 (supervised head: l2-normalise, classification losses).  All small,
 // elementwise / row-reduction kernels: one wave per row for the reductions, float4 lanes elsewhere.
 #include "gs_common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -555,6 +556,74 @@ __global__ __launch_bounds__(512) void maxpool_sparse_wgrad_kernel(const float* 
     }
 }
 
+// Column-per-lane form (the default): thread t owns hidden column c = 512 z + t and 64 feature accumulators; the s
+// feature-row segments of a group are staged in LDS with an ODD row stride (65 floats), so that lanes reading DIFFERENT
+// arg-max rows at the same feature hit different banks and lanes reading the same row get a broadcast.  The arg-max row
+// and the value of a column are per-lane registers (coalesced loads, no v_readlane), the row base address is computed
+// once per group and every FMA is ONE ds_read_b32 with an immediate offset + ONE v_fmac: 2 instructions per useful FMA
+// instead of ~5 (two v_readlane + address add + ds_read + half a packed FMA).  LDS-bandwidth bound: 512 x 64 x 4 B per
+// (group, feature block).
+#define GS_SPW_LDS_STRIDE 65
+__global__ __launch_bounds__(512) void maxpool_sparse_wgrad_cols_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                         const int32_t* __restrict__ ids, int64_t G, int32_t s,
+                                                                         int32_t d, const int32_t* __restrict__ argmax,
+                                                                         int64_t lda, const float* __restrict__ dpm, int64_t ldd,
+                                                                         int32_t hidden, int64_t groups_per_slice,
+                                                                         float* __restrict__ slabs, int64_t ld_slab) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [s][65]
+    const int dpad = (d + 3) & ~3;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int f0 = blockIdx.x * GS_SPW_FB;
+    const int c = blockIdx.z * 512 + tid;
+    const bool col_ok = c < hidden;
+    const int64_t g0 = (int64_t)blockIdx.y * groups_per_slice;
+    const int64_t g1 = min(G, g0 + groups_per_slice);
+    const int n4 = s * (GS_SPW_FB / 4);                          // float4 of a group's row segments
+    float acc[GS_SPW_FB];
+#pragma unroll
+    for (int f = 0; f < GS_SPW_FB; ++f) acc[f] = 0.f;
+    f32x4 pf[GS_SPW_PF];
+    int a_nx = 0;
+    float v_nx = 0.f;
+    auto prefetch = [&](int64_t g) {
+#pragma unroll
+        for (int u = 0; u < GS_SPW_PF; ++u) {
+            const int t = tid + u * nthreads;
+            pf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < n4) {
+                const int r = t >> 4, q = t & 15;
+                if (f0 + q * 4 < dpad) pf[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)ids[g * s + r] * ldx + f0 + q * 4);
+            }
+        }
+        a_nx = col_ok ? argmax[g * lda + c] : 0;
+        v_nx = col_ok ? dpm[g * ldd + c] : 0.f;
+    };
+    if (g0 < g1) prefetch(g0);
+    for (int64_t g = g0; g < g1; ++g) {
+        __syncthreads();  // the previous group's segments are no longer read
+#pragma unroll
+        for (int u = 0; u < GS_SPW_PF; ++u) {
+            const int t = tid + u * nthreads;
+            if (t < n4) {
+                float* dst = xs + (t >> 4) * GS_SPW_LDS_STRIDE + (t & 15) * 4;
+                dst[0] = pf[u].x; dst[1] = pf[u].y; dst[2] = pf[u].z; dst[3] = pf[u].w;
+            }
+        }
+        const float v = v_nx;
+        const float* row = xs + a_nx * GS_SPW_LDS_STRIDE;
+        __syncthreads();
+        if (g + 1 < g1) prefetch(g + 1);
+#pragma unroll
+        for (int f = 0; f < GS_SPW_FB; ++f) acc[f] += v * row[f];
+    }
+    if (col_ok) {
+        float* dst = slabs + ((int64_t)blockIdx.y * d + f0) * ld_slab + c;
+#pragma unroll
+        for (int f = 0; f < GS_SPW_FB; ++f)
+            if (f0 + f < d) dst[(int64_t)f * ld_slab] = acc[f];
+    }
+}
+
 extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
                                        int32_t d, const int32_t* argmax, int64_t lda, const float* d_pooled_masked,
                                        int64_t ldd, int32_t hidden, int32_t n_slabs, float* slabs, int64_t ld_slab,
@@ -572,10 +641,17 @@ extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_
     }
     const int64_t gps = gs_ceil_div(n_groups, n_slabs);
     const dim3 grid((unsigned)gs_ceil_div(d, GS_SPW_FB), (unsigned)n_slabs, (unsigned)gs_ceil_div(hidden, 512));
-    // one group per barrier pair: staging 2 or 4 groups per pair measured slower (more VGPRs -> fewer resident blocks)
-    hipLaunchKernelGGL(maxpool_sparse_wgrad_kernel<1>, grid, dim3(threads), (size_t)s * GS_SPW_FB * sizeof(float),
-                       (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
-                       slabs, ld_slab);
+    static const bool feature_lanes = getenv("GS_SPW_FEATURE_LANES") != nullptr;   // the first form (lane = feature), kept for A/B
+    if (feature_lanes) {
+        // one group per barrier pair: staging 2 or 4 groups per pair measured slower (more VGPRs -> fewer resident blocks)
+        hipLaunchKernelGGL(maxpool_sparse_wgrad_kernel<1>, grid, dim3(threads), (size_t)s * GS_SPW_FB * sizeof(float),
+                           (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
+                           slabs, ld_slab);
+    } else {
+        hipLaunchKernelGGL(maxpool_sparse_wgrad_cols_kernel, grid, dim3(threads), (size_t)s * GS_SPW_LDS_STRIDE * sizeof(float),
+                           (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
+                           slabs, ld_slab);
+    }
     GS_LAUNCH_CHECK("maxpool_sparse_wgrad_kernel");
     return GS_OK;
 }
