@@ -178,6 +178,9 @@ def load(build_if_missing=True):
     # /opt/rocm's copy and torch would then bring in a second HIP runtime (its NEEDED entry is the un-versioned
     # name) -- two runtimes in one process do not share streams or allocations ("no ROCm-capable device").
     import torch  # noqa: F401
+    alt = os.environ.get("GS_LIB")          # A/B hook: load this prebuilt library instead (no build / digest check)
+    if alt:
+        build_if_missing = False
     if build_if_missing:
         try:
             from . import build as _build
@@ -185,9 +188,10 @@ def load(build_if_missing=True):
         except Exception as e:  # no hipcc on this box: fall through to the prebuilt library check
             if not os.path.exists(LIB_PATH):
                 raise GraphsageAmdError("libgraphsage_amd.so is missing and could not be built: %s" % e)
-    if not os.path.exists(LIB_PATH):
-        raise GraphsageAmdError("HIP extension not found at %s (run python -m graphsage_amd.build)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+    path = alt or LIB_PATH
+    if not os.path.exists(path):
+        raise GraphsageAmdError("HIP extension not found at %s (run python -m graphsage_amd.build)" % path)
+    lib = ctypes.CDLL(path)
     lib.gs_last_error.restype = c_char_p
     lib.gs_last_error.argtypes = []
     lib.gs_abi_version.restype = c_int
