@@ -12,7 +12,9 @@ LIB_PATH = os.path.join(_HERE, "_C", "libgraphsage_amd.so")
 
 ACT_IDENTITY = 0
 ACT_RELU = 1
-GS_ABI_VERSION = 2      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
+SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
+GS_ABI_VERSION = 3      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -26,7 +28,7 @@ _PROTOS = {
     "gs_device_info": [POINTER(c_int), POINTER(c_int), ctypes.c_char_p, c_int],
     "gs_sample_padded": [_P, c_int64, c_int32, _P, c_int64, _P, c_int32, _P, _P],
     "gs_sample_uniform_csr": [_P, _P, c_int64, c_int32, _P, c_int64, c_int32, c_uint64, c_uint64, _P, c_uint32,
-                              c_int64, _P, _P],
+                              c_int64, c_int32, c_int32, _P, _P],
     "gs_select_batch": [_P, c_int64, _P, c_int64, _P, _P],
     "gs_advance_counter": [_P, c_uint64, _P],
     "gs_gather_rows": [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P],
@@ -88,7 +90,7 @@ _PROTOS = {
     "gs_head_fwd_bwd": [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int64, c_int32, c_int, _P, c_int64, _P,
                         c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P],
     "gs_sample_fanout_csr": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_int64, c_uint64, c_uint64, _P, c_uint32,
-                             c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
+                             c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, c_int32, c_int32, _P],
     "gs_finalize_step": [_P, c_int64, c_float, _P, c_int, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_sage_dense_fwd_cogather": [_P, c_int64, _P, c_int32, _P, c_int64, _P, c_int32, c_int64, _P, c_int64, _P, c_int64,
                                    c_int32, c_int, c_int, _P, _P, c_int64, _P, c_int32, _P],
@@ -155,7 +157,8 @@ class FanoutDesc(ctypes.Structure):
                 ("label_table", c_void_p), ("ld_table", c_int64),
                 ("labels_out", c_void_p), ("ld_out", c_int64),
                 ("offsets", c_int64 * 4), ("fan", c_int32 * 3),
-                ("pad_id", c_int32), ("n_hops", c_int32), ("C", c_int32), ("hop0", c_uint32)]
+                ("pad_id", c_int32), ("n_hops", c_int32), ("C", c_int32), ("hop0", c_uint32),
+                ("law", c_int32), ("max_degree", c_int32)]
 
 
 class VarDesc(ctypes.Structure):

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void sample_csr_kernel(const int64_t* __restri
                                                          int32_t pad_id, const int32_t* __restrict__ ids, int64_t n,
                                                          int32_t s, uint64_t seed, uint64_t step,
                                                          const uint64_t* __restrict__ step_dev, uint32_t hop,
-                                                         int64_t global_row_offset, int32_t* __restrict__ out) {
+                                                         int64_t global_row_offset, const SampleLaw law,
+                                                         int32_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t total = n * (int64_t)s;
     const int64_t n_waves = gs_ceil_div(total, 64);
@@ -59,11 +60,12 @@ __global__ __launch_bounds__(256) void sample_csr_kernel(const int64_t* __restri
         const int64_t i_first = o0 / s;
         // ---- per-wave row table: lane l holds (begin, deg) of source row i_first + l
         int64_t beg = 0;
-        int32_t deg = 0;
+        int32_t deg = 0, row_id = 0;
         {
             int64_t i = i_first + lane;
             if (i < n) {
                 int32_t id = ids[i];
+                row_id = id;
                 if (id >= 0 && (int64_t)id < n_nodes) {
                     int64_t b = rowptr[id], e = rowptr[id + 1];
                     beg = b;
@@ -79,15 +81,13 @@ __global__ __launch_bounds__(256) void sample_csr_kernel(const int64_t* __restri
         const int32_t my_deg = __shfl(deg, src_lane, 64);
         const uint32_t beg_lo = (uint32_t)__shfl((int)(uint32_t)beg, src_lane, 64);
         const uint32_t beg_hi = (uint32_t)__shfl((int)(uint32_t)(beg >> 32), src_lane, 64);
+        const int32_t my_id = __shfl(row_id, src_lane, 64);
         const int64_t my_beg = (int64_t)(((uint64_t)beg_hi << 32) | beg_lo);
         if (o < total) {
             const uint32_t j = (uint32_t)(o - i * s);
             int32_t pick = pad_id;
             if (my_deg > 0) {
-                const uint64_t u = gs_mix64(key + (uint64_t)(global_row_offset + i) * 0xD1342543DE82EF95ull + j);
-                const uint32_t r = (uint32_t)(u >> 32);
-                const uint32_t k = (uint32_t)(((uint64_t)r * (uint64_t)(uint32_t)my_deg) >> 32);  // Lemire range map
-                pick = col[my_beg + k];
+                pick = col[my_beg + gs_draw(law, seed, key, global_row_offset + i, j, s, my_id, (uint32_t)my_deg)];
             }
             out[o] = pick;  // 64 lanes -> one 256-byte coalesced store
         }
@@ -97,16 +97,18 @@ __global__ __launch_bounds__(256) void sample_csr_kernel(const int64_t* __restri
 extern "C" int gs_sample_uniform_csr(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,
                                      const int32_t* ids, int64_t n, int32_t num_samples, uint64_t seed,
                                      uint64_t step, const uint64_t* step_dev, uint32_t hop,
-                                     int64_t global_row_offset, int32_t* out, void* stream) {
+                                     int64_t global_row_offset, int32_t law, int32_t max_degree, int32_t* out,
+                                     void* stream) {
     if (n == 0) return GS_OK;  // empty input: nothing to launch (pointers may be null)
     GS_REQUIRE(rowptr && col && ids && out, "gs_sample_uniform_csr: null pointer");
     GS_REQUIRE(n >= 0 && n_nodes > 0 && num_samples > 0, "gs_sample_uniform_csr: bad sizes");
     GS_REQUIRE(hop < 256, "gs_sample_uniform_csr: hop must be < 256");
-    if (n == 0) return GS_OK;
+    SampleLaw lw;
+    if (gs_law_args(law, max_degree, &num_samples, 1, &lw) != GS_OK) return GS_EINVAL;
     int64_t total = n * (int64_t)num_samples;
     int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 4096);
     hipLaunchKernelGGL(sample_csr_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, n_nodes,
-                       pad_id, ids, n, num_samples, seed, step, step_dev, hop, global_row_offset, out);
+                       pad_id, ids, n, num_samples, seed, step, step_dev, hop, global_row_offset, lw, out);
     GS_LAUNCH_CHECK("sample_csr_kernel");
     return GS_OK;
 }
@@ -175,12 +177,13 @@ extern "C" int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, i
                                     const uint64_t* step_dev, uint32_t hop0, int64_t root_offset,
                                     const int32_t* order, int64_t n_order, const uint64_t* cursor_dev,
                                     const float* label_table, int64_t ld_table, int32_t C, float* labels_out,
-                                    int64_t ld_out, void* stream) {
+                                    int64_t ld_out, int32_t law, int32_t max_degree, void* stream) {
     if (B == 0) return GS_OK;
     FanoutArgs a;
     int64_t kmax = 0;
     int rc = gs_fanout_args(rowptr, col, n_nodes, pad_id, n_hops, fan_host, offsets_host, ids_all, B, seed, step, step_dev, hop0,
-                            root_offset, order, n_order, cursor_dev, label_table, ld_table, C, labels_out, ld_out, &a, &kmax);
+                            root_offset, order, n_order, cursor_dev, label_table, ld_table, C, labels_out, ld_out, law, max_degree,
+                            &a, &kmax);
     if (rc != GS_OK) return rc;
     GS_REQUIRE(kmax <= GS_FANOUT_LDS, "gs_sample_fanout_csr: per-root fan-out %lld exceeds the LDS buffer", (long long)kmax);
     hipLaunchKernelGGL(sample_fanout_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);

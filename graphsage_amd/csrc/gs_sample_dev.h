@@ -5,6 +5,76 @@
 #include "gs_common.h"
 
 #define GS_MAX_HOPS 3
+
+// ---- sampling laws (gs_sample_law in include/graphsage_amd.h) --------------------------------------------------------
+// gs_perm_index(key, j, n): the j-th element of a keyed pseudo-random PERMUTATION of [0, n): a balanced Feistel network
+// (6 rounds; 12 when a half is <= 3 bits -- measured: pairs of outputs are chi-square uniform from there on) on
+// 2*half >= ceil(log2 n) bits with cycle walking (a permutation of the power-of-two domain restricted to
+// [0, n) by re-applying it until the value lands inside; terminates because the walk stays on the cycle of j).  A
+// pure function, so "s distinct columns" and "a frozen max_degree subset of a long neighbor list" need no state and
+// no table.  Restated bit-for-bit in oracle/sampler_hash.py::perm_index.
+__device__ __forceinline__ uint32_t gs_perm_index(uint64_t key, uint32_t j, uint32_t n) {
+    if (n <= 1u) return 0u;
+    const int bits = 32 - __clz((int)(n - 1u));
+    const int half = (bits + 1) >> 1;
+    const uint32_t mask = (1u << half) - 1u;
+    const int rounds = half <= 3 ? 12 : 6;
+    uint32_t x = j;
+    do {
+        uint32_t L = x >> half, R = x & mask;
+        for (int r = 0; r < rounds; ++r) {
+            const uint32_t f = (uint32_t)(gs_mix64(key + ((uint64_t)r << 32) + (uint64_t)R) >> 32) & mask;
+            const uint32_t t = L ^ f;
+            L = R;
+            R = t;
+        }
+        x = (L << half) | R;
+    } while (x >= n);
+    return x;
+}
+
+struct SampleLaw {
+    int32_t law;          // GS_LAW_IID | GS_LAW_REFERENCE | GS_LAW_DISTINCT
+    int32_t max_degree;   // cap of the (virtual) padded table; 0 = uncapped (GS_LAW_DISTINCT only)
+};
+
+// key of node v's row of the VIRTUAL padded table (minibatch.py:227-245: built once, frozen for the run): a function
+// of (seed, node id) only -- never of the step.
+__device__ __forceinline__ uint64_t gs_table_key(uint64_t seed, int32_t v) {
+    return gs_mix64(seed ^ 0x7AB1E5EEDull ^ ((uint64_t)(uint32_t)v * 0xD1342543DE82EF95ull));
+}
+
+// entry c (< M) of node v's virtual padded row -> position in its CSR neighbor list (deg > 0):
+//   deg >  M : np.random.choice(neighbors, M, replace=False) (minibatch.py:240-241)  = first M of a keyed permutation
+//   deg <  M : np.random.choice(neighbors, M, replace=True)  (:242-243)              = M frozen iid draws
+//   deg == M : the list itself
+__device__ __forceinline__ uint32_t gs_table_entry(uint64_t tkey, uint32_t c, uint32_t deg, uint32_t M) {
+    if (deg > M) return gs_perm_index(tkey, c, deg);
+    if (deg == M) return c;
+    return (uint32_t)(((gs_mix64(tkey + (uint64_t)c) >> 32) * (uint64_t)deg) >> 32);
+}
+
+// position in the neighbor list of slot j of global row `grow` (deg > 0).  callkey = hash of (seed, step, hop).
+__device__ __forceinline__ uint32_t gs_draw(const SampleLaw lw, uint64_t seed, uint64_t callkey, int64_t grow, uint32_t j,
+                                            int32_t s, int32_t id, uint32_t deg) {
+    if (lw.law == GS_LAW_REFERENCE) {
+        // neigh_samplers.py:26-28: ONE column permutation per call shared by all rows, first s columns
+        const uint32_t M = (uint32_t)lw.max_degree;
+        const uint32_t c = gs_perm_index(gs_mix64(callkey ^ 0xC0115ull), j, M);
+        return gs_table_entry(gs_table_key(seed, id), c, deg, M);
+    }
+    const uint64_t rowkey = callkey + (uint64_t)grow * 0xD1342543DE82EF95ull;
+    if (lw.law == GS_LAW_DISTINCT) {
+        // without replacement whenever the (capped) list holds at least s entries, per-row independent
+        const uint32_t M = (uint32_t)lw.max_degree;
+        const uint32_t eff = (M > 0u && deg > M) ? M : deg;
+        uint32_t c;
+        if (eff >= (uint32_t)s) c = gs_perm_index(gs_mix64(rowkey), j, eff);
+        else c = (uint32_t)(((gs_mix64(rowkey + j) >> 32) * (uint64_t)eff) >> 32);
+        return eff != deg ? gs_perm_index(gs_table_key(seed, id), c, deg) : c;
+    }
+    return (uint32_t)(((gs_mix64(rowkey + j) >> 32) * (uint64_t)deg) >> 32);    // GS_LAW_IID: Lemire range map
+}
 #define GS_FANOUT_LDS 8192          // per-root ids of the kept hops, standalone kernel
 #define GS_FANOUT_LDS_SMALL 512     // ... when the sampler rides in another launch (e.g. 10 for fan-out 25x10)
 struct FanoutArgs {
@@ -21,6 +91,7 @@ struct FanoutArgs {
     const uint64_t* step_dev;
     uint32_t hop0;
     int64_t root_offset;  // global index of this rank's first root (data-parallel invariance)
+    SampleLaw law;
     // optional batch staging (order == nullptr -> roots are already in ids_all)
     const int32_t* order;
     int64_t n_order;
@@ -70,9 +141,7 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
                 const int32_t deg = (int32_t)(a.rowptr[id + 1] - b);
                 if (deg > 0) {
                     const int64_t grow = (a.root_offset + i) * count_prev + pl;  // global row at this hop
-                    const uint64_t u = gs_mix64(key + (uint64_t)grow * 0xD1342543DE82EF95ull + j);
-                    const uint32_t r = (uint32_t)(u >> 32);
-                    pick = a.col[b + (int64_t)(((uint64_t)r * (uint64_t)(uint32_t)deg) >> 32)];
+                    pick = a.col[b + (int64_t)gs_draw(a.law, a.seed, key, grow, j, s, id, (uint32_t)deg)];
                 }
             }
             if (keep) next[t] = pick;
@@ -83,13 +152,28 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
     }
 }
 
+// host: validate (law, max_degree) against the fan-outs of the calls it will serve
+static inline int gs_law_args(int32_t law, int32_t max_degree, const int32_t* fans, int32_t n_fans, SampleLaw* out) {
+    GS_REQUIRE(law == GS_LAW_IID || law == GS_LAW_REFERENCE || law == GS_LAW_DISTINCT, "sampler: unknown law %d", law);
+    GS_REQUIRE(max_degree >= 0, "sampler: max_degree must be >= 0");
+    if (law == GS_LAW_REFERENCE) {
+        GS_REQUIRE(max_degree > 0, "sampler: GS_LAW_REFERENCE needs max_degree > 0 (the padded table width)");
+        for (int h = 0; h < n_fans; ++h)
+            GS_REQUIRE(fans[h] <= max_degree, "sampler: num_samples=%d must be <= max_degree=%d (tf.slice would fail)",
+                       fans[h], max_degree);
+    }
+    out->law = law;
+    out->max_degree = law == GS_LAW_IID ? 0 : max_degree;
+    return GS_OK;
+}
+
 // host: C-ABI arguments -> FanoutArgs (shared validation); *kept_max = largest per-root count of a kept hop
 static inline int gs_fanout_args(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id, int32_t n_hops,
                                  const int32_t* fan_host, const int64_t* offsets_host, int32_t* ids_all, int64_t B, uint64_t seed,
                                  uint64_t step, const uint64_t* step_dev, uint32_t hop0, int64_t root_offset,
                                  const int32_t* order, int64_t n_order, const uint64_t* cursor_dev, const float* label_table,
-                                 int64_t ld_table, int32_t C, float* labels_out, int64_t ld_out, FanoutArgs* out,
-                                 int64_t* kept_max) {
+                                 int64_t ld_table, int32_t C, float* labels_out, int64_t ld_out, int32_t law,
+                                 int32_t max_degree, FanoutArgs* out, int64_t* kept_max) {
     GS_REQUIRE(rowptr && col && ids_all && fan_host && offsets_host && n_nodes > 0, "gs_sample_fanout_csr: null pointer");
     GS_REQUIRE(n_hops >= 1 && n_hops <= GS_MAX_HOPS, "gs_sample_fanout_csr: 1..%d hops", GS_MAX_HOPS);
     GS_REQUIRE(hop0 + n_hops <= 256, "gs_sample_fanout_csr: hop ids must be < 256");
@@ -97,6 +181,7 @@ static inline int gs_fanout_args(const int64_t* rowptr, const int32_t* col, int6
     GS_REQUIRE(!label_table || (labels_out && C > 0 && ld_table >= C && ld_out >= ((C + 3) & ~3) && order),
                "gs_sample_fanout_csr: bad label staging arguments");
     FanoutArgs a = {};
+    if (gs_law_args(law, max_degree, fan_host, n_hops, &a.law) != GS_OK) return GS_EINVAL;
     a.rowptr = rowptr; a.col = col; a.n_nodes = n_nodes; a.pad_id = pad_id; a.n_hops = n_hops;
     int64_t count = 1, kmax = 1;
     for (int h = 0; h < n_hops; ++h) {

@@ -65,8 +65,19 @@ class AdjInfo(object):
 class UniformNeighborSampler(Layer):
     """Uniformly samples neighbors (graphsage/neigh_samplers.py:15-29)."""
 
-    def __init__(self, adj_info, seed=123, **kwargs):
+    def __init__(self, adj_info, seed=123, law="iid", max_degree=0, **kwargs):
+        """`law` (CSR adjacency only; gs_sample_uniform_csr in include/graphsage_amd.h):
+          "iid"        independent uniform draws with replacement from the true neighbor list (default)
+          "reference"  the reference's joint law: virtual padded [N+1, max_degree] table frozen for the run
+                       (minibatch.py:227-245) + num_samples distinct columns per call shared by all rows
+                       (neigh_samplers.py:26-28); needs max_degree (FLAGS.max_degree, 128 by default)
+          "distinct"   per-row draws without replacement when the (optionally max_degree-capped) list is long enough"""
         super(UniformNeighborSampler, self).__init__(**kwargs)
+        if law not in ops._lib.SAMPLER_LAWS:
+            raise ops._lib.GraphsageAmdError("unknown sampler law %r (iid | reference | distinct)" % (law,))
+        self.law, self.max_degree = ops._lib.SAMPLER_LAWS[law], int(max_degree)
+        if law == "reference" and self.max_degree <= 0:
+            raise ops._lib.GraphsageAmdError("sampler law 'reference' needs max_degree > 0 (the padded table width)")
         if not isinstance(adj_info, AdjInfo):
             adj_info = AdjInfo(adj_info)
         self.adj_info = adj_info
@@ -108,7 +119,8 @@ class UniformNeighborSampler(Layer):
         else:
             ops.sample_uniform_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, ids, num_samples, self.seed,
                                    step=0, step_dev=e.sample_clock_dev, hop=self._call_index,
-                                   global_row_offset=self.global_row_offset, out=out, stream=e.stream)
+                                   global_row_offset=self.global_row_offset, out=out, stream=e.stream,
+                                   law=self.law, max_degree=self.max_degree)
         self._call_index += 1
         return out[: n * num_samples].view(n, num_samples)
 
@@ -127,10 +139,11 @@ class UniformNeighborSampler(Layer):
             e._deferred_sampler = ops.fanout_desc(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all,
                                                   batch_size, self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index,
                                                   root_offset=root_offset, order=order, cursor_dev=cursor,
-                                                  label_table=table, labels_out=labels_out)
+                                                  label_table=table, labels_out=labels_out, law=self.law,
+                                                  max_degree=self.max_degree)
         else:
             ops.sample_fanout_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all, batch_size,
                                   self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,
                                   order=order, cursor_dev=cursor, label_table=table, labels_out=labels_out,
-                                  stream=e.stream)
+                                  stream=e.stream, law=self.law, max_degree=self.max_degree)
         self._call_index += len(fans)

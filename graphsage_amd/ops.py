@@ -88,17 +88,18 @@ def sample_padded(adj, ids, col_perm, num_samples, out=None, stream=None):
 
 
 def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, step=0, step_dev=None, hop=0,
-                       global_row_offset=0, out=None, stream=None):
+                       global_row_offset=0, out=None, stream=None, law=0, max_degree=0):
     n = ids.numel()
     if out is None:
         out = torch.empty((n * num_samples,), dtype=torch.int32, device=ids.device)
     call("gs_sample_uniform_csr", ptr(rowptr), ptr(col), n_nodes, pad_id, ptr(ids), n, num_samples,
-         seed & 0xFFFFFFFFFFFFFFFF, step, ptr(step_dev), hop, global_row_offset, ptr(out), _s(stream))
+         seed & 0xFFFFFFFFFFFFFFFF, step, ptr(step_dev), hop, global_row_offset, law, max_degree, ptr(out), _s(stream))
     return out
 
 
 def sample_fanout_csr(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, step_dev=None, hop0=0,
-                      root_offset=0, order=None, cursor_dev=None, label_table=None, labels_out=None, stream=None):
+                      root_offset=0, order=None, cursor_dev=None, label_table=None, labels_out=None, stream=None,
+                      law=0, max_degree=0):
     """Fused multi-hop sampler (+ optional batch/label staging); see gs_sample_fanout_csr."""
     import ctypes
     fan = (ctypes.c_int32 * len(fans))(*fans)
@@ -108,11 +109,11 @@ def sample_fanout_csr(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, s
          ptr(order), order.numel() if order is not None else 0, ptr(cursor_dev),
          label_table.ptr if label_table is not None else None, label_table.ld if label_table is not None else 0,
          label_table.d if label_table is not None else 0, labels_out.ptr if labels_out is not None else None,
-         labels_out.ld if labels_out is not None else 0, _s(stream))
+         labels_out.ld if labels_out is not None else 0, law, max_degree, _s(stream))
 
 
 def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, step_dev=None, hop0=0, root_offset=0,
-                order=None, cursor_dev=None, label_table=None, labels_out=None):
+                order=None, cursor_dev=None, label_table=None, labels_out=None, law=0, max_degree=0):
     """The arguments of sample_fanout_csr as a struct gs_fanout_desc (for gs_flat_reduce_adam_sample).  The tensors are
     kept alive on the descriptor object."""
     q = _lib.FanoutDesc()
@@ -124,6 +125,7 @@ def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, s
         q.offsets[k] = o
     q.ids_all, q.B, q.seed, q.step, q.step_dev = ptr(ids_all), B, seed & 0xFFFFFFFFFFFFFFFF, 0, ptr(step_dev)
     q.hop0, q.root_offset = hop0, root_offset
+    q.law, q.max_degree = law, max_degree
     q.order, q.n_order, q.cursor_dev = ptr(order), (order.numel() if order is not None else 0), ptr(cursor_dev)
     if label_table is not None:
         q.label_table, q.ld_table, q.C = label_table.ptr, label_table.ld, label_table.d

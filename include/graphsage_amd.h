@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -70,13 +70,26 @@ int gs_sample_padded(const int32_t* adj, int64_t n_adj_rows, int32_t max_deg,
  *   (seed, step + *step_dev, hop, global_row_offset + i, j)
  * so the draw for a given root row does not depend on how rows are sharded over GPUs.
  * ids >= n_nodes (the pad id) yield pad_id (the all-pad row N of the reference table).
- * Uniform WITH replacement over the true neighbor set: the per-slot marginal equals the
- * reference's (padded row resampled once + distinct columns); see DESIGN.md "sampler semantics".
+ * law = GS_LAW_IID: uniform WITH replacement over the true neighbor set (the formula above): the per-slot marginal
+ *   equals the reference's (padded row resampled once + distinct columns); max_degree ignored.
+ * law = GS_LAW_REFERENCE: the reference's joint law without its table.  Node v's row of the padded [N+1, max_degree]
+ *   table of minibatch.py:227-245 is VIRTUAL -- entry c is a pure function of (seed, v, c): the first max_degree
+ *   elements of a keyed permutation of the neighbor list when deg > max_degree (np.random.choice(replace=False),
+ *   :240-241), max_degree frozen iid draws when deg < max_degree (replace=True, :242-243), the list itself when equal
+ *   -- frozen for the run like the reference's table; per call, num_samples DISTINCT columns are the head of ONE keyed
+ *   permutation of [0, max_degree) shared by all rows (tf.random_shuffle of the transposed rows, neigh_samplers.py:27-28).
+ *   Requires num_samples <= max_degree (tf.slice fails otherwise).
+ * law = GS_LAW_DISTINCT: per-row independent draws WITHOUT replacement whenever the list (capped to a frozen
+ *   max_degree subset if max_degree > 0) holds >= num_samples entries, with replacement otherwise.
+ * All three are pure functions of (seed, step, hop, global row, j[, node id]); restated in oracle/sampler_hash.py.
  * step_dev may be NULL. */
+#define GS_LAW_IID 0
+#define GS_LAW_REFERENCE 1
+#define GS_LAW_DISTINCT 2
 int gs_sample_uniform_csr(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,
                           const int32_t* ids, int64_t n, int32_t num_samples,
                           uint64_t seed, uint64_t step, const uint64_t* step_dev, uint32_t hop,
-                          int64_t global_row_offset, int32_t* out, void* stream);
+                          int64_t global_row_offset, int32_t law, int32_t max_degree, int32_t* out, void* stream);
 
 /* Fused multi-hop fan-out (replaces the K calls of models.py:268-274 with ONE launch): one workgroup per root,
  * hop h kept in an LDS fan-out buffer for hop h+1, all hops written to the contiguous buffer
@@ -91,7 +104,7 @@ int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, int64_t n_no
                          uint32_t hop0, int64_t root_offset,
                          const int32_t* order, int64_t n_order, const uint64_t* cursor_dev,
                          const float* label_table, int64_t ld_table, int32_t C, float* labels_out, int64_t ld_out,
-                         void* stream);
+                         int32_t law, int32_t max_degree, void* stream);
 
 /* batch[i] = order[(*cursor_dev + i) % n_order] for i < n  (epoch order lives on the device so the
  * whole training step can be one hipGraph).  Replaces the host slicing of minibatch.py:302-307. */
@@ -388,6 +401,7 @@ typedef struct gs_fanout_desc {
     int32_t fan[3];
     int32_t pad_id, n_hops, C;
     uint32_t hop0;
+    int32_t law, max_degree;      /* GS_LAW_*, see gs_sample_uniform_csr */
 } gs_fanout_desc;
 int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
                                int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,

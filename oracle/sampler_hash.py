@@ -26,20 +26,110 @@ def mix64(z):
     return z
 
 
-def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, step, hop, global_row_offset=0):
-    ids = np.asarray(ids, dtype=np.int64)
-    n = ids.shape[0]
+LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* of include/graphsage_amd.h
+
+
+def perm_index(key, j, n):
+    """gs_perm_index (gs_sample_dev.h): j-th element of the keyed pseudo-random permutation of [0, n) -- balanced
+    Feistel (6 rounds, 12 when a half is <= 3 bits) on 2*half >= ceil(log2 n) bits, cycle-walked back into [0, n).
+    key/j/n broadcast (uint64)."""
+    key, j, n = np.broadcast_arrays(np.asarray(key, dtype=np.uint64), np.asarray(j, dtype=np.uint64),
+                                    np.asarray(n, dtype=np.uint64))
+    nm1 = np.maximum(n, np.uint64(1)) - np.uint64(1)
+    x = np.minimum(j, nm1)      # a walk started outside [0, n) need not come back: callers mask such lanes, clamp them here
+    bits = np.zeros(n.shape, dtype=np.uint64)
+    t = nm1.copy()
+    while (t > 0).any():                       # bits = bit_length(n - 1)
+        bits += (t > 0).astype(np.uint64)
+        t >>= np.uint64(1)
+    half = (bits + np.uint64(1)) >> np.uint64(1)
+    mask = (np.uint64(1) << half) - np.uint64(1)
+    todo = n > np.uint64(1)
+    x = np.where(todo, x, np.uint64(0))
+    while todo.any():
+        L, R = x >> half, x & mask
+        with np.errstate(over="ignore"):
+            for r in range(12):
+                f = (mix64(key + (np.uint64(r) << np.uint64(32)) + R) >> np.uint64(32)) & mask
+                live = (r < 6) | (half <= np.uint64(3))
+                L, R = np.where(live, R, L), np.where(live, L ^ f, R)
+        y = (L << half) | R
+        x = np.where(todo, y, x)
+        todo = todo & (x >= n)
+    return x
+
+
+def _table_key(seed, v):
+    with np.errstate(over="ignore"):
+        return mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ np.uint64(0x7AB1E5EED)
+                     ^ ((np.asarray(v, dtype=np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF)) * _R))
+
+
+def table_entry(tkey, c, deg, M):
+    """gs_table_entry: entry c of a node's VIRTUAL padded row (minibatch.py:240-243) -> position in its neighbor list."""
+    tkey, c, deg = np.broadcast_arrays(np.asarray(tkey, dtype=np.uint64), np.asarray(c, dtype=np.uint64),
+                                       np.asarray(deg, dtype=np.uint64))
+    M = np.uint64(M)
+    with np.errstate(over="ignore"):
+        iid = ((mix64(tkey + c) >> np.uint64(32)) * deg) >> np.uint64(32)
+    out = np.where(deg == M, c, iid)
+    big = deg > M
+    if big.any():
+        out = out.copy()
+        out[big] = perm_index(tkey[big], c[big], deg[big])
+    return out
+
+
+def virtual_padded_table(rowptr, col, n_nodes, pad_id, seed, max_degree, nodes=None):
+    """The [len(nodes), max_degree] rows of the virtual padded table GS_LAW_REFERENCE samples from (the analogue of
+    NodeMinibatchIterator.construct_adj's `adj`); row of a degree-0 node = all pad."""
+    nodes = np.arange(n_nodes) if nodes is None else np.asarray(nodes)
+    beg = np.asarray(rowptr)[nodes].astype(np.int64)
+    deg = (np.asarray(rowptr)[nodes + 1] - beg).astype(np.int64)
+    c = np.arange(max_degree, dtype=np.uint64)[None, :]
+    k = table_entry(_table_key(seed, nodes)[:, None], c, np.maximum(deg, 1)[:, None], max_degree).astype(np.int64)
+    picked = np.asarray(col)[np.where(deg[:, None] > 0, beg[:, None] + k, 0)]
+    return np.where(deg[:, None] > 0, picked, pad_id).astype(np.int32)
+
+
+def call_columns(seed, step, hop, num_samples, max_degree):
+    """The num_samples distinct columns GS_LAW_REFERENCE uses for call (step, hop): head of ONE keyed permutation of
+    [0, max_degree) shared by all rows (neigh_samplers.py:27-28)."""
     with np.errstate(over="ignore"):
         key = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (np.uint64(step) * _G) ^ (np.uint64(hop) << np.uint64(56)))
-        i = (np.arange(n, dtype=np.uint64) + np.uint64(global_row_offset))[:, None]
-        j = np.arange(num_samples, dtype=np.uint64)[None, :]
-        u = mix64(key + i * _R + j)
-    r = (u >> np.uint64(32)).astype(np.uint64)
+        ck = mix64(key ^ np.uint64(0xC0115))
+    return perm_index(ck, np.arange(num_samples, dtype=np.uint64), np.uint64(max_degree)).astype(np.int64)
+
+
+def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, step, hop, global_row_offset=0,
+                       law=LAW_IID, max_degree=0):
+    ids = np.asarray(ids, dtype=np.int64)
+    n = ids.shape[0]
     valid = (ids >= 0) & (ids < n_nodes)
     safe = np.where(valid, ids, 0)
     beg = np.where(valid, rowptr[safe], 0).astype(np.int64)
     deg = np.where(valid, rowptr[safe + 1] - rowptr[safe], 0).astype(np.int64)
-    k = ((r * deg[:, None].astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
+    degu = np.maximum(deg, 1)[:, None].astype(np.uint64)
+    with np.errstate(over="ignore"):
+        key = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (np.uint64(step) * _G) ^ (np.uint64(hop) << np.uint64(56)))
+        i = (np.arange(n, dtype=np.uint64) + np.uint64(global_row_offset))[:, None]
+        j = np.arange(num_samples, dtype=np.uint64)[None, :]
+        rowkey = key + i * _R
+        if law == LAW_REFERENCE:
+            assert 0 < num_samples <= max_degree
+            cols = call_columns(seed, step, hop, num_samples, max_degree).astype(np.uint64)[None, :]
+            k = table_entry(_table_key(seed, safe)[:, None], cols, degu, max_degree)
+        elif law == LAW_DISTINCT:
+            M = np.uint64(max_degree)
+            capped = (degu > M) if max_degree > 0 else np.zeros_like(degu, dtype=bool)
+            eff = np.where(capped, M, degu)
+            iid = ((mix64(rowkey + j) >> np.uint64(32)) * eff) >> np.uint64(32)
+            wor = perm_index(mix64(rowkey), j, eff)
+            c = np.where(eff >= np.uint64(num_samples), wor, iid)
+            k = np.where(capped, perm_index(_table_key(seed, safe)[:, None], c, degu), c)
+        else:
+            k = ((mix64(rowkey + j) >> np.uint64(32)) * degu) >> np.uint64(32)
+    k = k.astype(np.int64)
     pos = beg[:, None] + k
     has = deg[:, None] > 0
     pos = np.where(has, pos, 0)

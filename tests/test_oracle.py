@@ -252,3 +252,94 @@ def test_hash_known_answers():
     m = sampler_hash.dropout_mask(dseed, clock, site, row0, n_rows, d, rate)
     assert np.array_equal(m > 0, k["keep"] == 1)
     assert np.allclose(m[m > 0], 1.0 / (1.0 - rate))
+
+
+def test_sampling_law_known_answers():
+    """GS_LAW_REFERENCE / GS_LAW_DISTINCT restated in oracle/sampler_hash.py vs the arbitrary-precision plain-loop
+    answers of tests/golden/make_law_kat.py (keyed Feistel permutation, virtual padded table, per-call columns)."""
+    k = np.load(os.path.join(GOLD_DIR, "law_kat.npz"))
+    for name in k.files:
+        if name.startswith("perm_") and name != "perm_key":
+            n = int(name[5:])
+            got = sampler_hash.perm_index(k["perm_key"], np.arange(n, dtype=np.uint64), np.uint64(n))
+            assert np.array_equal(got.astype(np.int64), k[name]), name
+    M, s, seed, step, hop, row_off, pad = [int(v) for v in k["args"]]
+    for law, cap in ((1, M), (2, M), (2, 0)):
+        got = sampler_hash.sample_uniform_csr(k["rowptr"], k["col"], 5, pad, k["ids"], s, seed, step, hop, row_off,
+                                              law=law, max_degree=cap)
+        assert np.array_equal(got, k["picked_law%d_cap%d" % (law, cap)]), (law, cap)
+
+
+def test_reference_law_is_the_padded_table_law():
+    """GS_LAW_REFERENCE == the reference sampler (neigh_samplers.py:24-29: adj[ids][:, perm[:s]]) applied to the VIRTUAL
+    padded table, and that table obeys construct_adj (minibatch.py:227-245): rows of nodes with deg > max_degree hold
+    max_degree DISTINCT neighbors, deg == max_degree the list itself, deg < max_degree only members of the list,
+    deg 0 all pad; frozen across steps; columns distinct within a call and fresh per call."""
+    rng = np.random.default_rng(11)
+    N, M, s = 300, 16, 5
+    deg = rng.integers(0, 60, size=N)
+    deg[:5] = [0, M, M + 1, 1, 59]
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = np.concatenate([rng.permutation(N)[:d] for d in deg]).astype(np.int32)     # distinct neighbors per node
+    table = sampler_hash.virtual_padded_table(rowptr, col, N, N, 123, M)
+    assert table.shape == (N, M)
+    for v in range(N):
+        nb = col[rowptr[v]:rowptr[v + 1]]
+        if deg[v] == 0:
+            assert (table[v] == N).all()
+        elif deg[v] > M:
+            assert len(set(table[v].tolist())) == M and np.isin(table[v], nb).all()
+        elif deg[v] == M:
+            assert np.array_equal(table[v], nb)
+        else:
+            assert np.isin(table[v], nb).all()
+    ids = rng.integers(0, N + 1, size=200)
+    padded = np.vstack([table, np.full((1, M), N, np.int32)])
+    seen_cols = set()
+    for step in range(4):
+        for hop in range(2):
+            cols = sampler_hash.call_columns(123, step, hop, s, M)
+            assert len(set(cols.tolist())) == s and cols.max() < M
+            seen_cols.add(tuple(cols.tolist()))
+            got = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, s, 123, step, hop, 77, law=1, max_degree=M)
+            want = orc.uniform_neighbor_sampler(padded, ids, s, np.concatenate([cols, np.setdiff1d(np.arange(M), cols)]))
+            assert np.array_equal(got, want)
+            # sharding invariance (the law ignores the global row: shared columns, per-node table)
+            assert np.array_equal(got[50:], sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids[50:], s, 123, step, hop,
+                                                                            127, law=1, max_degree=M))
+    assert len(seen_cols) == 8
+
+
+def test_distinct_law_properties():
+    rng = np.random.default_rng(12)
+    N, s = 200, 6
+    deg = rng.integers(0, 40, size=N)
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = np.concatenate([rng.permutation(N)[:d] for d in deg]).astype(np.int32)
+    ids = np.arange(N)
+    for cap in (0, 10):
+        a = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, s, 5, 2, 0, law=2, max_degree=cap)
+        b = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, s, 5, 3, 0, law=2, max_degree=cap)
+        for v in range(N):
+            nb = col[rowptr[v]:rowptr[v + 1]]
+            if deg[v] == 0:
+                assert (a[v] == N).all()
+                continue
+            assert np.isin(a[v], nb).all()
+            if deg[v] >= s:
+                assert len(set(a[v].tolist())) == s                  # without replacement
+        assert not np.array_equal(a, b)
+        if cap:
+            # the frozen max_degree subset: over many steps a capped node only ever shows <= cap distinct neighbors
+            v = int(np.argmax(deg))
+            seen = set()
+            for step in range(60):
+                seen.update(sampler_hash.sample_uniform_csr(rowptr, col, N, N, [v], s, 5, step, 0, law=2, max_degree=cap)[0].tolist())
+            assert len(seen) == cap < deg[v]
+    # below s entries the law falls back to the iid draw
+    low = np.where((deg > 0) & (deg < s))[0]
+    a0 = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, s, 5, 2, 0)
+    a2 = sampler_hash.sample_uniform_csr(rowptr, col, N, N, ids, s, 5, 2, 0, law=2)
+    assert np.array_equal(a0[low], a2[low])
