@@ -41,7 +41,7 @@ def placeholders(unsup=False):
             'batch_size': Placeholder('batch_size')}
 
 
-def build_model(DG, args, world, rank, model_name, unsupervised=False):
+def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_seed=123, sampler_law="iid"):
     """A fresh engine + model on the device-resident graph DG (features / CSR / labels are shared, not copied)."""
     from graphsage_amd import engine as eng
     from graphsage_amd.models import SAGEInfo, SampleAndAggregate
@@ -51,7 +51,7 @@ def build_model(DG, args, world, rank, model_name, unsupervised=False):
     e = eng.get_engine()
     train_adj = CSRAdjacency.from_device(DG.train_csr[0], DG.train_csr[1], DG.n_nodes)
     adj_info = AdjInfo(train_adj)
-    sampler = UniformNeighborSampler(adj_info, seed=123)
+    sampler = UniformNeighborSampler(adj_info, seed=sampler_seed, law=sampler_law, max_degree=128)
     ph = placeholders(unsupervised)
     if unsupervised:
         layer_infos = [SAGEInfo("node", sampler, args.samples_1, args.dim_1), SAGEInfo("node", sampler, args.samples_2, args.dim_2)]
@@ -154,7 +154,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--f1-steps", dest="f1_steps", type=int, default=100,
                     help="training steps of the micro-F1 leg (MI355X engine and CPU port, same graph / order / steps)")
-    ap.add_argument("--f1-val-nodes", dest="f1_val_nodes", type=int, default=2048)
+    ap.add_argument("--f1-val-nodes", dest="f1_val_nodes", type=int, default=4096)
+    ap.add_argument("--f1-seeds", dest="f1_seeds", type=int, default=5,
+                    help="seeds (weights / epoch order / sampler stream) of the micro-F1 legs; mean +- std are reported")
     ap.add_argument("--no-aux", action="store_true", help="skip the short configs[2..4] runs reported under `aux`")
     ap.add_argument("--aux-steps", dest="aux_steps", type=int, default=40)
     ap.add_argument("--steps-per-launch", dest="steps_per_launch", type=int, default=8,
@@ -366,45 +368,15 @@ def main():
                               "avg_launch_us": mlp_us, "algorithmic_flops_per_launch": flops}
 
     headline = (rank == 0 and world == 1 and args.model == "graphsage_mean" and DG is not None and not args.unsupervised)
-    # ---------------- micro-F1 half of the metric + the CPU baseline: the torch-CPU port of the reference graph and the
-    # MI355X engine train on the SAME graph, epoch order and number of steps; validation micro-F1 on the same val nodes
+    # ---------------- micro-F1 half of the metric + the CPU baseline (see f1_legs)
     if headline and not args.no_cpu_baseline:
-        from oracle import graphsage_oracle as orc
-        from oracle.cpu_baseline import port_micro_f1, time_cpu_baseline
         tc = time.time()
-        feats_h, adj_h, test_adj_h, labels_h = DG.host_view(max_degree=128)
-        S = args.f1_steps
-        val = DG.val_nodes[: args.f1_val_nodes].astype(np.int32)
-        cb, port = time_cpu_baseline(feats_h, adj_h, labels_h, DG.train_nodes, DG.num_classes, batch_size=B,
-                                     num_samples=(s1, s2), dims=(F, args.dim_1, args.dim_2), order=epoch, fixed_steps=S,
-                                     return_model=True)
-        f1_cpu = port_micro_f1(port, test_adj_h, labels_h, val, batch_size=B)
-        cb.pop("s_per_step", None)
-        cb.pop("steps_trained", None)
+        del model                                   # its workspaces are not needed any more (the legs build their own)
+        f1, cb = f1_legs(DG, args, B, s1, s2, F, spl, seeds=args.f1_seeds, steps=args.f1_steps, n_val=args.f1_val_nodes)
         result["cpu_baseline"] = cb
-        # the engine: back to its initial weights, same order, same number of steps, then eval on the test adjacency
-        from graphsage_amd.neigh_samplers import CSRAdjacency
-        model.set_epoch_order(epoch)
-        e.reset_parameters()
-        t1 = time.time()
-        model.train_steps_device(B, S, steps_per_launch=spl)
-        e.sync()
-        t_gpu = time.time() - t1
-        train_adj = adj_info.current
-        test_adj = CSRAdjacency.from_device(DG.test_csr[0], DG.test_csr[1], DG.n_nodes)
-        adj_info.assign(test_adj)                                   # supervised_train.py:280
-        preds = []
-        for a in range(0, len(val), B):
-            b = val[a:a + B]
-            _, p = model.eval_step({ph['batch']: b, ph['labels']: labels_h[b], ph['batch_size']: len(b)})
-            preds.append(p)
-        adj_info.assign(train_adj)                                  # supervised_train.py:285
-        f1_gpu = orc.calc_f1_micro(labels_h[val], np.vstack(preds), False)
-        result["micro_f1"] = {"mi355x": f1_gpu, "cpu_port": f1_cpu, "train_steps": S, "val_nodes": int(len(val)),
-                              "note": "same synthetic graph, epoch order, steps, lr; validation on the full (test) adjacency; "
-                                      "statistical parity (different sampler joint law and init streams)",
-                              "train_wall_s_mi355x": t_gpu}
-        log("cpu baseline + micro-F1 legs took %.1fs (F1 mi355x %.4f, cpu port %.4f)" % (time.time() - tc, f1_gpu, f1_cpu))
+        result["micro_f1"] = f1
+        log("cpu baseline + micro-F1 legs took %.1fs: %s" % (time.time() - tc, json.dumps(
+            {k: (round(v["mean"], 4), round(v["std"], 4)) for k, v in f1["legs"].items()})))
 
     # ---------------- driver-visible short runs of BASELINE configs[2], [3], [4] (own models, same process)
     if headline and not args.no_aux:
@@ -416,6 +388,111 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def f1_legs(DG, args, B, s1, s2, F, spl, seeds=5, steps=100, n_val=4096):
+    """micro-F1 half of the metric as a MEASUREMENT: for each of `seeds` seeds (weights, epoch order, sampler stream)
+    four models train for `steps` steps on the same graph / order / learning rate FROM THE SAME INITIAL WEIGHTS and are
+    validated on the same held-out nodes on the full (test) adjacency (supervised_train.py:280):
+      cpu_port                   torch-CPU port of the reference graph: padded table (minibatch.py:227-259), one shared
+                                 column permutation per sampler call (neigh_samplers.py:24-29)
+      mi355x_padded_same_draws   the MI355X engine on THE SAME padded tables with THE SAME permutations injected
+                                 (gs_sample_padded): isolates the kernels' numerics from the sampler law
+      mi355x_csr_reference_law   the MI355X engine, native CSR sampler with law="reference" (the reference's joint law
+                                 on a virtual padded table, device-epoch hipGraph path)
+      mi355x_csr_iid             the MI355X engine as bench.py times it (law="iid")
+    Returns (micro_f1 dict with per-leg mean/std/values and paired differences vs cpu_port, cpu_baseline dict)."""
+    from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, PaddedAdjacency
+    from oracle import graphsage_oracle as orc
+    from oracle.cpu_baseline import port_micro_f1, time_cpu_baseline
+    feats_h, adj_h, test_adj_h, labels_h = DG.host_view(max_degree=128)
+    val = DG.val_nodes[:n_val].astype(np.int32)
+    n_vb = (len(val) + B - 1) // B
+    legs = {"cpu_port": [], "mi355x_padded_same_draws": [], "mi355x_csr_reference_law": [], "mi355x_csr_iid": []}
+    cb = None
+    wall = {}
+
+    def eval_gpu(model, ph, adj_info, test_adj, perms=None):
+        train_adj = adj_info.current
+        adj_info.assign(test_adj)                                   # supervised_train.py:280
+        preds = []
+        for i, a in enumerate(range(0, len(val), B)):
+            b = val[a:a + B]
+            if perms is not None:
+                model.layer_infos[0].neigh_sampler.inject_perms(perms[i])
+            _, p = model.eval_step({ph['batch']: b, ph['labels']: labels_h[b], ph['batch_size']: len(b)})
+            preds.append(p)
+        adj_info.assign(train_adj)                                  # supervised_train.py:285
+        return orc.calc_f1_micro(labels_h[val], np.vstack(preds), False)
+
+    def init_from_port(e, model, port):
+        for agg, (wn, ws) in zip(model.aggregators, port.params):
+            agg.vars['neigh_weights'].assign(wn.detach().numpy())
+            agg.vars['self_weights'].assign(ws.detach().numpy())
+        model.node_pred.vars['weights'].assign(port.W.detach().numpy())
+        model.node_pred.vars['bias'].assign(port.b.detach().numpy())
+        e.snapshot_initial_parameters()
+
+    for sd in range(seeds):
+        seed = 123 + sd
+        epoch = np.random.RandomState(seed).permutation(DG.train_nodes)
+        prng = np.random.RandomState(1000 + seed)
+        perms_train = [[prng.permutation(128) for _ in range(2)] for _ in range(steps)]
+        perms_val = [[prng.permutation(128) for _ in range(2)] for _ in range(n_vb)]
+        # ---- the CPU port (timed: the first seed's run is the cpu_baseline leg)
+        from oracle.cpu_baseline import CpuSupervisedMean
+        init = CpuSupervisedMean(feats_h[:1], adj_h[:1], [F, args.dim_1, args.dim_2], DG.num_classes, [s1, s2], seed=seed)
+        t0 = time.time()
+        c, port = time_cpu_baseline(feats_h, adj_h, labels_h, DG.train_nodes, DG.num_classes, batch_size=B,
+                                    num_samples=(s1, s2), dims=(F, args.dim_1, args.dim_2), order=epoch, fixed_steps=steps,
+                                    return_model=True, seed=seed, perms=perms_train)
+        legs["cpu_port"].append(port_micro_f1(port, test_adj_h, labels_h, val, batch_size=B, perms=perms_val))
+        wall.setdefault("cpu_port", []).append(time.time() - t0)
+        if cb is None:
+            c.pop("s_per_step", None)
+            c.pop("steps_trained", None)
+            cb = c
+        # ---- MI355X, padded tables + the same injected permutations (host-fed eager steps: the permutation is a host input)
+        t0 = time.time()
+        e, model, ph, adj_info = build_model(DG, args, 1, 0, "graphsage_mean", sampler_seed=seed)
+        init_from_port(e, model, init)
+        adj_info.assign(PaddedAdjacency(adj_h, e.device))
+        sampler = model.layer_infos[0].neigh_sampler
+        for t in range(steps):
+            b = epoch[t * B:(t + 1) * B]
+            sampler.inject_perms(perms_train[t])
+            model.train_step({ph['batch']: b, ph['labels']: labels_h[b], ph['batch_size']: len(b)}, fetch=False)
+        legs["mi355x_padded_same_draws"].append(eval_gpu(model, ph, adj_info, PaddedAdjacency(test_adj_h, e.device), perms_val))
+        wall.setdefault("mi355x_padded_same_draws", []).append(time.time() - t0)
+        del model
+        # ---- MI355X, CSR sampler, device epoch + hipGraphs (the timed path), both laws
+        for law, leg in (("reference", "mi355x_csr_reference_law"), ("iid", "mi355x_csr_iid")):
+            t0 = time.time()
+            e, model, ph, adj_info = build_model(DG, args, 1, 0, "graphsage_mean", sampler_seed=seed, sampler_law=law)
+            init_from_port(e, model, init)
+            model.attach_device_epoch(epoch, DG.label_table)
+            model.train_steps_device(B, steps, steps_per_launch=spl)
+            e.sync()
+            test_adj = CSRAdjacency.from_device(DG.test_csr[0], DG.test_csr[1], DG.n_nodes)
+            legs[leg].append(eval_gpu(model, ph, adj_info, test_adj))
+            wall.setdefault(leg, []).append(time.time() - t0)
+            del model
+    out_legs, paired = {}, {}
+    ref = np.asarray(legs["cpu_port"])
+    for k, v in legs.items():
+        v = np.asarray(v)
+        out_legs[k] = {"mean": float(v.mean()), "std": float(v.std(ddof=1)) if len(v) > 1 else 0.0, "values": [float(x) for x in v],
+                       "wall_s_per_seed": float(np.mean(wall[k]))}
+        if k != "cpu_port":
+            d = v - ref
+            paired[k] = {"mean": float(d.mean()), "stderr": float(d.std(ddof=1) / np.sqrt(len(d))) if len(d) > 1 else None}
+    f1 = {"mi355x": out_legs["mi355x_csr_iid"]["mean"], "cpu_port": out_legs["cpu_port"]["mean"], "seeds": seeds,
+          "train_steps": steps, "val_nodes": int(len(val)), "legs": out_legs, "paired_delta_vs_cpu_port": paired,
+          "note": "per seed: same synthetic graph, epoch order, steps, lr and INITIAL WEIGHTS for every leg; validation on the "
+                  "full (test) adjacency; mean / sample std over seeds; paired_delta = leg - cpu_port per seed (mean, standard "
+                  "error).  mi355x_padded_same_draws isolates numerics (same tables, same permutations); the two CSR legs "
+                  "differ from it only in the sampler law."}
+    return f1, cb
 
 
 def run_aux(DG, args, B, s1, s2):

@@ -121,6 +121,15 @@ class Engine(object):
         torch.cuda.synchronize()
         self.finalized = True
 
+    def snapshot_initial_parameters(self):
+        """Make the CURRENT weights the ones reset_parameters() returns to (after assigning weights from outside)."""
+        self.sync()
+        torch.cuda.synchronize()
+        self._init_params.copy_(self.params)
+        torch.cuda.synchronize()
+        self._params_updated()
+        self.sync()
+
     def reset_parameters(self):
         """Back to the initial weights with fresh optimizer state (Adam moments, step counter, sampler clock): a second
         training run on the same model / captured graphs (bench.py's micro-F1 leg)."""

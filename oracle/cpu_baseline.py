@@ -113,11 +113,11 @@ class CpuSupervisedMean(object):
 
 def time_cpu_baseline(features, adj, label_matrix, train_nodes, num_classes, batch_size=512, num_samples=(25, 10),
                       dims=(602, 128, 128), budget_s=15.0, warmup=2, max_steps=100, order=None, fixed_steps=None,
-                      return_model=False):
+                      return_model=False, seed=123, perms=None):
     """Times full training steps of the port on a bounded sample of the workload (~budget_s of CPU time).
     `order` (epoch order of root nodes) and `fixed_steps` make the run reproducible step for step (bench.py's micro-F1
     leg trains the MI355X engine on the same order for the same number of steps)."""
-    model = CpuSupervisedMean(features, adj, list(dims), num_classes, list(num_samples))
+    model = CpuSupervisedMean(features, adj, list(dims), num_classes, list(num_samples), seed=seed)
     if order is None:
         order = np.random.RandomState(123).permutation(train_nodes)
     times, i = [], 0
@@ -128,7 +128,7 @@ def time_cpu_baseline(features, adj, label_matrix, train_nodes, num_classes, bat
         else:
             b = order[(i * batch_size) % max(1, len(order) - batch_size):][:batch_size]
         t0 = time.time()
-        model.train_step(b, label_matrix[b])
+        model.train_step(b, label_matrix[b], perms[i] if perms is not None else None)   # perms: injected column draws
         dt = time.time() - t0
         if i >= warmup:
             times.append(dt)
@@ -148,16 +148,16 @@ def time_cpu_baseline(features, adj, label_matrix, train_nodes, num_classes, bat
     return (res, model) if return_model else res
 
 
-def port_micro_f1(model, test_adj, label_matrix, val_nodes, batch_size=512, sigmoid=False):
+def port_micro_f1(model, test_adj, label_matrix, val_nodes, batch_size=512, sigmoid=False, perms=None):
     """Validation micro-F1 of the port (supervised_train.py:63-70, 73-79): forward on the TEST adjacency
-    (supervised_train.py:280), argmax / 0.5-threshold, micro average."""
+    (supervised_train.py:280), argmax / 0.5-threshold, micro average.  perms[i]: injected column draws of batch i."""
     from . import graphsage_oracle as orc
     model.adj = torch.from_numpy(np.ascontiguousarray(test_adj, dtype=np.int64))
     preds = []
     with torch.no_grad():
         for a in range(0, len(val_nodes), batch_size):
             b = val_nodes[a:a + batch_size]
-            samples, sizes = model.sample(b)
+            samples, sizes = model.sample(b, perms[a // batch_size] if perms is not None else None)
             _, logits = model.forward(samples, sizes, label_matrix[b])
             preds.append((torch.sigmoid(logits) if sigmoid else torch.softmax(logits, dim=1)).numpy())
     return orc.calc_f1_micro(label_matrix[val_nodes], np.vstack(preds), sigmoid)
