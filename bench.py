@@ -172,6 +172,10 @@ def parse_args(argv=None):
     return args
 
 
+def roots_of(args):
+    return (2 * args.batch_size + 20) if args.unsupervised else args.batch_size
+
+
 def pmc_profile_path(args):
     """Committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE passes of THIS command) for this configuration."""
     tag = "deg%d_b%d_%dx%d_f%d" % (args.avg_degree, args.batch_size, args.samples_1, args.samples_2, args.feat_dim)
@@ -236,13 +240,21 @@ def main():
             epoch = np.random.RandomState(123).permutation(DG.train_nodes)
             order = gsd.shard_order(epoch, rank, world, B) if world > 1 else epoch
             model.attach_device_epoch(order, DG.label_table)
+    dp_info = None
     if world > 1:
         model.grad_hook = gsd.make_grad_hook(e, log=log)
         if rank == 0:
             log("gradient all-reduce: %s" % type(model.grad_hook).__name__)
     elif os.environ.get("GS_PROBE_DP_SCHEDULE"):
-        # diagnostic: run the data-parallel step schedule on one GPU with a no-op hook, to see its host-side cost
-        model.grad_hook = lambda m: None
+        # diagnostic: the data-parallel step schedule on ONE GPU, the collective replaced by a wave that sleeps for the given
+        # number of microseconds (0 = no-op hook); GS_COGATHER_DP_FORK=0 gives the schedule without the forked gather branch
+        model.grad_hook = gsd.SpinHook(e, float(os.environ["GS_PROBE_DP_SCHEDULE"]))
+    if model.grad_hook is not None:
+        dp_info = model.calibrate_dp_fork(n_gather_rows=(roots_of(args) * (1 + args.samples_2)), log=log if rank == 0 else None) or {}
+        dp_info["allreduce"] = type(model.grad_hook).__name__
+        dp_info["in_graph"] = bool(model._dp_in_graph())
+        if hasattr(model.grad_hook, "ranks"):
+            dp_info["rccl_ranks"] = model.grad_hook.ranks()          # ncclCommCount: what RCCL itself says it spans
 
     def barrier():
         if world > 1:
@@ -283,8 +295,31 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss_after": loss_after,
-                   "steps_per_graph_launch": spl},
+                   "steps_per_graph_launch": spl,
+                   "allreduce": dp_info["allreduce"] if dp_info else None,
+                   "rccl_ranks": dp_info.get("rccl_ranks") if dp_info else None},
     }
+    if dp_info:
+        # how the collective sits in the step: its stand-alone duration, the gather share forked beside it, and the
+        # EXPOSED time = this step minus the same schedule with a no-op hook in the collective's place (all ranks swap
+        # together, so no rank waits for a peer)
+        real_hook = model.grad_hook
+        model.grad_hook = gsd.SpinHook(e, 0.0) if getattr(real_hook, "capturable", False) else (lambda m: None)
+        run_steps(warm_steps)
+        barrier()
+        t1 = time.time()
+        run_steps(args.steps)
+        e.sync()
+        torch.cuda.synchronize()
+        dt0 = time.time() - t1
+        if world > 1:
+            t = torch.tensor([dt0], dtype=torch.float64, device=e.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt0 = float(t.item())
+        model.grad_hook = real_hook
+        dp_info["ms_per_step_without_collective"] = dt0 / args.steps * 1e3
+        dp_info["exposed_allreduce_us_per_step"] = (dt - dt0) / args.steps * 1e6
+        result["dp_schedule"] = dp_info
 
     # ---------------- roofline of the gather (K2 hop-2 gather+mean), HIP events on the engine stream.
     # Every rank runs the region (the interleaved training steps all-reduce under N>1); rank 0 reports.

@@ -50,6 +50,8 @@ _PROTOS = {
     "gs_class_loss": [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int, _P, _P, c_int64, _P, c_int64, _P],
     "gs_reduce_slabs": [_P, c_int32, c_int64, c_int32, c_int32, c_int64, c_float, _P, c_int64, _P, c_int64, c_int, _P],
     "gs_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, _P, c_int32, _P],
+    "gs_comm_available": [],
+    "gs_comm_count": [_P, POINTER(c_int32)],
     "gs_comm_unique_id": [_P, c_int32],
     "gs_comm_init_rank": [POINTER(c_void_p), c_int32, c_int32, _P, c_int32],
     "gs_comm_allreduce_sum_f32": [_P, _P, c_int64, _P],
@@ -57,6 +59,7 @@ _PROTOS = {
     "gs_sum_scaled": [_P, c_int64, c_float, _P, c_int, _P],
     "gs_sumsq_scaled": [_P, c_int64, c_float, _P, c_int, _P],
     "gs_stream_create": [POINTER(c_void_p)],
+    "gs_spin_us": [c_float, _P],
     "gs_stream_destroy": [_P],
     "gs_stream_sync": [_P],
     "gs_capture_begin": [_P],

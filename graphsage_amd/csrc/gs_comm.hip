@@ -16,6 +16,7 @@ typedef ncclResult_t (*fn_comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int);
 typedef ncclResult_t (*fn_comm_destroy)(ncclComm_t);
 typedef ncclResult_t (*fn_all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
 typedef const char* (*fn_error_string)(ncclResult_t);
+typedef ncclResult_t (*fn_comm_count)(const ncclComm_t, int*);
 
 static struct {
     void* handle;
@@ -24,7 +25,8 @@ static struct {
     fn_comm_destroy comm_destroy;
     fn_all_reduce all_reduce;
     fn_error_string error_string;
-} g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fn_comm_count comm_count;
+} g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 static int load_rccl() {
     if (g_rccl.handle) return GS_OK;
@@ -41,6 +43,7 @@ static int load_rccl() {
     g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
     g_rccl.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
+    g_rccl.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) {
         gs_set_error("RCCL symbols missing in the mapped librccl");
         return GS_ENOTSUP;
@@ -62,6 +65,20 @@ struct GsComm {
     ncclComm_t comm;
     int nranks, rank;
 };
+
+// Can this process bind RCCL at all?  Ranks agree on the answer (over their existing bootstrap transport) BEFORE any
+// of them enters the collective ncclCommInitRank, so that a rank without RCCL cannot leave its peers blocked there.
+extern "C" int gs_comm_available(void) { return load_rccl(); }
+
+// Number of ranks of the communicator as RCCL itself reports it (ncclCommCount) -- lets a run describe itself.
+extern "C" int gs_comm_count(void* comm, int32_t* n_out) {
+    GS_REQUIRE(comm && n_out, "gs_comm_count: bad args");
+    GsComm* c = (GsComm*)comm;
+    int n = c->nranks;
+    if (g_rccl.comm_count) GS_RCCL(g_rccl.comm_count(c->comm, &n));
+    *n_out = n;
+    return GS_OK;
+}
 
 extern "C" int gs_comm_unique_id(void* id_out_host, int32_t len) {
     GS_REQUIRE(id_out_host && len >= (int32_t)sizeof(ncclUniqueId), "gs_comm_unique_id: need a %d-byte host buffer",

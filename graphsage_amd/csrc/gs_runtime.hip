@@ -119,6 +119,21 @@ extern "C" int gs_event_destroy(void* ev) {
 __global__ void advance_counter_kernel(uint64_t* c, uint64_t delta) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta;
 }
+// Diagnostics: ONE wave that sleeps for `us` microseconds of wall clock (100 MHz constant counter) -- the stand-in for a
+// latency-bound collective when the data-parallel step schedule is probed on a single GPU (it holds one CU's wave slot
+// and leaves the rest of the chip free, like an all-reduce of 0.9 MB waiting on its peers).
+__global__ void spin_us_kernel(const uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int gs_spin_us(float us, void* stream) {
+    GS_REQUIRE(us >= 0.f && us <= 1.0e6f, "gs_spin_us: 0 .. 1e6 us");
+    hipLaunchKernelGGL(spin_us_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint64_t)(us * 100.0f));
+    GS_LAUNCH_CHECK("spin_us_kernel");
+    return GS_OK;
+}
+
 extern "C" int gs_advance_counter(uint64_t* counter_dev, uint64_t delta, void* stream) {
     GS_REQUIRE(counter_dev, "gs_advance_counter: null counter");
     hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter_dev, delta);

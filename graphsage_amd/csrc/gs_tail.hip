@@ -43,7 +43,11 @@ struct TailArgs {
     float* d_h0; int64_t lddh;
     uint64_t* c0; uint64_t d0; uint64_t* c1; uint64_t d1; uint64_t* c2; uint64_t d2;
     int32_t train;
-    uint32_t* sync;       // [groups] arrival counters of the z helpers (zero outside the kernel)
+    // hand-over state of the z helpers, G = ceil(n / 16) groups: [0, G) monotonic arrival counters (helpers add 1),
+    // [G, 2G) arrivals already consumed by earlier launches (written only by the group's main workgroup), [2G] error
+    // flags (bit 0: a main workgroup gave up waiting, bit 1: a group saw a number of arrivals other than HP).  Nothing
+    // is ever reset, so a launch does not depend on a reset store of the previous one.
+    uint32_t* sync;
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -180,6 +184,18 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores are acknowledged ...
     __syncthreads();                                             // ... and everybody else's
     if (tid == 0) __hip_atomic_fetch_add(a.sync + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// End of a main workgroup: exactly HP helpers of THIS launch must have arrived since `base` (the helpers never wait, and
+// this runs ~15 us after the hand-over); anything else -- leftovers of a launch that did not finish, a helper that
+// never ran -- is flagged.  The consumed count is then published for the next launch (no reset of the counter).
+template <int HP>
+__device__ __forceinline__ void tail_sync_done(const TailArgs& a, const int G, const int grp, const uint32_t base) {
+    if (threadIdx.x == 0) {
+        const uint32_t cur = __hip_atomic_load(a.sync + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur - base != (uint32_t)HP) __hip_atomic_fetch_or(a.sync + 2 * G, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sync + G + grp, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <int D, int O>
@@ -321,9 +337,20 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     TAIL_STAMP(2);
 
     // ---------------- phase 1: pick up z from the helpers
+    // The wait is BOUNDED (~0.3 s): if the helpers of this launch never arrive (a tool that serialises workgroups, a
+    // dispatch order that starves them) the workgroup sets the error flag and goes on with whatever z holds -- the step's
+    // numbers are then garbage but the stream does not hang, and the host raises on the flag at its next fetch.
+    uint32_t sync_base = 0u;
     if (tid == 0) {
-        while (__hip_atomic_load(a.sync + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)HP) __builtin_amdgcn_s_sleep(2);
-        __hip_atomic_store(a.sync + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        sync_base = __hip_atomic_load(a.sync + G + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0u;
+        while (__hip_atomic_load(a.sync + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sync_base < (uint32_t)HP) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) {
+                __hip_atomic_fetch_or(a.sync + 2 * G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
     }
     __syncthreads();
     {
@@ -424,6 +451,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         if (valid && lane == 0) a.loss_rows[i] = loss;
     }
     if (!a.train) {
+        tail_sync_done<HP>(a, G, grp, sync_base);
         if (grp == 0 && tid == 0) {
             if (a.c0) *a.c0 += a.d0;
             if (a.c1) *a.c1 += a.d1;
@@ -545,6 +573,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     }
     TAIL_STAMP(10);
+    tail_sync_done<HP>(a, G, grp, sync_base);
     if (grp == 0 && tid == 0) {                       // device counters (sampler clock / epoch cursor / optimizer step)
         if (a.c0) *a.c0 += a.d0;
         if (a.c1) *a.c1 += a.d1;
@@ -625,7 +654,8 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     a.loss_rows = q->loss_rows; a.dz = q->dz; a.lddz = q->lddz; a.d_h0 = q->d_h0; a.lddh = q->lddh;
     a.c0 = q->c0; a.d0 = q->d0; a.c1 = q->c1; a.d1 = q->d1; a.c2 = q->c2; a.d2 = q->d2;
     a.train = q->train ? 1 : 0;
-    GS_REQUIRE(q->sync, "gs_sage_tail_fwd_bwd: sync (ceil(n / 16) zero-initialised uint32 counters) missing");
+    GS_REQUIRE(q->sync, "gs_sage_tail_fwd_bwd: sync (2 * ceil(n / 16) + 2 zero-initialised uint32 words, private to the "
+                        "caller's stream) missing");
     a.sync = q->sync;
     hipStream_t st = (hipStream_t)stream;
     CoGatherS J = {};

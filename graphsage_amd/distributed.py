@@ -58,44 +58,101 @@ class GradAllReduce(object):
             allreduce_sum_(self.engine.grads)
 
 
+def _agree(ok, engine):
+    """MIN of a 0/1 flag over all ranks (identity without a process group): every rank learns whether ALL succeeded."""
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return int(bool(ok))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                        device=engine.device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item())
+
+
 class NativeAllReduce(object):
     """grad_hook backed by the C ABI's RCCL binding (gs_comm_*): ONE ncclAllReduce(sum, fp32) of the flat gradient
     buffer, enqueued on the ENGINE stream.  `capturable = True`: the model records it inside the step's hipGraph, so a
     data-parallel step is one graph launch (backward | all-reduce | clip+Adam) and several steps replay per launch.
-    The RCCL unique id travels from rank 0 to the other ranks over torch.distributed (plumbing only)."""
+    The RCCL unique id travels from rank 0 to the other ranks over torch.distributed (plumbing only).
+
+    Construction is failure-safe ACROSS ranks: before any rank enters the collective ncclCommInitRank the ranks agree
+    (MIN all-reduce over the bootstrap process group) that RCCL can be bound everywhere and that rank 0 produced an id;
+    ncclCommInitRank itself runs under a watchdog (GS_DP_INIT_TIMEOUT_S, default 180 s): a rank whose peers never show
+    up raises instead of blocking forever, and make_grad_hook() then lets all ranks fall back together."""
     capturable = True
 
     def __init__(self, engine, world_size=None, rank=None):
         import ctypes
+        import threading
         import torch.distributed as dist
         from . import _lib, ops
         self.engine = engine
+        self._comm = None
+        self._lib = _lib
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
             rank = dist.get_rank() if dist.is_initialized() else 0
         self.world_size, self.rank = int(world_size), int(rank)
+        multi = self.world_size > 1
+        # ---- 1. can every rank bind RCCL?  (a collective decision BEFORE the collective init)
+        err = None
+        try:
+            ops.call("gs_comm_available")
+        except Exception as ex:
+            err = ex
+        if multi and not _agree(err is None, engine):
+            raise RuntimeError("RCCL cannot be bound on every rank (this rank: %r)" % (err,))
+        if err is not None:
+            raise RuntimeError("RCCL cannot be bound: %r" % (err,))
+        # ---- 2. rank 0's unique id reaches everybody, and everybody agrees that it is valid
         nbytes = 128
         buf = (ctypes.c_uint8 * nbytes)()
         id_error = None
         if self.rank == 0:
             try:
                 ops.call("gs_comm_unique_id", ctypes.addressof(buf), nbytes)
-            except Exception as ex:      # still take part in the broadcast below (an all-zero id): the other ranks must not hang
+            except Exception as ex:      # still take part in the broadcast below (an all-zero id)
                 id_error = ex
                 buf = (ctypes.c_uint8 * nbytes)()
-        if self.world_size > 1:
+        if multi:
             dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
             t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=0)
             raw = bytes(t.cpu().tolist())
             buf = (ctypes.c_uint8 * nbytes)(*raw)
-        if id_error is not None or not any(bytes(buf)):
+        if id_error is not None or not any(bytes(buf)):       # identical on every rank: all raise together
             raise RuntimeError("RCCL unique id unavailable on rank 0: %r" % (id_error,))
+        # ---- 3. the collective init under a watchdog
         h = ctypes.c_void_p()
         torch.cuda.set_device(engine.device)
-        ops.call("gs_comm_init_rank", ctypes.byref(h), self.world_size, self.rank, ctypes.addressof(buf), nbytes)
+        box = {}
+
+        def init():
+            try:
+                torch.cuda.set_device(engine.device)          # ncclCommInitRank binds the calling thread's device
+                ops.call("gs_comm_init_rank", ctypes.byref(h), self.world_size, self.rank, ctypes.addressof(buf), nbytes)
+                box["ok"] = True
+            except Exception as ex:
+                box["err"] = ex
+
+        timeout = float(os.environ.get("GS_DP_INIT_TIMEOUT_S", "180"))
+        th = threading.Thread(target=init, name="gs_comm_init_rank", daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            raise RuntimeError("ncclCommInitRank did not return within %.0f s on rank %d (a peer failed before entering it?)"
+                               % (timeout, self.rank))
+        if "err" in box:
+            raise box["err"]
         self._comm = h.value
-        self._lib = _lib
+
+    def ranks(self):
+        """ncclCommCount of the communicator (what RCCL itself says it spans)."""
+        import ctypes
+        from . import ops
+        n = ctypes.c_int32()
+        ops.call("gs_comm_count", self._comm, ctypes.byref(n))
+        return int(n.value)
 
     def all_reduce(self, flat, stream=None):
         from . import ops
@@ -135,25 +192,45 @@ class NativeAllReduce(object):
             self._comm = None
 
 
+class SpinHook(object):
+    """Diagnostics: a grad_hook that holds the engine stream for `us` microseconds with ONE sleeping wave (gs_spin_us) --
+    the single-GPU stand-in for a latency-bound all-reduce when the data-parallel step schedule is probed without peers
+    (bench.py GS_PROBE_DP_SCHEDULE=<us>; us = 0: a no-op hook, the schedule's own cost).  Capturable like NativeAllReduce."""
+    capturable = True
+
+    def __init__(self, engine, us=0.0):
+        self.engine, self.us = engine, float(us)
+
+    def __call__(self, model):
+        if self.us > 0:
+            from . import ops
+            ops.call("gs_spin_us", self.us, self.engine.stream)
+
+
 def make_grad_hook(engine, log=None):
     """The gradient all-reduce hook of a data-parallel run: the in-graph RCCL binding of the C ABI when it initialises
-    and passes its self test on EVERY rank (the decision is collective), else the eager torch.distributed all-reduce
-    between two graphs (GradAllReduce).  GS_DP_NATIVE=0 forces the fallback."""
+    and passes its self test on EVERY rank (each stage's outcome is agreed collectively, so no rank is left inside a
+    collective its peers never enter), else the eager torch.distributed all-reduce between two graphs (GradAllReduce).
+    GS_DP_NATIVE=0 forces the fallback."""
     import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
     hook, ok = None, 0
     if os.environ.get("GS_DP_NATIVE", "1") == "1":
         try:
             hook = NativeAllReduce(engine)
-            hook.self_test()
             ok = 1
-        except Exception as ex:      # RCCL missing / init or capture failure: every rank falls back together
+        except Exception as ex:      # RCCL missing / id / init failure / watchdog
             if log:
-                log("native RCCL hook unavailable on rank %d: %r" % (dist.get_rank() if dist.is_initialized() else 0, ex))
-            ok = 0
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        flag = torch.tensor([ok], dtype=torch.int32, device=engine.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
+                log("native RCCL hook unavailable on rank %d: %r" % (rank, ex))
+        ok = _agree(ok, engine)      # every rank constructed it -- only then is the (collective) self test entered
+        if ok:
+            try:
+                hook.self_test()
+            except Exception as ex:
+                ok = 0
+                if log:
+                    log("native RCCL hook failed its self test on rank %d: %r" % (rank, ex))
+            ok = _agree(ok, engine)
     if ok:
         return hook
     if hook is not None:

@@ -74,6 +74,13 @@ class Engine(object):
         self._n_sites = 0
         # "stream" contraction kernels (gs_stream.hip) for the layer-0 forward and the grouped weight gradients
         self.stream_gemm = os.environ.get("GS_STREAM_GEMM", "1") == "1"
+        # split-K policy knobs (tuning hooks, benchmarks/slab_sweep.sh), read ONCE
+        self._wgrad_blocks = int(os.environ.get("GS_WGRAD_BLOCKS", 768))
+        self._wgrad_max_slabs = int(os.environ.get("GS_WGRAD_MAX_SLABS", 32))
+        self._wgrad_big_n = int(os.environ.get("GS_WGRAD_BIG_N", 16384))
+        self._stream_max_slabs = int(os.environ.get("GS_STREAM_MAX_SLABS", 32))
+        self._stream_slice_rows = float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))
+        self._pending_stream_ok = True
         # second stream for the data chain (sampling + gathers of the NEXT step overlap this step's compute)
         self._stream2_obj = None
         self.stream2 = None
@@ -181,14 +188,13 @@ class Engine(object):
         for v in self.variables:
             v.n_slabs = 1 if v.scatter else 0
         self._pending = []
+        self._pending_stream_ok = True
 
-    @staticmethod
-    def pick_slabs(n_rows, tiles):
+    def pick_slabs(self, n_rows, tiles):
         """Split-K slices for a weight gradient.  The kernel is latency-bound per workgroup (one global round trip
         per 32-row stage), so the goal is many short workgroups: ~768 (tile x slice) workgroups per problem, at
         least 64 reduction rows per slice, at most 32 slices."""
-        target = int(os.environ.get("GS_WGRAD_BLOCKS", 768))      # tuning hooks (benchmarks/slab_sweep.sh)
-        cap = int(os.environ.get("GS_WGRAD_MAX_SLABS", 32))
+        target, cap = self._wgrad_blocks, self._wgrad_max_slabs
         want = max(1, (target + tiles - 1) // tiles)
         return int(max(1, min(cap, want, (n_rows + 63) // 64)))
 
@@ -207,15 +213,24 @@ class Engine(object):
         """Queue var.slabs += A[a_idx]^T · dZ[:, col0:col0+var.cols] (split-K slabs); all queued problems of a
         backward pass are issued as ONE grouped launch by launch_wgrads()."""
         assert A.d == var.rows, (var.name, A.d, var.rows)
-        big = n >= int(os.environ.get("GS_WGRAD_BIG_N", 16384)) and var.rows >= 128 and var.cols >= 128   # throughput-bound: own launch with 128x128 tiles
+        big = n >= self._wgrad_big_n and var.rows >= 128 and var.cols >= 128   # throughput-bound: own launch with 128x128 tiles
         t = 128 if big else 64
         tiles = ((var.rows + t - 1) // t) * ((var.cols + t - 1) // t)
         k = self.pick_slabs(n, tiles)
-        if self.stream_gemm and not big:
+        if self.stream_gemm and not big and self._pending_stream_ok:
             # stream kernel: one WAVE per (64x64 tile, slice); ~1 contraction wave per SIMD over the whole launch
-            # (~900 items for the Reddit step) with >= 256 reduction rows per slice
-            k = int(max(1, min(int(os.environ.get("GS_STREAM_MAX_SLABS", 32)), MAX_SLABS - var.n_slabs,
-                           round(n / float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))))))
+            # (~900 items for the Reddit step) with >= 256 reduction rows per slice.  Eligibility is decided HERE, per
+            # problem, so that a problem the stream kernel cannot take keeps the slab count tuned for the tiled kernel.
+            ks = int(max(1, min(self._stream_max_slabs, MAX_SLABS - var.n_slabs, round(n / self._stream_slice_rows))))
+            lda, ldz = A.ld, dZ.ld
+            if a_idx is not None:
+                ok = (n + ks - 1) // ks <= 510 and (A.rows + 1) * lda * 4 < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
+            else:
+                ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
+            if ok:
+                k = ks
+            else:
+                self._pending_stream_ok = False      # the whole grouped launch takes the tiled kernel
         if var.n_slabs + k > MAX_SLABS:
             raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
         if big:
@@ -256,22 +271,21 @@ class Engine(object):
         """ONE grouped launch for every queued weight gradient; `side_jobs` (gather+mean descriptors of the next step)
         ride along in the same launch (horizontal fusion)."""
         if not self._pending:
-            for j in side_jobs or ():
-                ops.call("gs_gather_mean_fwd", j.X, j.ldx, j.idx, j.n, j.s, j.d, j.self_src, j.ld_self, j.self_idx, j.out,
-                         j.ldo, self.stream)
+            self.launch_gather_jobs(side_jobs)
             return
-        arr = (ops._lib.WgradDesc * len(self._pending))(*self._pending)
-        def stream_ok(d):      # slices of a gathered problem fit the register-cached row offsets; 32-bit byte offsets
-            if d.a_idx and ((d.n + d.n_slabs - 1) // d.n_slabs > 510 or (d.a_rows + 1) * d.lda * 4 >= 1 << 32):
-                return False
-            return (d.n + 1) * max(d.lda if not d.a_idx else 0, d.ldz) * 4 < 1 << 32
-        if self.stream_gemm and len(self._pending) <= 12 and all(stream_ok(d) for d in self._pending):
+        if self.stream_gemm and self._pending_stream_ok:
+            # (eligibility was decided per problem in wgrad(); the kernel takes up to 12 problems per launch)
             jobs = list(side_jobs or ())
-            jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
-            ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr), len(self._pending), ctypes.addressof(jarr),
-                     len(jobs), self.stream)
+            for a in range(0, len(self._pending), 12):
+                chunk = self._pending[a:a + 12]
+                arr = (ops._lib.WgradDesc * len(chunk))(*chunk)
+                jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
+                ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr), len(chunk), ctypes.addressof(jarr),
+                         len(jobs), self.stream)
+                jobs = []
             self._pending = []
             return
+        arr = (ops._lib.WgradDesc * len(self._pending))(*self._pending)
         if side_jobs:
             jarr = (ops._lib.GatherDesc * len(side_jobs))(*side_jobs)
             ops.call("gs_dense_wgrad_grouped_cogather", ctypes.addressof(arr), len(self._pending), ctypes.addressof(jarr),
@@ -344,21 +358,31 @@ class Engine(object):
             self._ev_fork, self._ev_join = ops.Event(), ops.Event()
         return self.stream2
 
-    def fork_join(self, main_fn, side_fn):
+    def fork_join(self, main_fn, side_fn, main_first=False):
         """Run side_fn on the second stream concurrently with main_fn on the engine stream (fork after what is
-        already queued, join before what comes next).  Works eagerly and inside a hipGraph capture."""
+        already queued, join before what comes next).  Works eagerly and inside a hipGraph capture.  main_first: enqueue
+        main_fn before side_fn (a collective's kernel should reach the chip before the work that fills it)."""
         s2 = self.ensure_stream2()
         s1 = self.stream
         self._ev_fork.record(s1)
         self._ev_fork.wait(s2)
+        if main_first:
+            main_fn()
         self.stream = s2
         try:
             side_fn()
         finally:
             self.stream = s1
-        main_fn()
+        if not main_first:
+            main_fn()
         self._ev_join.record(s2)
         self._ev_join.wait(s1)
+
+    def launch_gather_jobs(self, jobs):
+        """Stand-alone gather+mean launches (K2) of a list of gs_gather_desc jobs on the current stream."""
+        for j in jobs or ():
+            ops.call("gs_gather_mean_fwd", j.X, j.ldx, j.idx, j.n, j.s, j.d, j.self_src, j.ld_self, j.self_idx, j.out,
+                     j.ldo, self.stream)
 
     def sync(self):
         ops.call("gs_stream_sync", self.stream)

@@ -116,6 +116,10 @@ class SampleAndAggregate(object):
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         self.cogather_opt = float(os.environ.get("GS_COGATHER_OPT", 0.0))      # share riding in the optimizer launch
+        # data-parallel with the all-reduce recorded in the step graph: share of the gather on a forked branch that runs
+        # concurrently with ncclAllReduce (the collective is latency-bound and leaves the chip idle); calibrate_dp_fork()
+        # sizes it from the measured duration of the collective
+        self.cogather_dp_fork = float(os.environ.get("GS_COGATHER_DP_FORK", 0.35))
         # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
         self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
@@ -351,7 +355,7 @@ class SampleAndAggregate(object):
         """`steps` steps on the device-resident pairs; on one GPU `steps_per_launch` consecutive steps are replayed per
         hipGraph launch (keeps the GPU fed when the host is slow or shared)."""
         k = steps_per_launch - (steps_per_launch % 2)
-        if not (self.grad_hook is None and self.use_graphs and k >= 2):
+        if not ((self.grad_hook is None or self._dp_in_graph()) and self.use_graphs and k >= 2):
             for _ in range(steps):
                 self._pipelined_steps_unsup(B, 1)
             return
@@ -368,9 +372,54 @@ class SampleAndAggregate(object):
                 self._pipelined_steps_unsup(B, 1)
                 done += 1
 
+    def _dp_in_graph(self):
+        """Data-parallel AND the all-reduce hook can be recorded inside the step's hipGraph (NativeAllReduce)."""
+        return self.grad_hook is not None and getattr(self.grad_hook, "capturable", False)
+
+    def calibrate_dp_fork(self, n_gather_rows=None, log=None):
+        """Size the gather share that runs beside the in-graph all-reduce from measurements: the collective's duration
+        (HIP events around eager calls of the hook on the gradient buffer -- every rank calls this, it is a collective)
+        against the duration of the step's whole layer-0 gather as a stand-alone launch.  Returns the measurements."""
+        e = self.engine
+        if not self._dp_in_graph():
+            return None
+        evs = [(ops.Event(), ops.Event()) for _ in range(12)]
+        for a, b in evs:
+            a.record(e.stream)
+            self.grad_hook(self)
+            b.record(e.stream)
+        e.sync()
+        ar_us = float(np.median([a.elapsed_ms(b) for a, b in evs[2:]])) * 1e3
+        e.grads.zero_()
+        torch.cuda.synchronize()
+        # the gather: what one step prefetches for the next (all hops of layer 0)
+        n_rows = int(n_gather_rows) if n_gather_rows else 5632
+        s = self.num_samples[0]
+        F = self.features
+        idx = torch.randint(0, F.rows, (n_rows * s,), device=e.device, dtype=torch.int64).to(torch.int32)
+        out = Mat.zeros(n_rows, F.d, e.device)
+        torch.cuda.synchronize()
+        evs = [(ops.Event(), ops.Event()) for _ in range(8)]
+        for a, b in evs:
+            a.record(e.stream)
+            ops.gather_mean_fwd(F, idx, n_rows, s, out=out, stream=e.stream)
+            b.record(e.stream)
+        e.sync()
+        k2_us = float(np.median([a.elapsed_ms(b) for a, b in evs[2:]])) * 1e3
+        share = max(0.0, min(0.85, ar_us / max(k2_us, 1e-3)))
+        if os.environ.get("GS_COGATHER_DP_FORK") is None:
+            self.cogather_dp_fork = round(share, 2)
+        res = {"allreduce_us_standalone": ar_us, "layer0_gather_us_standalone": k2_us, "fork_share": self.cogather_dp_fork}
+        if log:
+            log("data-parallel schedule: all-reduce %.1f us, layer-0 gather %.1f us stand-alone -> %.0f %% of the gather runs "
+                "beside the collective" % (ar_us, k2_us, 100 * self.cogather_dp_fork))
+        return res
+
     def _pipelined_steps_unsup(self, B, k):
         e = self.engine
-        fused = self.grad_hook is None
+        local_adam = self.grad_hook is None
+        in_graph = self._dp_in_graph()
+        fused = local_adam or in_graph
 
         def sample_next(parity):
             roots, n_roots = self._roots(B, parity=parity)
@@ -401,12 +450,24 @@ class SampleAndAggregate(object):
                 roots, n_roots, pre = self._prefetched[(B, p)]
                 self._parity = p
                 fwd_jobs, wgrad_jobs = ops.split_gather_jobs(jobs, self.cogather_split)
+                fork_jobs = []
+                if in_graph and self.cogather_dp_fork > 0:
+                    left = max(1e-6, 1.0 - self.cogather_split)
+                    wgrad_jobs, fork_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dp_fork / left))
                 self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs)
-                self._backward_unsup(B, n_roots, fuse_adam=fused, wgrad_jobs=wgrad_jobs,
-                                     epilogue=dict(step=1 if fused else 0, clock=1, cursor=self._cursor, cursor_delta=B))
+                self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs,
+                                     epilogue=dict(step=1 if local_adam else 0, clock=1, cursor=self._cursor, cursor_delta=B))
+                if in_graph:
+                    # backward | ncclAllReduce (recorded in the graph; a gather share runs beside it) | clip + Adam
+                    if fork_jobs:
+                        e.fork_join(lambda: self.grad_hook(self), lambda: e.launch_gather_jobs(fork_jobs), main_first=True)
+                    else:
+                        self.grad_hook(self)
+                    self._optimize()
                 p = q
 
-        self._run(("updtrain" if fused else "updtrain_fb", B, k, p0, self._adj_version()), body)
+        self._run(("updtrain" if local_adam else ("updtrain_dp" if in_graph else "updtrain_fb"), B, k, p0,
+                   self._adj_version()), body)
         if not fused:
             assert k == 1
             self.grad_hook(self)
@@ -610,12 +671,23 @@ class SampleAndAggregate(object):
         means0 = self.aggregators[0].prefetch(self_all, neighs, tag=parity) if self_all is not None else None
         return samples, support_sizes, means0
 
+    def _schedule_signature(self):
+        """Everything that shapes the launches a captured step graph contains: changing one of these on a live model
+        (tests and A/B runs do) selects / captures another graph instead of silently replaying the old one."""
+        e = self.engine
+        law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
+        return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
+                self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.cogather_opt,
+                self.cogather_dp_fork, e.stream_gemm, str(getattr(self, "pipeline", None)), type(self.grad_hook).__name__,
+                id(self.grad_hook), law)
+
     def _run(self, key, fn):
         """Eager on first use, captured into a hipGraph on the second, replayed afterwards.  The Python attributes
         that name a step's output buffers are snapshotted per key and restored on replay (the Python of `fn` does
         not run again, and other step shapes -- e.g. a validation batch -- may have re-pointed them meanwhile)."""
         e = self.engine
-        key = tuple(key) + (self._dropout_rate(),)     # the rate is baked into the captured launches
+        # the dropout rate and the schedule choices are baked into the captured launches
+        key = tuple(key) + (self._dropout_rate(), self._schedule_signature())
         g = self._graphs.get(key)
         if g is not None:
             for name, val in self._graph_outputs[key].items():

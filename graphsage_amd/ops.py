@@ -385,23 +385,29 @@ def sage_tail_supported(d_in, out_dim, C):
     return bool(_lib.load().gs_sage_tail_supported(int(d_in), int(out_dim), int(C)))
 
 
-_tail_sync = {}
+def tail_sync_words(n):
+    """Size (uint32 words) of the hand-over buffer gs_sage_tail_fwd_bwd needs for n batch rows."""
+    return 2 * ((n + 15) // 16) + 2
+
+
+def tail_sync_error(sync, n):
+    """The error word of a tail hand-over buffer (0 = fine); synchronises."""
+    return int(sync[2 * ((n + 15) // 16)].item())
 
 
 def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels, C, sigmoid_loss, means, z, y, logits,
                       preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), jobs=(), stream=None, sync=None):
     """gs_sage_tail_fwd_bwd: layer 1 + head (+ their input gradients when dz / d_h0 are given) in ONE launch.
     counters: up to three (device int64 tensor, delta) pairs advanced at the end of the launch.
-    sync: int32 device tensor of ceil(n / 16) zeros (kernel-internal arrival counters, left zero); one is kept per
-    (device, size) if not given."""
+    sync: int32 device tensor of tail_sync_words(n) words, zero-initialised once and owned by ONE caller / stream
+    (kernel-internal hand-over state + an error word, see tail_sync_error); a fresh one is allocated if not given."""
     if sync is None:
         import torch
-        key = (str(h0.buf.device), (n + 15) // 16)
-        sync = _tail_sync.get(key)
-        if sync is None:
-            sync = _tail_sync[key] = torch.zeros(key[1], dtype=torch.int32, device=h0.buf.device)
-            torch.cuda.synchronize()
+        sync = torch.zeros(tail_sync_words(n), dtype=torch.int32, device=h0.buf.device)
+        torch.cuda.synchronize()
+    assert sync.numel() >= tail_sync_words(n)
     q = _lib.TailDesc()
+    q._keep = sync
     q.sync = ptr(sync)
     q.h0, q.ldh, q.n = h0.ptr, h0.ld, n
     q.W_self, q.ldws, q.W_neigh, q.ldwn = W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld

@@ -37,6 +37,7 @@ class SupervisedGraphsage(SampleAndAggregate):
         self.build()
 
     _OUT_ATTRS = ("preds", "samples1", "outputs1", "node_preds", "agg_out", "_loss_rows", "_dlogits", "_loss_accumulate",
+                  "_tail_sync", "_tail_sync_n",
                   "_head_fused", "_d_agg_out", "_tape", "_tail_used", "_tail_means", "_tail_dz", "_tail_dh0", "_tail_h0",
                   "_tail_step_advanced")
 
@@ -80,7 +81,10 @@ class SupervisedGraphsage(SampleAndAggregate):
             prefetched = self._data_phase(batch, n, getattr(self, "_parity", 0), stage=getattr(self, "_pending_stage", None))
         samples1, support_sizes1, means0 = prefetched
         C = self.num_classes
-        self._tail_used = bool(train and self._tail_ok())
+        # the fused tail needs the hops of layer 0 in ONE contiguous buffer (model.sample on the model's id buffer);
+        # anything else takes the per-operator schedule
+        contiguous = all(b.data_ptr() == a.data_ptr() + 4 * a.numel() for a, b in zip(samples1[:-1], samples1[1:]))
+        self._tail_used = bool(train and contiguous and self._tail_ok())
         out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n,
                                 aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
                                 layer0_means=means0, layer0_side_jobs=side_jobs,
@@ -107,6 +111,9 @@ class SupervisedGraphsage(SampleAndAggregate):
             self._head_fused = True
             counters = []
             self._tail_step_advanced = False
+            # hand-over state of the launch's helper workgroups: private to this model (its engine stream)
+            self._tail_sync = e.ws_i32(("tail_sync", self.name), ops.tail_sync_words(n))
+            self._tail_sync_n = n
             if epilogue:
                 if epilogue.get("step"):
                     counters.append((e.step_dev, epilogue["step"]))
@@ -119,7 +126,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                                   self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels, C,
                                   self.sigmoid_loss, self._tail_means, self.agg_out, self.outputs1, self.node_preds,
                                   self.preds, self._dlogits, self._loss_rows, dz=self._tail_dz, d_h0=self._tail_dh0,
-                                  counters=counters, jobs=tail_jobs, stream=e.stream)
+                                  counters=counters, jobs=tail_jobs, stream=e.stream, sync=self._tail_sync)
         else:
             self.agg_out = out
             self.outputs1 = e.ws_mat("outputs1", n, out.d)
@@ -197,10 +204,6 @@ class SupervisedGraphsage(SampleAndAggregate):
         if not advanced:
             e.advance(step=1)
 
-    def _dp_in_graph(self):
-        """Data-parallel AND the all-reduce hook can be recorded inside the step's hipGraph (NativeAllReduce)."""
-        return self.grad_hook is not None and getattr(self.grad_hook, "capturable", False)
-
     # ------------------------------------------------------------------------------ feeds
     def _stage_feed(self, feed_dict):
         """Copy the host feed (batch ids + label matrix) into persistent device buffers."""
@@ -260,6 +263,13 @@ class SupervisedGraphsage(SampleAndAggregate):
 
     def _fetch(self, n):
         self.engine.sync()
+        if getattr(self, "_tail_sync", None) is not None:
+            err = ops.tail_sync_error(self._tail_sync, self._tail_sync_n)
+            if err:
+                raise ops._lib.GraphsageAmdError(
+                    "fused tail launch: hand-over between its workgroups failed (flags %d: 1 = a row-group workgroup "
+                    "gave up waiting for its helpers, 2 = unexpected arrival count); results since the last fetch are "
+                    "invalid -- set model.fuse_tail = False to use the per-operator schedule" % err)
         loss = float(self.loss_dev.item())
         preds = self.preds.view()[:n].detach().cpu().numpy()
         return loss, preds
@@ -357,22 +367,40 @@ class SupervisedGraphsage(SampleAndAggregate):
             self._parity = p
             # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
-            opt_jobs = []
+            opt_jobs, fork_jobs = [], []
             if side_jobs and self.cogather_tail > 0 and self._tail_ok():
                 # the fused tail launch keeps only n/16 CUs busy: the rest of the chip streams a share of the gather
-                fwd_jobs, rest = ops.split_gather_jobs(side_jobs, self.cogather_split3)
-                tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, self.cogather_tail / max(1e-6, 1.0 - self.cogather_split3)))
+                f_fwd, f_tail = self.cogather_split3, self.cogather_tail
+                f_fork = min(self.cogather_dp_fork, 1.0 - f_fwd) if in_graph else 0.0
+                if f_fork > 0:
+                    # data-parallel: the collective is latency-bound and leaves the chip idle -- that share of the gather
+                    # runs on a forked branch concurrently with ncclAllReduce; the tail launch keeps what is left
+                    f_tail = max(0.0, min(f_tail, 1.0 - f_fwd - f_fork))
+                fwd_jobs, rest = ops.split_gather_jobs(side_jobs, f_fwd)
+                tail_jobs, rest = ops.split_gather_jobs(rest, min(1.0, f_tail / max(1e-6, 1.0 - f_fwd)))
+                if f_fork > 0:
+                    left = max(1e-6, 1.0 - f_fwd - f_tail)
+                    wgrad_jobs, fork_jobs = ops.split_gather_jobs(rest, max(0.0, 1.0 - f_fork / left))
+                else:
+                    wgrad_jobs = rest
                 if self.cogather_opt > 0 and local_adam:
-                    left = max(1e-6, 1.0 - self.cogather_split3 - self.cogather_tail)
+                    left = max(1e-6, 1.0 - f_fwd - f_tail)
                     wgrad_jobs, opt_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_opt / left))
             else:
                 fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
                 tail_jobs = []
+                if side_jobs and in_graph and self.cogather_dp_fork > 0:
+                    left = max(1e-6, 1.0 - self.cogather_split)
+                    wgrad_jobs, fork_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dp_fork / left))
             self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue,
                           tail_jobs=tail_jobs)
             self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue, opt_jobs=opt_jobs)
             if in_graph:
-                self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
+                # ncclAllReduce on the engine stream, recorded in the graph; the forked gather share runs beside it
+                if fork_jobs:
+                    e.fork_join(lambda: self.grad_hook(self), lambda: e.launch_gather_jobs(fork_jobs), main_first=True)
+                else:
+                    self.grad_hook(self)
                 self._optimize(advanced=True)
 
         def sample_into(parity):

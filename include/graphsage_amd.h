@@ -441,8 +441,11 @@ typedef struct gs_tail_desc {
     uint64_t* c1; uint64_t d1;
     uint64_t* c2; uint64_t d2;
     int32_t s, d_in, out_dim, C, sigmoid, train;
-    uint32_t* sync;        /* [ceil(n / 16)] device counters, zero on entry and left zero (in-kernel hand-over of the layer-1
-                              pre-activations from the helper workgroups to the row-group workgroups) */
+    uint32_t* sync;        /* [2 * ceil(n / 16) + 2] device words, zero-initialised ONCE by the caller and private to one
+                              stream (in-kernel hand-over of the layer-1 pre-activations from the helper workgroups to the
+                              row-group workgroups): monotonic arrival counters, consumed counts, and at index
+                              2 * ceil(n / 16) an error word the caller should check when it fetches results (bit 0: a
+                              row-group workgroup gave up waiting (bounded wait), bit 1: unexpected arrival count). */
 } gs_tail_desc;
 int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
 /* jobs_host / n_jobs (0..6): gather+mean jobs of the NEXT step co-scheduled in the launch (as gs_sage_dense_fwd_cogather):
@@ -530,8 +533,13 @@ int gs_sumsq_scaled(const float* x, int64_t count, float scale, float* out, int 
  *   gs_comm_unique_id : rank 0 fills a >= 128-byte HOST buffer which the host code ships to every rank
  *                       (torch.distributed / MPI / a file -- not this library's business)
  *   gs_comm_init_rank : collective over all ranks; uses the calling thread's current HIP device
+ *   gs_comm_available : GS_OK iff RCCL can be bound in this process -- ranks agree on this over their bootstrap
+ *                       transport BEFORE any of them enters the collective gs_comm_init_rank
+ *   gs_comm_count     : ncclCommCount of the communicator (a run can report the size RCCL really has)
  * ------------------------------------------------------------------------------------------- */
 #define GS_COMM_ID_BYTES 128
+int gs_comm_available(void);
+int gs_comm_count(void* comm, int32_t* n_ranks_out_host);
 int gs_comm_unique_id(void* id_out_host, int32_t len);
 int gs_comm_init_rank(void** comm_out, int32_t nranks, int32_t rank, const void* id_host, int32_t len);
 int gs_comm_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);
@@ -541,6 +549,9 @@ int gs_comm_destroy(void* comm);
  * hipGraph helpers: the per-step kernel chain is captured once and replayed (no tracing compiler).
  * ------------------------------------------------------------------------------------------- */
 int gs_stream_create(void** stream_out);
+/* Diagnostics: one wave sleeping `us` microseconds on `stream` (the stand-in for a latency-bound collective when the
+ * data-parallel step schedule is probed on one GPU; bench.py GS_PROBE_DP_SCHEDULE). */
+int gs_spin_us(float us, void* stream);
 int gs_stream_destroy(void* stream);
 int gs_stream_sync(void* stream);
 int gs_capture_begin(void* stream);

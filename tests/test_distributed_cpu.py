@@ -65,3 +65,60 @@ def test_dp_gradient_equals_global_batch_gradient():
         assert p.exitcode == 0
     for rank, err, scale in res:
         assert err < 1e-5 * max(1.0, scale), (rank, err, scale)
+
+
+def _agree_worker(rank, world, port, q):
+    """NativeAllReduce's construction with a rank that cannot bind RCCL: the ranks must AGREE (before anyone enters the
+    collective ncclCommInitRank) and all raise promptly -- nobody hangs."""
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "GS_DIST_BACKEND": "gloo"})
+    import time
+    import torch.distributed as dist
+    from graphsage_amd import distributed as gsd
+    from graphsage_amd import ops
+    gsd.init_from_env()
+    real_call = ops.call
+    calls = []
+
+    def fake_call(name, *args):
+        calls.append(name)
+        if name == "gs_comm_available" and rank == 1:
+            raise ops._lib.GraphsageAmdError("RCCL not found (test)")
+        if name == "gs_comm_init_rank":
+            raise AssertionError("a rank entered ncclCommInitRank although a peer cannot bind RCCL")
+        return real_call(name, *args)
+
+    ops.call = fake_call
+
+    class FakeEngine(object):
+        device = torch.device("cpu")
+
+    t0 = time.time()
+    try:
+        gsd.NativeAllReduce(FakeEngine())
+        outcome = "constructed"
+    except RuntimeError as ex:
+        outcome = "raised: %s" % ex
+    # the collective helper itself: MIN over ranks
+    assert gsd._agree(rank == 0, FakeEngine()) == 0 and gsd._agree(True, FakeEngine()) == 1
+    q.put((rank, outcome, time.time() - t0, "gs_comm_init_rank" in calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_allreduce_init_is_failure_safe_across_ranks():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outcome, dt, entered_init in res:
+        assert outcome.startswith("raised: RCCL cannot be bound on every rank"), (rank, outcome)
+        assert not entered_init and dt < 60

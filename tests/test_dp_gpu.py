@@ -106,3 +106,113 @@ def test_native_rccl_hook_in_graph_single_rank(dev):
             hook.close()
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
     np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7)
+
+
+def test_dp_fork_schedule_single_rank_matches_and_unsup_in_graph(dev):
+    """(a) supervised: the data-parallel in-graph schedule WITH the forked gather branch beside the collective (here the
+    1-rank RCCL all-reduce, and a sleeping-wave stand-in) gives the same parameters as the single-GPU fused schedule;
+    (b) unsupervised: the in-graph data-parallel schedule (backward | all-reduce | clip+Adam in ONE graph, several steps
+    per launch) == the single-GPU schedule."""
+    import numpy as np
+    from graphsage_amd import engine as eng
+    from graphsage_amd.distributed import NativeAllReduce, SpinHook
+    from test_model_gpu import build
+    outs = []
+    for mode in ("single", "rccl_fork", "spin_fork", "rccl_nofork"):
+        G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
+        hook = None
+        if mode != "single":
+            hook = NativeAllReduce(eng.get_engine(), world_size=1, rank=0) if mode.startswith("rccl") else SpinHook(eng.get_engine(), 20.0)
+            model.grad_hook = hook
+            model.cogather_dp_fork = 0.0 if mode == "rccl_nofork" else 0.4
+            assert model._dp_in_graph()
+            if mode == "rccl_fork":
+                info = model.calibrate_dp_fork(n_gather_rows=32 * 4)
+                assert info["allreduce_us_standalone"] > 0 and 0.0 <= model.cogather_dp_fork <= 0.85
+                assert hook.ranks() == 1
+                model.cogather_dp_fork = 0.4
+        model.attach_device_epoch(it.train_nodes[:320], it.label_matrix)
+        model.train_steps_device(32, 9, steps_per_launch=2)
+        loss, preds = model._fetch(32)
+        outs.append((loss, eng.get_engine().params.cpu().numpy().copy()))
+        if hook is not None and hasattr(hook, "close"):
+            hook.close()
+    for o in outs[1:]:
+        np.testing.assert_allclose(outs[0][0], o[0], rtol=1e-5)
+        np.testing.assert_allclose(outs[0][1], o[1], rtol=1e-5, atol=1e-7)
+    assert np.array_equal(outs[1][1], outs[2][1]) and np.array_equal(outs[1][1], outs[3][1])   # schedules differ, bits do not
+    # ---- unsupervised
+    from test_unsup_gpu import build as build_unsup
+    res = []
+    for dp in (False, True):
+        G, it, ph, sampler, model, ns = build_unsup("mean", True, csr=True)
+        if dp:
+            hook = NativeAllReduce(eng.get_engine(), world_size=1, rank=0)
+            model.grad_hook = hook
+            model.cogather_dp_fork = 0.3
+        model.attach_device_pairs(it.train_edges[:320])
+        model.train_steps_device(32, 9, steps_per_launch=2)
+        eng.get_engine().sync()
+        res.append(eng.get_engine().params.cpu().numpy().copy())
+        if dp:
+            assert any(k[0] == "updtrain_dp" and k[2] == 2 for k in model._graphs), list(model._graphs)
+            hook.close()
+    np.testing.assert_allclose(res[0], res[1], rtol=1e-5, atol=1e-7)
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank), "GS_DIST_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(rank)
+    from graphsage_amd import distributed as gsd
+    from graphsage_amd import engine as eng
+    from test_model_gpu import build
+    gsd.init_from_env()
+    out = {}
+    for mode in ("native", "eager"):
+        os.environ["GS_DP_NATIVE"] = "1" if mode == "native" else "0"
+        G, it, ph, sampler, model, ns = build(torch.device("cuda:%d" % rank), "mean", True, False, csr=True)
+        model.world_size, model.rank = world, rank
+        model.row_offset = rank * B
+        order = it.train_nodes[: 8 * B * 2]
+        e = eng.get_engine()
+        model.grad_hook = gsd.make_grad_hook(e)
+        if mode == "native":
+            assert type(model.grad_hook).__name__ == "NativeAllReduce" and model.grad_hook.ranks() == world
+            model.calibrate_dp_fork(n_gather_rows=B * 4)
+        model.attach_device_epoch(gsd.shard_order(order, rank, world, B), it.label_matrix)
+        model.train_steps_device(B, 7, steps_per_launch=2)
+        e.sync()
+        torch.cuda.synchronize()
+        out[mode] = e.params.cpu().numpy().copy()
+        if mode == "native":
+            assert any(k[0] == "ptrain_dp" for k in model._graphs)
+    q.put((rank, out["native"], out["eager"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_rccl_in_graph_matches_eager_hook():
+    """TWO GPUs, real RCCL: the in-graph schedule (ncclAllReduce recorded in the step hipGraph, gather share forked
+    beside it, 2 steps per launch) == the eager torch.distributed hook between two graphs; replicas stay identical.
+    Auto-skips on a 1-GPU box (the driver's multi-GPU run is the first to execute it)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (a, b)) for r, a, b in [q.get(timeout=300) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])      # replicas identical
+    np.testing.assert_allclose(res[0][0], res[0][1], rtol=1e-5, atol=1e-7)                    # in-graph == eager hook

@@ -774,6 +774,52 @@ def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
     np.testing.assert_allclose(dh0.numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
+def test_fused_tail_handover_stress(dev):
+    """The in-kernel hand-over of the fused tail (helper workgroups -> row-group workgroups through monotonic arrival
+    counters, bounded wait, error word) under stress: 4000 rows = 1250 workgroups (far more than resident at once),
+    30 back-to-back launches on ONE hand-over buffer while a second stream keeps the chip busy with gathers, plus gather
+    riders in the launch itself.  Every launch must give the same bits, the error word stays 0, and a second model
+    sharing the device (own buffer) is not disturbed."""
+    rng = np.random.default_rng(7)
+    n, s, D, O, C = 4000, 10, 256, 128, 41
+    rows, Z = n + n * s, 2 * O
+    h0 = Mat.from_numpy(np.maximum(_asym(rng, (rows, D)), 0).astype(np.float32), dev)
+    Ws, Wn = Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev), Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev)
+    Wh, bh = Mat.from_numpy(_asym(rng, (Z, C)) * 0.3, dev), torch.from_numpy(_asym(rng, (C,)) * 0.1).to(dev)
+    lab = Mat.from_numpy(np.eye(C, dtype=np.float32)[rng.integers(0, C, n)], dev)
+    Xg = Mat.from_numpy(_asym(rng, (20000, 602)), dev, ld_multiple=32)
+    idx = _i32(rng.integers(0, 20000, size=5120 * 25), dev)
+    side = torch.cuda.Stream()
+    sync = torch.zeros(ops.tail_sync_words(n), dtype=torch.int32, device=dev)
+    main = ops.Stream()
+    outs = []
+    for it in range(30):
+        means, z, y = Mat.zeros(n, D, dev), Mat.zeros(n, Z, dev), Mat.zeros(n, Z, dev)
+        lo, pr, dl = Mat.zeros(n, C, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
+        lr, dz, dh0 = torch.zeros(n, device=dev), Mat.zeros(n, Z, dev), Mat.zeros(rows, D, dev)
+        gm = Mat.zeros(5120, 602, dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):                                    # concurrent work on another stream
+            for _ in range(3):
+                ops.gather_mean_fwd(Xg, idx, 5120, 25, out=Mat.zeros(5120, 602, dev), stream=side.cuda_stream)
+        jobs = [ops.gather_job(Xg, idx, 5120, 25, gm)] if it % 2 else []
+        ops.sage_tail_fwd_bwd(h0, n, s, Ws, Wn, O, Wh, bh, lab, C, False, means, z, y, lo, pr, dl, lr, dz=dz, d_h0=dh0,
+                              jobs=jobs, stream=main.handle, sync=sync)
+        ops.call("gs_stream_sync", main.handle)
+        torch.cuda.synchronize()
+        assert ops.tail_sync_error(sync, n) == 0, "launch %d" % it
+        outs.append((z.numpy(), dz.numpy(), dh0.numpy(), lr.cpu().numpy()))
+        for a, b in zip(outs[0], outs[-1]):
+            assert np.array_equal(a, b), "launch %d differs from launch 0" % it
+    G = (n + 15) // 16
+    st = sync.cpu().numpy().astype(np.int64)
+    assert (st[:G] == 30 * (Z // 64)).all() and (st[G:2 * G] == st[:G]).all() and st[2 * G] == 0
+    h64 = h0.numpy().astype(np.float64)
+    zz, _ = orc.mean_aggregator_fwd(h64[:n], h64[n:].reshape(n, s, D), Ws.numpy().astype(np.float64),
+                                    Wn.numpy().astype(np.float64), True, "id")
+    np.testing.assert_allclose(outs[0][0], zz, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("n,d,out,two,act,bias,gathered", [
     (5632, 602, 128, True, ops.ACT_RELU, False, True), (2500, 100, 128, True, ops.ACT_IDENTITY, True, False),
     (3001, 602, 256, False, ops.ACT_RELU, False, False), (2049, 37, 40, True, ops.ACT_RELU, True, True),
