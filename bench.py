@@ -41,7 +41,7 @@ def placeholders(unsup=False):
             'batch_size': Placeholder('batch_size')}
 
 
-def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_seed=123, sampler_law="iid"):
+def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_seed=123, sampler_law=None):
     """A fresh engine + model on the device-resident graph DG (features / CSR / labels are shared, not copied)."""
     from graphsage_amd import engine as eng
     from graphsage_amd.models import SAGEInfo, SampleAndAggregate
@@ -51,6 +51,7 @@ def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_s
     e = eng.get_engine()
     train_adj = CSRAdjacency.from_device(DG.train_csr[0], DG.train_csr[1], DG.n_nodes)
     adj_info = AdjInfo(train_adj)
+    sampler_law = sampler_law or os.environ.get("GS_SAMPLER_LAW", "iid")       # A/B hook: iid | reference | distinct
     sampler = UniformNeighborSampler(adj_info, seed=sampler_seed, law=sampler_law, max_degree=128)
     ph = placeholders(unsupervised)
     if unsupervised:
@@ -180,6 +181,30 @@ def pmc_profile_path(args):
     """Committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE passes of THIS command) for this configuration."""
     tag = "deg%d_b%d_%dx%d_f%d" % (args.avg_degree, args.batch_size, args.samples_1, args.samples_2, args.feat_dim)
     return os.path.join(ROOT, "profiles", "k2_pmc_%s.json" % tag)
+
+
+def step_traffic_profile(args):
+    """Per-step fabric-side bytes from the newest committed whole-step PMC profile (profiles/r*_step_traffic.json,
+    benchmarks/profile_step_traffic.sh) -- only for the headline configuration it was taken on."""
+    import glob
+    if args.workload != "reddit" or args.unsupervised or args.model != "graphsage_mean" or args.avg_degree != 492 \
+            or (args.batch_size, args.samples_1, args.samples_2, args.feat_dim) != (512, 25, 10, 602):
+        return None
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")))
+    if not paths:
+        return None
+    with open(paths[-1]) as f:
+        d = json.load(f)
+    by = {}
+    for l in d["launches"]:
+        # the steady-state launch of a kernel is the most frequent grid; the sampler rides in the optimizer launch
+        k = l["kernel"]
+        if k == "sample_fanout_kernel":
+            continue
+        if k not in by or l["launches_seen"] > by[k]["launches_seen"]:
+            by[k] = l
+    total = sum((l["hbm_read_MB"] + l["hbm_write_MB"]) * 1e6 for l in by.values())
+    return {"bytes_per_step": total, "path": os.path.relpath(paths[-1], ROOT)}
 
 
 def timed_events(e, fn, iters, between=None):
@@ -346,8 +371,11 @@ def main():
         with open(pmc) as fpm:
             traffic = json.load(fpm)["traffic_bytes_per_launch"]
         traffic_src = ("PROFILE-SOURCED, not measured by this run: %s (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of "
-                       "this command on this graph; FETCH_SIZE calibrated on a known-byte gather, MI355X_MICROARCH.md HBM)"
+                       "this command on this graph; FETCH_SIZE calibrated on a known-byte gather, MI355X_MICROARCH.md HBM). "
+                       "FETCH_SIZE counts at the L2's FABRIC side: reads served by the Infinity Cache (MALL) are included, so "
+                       "this is an UPPER bound on the bytes that reached HBM; the unique-row bytes are the lower bound."
                        % os.path.relpath(pmc, ROOT))
+    unique_gbs = unique_bytes / (k2_us * 1e-6) / 1e9
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "kernel": "gather_mean_kernel<8> (K2, hop-2: [%d x %d] rows of %d fp32), standalone launch interleaved with "
                       "training steps" % (n2, s1, F),
@@ -355,15 +383,33 @@ def main():
             "frac_algorithmic": achieved / HBM_PEAK_GBS,
             "unique_row_bytes_per_launch": unique_bytes,
             "unique_rows_frac": float(np.mean(uniq)) / float(n2 * s1),
-            "traffic": traffic, "traffic_source": traffic_src}
+            "frac_unique_lower": min(achieved, unique_gbs) / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_basis": "L2 fabric-side bytes (Infinity-Cache hits included): upper bound on HBM bytes"}
     if traffic is not None:
         roof["frac"] = traffic / (k2_us * 1e-6) / 1e9 / HBM_PEAK_GBS
-        roof["frac_basis"] = "HBM-side bytes (traffic) / avg_launch_us / peak"
+        roof["frac_basis"] = ("L2 fabric-side bytes (traffic, upper bound on HBM bytes) / avg_launch_us / peak; the true HBM "
+                              "fraction lies in [frac_unique_lower, frac]")
     else:
-        roof["frac"] = min(achieved, unique_bytes / (k2_us * 1e-6) / 1e9) / HBM_PEAK_GBS
+        roof["frac"] = min(achieved, unique_gbs) / HBM_PEAK_GBS
         roof["frac_basis"] = ("unique-row bytes (live lower bound of the HBM-side traffic: duplicate rows of a launch can be "
                               "served by L2/MALL) / avg_launch_us / peak; no committed PMC profile for this configuration")
     result["roofline"] = roof
+    # ---------------- the WHOLE step against the same roof: algorithmic bytes of a step (rows*F*4 + ids +
+    # mean writes, all hops) / ms_per_step, and the fabric-side counter bytes of the step's launches from the committed
+    # whole-step PMC profile (their ratio = traffic the step moves beyond its algorithmic bytes)
+    rows_step = roots * (1 + s2 + s2 * s1)
+    alg_step = rows_step * F * 4 + roots * (s2 + s2 * s1) * 4 + roots * (1 + s2) * F * 4
+    step = {"algorithmic_bytes_per_step": alg_step, "ms_per_step": dt / args.steps * 1e3,
+            "achieved": alg_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac_algorithmic": alg_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "counter_bytes_per_step": None}
+    stp = step_traffic_profile(args)
+    if stp is not None:
+        step["counter_bytes_per_step"] = stp["bytes_per_step"]
+        step["frac_counter"] = stp["bytes_per_step"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
+        step["wasted_traffic_ratio"] = stp["bytes_per_step"] / alg_step
+        step["counter_source"] = "PROFILE-SOURCED: %s (L2 fabric-side bytes, upper bound on HBM bytes)" % stp["path"]
+    result["roofline_step"] = step
 
     # ---------------- roofline of the launch that dominates the step: the layer-0 contraction with the next step's
     # gather+mean co-scheduled in it (both roofs at once).  The exact launch of the step is re-issued between events.

@@ -7,28 +7,40 @@
 #define GS_MAX_HOPS 3
 
 // ---- sampling laws (gs_sample_law in include/graphsage_amd.h) --------------------------------------------------------
-// gs_perm_index(key, j, n): the j-th element of a keyed pseudo-random PERMUTATION of [0, n): a balanced Feistel network
-// (6 rounds; 12 when a half is <= 3 bits -- measured: pairs of outputs are chi-square uniform from there on) on
-// 2*half >= ceil(log2 n) bits with cycle walking (a permutation of the power-of-two domain restricted to
-// [0, n) by re-applying it until the value lands inside; terminates because the walk stays on the cycle of j).  A
-// pure function, so "s distinct columns" and "a frozen max_degree subset of a long neighbor list" need no state and
-// no table.  Restated bit-for-bit in oracle/sampler_hash.py::perm_index.
+// gs_perm_index(key, j, n): the j-th element of a keyed pseudo-random PERMUTATION of [0, n): an alternating (unbalanced)
+// Feistel network on bits = ceil(log2 n) bits -- the value is split into a high part of floor(bits/2) and a low part of
+// ceil(bits/2) bits; even rounds xor a 32-bit hash of the low part into the high part, odd rounds the other way round
+// (every round is invertible, so the whole map is a permutation of [0, 2^bits)) -- with cycle walking: the map is
+// re-applied until the value lands in [0, n) (it stays on the cycle of j, so it terminates; 2^bits < 2n, so fewer than
+// two applications on average).  Rounds: 8 (12 for bits <= 6, 24 for bits <= 4: measured, pairs of outputs are
+// chi-square uniform from there on).  All arithmetic is 32-bit (the sampler chain is latency-critical: 64-bit multiplies
+// cost ~4x).  A pure function, so "s distinct columns" and "a frozen max_degree subset of a long neighbor list" need no
+// state and no table.  Restated bit-for-bit in oracle/sampler_hash.py::perm_index.
+__device__ __forceinline__ uint32_t gs_fmix32(uint32_t h) {      // murmur3 finalizer
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
 __device__ __forceinline__ uint32_t gs_perm_index(uint64_t key, uint32_t j, uint32_t n) {
     if (n <= 1u) return 0u;
-    const int bits = 32 - __clz((int)(n - 1u));
-    const int half = (bits + 1) >> 1;
-    const uint32_t mask = (1u << half) - 1u;
-    const int rounds = half <= 3 ? 12 : 6;
+    int bits = 32 - __clz((int)(n - 1u));
+    bits = bits < 2 ? 2 : bits;
+    const int a = bits >> 1, b = bits - a;
+    const uint32_t mA = (1u << a) - 1u, mB = (1u << b) - 1u;
+    const int rounds = bits <= 4 ? 24 : (bits <= 6 ? 12 : 8);
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
     uint32_t x = j;
     do {
-        uint32_t L = x >> half, R = x & mask;
-        for (int r = 0; r < rounds; ++r) {
-            const uint32_t f = (uint32_t)(gs_mix64(key + ((uint64_t)r << 32) + (uint64_t)R) >> 32) & mask;
-            const uint32_t t = L ^ f;
-            L = R;
-            R = t;
+        uint32_t L = x >> b, R = x & mB;
+        for (int r = 0; r < rounds; r += 2) {
+            L ^= ((gs_fmix32(R + k0 + (uint32_t)r * 0x9E3779B9u) ^ k1) >> 7) & mA;
+            R ^= ((gs_fmix32(L + k0 + (uint32_t)(r + 1) * 0x9E3779B9u) ^ k1) >> 7) & mB;
         }
-        x = (L << half) | R;
+        x = (L << b) | R;
     } while (x >= n);
     return x;
 }
@@ -54,13 +66,19 @@ __device__ __forceinline__ uint32_t gs_table_entry(uint64_t tkey, uint32_t c, ui
     return (uint32_t)(((gs_mix64(tkey + (uint64_t)c) >> 32) * (uint64_t)deg) >> 32);
 }
 
-// position in the neighbor list of slot j of global row `grow` (deg > 0).  callkey = hash of (seed, step, hop).
+// column j of the call's column permutation under GS_LAW_REFERENCE (neigh_samplers.py:26-28: ONE permutation per call
+// shared by all rows, first s columns).  callkey = hash of (seed, step, hop).
+__device__ __forceinline__ uint32_t gs_call_column(uint64_t callkey, uint32_t j, uint32_t M) {
+    return gs_perm_index(gs_mix64(callkey ^ 0xC0115ull), j, M);
+}
+
+// position in the neighbor list of slot j of global row `grow` (deg > 0).  cols: the call's columns precomputed by the
+// caller (LDS), or nullptr.
 __device__ __forceinline__ uint32_t gs_draw(const SampleLaw lw, uint64_t seed, uint64_t callkey, int64_t grow, uint32_t j,
-                                            int32_t s, int32_t id, uint32_t deg) {
+                                            int32_t s, int32_t id, uint32_t deg, const int32_t* cols = nullptr) {
     if (lw.law == GS_LAW_REFERENCE) {
-        // neigh_samplers.py:26-28: ONE column permutation per call shared by all rows, first s columns
         const uint32_t M = (uint32_t)lw.max_degree;
-        const uint32_t c = gs_perm_index(gs_mix64(callkey ^ 0xC0115ull), j, M);
+        const uint32_t c = cols ? (uint32_t)cols[j] : gs_call_column(callkey, j, M);
         return gs_table_entry(gs_table_key(seed, id), c, deg, M);
     }
     const uint64_t rowkey = callkey + (uint64_t)grow * 0xD1342543DE82EF95ull;
@@ -103,10 +121,13 @@ struct FanoutArgs {
     int64_t ldo;
 };
 
+#define GS_LAW_COLS 128      // per-call columns kept in LDS up to this fan-out (larger fan-outs compute them per slot)
+
 // One workgroup (any size) per root `i`; lvl = two LDS fan-out buffers of CAP ints each.
 template <int CAP>
 __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const int64_t i, int32_t (*lvl)[CAP]) {
     const int tid = threadIdx.x, nthr = blockDim.x;
+    __shared__ int32_t law_cols[GS_LAW_COLS];
     int32_t root;
     if (a.order) {
         const uint64_t c = a.cursor ? *a.cursor : 0ull;
@@ -131,6 +152,14 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
         const int32_t* prev = lvl[h & 1];
         int32_t* next = lvl[(h + 1) & 1];
         const bool keep = (h + 1 < a.n_hops);  // the last hop is only written to global memory
+        const int32_t* cols = nullptr;
+        if (a.law.law == GS_LAW_REFERENCE && s <= GS_LAW_COLS) {
+            // the call's s columns once per workgroup instead of once per slot (the previous hop's readers are past the
+            // barrier that ended that hop)
+            for (int jj = tid; jj < s; jj += nthr) law_cols[jj] = (int32_t)gs_call_column(key, (uint32_t)jj, (uint32_t)a.law.max_degree);
+            __syncthreads();
+            cols = law_cols;
+        }
         for (int64_t t = tid; t < count; t += nthr) {
             const int64_t pl = t / s;  // parent slot in the previous level
             const uint32_t j = (uint32_t)(t - pl * s);
@@ -141,7 +170,7 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
                 const int32_t deg = (int32_t)(a.rowptr[id + 1] - b);
                 if (deg > 0) {
                     const int64_t grow = (a.root_offset + i) * count_prev + pl;  // global row at this hop
-                    pick = a.col[b + (int64_t)gs_draw(a.law, a.seed, key, grow, j, s, id, (uint32_t)deg)];
+                    pick = a.col[b + (int64_t)gs_draw(a.law, a.seed, key, grow, j, s, id, (uint32_t)deg, cols)];
                 }
             }
             if (keep) next[t] = pick;

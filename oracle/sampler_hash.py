@@ -29,34 +29,57 @@ def mix64(z):
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* of include/graphsage_amd.h
 
 
+def fmix32(h):
+    """murmur3 finalizer on uint32 arrays (gs_fmix32)."""
+    h = np.asarray(h).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        h = h ^ (h >> np.uint32(16))
+        h = h * np.uint32(0x85EBCA6B)
+        h = h ^ (h >> np.uint32(13))
+        h = h * np.uint32(0xC2B2AE35)
+        h = h ^ (h >> np.uint32(16))
+    return h
+
+
 def perm_index(key, j, n):
-    """gs_perm_index (gs_sample_dev.h): j-th element of the keyed pseudo-random permutation of [0, n) -- balanced
-    Feistel (6 rounds, 12 when a half is <= 3 bits) on 2*half >= ceil(log2 n) bits, cycle-walked back into [0, n).
-    key/j/n broadcast (uint64)."""
-    key, j, n = np.broadcast_arrays(np.asarray(key, dtype=np.uint64), np.asarray(j, dtype=np.uint64),
-                                    np.asarray(n, dtype=np.uint64))
-    nm1 = np.maximum(n, np.uint64(1)) - np.uint64(1)
-    x = np.minimum(j, nm1)      # a walk started outside [0, n) need not come back: callers mask such lanes, clamp them here
-    bits = np.zeros(n.shape, dtype=np.uint64)
+    """gs_perm_index (gs_sample_dev.h): j-th element of the keyed pseudo-random permutation of [0, n) -- alternating
+    Feistel on bits = max(2, ceil(log2 n)) bits (high part floor(bits/2), low part the rest; even rounds hash the low part
+    into the high part, odd rounds the reverse; 8 rounds, 12 for bits <= 6, 24 for bits <= 4; 32-bit arithmetic),
+    cycle-walked back into [0, n).  key (uint64) / j / n broadcast; returns uint64."""
+    u32 = np.uint32
+    key = np.asarray(key, dtype=np.uint64)
+    k0 = (key & np.uint64(0xFFFFFFFF)).astype(u32)
+    k1 = (key >> np.uint64(32)).astype(u32)
+    k0, k1, j, n = np.broadcast_arrays(k0, k1, np.asarray(j).astype(u32), np.asarray(n).astype(u32))
+    nm1 = np.maximum(n, u32(1)) - u32(1)
+    bits = np.zeros(n.shape, dtype=u32)
     t = nm1.copy()
     while (t > 0).any():                       # bits = bit_length(n - 1)
-        bits += (t > 0).astype(np.uint64)
-        t >>= np.uint64(1)
-    half = (bits + np.uint64(1)) >> np.uint64(1)
-    mask = (np.uint64(1) << half) - np.uint64(1)
-    todo = n > np.uint64(1)
-    x = np.where(todo, x, np.uint64(0))
+        bits += (t > 0).astype(u32)
+        t = t >> u32(1)
+    bits = np.maximum(bits, u32(2))
+    a = bits >> u32(1)
+    b = bits - a
+    mA = (u32(1) << a) - u32(1)
+    mB = (u32(1) << b) - u32(1)
+    rounds = np.where(bits <= 4, 24, np.where(bits <= 6, 12, 8))
+    todo = n > u32(1)
+    # a walk started outside [0, n) need not come back: callers mask such lanes, clamp them here
+    x = np.where(todo, np.minimum(j, nm1), u32(0)).astype(u32)
     while todo.any():
-        L, R = x >> half, x & mask
+        L, R = x >> b, x & mB
         with np.errstate(over="ignore"):
-            for r in range(12):
-                f = (mix64(key + (np.uint64(r) << np.uint64(32)) + R) >> np.uint64(32)) & mask
-                live = (r < 6) | (half <= np.uint64(3))
-                L, R = np.where(live, R, L), np.where(live, L ^ f, R)
-        y = (L << half) | R
+            for r in range(24):
+                live = r < rounds
+                kr = k0 + u32(r) * u32(0x9E3779B9)
+                if r % 2 == 0:
+                    L = np.where(live, L ^ (((fmix32(R + kr) ^ k1) >> u32(7)) & mA), L)
+                else:
+                    R = np.where(live, R ^ (((fmix32(L + kr) ^ k1) >> u32(7)) & mB), R)
+        y = ((L << b) | R).astype(u32)
         x = np.where(todo, y, x)
         todo = todo & (x >= n)
-    return x
+    return x.astype(np.uint64)
 
 
 def _table_key(seed, v):

@@ -28,20 +28,38 @@ def mix64(z):
     return z
 
 
+M32 = (1 << 32) - 1
+
+
+def fmix32(h):
+    h &= M32
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & M32
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M32
+    h ^= h >> 16
+    return h
+
+
 def perm_index(key, j, n):
     if n <= 1:
         return 0
-    bits = (n - 1).bit_length()
-    half = (bits + 1) >> 1
-    mask = (1 << half) - 1
-    rounds = 12 if half <= 3 else 6
+    bits = max(2, (n - 1).bit_length())
+    a = bits >> 1
+    b = bits - a
+    mA, mB = (1 << a) - 1, (1 << b) - 1
+    rounds = 24 if bits <= 4 else (12 if bits <= 6 else 8)
+    k0, k1 = key & M32, (key >> 32) & M32
     x = j
     while True:
-        L, Rr = x >> half, x & mask
+        L, Rr = x >> b, x & mB
         for r in range(rounds):
-            f = (mix64((key + (r << 32) + Rr) & M64) >> 32) & mask
-            L, Rr = Rr, L ^ f
-        x = (L << half) | Rr
+            kr = (k0 + r * 0x9E3779B9) & M32
+            if r % 2 == 0:
+                L ^= ((fmix32((Rr + kr) & M32) ^ k1) >> 7) & mA
+            else:
+                Rr ^= ((fmix32((L + kr) & M32) ^ k1) >> 7) & mB
+        x = (L << b) | Rr
         if x < n:
             return x
 
@@ -92,13 +110,13 @@ def main():
                 rows.append([col[rowptr[node] + draw(law, cap, seed, callkey, i + row_off, j, s, node, deg)] if deg else pad
                              for j in range(s)])
             out["picked_law%d_cap%d" % (law, cap)] = np.array(rows, np.int32)
-    perm_cases = [(0xDEADBEEF, n) for n in (1, 2, 5, 8, 37, 128, 129, 1000)]
+    perm_cases = [(0xDEADBEEF0BADF00D, n) for n in (1, 2, 5, 8, 37, 128, 129, 1000)]
     perms = {("perm_%d" % n): np.array([perm_index(k, j, n) for j in range(n)], np.int64) for k, n in perm_cases}
     for n, p in perms.items():
         assert sorted(p.tolist()) == list(range(len(p))), n
     np.savez(os.path.join(HERE, "law_kat.npz"), rowptr=np.array(rowptr, np.int64), col=np.array(col, np.int32),
              ids=np.array(ids, np.int32), args=np.array([M, s, seed, step, hop, row_off, pad], np.int64),
-             perm_key=np.uint64(0xDEADBEEF), **out, **perms)
+             perm_key=np.uint64(0xDEADBEEF0BADF00D), **out, **perms)
     for k, v in out.items():
         print(k, v.tolist())
 
