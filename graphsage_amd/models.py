@@ -116,10 +116,13 @@ class SampleAndAggregate(object):
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         self.cogather_opt = float(os.environ.get("GS_COGATHER_OPT", 0.0))      # share riding in the optimizer launch
-        # data-parallel with the all-reduce recorded in the step graph: share of the gather on a forked branch that runs
-        # concurrently with ncclAllReduce (the collective is latency-bound and leaves the chip idle); calibrate_dp_fork()
-        # sizes it from the measured duration of the collective
-        self.cogather_dp_fork = float(os.environ.get("GS_COGATHER_DP_FORK", 0.35))
+        # data-parallel with the all-reduce recorded in the step graph: share of the gather on a forked graph branch that
+        # runs beside ncclAllReduce (the collective is latency-bound and leaves the chip idle).  OFF by default: measured
+        # on one MI355X with a 30 us sleeping-wave stand-in for the collective (profiles/r03_dp_schedule.json), a fork/join
+        # inside the step hipGraph costs ~8 us by itself and the two branches overlap only partly, so the forked schedule
+        # (149.9 / 157.5 us at 35 % / 62 %) loses against the plain in-graph one (147.9 us).  GS_COGATHER_DP_FORK=<share>
+        # or GS_DP_FORK_AUTO=1 (calibrate_dp_fork sizes the share from the measured collective) turn it on.
+        self.cogather_dp_fork = float(os.environ.get("GS_COGATHER_DP_FORK", 0.0))
         # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
         self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
@@ -407,11 +410,12 @@ class SampleAndAggregate(object):
         e.sync()
         k2_us = float(np.median([a.elapsed_ms(b) for a, b in evs[2:]])) * 1e3
         share = max(0.0, min(0.85, ar_us / max(k2_us, 1e-3)))
-        if os.environ.get("GS_COGATHER_DP_FORK") is None:
+        if os.environ.get("GS_COGATHER_DP_FORK") is None and os.environ.get("GS_DP_FORK_AUTO", "0") == "1":
             self.cogather_dp_fork = round(share, 2)
-        res = {"allreduce_us_standalone": ar_us, "layer0_gather_us_standalone": k2_us, "fork_share": self.cogather_dp_fork}
+        res = {"allreduce_us_standalone": ar_us, "layer0_gather_us_standalone": k2_us, "fork_share": self.cogather_dp_fork,
+               "fork_share_suggested": round(share, 2)}
         if log:
-            log("data-parallel schedule: all-reduce %.1f us, layer-0 gather %.1f us stand-alone -> %.0f %% of the gather runs "
+            log("data-parallel schedule: all-reduce %.1f us, layer-0 gather %.1f us stand-alone; %.0f %% of the gather runs "
                 "beside the collective" % (ar_us, k2_us, 100 * self.cogather_dp_fork))
         return res
 
