@@ -129,6 +129,29 @@ class relu_ties_from(object):
         _relu_ties = None
 
 
+# reduce_max over neighbors whose two largest entries agree to summation noise: WHICH row is the arg-max is decided by
+# the summation order of the MLP contraction (TF/Eigen, this oracle and the device all differ), and the backward pass
+# routes d_pooled * x_row to that row's features -- a different row is a different (equally valid) gradient.  Like the
+# relu ties, the choice is INJECTED: `argmax_ties_from(fn)`; fn(shape [n, hidden]) -> the other side's arg-max, consulted
+# by every max-pool call in call order; an entry follows it only where that row's activation is within _ARGMAX_EPS of the
+# maximum (so a genuinely wrong arg-max on the other side still shows up as a mismatch).
+_ARGMAX_EPS = 1e-5
+_argmax_ties = None
+
+
+class argmax_ties_from(object):
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _argmax_ties
+        _argmax_ties = self.fn
+
+    def __exit__(self, *exc):
+        global _argmax_ties
+        _argmax_ties = None
+
+
 def _act(x, act):
     if act == "relu":
         y = np.maximum(x, 0)
@@ -238,6 +261,14 @@ def maxpool_aggregator_fwd(self_vecs, neigh_vecs, W_mlp, b_mlp, W_self, W_neigh,
     h = np.maximum(h, 0).reshape(n, s, -1)
     if pool == "max":
         arg = h.argmax(axis=1)
+        if _argmax_ties is not None:
+            other = _argmax_ties(arg.shape)
+            if other is not None:
+                other = np.asarray(other, dtype=np.int64).reshape(arg.shape)
+                mx = np.take_along_axis(h, arg[:, None, :], axis=1)[:, 0, :]
+                ho = np.take_along_axis(h, np.clip(other, 0, s - 1)[:, None, :], axis=1)[:, 0, :]
+                near = (other >= 0) & (other < s) & (mx - ho <= _ARGMAX_EPS * np.maximum(1.0, np.abs(mx)))
+                arg = np.where(near, other, arg)
         pooled = np.take_along_axis(h, arg[:, None, :], axis=1)[:, 0, :]
     else:
         arg = None
