@@ -51,8 +51,7 @@ def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_s
     e = eng.get_engine()
     train_adj = CSRAdjacency.from_device(DG.train_csr[0], DG.train_csr[1], DG.n_nodes)
     adj_info = AdjInfo(train_adj)
-    sampler_law = sampler_law or os.environ.get("GS_SAMPLER_LAW", "iid")       # A/B hook: iid | reference | distinct
-    sampler = UniformNeighborSampler(adj_info, seed=sampler_seed, law=sampler_law, max_degree=128)
+    sampler = UniformNeighborSampler(adj_info, seed=sampler_seed, law=sampler_law or args.sampler_law, max_degree=args.max_degree)
     ph = placeholders(unsupervised)
     if unsupervised:
         layer_infos = [SAGEInfo("node", sampler, args.samples_1, args.dim_1), SAGEInfo("node", sampler, args.samples_2, args.dim_2)]
@@ -116,7 +115,7 @@ def build_rmat(args, world, rank):
     torch.cuda.synchronize()
     ph = placeholders()
     adj_info = AdjInfo(CSRAdjacency.from_device(rowptr, col, N))
-    sampler = UniformNeighborSampler(adj_info, seed=123)
+    sampler = UniformNeighborSampler(adj_info, seed=123, law=args.sampler_law, max_degree=args.max_degree)
     layer_infos = [SAGEInfo("node", sampler, args.samples_1, args.dim_1), SAGEInfo("node", sampler, args.samples_2, args.dim_2)]
     model = SupervisedGraphsage(C, ph, feats, adj_info, None, layer_infos, concat=True, aggregator_type="mean",
                                 sigmoid_loss=False, learning_rate=0.01, weight_decay=0.0, world_size=world, rank=rank)
@@ -151,6 +150,10 @@ def parse_args(argv=None):
     ap.add_argument("--rmat-edges", dest="rmat_edges", type=int, default=200000000)
     ap.add_argument("--unsupervised", action="store_true",
                     help="BASELINE configs[3]: unsupervised graphsage_mean on random-walk pairs (20 negatives, xent, MRR)")
+    ap.add_argument("--sampler_law", default=os.environ.get("GS_SAMPLER_LAW", "reference"), choices=["reference", "iid", "distinct"],
+                    help="sampling law of the CSR sampler (reference = the reference's joint law on a virtual padded "
+                         "[N+1, max_degree] table; iid = independent draws with replacement from the full list)")
+    ap.add_argument("--max_degree", type=int, default=128, help="FLAGS.max_degree (supervised_train.py:40): width of the padded table")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU port legs (cpu_baseline and micro_f1)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--f1-steps", dest="f1_steps", type=int, default=100,
@@ -320,7 +323,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss_after": loss_after,
-                   "steps_per_graph_launch": spl,
+                   "steps_per_graph_launch": spl, "sampler_law": args.sampler_law, "max_degree": args.max_degree,
                    "allreduce": dp_info["allreduce"] if dp_info else None,
                    "rccl_ranks": dp_info.get("rccl_ranks") if dp_info else None},
     }
@@ -481,15 +484,18 @@ def f1_legs(DG, args, B, s1, s2, F, spl, seeds=5, steps=100, n_val=4096):
                                  (gs_sample_padded): isolates the kernels' numerics from the sampler law
       mi355x_csr_reference_law   the MI355X engine, native CSR sampler with law="reference" (the reference's joint law
                                  on a virtual padded table, device-epoch hipGraph path)
-      mi355x_csr_iid             the MI355X engine as bench.py times it (law="iid")
+      mi355x_csr_iid             the MI355X engine, law="iid" (independent draws with replacement from the full list)
+      mi355x_csr_distinct        the MI355X engine, law="distinct" (per-row draws without replacement, max_degree cap)
+    "mi355x" in the result is the leg of the law the timed path runs (--sampler_law, default reference).
     Returns (micro_f1 dict with per-leg mean/std/values and paired differences vs cpu_port, cpu_baseline dict)."""
     from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, PaddedAdjacency
     from oracle import graphsage_oracle as orc
     from oracle.cpu_baseline import port_micro_f1, time_cpu_baseline
-    feats_h, adj_h, test_adj_h, labels_h = DG.host_view(max_degree=128)
+    feats_h, adj_h, test_adj_h, labels_h = DG.host_view(max_degree=args.max_degree)
     val = DG.val_nodes[:n_val].astype(np.int32)
     n_vb = (len(val) + B - 1) // B
-    legs = {"cpu_port": [], "mi355x_padded_same_draws": [], "mi355x_csr_reference_law": [], "mi355x_csr_iid": []}
+    legs = {"cpu_port": [], "mi355x_padded_same_draws": [], "mi355x_csr_reference_law": [], "mi355x_csr_iid": [],
+            "mi355x_csr_distinct": []}
     cb = None
     wall = {}
 
@@ -518,8 +524,8 @@ def f1_legs(DG, args, B, s1, s2, F, spl, seeds=5, steps=100, n_val=4096):
         seed = 123 + sd
         epoch = np.random.RandomState(seed).permutation(DG.train_nodes)
         prng = np.random.RandomState(1000 + seed)
-        perms_train = [[prng.permutation(128) for _ in range(2)] for _ in range(steps)]
-        perms_val = [[prng.permutation(128) for _ in range(2)] for _ in range(n_vb)]
+        perms_train = [[prng.permutation(args.max_degree) for _ in range(2)] for _ in range(steps)]
+        perms_val = [[prng.permutation(args.max_degree) for _ in range(2)] for _ in range(n_vb)]
         # ---- the CPU port (timed: the first seed's run is the cpu_baseline leg)
         from oracle.cpu_baseline import CpuSupervisedMean
         init = CpuSupervisedMean(feats_h[:1], adj_h[:1], [F, args.dim_1, args.dim_2], DG.num_classes, [s1, s2], seed=seed)
@@ -547,7 +553,7 @@ def f1_legs(DG, args, B, s1, s2, F, spl, seeds=5, steps=100, n_val=4096):
         wall.setdefault("mi355x_padded_same_draws", []).append(time.time() - t0)
         del model
         # ---- MI355X, CSR sampler, device epoch + hipGraphs (the timed path), both laws
-        for law, leg in (("reference", "mi355x_csr_reference_law"), ("iid", "mi355x_csr_iid")):
+        for law, leg in (("reference", "mi355x_csr_reference_law"), ("iid", "mi355x_csr_iid"), ("distinct", "mi355x_csr_distinct")):
             t0 = time.time()
             e, model, ph, adj_info = build_model(DG, args, 1, 0, "graphsage_mean", sampler_seed=seed, sampler_law=law)
             init_from_port(e, model, init)
@@ -567,7 +573,8 @@ def f1_legs(DG, args, B, s1, s2, F, spl, seeds=5, steps=100, n_val=4096):
         if k != "cpu_port":
             d = v - ref
             paired[k] = {"mean": float(d.mean()), "stderr": float(d.std(ddof=1) / np.sqrt(len(d))) if len(d) > 1 else None}
-    f1 = {"mi355x": out_legs["mi355x_csr_iid"]["mean"], "cpu_port": out_legs["cpu_port"]["mean"], "seeds": seeds,
+    timed = {"reference": "mi355x_csr_reference_law", "iid": "mi355x_csr_iid", "distinct": "mi355x_csr_distinct"}[args.sampler_law]
+    f1 = {"mi355x": out_legs[timed]["mean"], "mi355x_leg": timed, "cpu_port": out_legs["cpu_port"]["mean"], "seeds": seeds,
           "train_steps": steps, "val_nodes": int(len(val)), "legs": out_legs, "paired_delta_vs_cpu_port": paired,
           "note": "per seed: same synthetic graph, epoch order, steps, lr and INITIAL WEIGHTS for every leg; validation on the "
                   "full (test) adjacency; mean / sample std over seeds; paired_delta = leg - cpu_port per seed (mean, standard "

@@ -55,6 +55,10 @@ def build_flags(argv=None):
     # additions of this engine
     p.add_argument('--synthetic', default='', help='ppi | reddit | small: generate a graph of that shape')
     p.add_argument('--sampler', default='csr', help='csr (MI355X-native) | padded (reference table semantics)')
+    p.add_argument('--sampler_law', default='reference',
+                   help='sampling law of the CSR sampler: reference (the reference\'s joint law on a virtual padded '
+                        '[N+1, max_degree] table, minibatch.py:227-245 + neigh_samplers.py:24-29) | iid (independent '
+                        'draws with replacement from the full neighbor list) | distinct (per-row without replacement)')
     p.add_argument('--feed_path', default='device',
                    help='device: epoch order + labels resident in HBM, host fetches only printed steps (CSR sampler); '
                         'host: the reference feed_dict path, one host round trip per step')
@@ -185,7 +189,7 @@ def train(G):
         train_adj = CSRAdjacency(minibatch.train_csr[0], minibatch.train_csr[1], G.n_nodes, e.device)
         test_adj = CSRAdjacency(minibatch.test_csr[0], minibatch.test_csr[1], G.n_nodes, e.device)
     adj_info = AdjInfo(train_adj)
-    sampler = UniformNeighborSampler(adj_info)
+    sampler = UniformNeighborSampler(adj_info, law=FLAGS.sampler_law, max_degree=FLAGS.max_degree)
 
     kw = dict(model_size=FLAGS.model_size, sigmoid_loss=FLAGS.sigmoid, identity_dim=FLAGS.identity_dim,
               learning_rate=FLAGS.learning_rate, weight_decay=FLAGS.weight_decay, logging=True)

@@ -49,6 +49,10 @@ def build_flags(argv=None):
     p.add_argument('--max_total_steps', type=int, default=10 ** 10, help='Maximum total number of iterations')
     p.add_argument('--synthetic', default='', help='ppi | reddit | small: generate a graph of that shape')
     p.add_argument('--sampler', default='csr', help='csr (MI355X-native) | padded (reference table semantics)')
+    p.add_argument('--sampler_law', default='reference',
+                   help='sampling law of the CSR sampler: reference (the reference\'s joint law on a virtual padded '
+                        '[N+1, max_degree] table, minibatch.py:227-245 + neigh_samplers.py:24-29) | iid (independent '
+                        'draws with replacement from the full neighbor list) | distinct (per-row without replacement)')
     p.add_argument('--max_walk_pairs', type=int, default=2000000, help='cap on generated random-walk pairs (synthetic data)')
     return p.parse_args(argv)
 
@@ -142,7 +146,7 @@ def train(G, context_pairs):
         train_adj = CSRAdjacency(minibatch.train_csr[0], minibatch.train_csr[1], G.n_nodes, e.device)
         test_adj = CSRAdjacency(minibatch.test_csr[0], minibatch.test_csr[1], G.n_nodes, e.device)
     adj_info = AdjInfo(train_adj)
-    sampler = UniformNeighborSampler(adj_info)
+    sampler = UniformNeighborSampler(adj_info, law=FLAGS.sampler_law, max_degree=FLAGS.max_degree)
     kw = dict(model_size=FLAGS.model_size, identity_dim=FLAGS.identity_dim, learning_rate=FLAGS.learning_rate,
               weight_decay=FLAGS.weight_decay, neg_sample_size=FLAGS.neg_sample_size, logging=True)
     if FLAGS.model in ('graphsage_mean', 'graphsage'):          # unsupervised_train.py:160-172

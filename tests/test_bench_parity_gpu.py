@@ -37,6 +37,9 @@ def graph():
     return _cache["G"]
 
 
+LAW, MAXDEG = sampler_hash.LAW_REFERENCE, 128          # bench.py's default sampling law (--sampler_law reference)
+
+
 def build(agg_type, lr=0.01):
     G, it = graph()
     eng.reset_engine()
@@ -45,7 +48,7 @@ def build(agg_type, lr=0.01):
     ph = {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'), 'dropout': Placeholder('dropout', 0.),
           'batch_size': Placeholder('batch_size')}
     adj_info = AdjInfo(CSRAdjacency(it.train_csr[0], it.train_csr[1], G.n_nodes, e.device))
-    sampler = UniformNeighborSampler(adj_info, seed=123)
+    sampler = UniformNeighborSampler(adj_info, seed=123, law="reference", max_degree=MAXDEG)
     mult = 2 if agg_type == "gcn" else 1                          # supervised_train.py:175-176
     layer_infos = [SAGEInfo("node", sampler, S1, mult * DIM), SAGEInfo("node", sampler, S2, mult * DIM)]
     model = SupervisedGraphsage(G.num_classes, ph, G.padded_features(), adj_info, it.deg, layer_infos,
@@ -96,8 +99,9 @@ def test_bench_path_matches_oracle(dev, agg_type, steps):
         batch = order[t * B:(t + 1) * B]
         got = [s.cpu().numpy() for s in model.samples1]
         assert np.array_equal(got[0], batch)
-        hop1 = sampler_hash.sample_uniform_csr(rowptr, col, G.n_nodes, G.n_nodes, batch, S2, 123, t, 0)
-        hop2 = sampler_hash.sample_uniform_csr(rowptr, col, G.n_nodes, G.n_nodes, hop1.reshape(-1), S1, 123, t, 1)
+        hop1 = sampler_hash.sample_uniform_csr(rowptr, col, G.n_nodes, G.n_nodes, batch, S2, 123, t, 0, law=LAW, max_degree=MAXDEG)
+        hop2 = sampler_hash.sample_uniform_csr(rowptr, col, G.n_nodes, G.n_nodes, hop1.reshape(-1), S1, 123, t, 1, law=LAW,
+                                               max_degree=MAXDEG)
         assert np.array_equal(got[1], hop1.reshape(-1)) and np.array_equal(got[2], hop2.reshape(-1))
         assert (got[2] != G.n_nodes).mean() > 0.9                             # real neighbors, not pad rows
         # ---- the oracle on exactly these neighbor sets

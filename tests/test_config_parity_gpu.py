@@ -49,11 +49,14 @@ def _layer0_ties(model, n_roots, s2):
     return ties
 
 
+LAW, MAXDEG = sampler_hash.LAW_REFERENCE, 128          # bench.py's default sampling law (--sampler_law reference)
+
+
 def _check_sampled_ids(got, roots, rowptr, col, N, fans, seed, t):
     assert np.array_equal(got[0], roots)
     prev, hop = roots, 0
     for f, g in zip(fans, got[1:]):
-        want = sampler_hash.sample_uniform_csr(rowptr, col, N, N, prev, f, seed, t, hop)
+        want = sampler_hash.sample_uniform_csr(rowptr, col, N, N, prev, f, seed, t, hop, law=LAW, max_degree=MAXDEG)
         assert np.array_equal(g, want.reshape(-1)), "hop %d ids differ from the hash restatement" % (hop + 1)
         prev, hop = want.reshape(-1), hop + 1
 
@@ -70,7 +73,7 @@ def test_unsupervised_benched_shapes_match_oracle(dev):
     ph = {'batch1': Placeholder('batch1'), 'batch2': Placeholder('batch2'), 'neg_samples': Placeholder('neg'),
           'dropout': Placeholder('dropout', 0.), 'batch_size': Placeholder('batch_size')}
     adj_info = AdjInfo(CSRAdjacency(rowptr, col, G.n_nodes, e.device))
-    sampler = UniformNeighborSampler(adj_info, seed=123)
+    sampler = UniformNeighborSampler(adj_info, seed=123, law="reference", max_degree=MAXDEG)
     layer_infos = [SAGEInfo("node", sampler, S1, DIM), SAGEInfo("node", sampler, S2, DIM)]
     model = SampleAndAggregate(ph, G.padded_features(), adj_info, it.deg, layer_infos, concat=True, aggregator_type="mean",
                                learning_rate=lr, weight_decay=0.0, neg_sample_size=NEG)
@@ -126,7 +129,7 @@ def test_unsupervised_benched_shapes_match_oracle(dev):
         inits.set_seed(11)
         e = eng.get_engine()
         adj_info = AdjInfo(CSRAdjacency(rowptr, col, G.n_nodes, e.device))
-        sampler = UniformNeighborSampler(adj_info, seed=123)
+        sampler = UniformNeighborSampler(adj_info, seed=123, law="reference", max_degree=MAXDEG)
         layer_infos = [SAGEInfo("node", sampler, S1, DIM), SAGEInfo("node", sampler, S2, DIM)]
         m2 = SampleAndAggregate(ph, feats, adj_info, it.deg, layer_infos, concat=True, aggregator_type="mean",
                                 learning_rate=lr, weight_decay=0.0, neg_sample_size=NEG)
@@ -199,7 +202,7 @@ def test_fullsize_training_steps_match_oracle(dev):
     ph = {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'), 'dropout': Placeholder('dropout', 0.),
           'batch_size': Placeholder('batch_size')}
     adj_info = AdjInfo(CSRAdjacency.from_device(DG.train_csr[0], DG.train_csr[1], DG.n_nodes))
-    sampler = UniformNeighborSampler(adj_info, seed=123)
+    sampler = UniformNeighborSampler(adj_info, seed=123, law="reference", max_degree=MAXDEG)
     layer_infos = [SAGEInfo("node", sampler, S1, DIM), SAGEInfo("node", sampler, S2, DIM)]
     model = SupervisedGraphsage(DG.num_classes, ph, DG.feats, adj_info, DG.deg, layer_infos, concat=True,
                                 aggregator_type="mean", sigmoid_loss=False, learning_rate=0.01, weight_decay=0.0)
