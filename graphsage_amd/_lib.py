@@ -100,6 +100,10 @@ _PROTOS = {
     "gs_unsup_stage": [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_uint64, _P, _P, _P],
     "gs_linkpred_fwd_bwd": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, _P, _P, c_int64, _P, c_int64,
                             _P, POINTER(c_int32), _P],
+    "gs_linkpred_norm_fwd_bwd": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, c_int64, _P, _P, _P, c_int64,
+                                 _P, c_int64, _P, _P],
+    "gs_sample_fanout_desc": [_P, _P],
+    "gs_finalize_step2": [_P, c_int64, c_float, _P, c_int, _P, c_float, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_maxpool_sparse_wgrad": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, c_int32, c_int32, _P,
                                 c_int64, _P],
     "gs_stage_batch": [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P],
@@ -161,7 +165,10 @@ class FanoutDesc(ctypes.Structure):
                 ("labels_out", c_void_p), ("ld_out", c_int64),
                 ("offsets", c_int64 * 4), ("fan", c_int32 * 3),
                 ("pad_id", c_int32), ("n_hops", c_int32), ("C", c_int32), ("hop0", c_uint32),
-                ("law", c_int32), ("max_degree", c_int32)]
+                ("law", c_int32), ("max_degree", c_int32),
+                ("pairs", c_void_p), ("n_pairs", c_int64), ("n_pair_roots", c_int64),
+                ("cdf", c_void_p), ("guide", c_void_p), ("n_cdf", c_int64),
+                ("n_neg", c_int32), ("guide_bits", c_int32), ("neg_seed", c_uint64)]
 
 
 class VarDesc(ctypes.Structure):

@@ -325,9 +325,7 @@ extern "C" int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t 
                                      loss_accumulate, nullptr, jobs_host, n_jobs, stream);
     FanoutArgs F;
     int64_t kmax = 0;
-    int rc = gs_fanout_args(s->rowptr, s->col, s->n_nodes, s->pad_id, s->n_hops, s->fan, s->offsets, s->ids_all, s->B, s->seed,
-                            s->step, s->step_dev, s->hop0, s->root_offset, s->order, s->n_order, s->cursor_dev, s->label_table,
-                            s->ld_table, s->C, s->labels_out, s->ld_out, s->law, s->max_degree, &F, &kmax);
+    int rc = gs_fanout_args_desc(s, &F, &kmax);
     if (rc != GS_OK) return rc;
     if (kmax > GS_FANOUT_LDS_SMALL) {
         gs_set_error("gs_flat_reduce_adam_sample: per-root fan-out %lld of a kept hop exceeds %d", (long long)kmax, GS_FANOUT_LDS_SMALL);

@@ -160,8 +160,19 @@ extern "C" int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint
 __global__ __launch_bounds__(256) void finalize_step_kernel(const float* __restrict__ loss_rows, int64_t n, float scale,
                                                             float* __restrict__ loss_out, int accumulate, uint64_t* c0,
                                                             uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2,
-                                                            uint64_t d2) {
+                                                            uint64_t d2, const float* __restrict__ aux_rows, float aux_scale,
+                                                            float* __restrict__ aux_out) {
     __shared__ float part[4];
+    __shared__ float part2[4];
+    if (aux_rows) {                            // a second mean in the same launch (unsupervised: mrr, models.py:404)
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < n; i += 256) s += aux_rows[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if ((threadIdx.x & 63) == 0) part2[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) aux_out[0] = ((part2[0] + part2[1]) + (part2[2] + part2[3])) * aux_scale;
+    }
     if (loss_rows) {
         float s = 0.f;
         for (int64_t i = threadIdx.x; i < n; i += 256) s += loss_rows[i];
@@ -185,7 +196,18 @@ extern "C" int gs_finalize_step(const float* loss_rows, int64_t n, float scale, 
                                 void* stream) {
     GS_REQUIRE(!loss_rows || (loss_out && n >= 0), "gs_finalize_step: bad args");
     hipLaunchKernelGGL(finalize_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, n, scale, loss_out,
-                       accumulate, c0, d0, c1, d1, c2, d2);
+                       accumulate, c0, d0, c1, d1, c2, d2, (const float*)nullptr, 0.f, (float*)nullptr);
+    GS_LAUNCH_CHECK("finalize_step_kernel");
+    return GS_OK;
+}
+
+extern "C" int gs_finalize_step2(const float* loss_rows, int64_t n, float scale, float* loss_out, int accumulate,
+                                 const float* aux_rows, float aux_scale, float* aux_out, uint64_t* c0, uint64_t d0,
+                                 uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream) {
+    GS_REQUIRE(!loss_rows || (loss_out && n >= 0), "gs_finalize_step2: bad args");
+    GS_REQUIRE(!aux_rows || aux_out, "gs_finalize_step2: aux_out missing");
+    hipLaunchKernelGGL(finalize_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows, n, scale, loss_out,
+                       accumulate, c0, d0, c1, d1, c2, d2, aux_rows, aux_scale, aux_out);
     GS_LAUNCH_CHECK("finalize_step_kernel");
     return GS_OK;
 }

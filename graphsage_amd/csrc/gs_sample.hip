@@ -190,3 +190,18 @@ extern "C" int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, i
     GS_LAUNCH_CHECK("sample_fanout_kernel");
     return GS_OK;
 }
+
+// The same launch from a descriptor (what gs_flat_reduce_adam_sample takes as a rider), including the optional
+// unsupervised root staging (edge-pair batch + unigram negatives, see gs_fanout_desc).
+extern "C" int gs_sample_fanout_desc(const gs_fanout_desc* desc_host, void* stream) {
+    GS_REQUIRE(desc_host, "gs_sample_fanout_desc: null descriptor");
+    if (desc_host->B == 0) return GS_OK;
+    FanoutArgs a;
+    int64_t kmax = 0;
+    int rc = gs_fanout_args_desc(desc_host, &a, &kmax);
+    if (rc != GS_OK) return rc;
+    GS_REQUIRE(kmax <= GS_FANOUT_LDS, "gs_sample_fanout_desc: per-root fan-out %lld exceeds the LDS buffer", (long long)kmax);
+    hipLaunchKernelGGL(sample_fanout_kernel, dim3((unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
+    GS_LAUNCH_CHECK("sample_fanout_kernel");
+    return GS_OK;
+}

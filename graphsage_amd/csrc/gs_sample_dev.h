@@ -119,6 +119,17 @@ struct FanoutArgs {
     int32_t C;
     float* labels_out;
     int64_t ldo;
+    // optional unsupervised root staging (pairs != nullptr; minibatch.py:113-132 + models.py:336-343 on the device):
+    // roots = [pairs[e][0] (n_pair_roots) | pairs[e][1] (n_pair_roots) | n_neg unigram negatives], e = (*cursor + i) % n_pairs;
+    // negative t = first node whose cdf exceeds a 32-bit draw keyed by (neg_seed, sampler clock, t) -- the draws of
+    // gs_unsup_stage, bit for bit (the guide table only narrows the binary search's starting interval)
+    const int32_t* pairs;
+    int64_t n_pairs, n_pair_roots;
+    const uint32_t* cdf;
+    const int32_t* guide;      // nullable: guide[b] = first index with cdf > (b << (32 - guide_bits)), 2^guide_bits + 1 entries
+    int64_t n_cdf;
+    int32_t n_neg, guide_bits;
+    uint64_t neg_seed;
 };
 
 #define GS_LAW_COLS 128      // per-call columns kept in LDS up to this fan-out (larger fan-outs compute them per slot)
@@ -128,8 +139,34 @@ template <int CAP>
 __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const int64_t i, int32_t (*lvl)[CAP]) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     __shared__ int32_t law_cols[GS_LAW_COLS];
-    int32_t root;
-    if (a.order) {
+    int32_t root = 0;
+    if (a.pairs) {
+        if (tid == 0) {
+            const uint64_t c = a.cursor ? *a.cursor : 0ull;
+            if (i < 2 * a.n_pair_roots) {
+                const int side = i >= a.n_pair_roots ? 1 : 0;
+                const int64_t e = (int64_t)((c + (uint64_t)(i - side * a.n_pair_roots)) % (uint64_t)a.n_pairs);
+                root = a.pairs[2 * e + side];
+            } else {
+                const uint64_t t = (uint64_t)(i - 2 * a.n_pair_roots);
+                const uint64_t stc = a.step + (a.step_dev ? *a.step_dev : 0ull);
+                const uint64_t nkey = gs_mix64(a.neg_seed ^ (stc * 0x9E3779B97F4A7C15ull) ^ (0xFFull << 56));
+                const uint32_t r = (uint32_t)(gs_mix64(nkey + t) >> 32);
+                int64_t lo = 0, hi = a.n_cdf - 1;  // first index with cdf[idx] > r
+                if (a.guide) {
+                    const uint32_t b = r >> (32 - a.guide_bits);
+                    lo = a.guide[b];
+                    hi = min((int64_t)a.guide[b + 1], a.n_cdf - 1);
+                }
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (a.cdf[mid] > r) hi = mid; else lo = mid + 1;
+                }
+                root = (int32_t)lo;
+            }
+            a.ids_all[a.offsets[0] + i] = root;
+        }
+    } else if (a.order) {
         const uint64_t c = a.cursor ? *a.cursor : 0ull;
         root = a.order[(int64_t)((c + (uint64_t)i) % (uint64_t)a.n_order)];
         if (tid == 0) a.ids_all[a.offsets[0] + i] = root;
@@ -229,5 +266,25 @@ static inline int gs_fanout_args(const int64_t* rowptr, const int32_t* col, int6
     GS_REQUIRE(B < (1ll << 31), "gs_sample_fanout_csr: batch too large");
     *out = a;
     *kept_max = kmax;
+    return GS_OK;
+}
+
+// host: struct gs_fanout_desc -> FanoutArgs (incl. the optional unsupervised root staging)
+static inline int gs_fanout_args_desc(const gs_fanout_desc* s, FanoutArgs* out, int64_t* kept_max) {
+    GS_REQUIRE(s, "gs_fanout_desc: null descriptor");
+    int rc = gs_fanout_args(s->rowptr, s->col, s->n_nodes, s->pad_id, s->n_hops, s->fan, s->offsets, s->ids_all, s->B, s->seed,
+                            s->step, s->step_dev, s->hop0, s->root_offset, s->order, s->n_order, s->cursor_dev, s->label_table,
+                            s->ld_table, s->C, s->labels_out, s->ld_out, s->law, s->max_degree, out, kept_max);
+    if (rc != GS_OK) return rc;
+    if (s->pairs) {
+        GS_REQUIRE(!s->order, "gs_fanout_desc: pairs and order are exclusive");
+        GS_REQUIRE(s->n_pairs > 0 && s->n_pair_roots >= 0 && s->n_neg >= 0 && 2 * s->n_pair_roots + s->n_neg == s->B,
+                   "gs_fanout_desc: pair staging needs B == 2 * n_pair_roots + n_neg");
+        GS_REQUIRE(s->n_neg == 0 || (s->cdf && s->n_cdf > 0), "gs_fanout_desc: negatives need the unigram cdf");
+        GS_REQUIRE(!s->guide || (s->guide_bits >= 1 && s->guide_bits <= 20), "gs_fanout_desc: guide_bits in 1..20");
+        out->pairs = s->pairs; out->n_pairs = s->n_pairs; out->n_pair_roots = s->n_pair_roots;
+        out->cdf = s->cdf; out->guide = s->guide; out->n_cdf = s->n_cdf; out->n_neg = s->n_neg; out->guide_bits = s->guide_bits;
+        out->neg_seed = s->neg_seed;
+    }
     return GS_OK;
 }

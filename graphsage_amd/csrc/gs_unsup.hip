@@ -152,3 +152,190 @@ extern "C" int gs_linkpred_fwd_bwd(const float* Y, int64_t ldy, int64_t B, int32
     GS_LAUNCH_CHECK("linkpred_fwd_bwd_kernel");
     return GS_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused unsupervised head (one launch instead of l2norm_fwd | linkpred | l2norm_bwd | sum):
+//   Y = l2_normalize(Z) (models.py:368-370), the xent link-prediction loss + MRR of linkpred_fwd_bwd_kernel on Y, and
+//   the gradient carried back THROUGH the normalisation to Z for the 2B pair rows:
+//     dZ = inv * (g - y <g, y>)          (inv = rsqrt(max(sum z^2, 1e-12)); clamped rows: dZ = g * inv)
+//   The negatives' gradient w.r.t. their NORMALISED rows leaves as per-workgroup slabs; linkpred_neg_bwd_kernel sums
+//   them in a fixed order and applies the same normalisation backward (20 rows).  Also writes mean-reduction inputs
+//   loss_rows / rr_rows (finalised by gs_finalize_step2).
+template <int DJ>
+__global__ __launch_bounds__(256) void linkpred_norm_fwd_bwd_kernel(const float* __restrict__ Z, int64_t ldz, int64_t B,
+                                                                    int32_t n_neg, float neg_w, float scale,
+                                                                    float* __restrict__ Y, int64_t ldy,
+                                                                    float* __restrict__ loss_rows, float* __restrict__ rr_rows,
+                                                                    float* __restrict__ aff_all, int64_t ld_aff,
+                                                                    float* __restrict__ dZ, int64_t lddz,
+                                                                    float* __restrict__ neg_slabs) {
+    constexpr int d = DJ * 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* negs = lds;                       // [n_neg][d]  normalised negative rows
+    float* part = lds + (size_t)n_neg * d;   // [4 waves][n_neg][d] partial dneg (w.r.t. the normalised rows)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = wave; q < n_neg; q += 4) {
+        float v[DJ], ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            v[j] = Z[(2 * B + q) * ldz + j * 64 + lane];
+            ss += v[j] * v[j];
+        }
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(wsum(ss), 1e-12f));
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            const float y = v[j] * inv;
+            negs[q * d + j * 64 + lane] = y;
+            if (blockIdx.x == 0) Y[(2 * B + q) * ldy + j * 64 + lane] = y;
+        }
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    const bool live = i < B;
+    const int64_t ic = live ? i : 0;
+    float o1[DJ], o2[DJ], g1[DJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        o1[j] = Z[ic * ldz + j * 64 + lane];
+        o2[j] = Z[(B + ic) * ldz + j * 64 + lane];
+        s1 += o1[j] * o1[j];
+        s2 += o2[j] * o2[j];
+    }
+    const float inv1 = __builtin_amdgcn_rsqf(fmaxf(wsum(s1), 1e-12f)), inv2 = __builtin_amdgcn_rsqf(fmaxf(wsum(s2), 1e-12f));
+    float aff = 0.f;
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        o1[j] *= inv1;
+        o2[j] *= inv2;
+        aff += o1[j] * o2[j];
+    }
+    aff = wsum(aff);
+    const float sa = 1.0f / (1.0f + expf(-aff));
+    const float da = (sa - 1.0f) * scale;
+    float loss = fmaxf(aff, 0.f) - aff + log1pf(expf(-fabsf(aff)));
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) g1[j] = da * o2[j];
+    float* mypart = part + (size_t)wave * n_neg * d;
+    for (int q = 0; q < n_neg; ++q) {
+        float na = 0.f;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) na += o1[j] * negs[q * d + j * 64 + lane];
+        na = wsum(na);
+        loss += neg_w * (fmaxf(na, 0.f) + log1pf(expf(-fabsf(na))));
+        rank += (na >= aff) ? 1 : 0;
+        const float gq = live ? neg_w * scale / (1.0f + expf(-na)) : 0.f;
+        if (aff_all && live && lane == 0) aff_all[i * ld_aff + q] = na;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            g1[j] += gq * negs[q * d + j * 64 + lane];
+            mypart[q * d + j * 64 + lane] = gq * o1[j];
+        }
+    }
+    if (live) {
+        // back through y = z * inv:  dz = inv (g - y <g, y>);  clamped (sum z^2 < 1e-12, inv = 1e6): dz = g * inv
+        float dot1 = 0.f, dot2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            dot1 += g1[j] * o1[j];
+            dot2 += da * o1[j] * o2[j];
+        }
+        dot1 = wsum(dot1);
+        dot2 = wsum(dot2);
+        const bool c1 = inv1 >= 1.0e6f, c2 = inv2 >= 1.0e6f;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            const float ga = g1[j], gb = da * o1[j];
+            Y[i * ldy + j * 64 + lane] = o1[j];
+            Y[(B + i) * ldy + j * 64 + lane] = o2[j];
+            dZ[i * lddz + j * 64 + lane] = c1 ? ga * inv1 : inv1 * (ga - o1[j] * dot1);
+            dZ[(B + i) * lddz + j * 64 + lane] = c2 ? gb * inv2 : inv2 * (gb - o2[j] * dot2);
+        }
+        if (lane == 0) {
+            loss_rows[i] = loss;
+            rr_rows[i] = 1.0f / (float)(rank + 1);
+            if (aff_all) aff_all[i * ld_aff + n_neg] = aff;
+        }
+    }
+    __syncthreads();
+    float* slab = neg_slabs + (size_t)blockIdx.x * n_neg * d;
+    for (int t = tid; t < n_neg * d; t += 256)
+        slab[t] = (part[t] + part[(size_t)n_neg * d + t]) + (part[2 * (size_t)n_neg * d + t] + part[3 * (size_t)n_neg * d + t]);
+}
+
+// One workgroup per negative row q: g = sum of the slabs (fixed order, 8 independent partial sums), then the
+// normalisation backward with the row's own inv (recomputed from Z) and y.
+__global__ __launch_bounds__(256) void linkpred_neg_bwd_kernel(const float* __restrict__ slabs, int32_t n_slabs, int32_t n_neg,
+                                                               int32_t d, const float* __restrict__ Z, int64_t ldz,
+                                                               int64_t row0, float* __restrict__ dZ, int64_t lddz) {
+    __shared__ float red[2][4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* zr = Z + (row0 + q) * ldz;
+    float g[2] = {0.f, 0.f}, z[2] = {0.f, 0.f};
+    float ss = 0.f;
+    for (int h = 0; h < 2; ++h) {
+        const int c = tid + 256 * h;
+        if (c < d) {
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+            const float* sp = slabs + (size_t)q * d + c;
+            const size_t stride = (size_t)n_neg * d;
+            int sI = 0;
+            for (; sI + 8 <= n_slabs; sI += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += sp[(size_t)(sI + u) * stride];
+            }
+            for (; sI < n_slabs; ++sI) acc[sI & 7] += sp[(size_t)sI * stride];
+            g[h] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            z[h] = zr[c];
+            ss += z[h] * z[h];
+        }
+    }
+    ss = wsum(ss);
+    if ((tid & 63) == 0) red[0][tid >> 6] = ss;
+    __syncthreads();
+    ss = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-12f));
+    float dot = g[0] * z[0] * inv + g[1] * z[1] * inv;
+    dot = wsum(dot);
+    if ((tid & 63) == 0) red[1][tid >> 6] = dot;
+    __syncthreads();
+    dot = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const bool clamped = inv >= 1.0e6f;
+    for (int h = 0; h < 2; ++h) {
+        const int c = tid + 256 * h;
+        if (c < d) dZ[(row0 + q) * lddz + c] = clamped ? g[h] * inv : inv * (g[h] - z[h] * inv * dot);
+    }
+}
+
+extern "C" int gs_linkpred_norm_fwd_bwd(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight,
+                                        float scale, float* Y, int64_t ldy, float* loss_rows, float* rr_rows, float* aff_all,
+                                        int64_t ld_aff, float* dZ, int64_t lddz, float* neg_slabs, void* stream) {
+    GS_REQUIRE(Z && Y && loss_rows && rr_rows && dZ && neg_slabs && B > 0 && n_neg > 0, "gs_linkpred_norm_fwd_bwd: bad args");
+    GS_REQUIRE(d == 64 || d == 128 || d == 256 || d == 512, "gs_linkpred_norm_fwd_bwd: d must be 64/128/256/512 (got %d)", d);
+    GS_REQUIRE(ldz >= d && ldy >= d && lddz >= d && (!aff_all || ld_aff >= n_neg + 1), "gs_linkpred_norm_fwd_bwd: ld too small");
+    const size_t lds_bytes = (size_t)5 * n_neg * d * sizeof(float);
+    GS_REQUIRE(lds_bytes <= 160 * 1024, "gs_linkpred_norm_fwd_bwd: %d negatives x d=%d do not fit LDS", n_neg, d);
+    const int64_t blocks = gs_ceil_div(B, 4);
+    hipStream_t st = (hipStream_t)stream;
+#define GS_LPN(DJ)                                                                                                        \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            GS_HIP(hipFuncSetAttribute((const void*)linkpred_norm_fwd_bwd_kernel<DJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((linkpred_norm_fwd_bwd_kernel<DJ>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, Z, ldz, B,  \
+                           n_neg, neg_weight, scale, Y, ldy, loss_rows, rr_rows, aff_all, ld_aff, dZ, lddz, neg_slabs);   \
+    } while (0)
+    if (d == 64) GS_LPN(1); else if (d == 128) GS_LPN(2); else if (d == 256) GS_LPN(4); else GS_LPN(8);
+#undef GS_LPN
+    GS_LAUNCH_CHECK("linkpred_norm_fwd_bwd_kernel");
+    hipLaunchKernelGGL(linkpred_neg_bwd_kernel, dim3((unsigned)n_neg), dim3(256), 0, st, neg_slabs, (int32_t)blocks, n_neg, d, Z,
+                       ldz, 2 * B, dZ, lddz);
+    GS_LAUNCH_CHECK("linkpred_neg_bwd_kernel");
+    return GS_OK;
+}

@@ -342,9 +342,17 @@ class Engine(object):
         for hook in self.post_update_hooks:
             hook()
 
-    def advance(self, step=0, clock=0, cursor=None, cursor_delta=0, loss_rows=None, n=0, loss_out=None, accumulate=False):
-        """Step epilogue, ONE launch: (optionally) loss_out = mean(loss_rows) and advance the optimizer step /
-        sampler clock / epoch cursor."""
+    def advance(self, step=0, clock=0, cursor=None, cursor_delta=0, loss_rows=None, n=0, loss_out=None, accumulate=False,
+                aux_rows=None, aux_out=None):
+        """Step epilogue, ONE launch: (optionally) loss_out = mean(loss_rows) [and aux_out = mean(aux_rows)] and advance
+        the optimizer step / sampler clock / epoch cursor."""
+        if aux_rows is not None:
+            ops.call("gs_finalize_step2", ops.ptr(loss_rows), n, (1.0 / n) if n else 0.0, ops.ptr(loss_out),
+                     1 if accumulate else 0, ops.ptr(aux_rows), (1.0 / n) if n else 0.0, ops.ptr(aux_out),
+                     ops.ptr(self.step_dev) if step else None, step,
+                     ops.ptr(self.sample_clock_dev) if clock else None, clock,
+                     ops.ptr(cursor) if (cursor is not None and cursor_delta) else None, cursor_delta, self.stream)
+            return
         ops.call("gs_finalize_step", ops.ptr(loss_rows), n, (1.0 / n) if n else 0.0, ops.ptr(loss_out),
                  1 if accumulate else 0,
                  ops.ptr(self.step_dev) if step else None, step,

@@ -198,11 +198,18 @@ class SampleAndAggregate(object):
         cdf[-1] = np.uint32(4294967295)
         self._neg_cdf = torch.from_numpy(cdf.view(np.int32).copy()).to(e.device)   # raw bits; the kernel reads uint32
         self._n_cdf = int(cdf.shape[0])
+        # guide table of the inverse-cdf search: guide[b] = first index whose cdf exceeds b << (32 - bits); a draw r then
+        # searches [guide[r >> s], guide[(r >> s) + 1]] only (same result, ~6 dependent loads instead of 18)
+        self._guide_bits = 12
+        thr = (np.arange((1 << self._guide_bits) + 1, dtype=np.uint64) << np.uint64(32 - self._guide_bits))
+        guide = np.searchsorted(cdf.astype(np.uint64), thr, side="right")
+        guide = np.minimum(guide, len(cdf) - 1).astype(np.int32)
+        self._neg_guide = torch.from_numpy(guide).to(e.device)
         self.neg_seed = 123
         torch.cuda.synchronize()
 
-    _OUT_ATTRS = ("samples1", "outputs_all", "outputs1", "agg_out", "_loss_rows", "_rr_rows", "aff_all", "_dY",
-                  "_loss_accumulate", "_tape", "_inv_norm")
+    _OUT_ATTRS = ("samples1", "outputs_all", "outputs1", "agg_out", "_loss_rows", "_rr_rows", "aff_all", "_d_agg_out",
+                  "_loss_accumulate", "_tape")
 
     def _roots(self, B, parity=None):
         """[batch1 (B) | batch2 (B) | negatives] = the head of the contiguous id buffer."""
@@ -230,16 +237,17 @@ class SampleAndAggregate(object):
         self.agg_out = out
         d = out.d
         self.outputs_all = e.ws_mat("outputs_all", n_roots, d)
-        self._inv_norm = e.ws_f32("inv_norm", n_roots)
-        ops.l2norm_fwd(out, n_roots, self.outputs_all, self._inv_norm, stream=e.stream)            # :368-370
         self.outputs1 = self.outputs_all.rows_slice(0, B)
         self._loss_rows = e.ws_f32("loss_rows", B)
         self._rr_rows = e.ws_f32("rr_rows", B)
         self.aff_all = e.ws_mat("aff_all", B, self.neg_sample_size + 1)
-        self._dY = e.ws_mat("d_outputs_all", n_roots, d)
-        self.link_pred_layer.loss_and_grads(self.outputs_all, B, self.neg_sample_size, 1.0 / B, self._loss_rows,
-                                            self._rr_rows, self.aff_all, self._dY)
-        # loss = (sum_vars wd*l2_loss + xent) / batch_size  (:386-390, :378); the xent mean is added by the epilogue
+        # l2_normalize (:368-370) + link-prediction loss / MRR ranks (:385-405) + their gradient carried back through the
+        # normalisation: ONE launch (+ a 20-workgroup one for the negatives' rows); d_agg_out = dLoss/d(aggregator output)
+        self._d_agg_out = e.ws_mat("d_agg_out", n_roots, d)
+        self.link_pred_layer.loss_and_grads_fused(out, self.outputs_all, B, self.neg_sample_size, 1.0 / B, self._loss_rows,
+                                                  self._rr_rows, self.aff_all, self._d_agg_out)
+        # loss = (sum_vars wd*l2_loss + xent) / batch_size  (:386-390, :378); the xent mean (and the mrr, :404) are formed
+        # by the epilogue launch
         self._loss_accumulate = False
         if self.weight_decay != 0.0:
             first = True
@@ -249,23 +257,25 @@ class SampleAndAggregate(object):
                              0 if first else 1, e.stream)
                     first = False
             self._loss_accumulate = not first
-        ops.sum_scaled(self._rr_rows, B, 1.0 / B, self.mrr_dev, stream=e.stream)                    # mrr (:404)
 
     def _backward_unsup(self, B, n_roots, fuse_adam, wgrad_jobs=None, epilogue=None):
+        """Reverse schedule.  The epilogue (loss / mrr means + device counters) runs FIRST: the fan-out sampler of a later
+        step may ride in this pass's optimizer launch and must see the advanced sampler clock and pair cursor; the
+        optimizer then uses step_offset = 0 if the step counter has been advanced already."""
         e = self.engine
-        e.begin_backward()
-        d_out = e.ws_mat("d_agg_out", n_roots, self.agg_out.d)
-        ops.l2norm_bwd(self._dY, self.outputs_all, self._inv_norm, n_roots, d_out, stream=e.stream)
-        self.aggregate_backward(d_out)
-        # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
-        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
-                          side_jobs=wgrad_jobs)
+        advanced = False
         if epilogue is not None:
             self._epilogue_unsup(B, **epilogue)
+            advanced = bool(epilogue.get("step"))
+        e.begin_backward()
+        self.aggregate_backward(self._d_agg_out)
+        # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
+        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
+                          side_jobs=wgrad_jobs, step_offset=0 if advanced else 1)
 
     def _epilogue_unsup(self, B, **counters):
         self.engine.advance(loss_rows=self._loss_rows, n=B, loss_out=self.loss_dev, accumulate=self._loss_accumulate,
-                            **counters)
+                            aux_rows=self._rr_rows, aux_out=self.mrr_dev, **counters)
 
     def _optimize(self):
         e = self.engine
@@ -425,11 +435,20 @@ class SampleAndAggregate(object):
         in_graph = self._dp_in_graph()
         fused = local_adam or in_graph
 
+        fusable = self._fanout_fusable()
+
         def sample_next(parity):
             roots, n_roots = self._roots(B, parity=parity)
             self._parity = parity
-            self._stage_negatives(roots, B, pairs=self._pairs, cursor=self._cursor)
-            samples, support = self._sample_phase(roots, n_roots, parity)
+            if fusable:
+                # the edge-pair batch and the negatives are staged by the fan-out sampler launch itself (one launch, and
+                # one that can ride in the optimizer launch)
+                stage = ("unsup", self._pairs, self._cursor, B, self._neg_cdf, self._neg_guide, self._guide_bits,
+                         self.neg_sample_size, self.neg_seed)
+                samples, support = self._sample_phase(roots, n_roots, parity, stage=stage)
+            else:
+                self._stage_negatives(roots, B, pairs=self._pairs, cursor=self._cursor)
+                samples, support = self._sample_phase(roots, n_roots, parity)
             return roots, n_roots, samples, support
 
         if self._primed != B:
@@ -442,14 +461,33 @@ class SampleAndAggregate(object):
             e.sync()
             self._primed = B
         p0 = self._pipe_parity
+        per_root = 1
+        for f in self.num_samples[:0:-1]:
+            per_root *= f
+        # inside a multi-step graph the sampler of the step after next rides in this step's optimizer launch
+        ride = self.sampler_rides and fused and k > 1 and fusable and per_root <= 512
 
         def body():
             p = p0
-            for _ in range(k):
+            staged = None
+            for j in range(k):
                 q = 1 - p
-                roots_q, n_roots_q, samples, support = sample_next(q)
+                if staged is None:
+                    staged = sample_next(q)                    # standalone sampler launch (first step of a graph)
+                roots_q, n_roots_q, samples, support = staged
                 self_all, neighs = self._layer0_inputs(samples, support, n_roots_q)
                 means_q, jobs = self.aggregators[0].prefetch_jobs(self_all, neighs, tag=q)
+                staged = None
+                if ride and j + 1 < k:
+                    # by the time the optimizer launch runs, this step's own id buffers (parity p) are free and the epilogue
+                    # has advanced the sampler clock and the pair cursor: the draws are those of the standalone launch
+                    e._defer_sampler = True
+                    try:
+                        staged = sample_next(p)
+                    finally:
+                        e._defer_sampler = False
+                    if e._deferred_sampler is None:
+                        raise ops._lib.GraphsageAmdError("sampler did not take the one-launch fan-out path")
                 self._prefetched[(B, q)] = (roots_q, n_roots_q, (samples, support, means_q))
                 roots, n_roots, pre = self._prefetched[(B, p)]
                 self._parity = p
@@ -461,8 +499,10 @@ class SampleAndAggregate(object):
                 self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs)
                 self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs,
                                      epilogue=dict(step=1 if local_adam else 0, clock=1, cursor=self._cursor, cursor_delta=B))
+                if e._deferred_sampler is not None:
+                    raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
                 if in_graph:
-                    # backward | ncclAllReduce (recorded in the graph; a gather share runs beside it) | clip + Adam
+                    # backward | ncclAllReduce (recorded in the graph; a gather share may run beside it) | clip + Adam
                     if fork_jobs:
                         e.fork_join(lambda: self.grad_hook(self), lambda: e.launch_gather_jobs(fork_jobs), main_first=True)
                     else:

@@ -132,6 +132,19 @@ class UniformNeighborSampler(Layer):
         adj = self.adj_info.current
         assert isinstance(adj, CSRAdjacency)
         order = cursor = table = labels_out = None
+        if stage is not None and len(stage) and isinstance(stage[0], str) and stage[0] == "unsup":
+            # the unsupervised model's roots [batch1 | batch2 | negatives] are staged by the launch itself
+            _, pairs, cursor, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed = stage
+            desc = ops.fanout_desc(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all, batch_size,
+                                   self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,
+                                   cursor_dev=cursor, law=self.law, max_degree=self.max_degree,
+                                   unsup=(pairs, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed))
+            if getattr(e, "_defer_sampler", False):
+                e._deferred_sampler = desc
+            else:
+                ops.sample_fanout_desc(desc, stream=e.stream)
+            self._call_index += len(fans)
+            return
         if stage is not None:
             order, cursor, table, labels_out = stage
         if getattr(e, "_defer_sampler", False):

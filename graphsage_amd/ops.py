@@ -113,8 +113,10 @@ def sample_fanout_csr(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, s
 
 
 def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, step_dev=None, hop0=0, root_offset=0,
-                order=None, cursor_dev=None, label_table=None, labels_out=None, law=0, max_degree=0):
-    """The arguments of sample_fanout_csr as a struct gs_fanout_desc (for gs_flat_reduce_adam_sample).  The tensors are
+                order=None, cursor_dev=None, label_table=None, labels_out=None, law=0, max_degree=0, unsup=None):
+    """unsup = (pairs [n_pairs, 2] int32, n_pair_roots, cdf (uint32 bits), guide or None, guide_bits, n_neg, neg_seed): the
+    roots are staged by the launch itself as [pairs[:, 0] | pairs[:, 1] | negatives] (see gs_fanout_desc).
+    The arguments of sample_fanout_csr as a struct gs_fanout_desc (for gs_flat_reduce_adam_sample).  The tensors are
     kept alive on the descriptor object."""
     q = _lib.FanoutDesc()
     q.rowptr, q.col, q.n_nodes, q.pad_id = ptr(rowptr), ptr(col), n_nodes, pad_id
@@ -131,8 +133,18 @@ def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, s
         q.label_table, q.ld_table, q.C = label_table.ptr, label_table.ld, label_table.d
     if labels_out is not None:
         q.labels_out, q.ld_out = labels_out.ptr, labels_out.ld
-    q._keep = (rowptr, col, ids_all, step_dev, order, cursor_dev, label_table, labels_out)
+    q._keep = (rowptr, col, ids_all, step_dev, order, cursor_dev, label_table, labels_out, unsup)
+    if unsup is not None:
+        pairs, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed = unsup
+        q.pairs, q.n_pairs, q.n_pair_roots = ptr(pairs), pairs.shape[0], n_pair_roots
+        q.cdf, q.guide, q.n_cdf = ptr(cdf), ptr(guide), cdf.numel()
+        q.n_neg, q.guide_bits, q.neg_seed = n_neg, guide_bits, neg_seed & 0xFFFFFFFFFFFFFFFF
     return q
+
+
+def sample_fanout_desc(desc, stream=None):
+    """Launch the fused fan-out sampler from a descriptor built by fanout_desc()."""
+    call("gs_sample_fanout_desc", ctypes.addressof(desc), _s(stream))
 
 
 def select_batch(order, cursor_dev, n, out, stream=None):

@@ -342,6 +342,16 @@ int gs_linkpred_fwd_bwd(const float* Y, int64_t ldy, int64_t B, int32_t d, int32
                         float* loss_rows, float* rr_rows, float* aff_all, int64_t ld_aff,
                         float* dY, int64_t lddy, float* neg_slabs, int32_t* n_slabs_out_host, void* stream);
 
+/* The same objective FUSED with the normalisation on both sides (one launch + a 20-workgroup one instead of
+ * l2norm_fwd | linkpred | reduce_slabs | l2norm_bwd):  Z [2B + n_neg, d] are the RAW aggregator outputs,
+ *   Y = l2_normalize(Z) (models.py:368-370) is written (outputs1 / outputs2 / neg_outputs),
+ *   loss_rows / rr_rows / aff_all as gs_linkpred_fwd_bwd on Y,
+ *   dZ [2B + n_neg, d] = scale * dLoss/dZ (the gradient carried back through the normalisation; the negatives' rows are
+ *   summed from ceil(B/4) per-workgroup slabs in neg_slabs [ceil(B/4), n_neg, d] in a fixed order). */
+int gs_linkpred_norm_fwd_bwd(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight, float scale,
+                             float* Y, int64_t ldy, float* loss_rows, float* rr_rows, float* aff_all, int64_t ld_aff,
+                             float* dZ, int64_t lddz, float* neg_slabs, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K6  optimizer               replaces supervised_models.py:95-99 (clip_by_value +-5, Adam) and the
  *                             weight-decay terms :104-108
@@ -402,7 +412,18 @@ typedef struct gs_fanout_desc {
     int32_t pad_id, n_hops, C;
     uint32_t hop0;
     int32_t law, max_degree;      /* GS_LAW_*, see gs_sample_uniform_csr */
+    /* optional unsupervised root staging (pairs != NULL, exclusive with order): the roots are
+     *   [pairs[e][0] (n_pair_roots) | pairs[e][1] (n_pair_roots) | n_neg negatives],  e = (*cursor_dev + i) % n_pairs,
+     * B == 2 * n_pair_roots + n_neg; negative t = first node whose cdf exceeds the 32-bit draw of gs_unsup_stage
+     * (neg_seed, *step_dev, t) -- same draws bit for bit; guide (nullable, 2^guide_bits + 1 entries: guide[b] = first
+     * index with cdf > b << (32 - guide_bits)) only shortens the binary search. */
+    const int32_t* pairs; int64_t n_pairs, n_pair_roots;
+    const uint32_t* cdf; const int32_t* guide; int64_t n_cdf;
+    int32_t n_neg, guide_bits;
+    uint64_t neg_seed;
 } gs_fanout_desc;
+/* gs_sample_fanout_csr from a descriptor (incl. the unsupervised root staging). */
+int gs_sample_fanout_desc(const gs_fanout_desc* desc_host, void* stream);
 int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
                                int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,
                                float eps, float clip, float grad_scale, const uint64_t* step_dev, int32_t step_offset,
@@ -505,6 +526,12 @@ typedef struct gs_pull_desc {
     int64_t ldo, rows;
 } gs_pull_desc;
 int gs_input_grad_pull(const gs_pull_desc* desc_host, void* stream);
+
+/* gs_finalize_step with a second mean in the same launch: aux_out[0] = aux_scale * sum(aux_rows[0:n]) (the unsupervised
+ * model's mrr, models.py:404). */
+int gs_finalize_step2(const float* loss_rows, int64_t n, float scale, float* loss_out, int accumulate,
+                      const float* aux_rows, float aux_scale, float* aux_out, uint64_t* c0, uint64_t d0, uint64_t* c1,
+                      uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);
 
 /* Up to three device counters advanced by one launch (cursor / sampler clock / optimizer step). */
 int gs_advance_counters(uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);

@@ -229,3 +229,86 @@ def test_unsupervised_train_driver(dev, tmp_path, capsys):
     assert npy and any(p.endswith("val.txt") for p in files)
     emb = np.load(npy[0])
     assert emb.shape == (3000, 64) and np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,d,nn", [(512, 256, 20), (37, 64, 5), (130, 128, 20), (9, 512, 3)])
+def test_linkpred_norm_fused_vs_oracle(dev, B, d, nn):
+    """gs_linkpred_norm_fwd_bwd (l2_normalize + xent link prediction + MRR + the gradient carried back through the
+    normalisation, one launch + the negatives' rows) vs the oracle's l2_normalize_fwd / linkpred_fwd_bwd / l2_normalize_bwd
+    (models.py:368-405, prediction.py:68-110) in fp64; includes a clamped (all-zero) row in every group."""
+    rng = np.random.default_rng(B + d + 1)
+    Z = (rng.normal(size=(2 * B + nn, d)) * rng.uniform(0.2, 3.0, size=(2 * B + nn, 1))).astype(np.float32)
+    Z[:B] = 0.7 * Z[:B] + 0.3 * Z[B:2 * B]
+    Z[1] = 0
+    Z[B + 2] = 0
+    Z[2 * B + 1] = 0                                                  # clamped rows (sum z^2 < 1e-12)
+    Zd = Mat.from_numpy(Z, dev)
+    Y, dZ = Mat.zeros(2 * B + nn, d, dev), Mat.zeros(2 * B + nn, d, dev)
+    loss_rows, rr = torch.zeros(B, device=dev), torch.zeros(B, device=dev)
+    aff = Mat.zeros(B, nn + 1, dev)
+    slabs = torch.zeros(((B + 3) // 4) * nn * d, device=dev)
+    ops.call("gs_linkpred_norm_fwd_bwd", Zd.ptr, Zd.ld, B, d, nn, 1.0, 1.0 / B, Y.ptr, Y.ld, ops.ptr(loss_rows), ops.ptr(rr),
+             aff.ptr, aff.ld, dZ.ptr, dZ.ld, ops.ptr(slabs), ops.current_stream())
+    _sync()
+    Z64 = Z.astype(np.float64)
+    y, cache = orc.l2_normalize_fwd(Z64)
+    want = orc.linkpred_fwd_bwd(y[:B], y[B:2 * B], y[2 * B:])
+    np.testing.assert_allclose(Y.numpy(), y, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(loss_rows.cpu().numpy().sum(), want["loss"], rtol=1e-4)
+    np.testing.assert_allclose(aff.numpy(), want["aff_all"], rtol=1e-4, atol=1e-5)
+    got_rank = np.round(1.0 / rr.cpu().numpy() - 1).astype(np.int64)
+    margin = np.abs(want["aff_all"][:, :-1] - want["aff_all"][:, -1:]).min(axis=1) > 1e-5
+    assert np.array_equal(got_rank[margin], want["ranks"][margin])
+    d_y = np.concatenate([want["d_o1"], want["d_o2"], want["d_neg"]], axis=0) / B
+    d_z = orc.l2_normalize_bwd(d_y, cache)
+    got = dZ.numpy().astype(np.float64)
+    live = np.ones(2 * B + nn, bool)
+    live[[1, B + 2, 2 * B + 1]] = False                               # clamped rows: 1e6-scaled, compared relatively below
+    scale = np.abs(d_z[live]).max()
+    np.testing.assert_allclose(got[live], d_z[live], rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(got[~live], d_z[~live], rtol=1e-3, atol=1e-4 * max(1.0, np.abs(d_z[~live]).max()))
+
+
+def test_fanout_unsup_staging_bit_exact(dev):
+    """The fan-out sampler staging its own roots (edge-pair batch + unigram negatives, gs_sample_fanout_desc) == the
+    separate gs_unsup_stage launch == the oracle hash, with and without the guide table; then the hops as usual."""
+    rng = np.random.default_rng(4)
+    N, B, nn, fans = 6000, 300, 20, [10, 25]
+    deg = rng.integers(0, 120, size=N)
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, N, size=int(rowptr[-1])).astype(np.int32)
+    cdf = sampler_hash.unigram_cdf_u32(deg)
+    bits = 12
+    thr = (np.arange((1 << bits) + 1, dtype=np.uint64) << np.uint64(32 - bits))
+    guide = np.minimum(np.searchsorted(cdf.astype(np.uint64), thr, side="right"), N - 1).astype(np.int32)
+    pairs = rng.integers(0, N, size=(1000, 2)).astype(np.int32)
+    n_roots = 2 * B + nn
+    sizes = [n_roots, n_roots * fans[0], n_roots * fans[0] * fans[1]]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rp, cl = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
+    cdf_dev = torch.from_numpy(cdf.view(np.int32).copy()).to(dev)
+    pairs_dev = torch.from_numpy(pairs).to(dev)
+    cur = torch.tensor([900], dtype=torch.int64, device=dev)
+    clk = torch.tensor([7], dtype=torch.int64, device=dev)
+    outs = []
+    for g in (None, torch.from_numpy(guide).to(dev)):
+        ids_all = torch.full((int(offs[-1]),), -3, dtype=torch.int32, device=dev)
+        desc = ops.fanout_desc(rp, cl, N, N, fans, offs.tolist(), ids_all, n_roots, 123, step_dev=clk, cursor_dev=cur,
+                               unsup=(pairs_dev, B, cdf_dev, g, bits, nn, 123))
+        ops.sample_fanout_desc(desc)
+        _sync()
+        outs.append(ids_all.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    got = outs[0]
+    sel = pairs[(900 + np.arange(B)) % 1000]
+    roots = np.concatenate([sel[:, 0], sel[:, 1], sampler_hash.sample_unigram(cdf, nn, 123, 7)]).astype(np.int32)
+    assert np.array_equal(got[:n_roots], roots)
+    staged = torch.full((n_roots,), -1, dtype=torch.int32, device=dev)
+    ops.call("gs_unsup_stage", ops.ptr(pairs_dev), 1000, ops.ptr(cur), B, ops.ptr(cdf_dev), N, nn, 123, ops.ptr(clk), ops.ptr(staged),
+             ops.current_stream())
+    _sync()
+    assert np.array_equal(staged.cpu().numpy(), roots)
+    hop1 = sampler_hash.sample_uniform_csr(rowptr, col, N, N, roots, fans[0], 123, 7, 0)
+    hop2 = sampler_hash.sample_uniform_csr(rowptr, col, N, N, hop1.reshape(-1), fans[1], 123, 7, 1)
+    assert np.array_equal(got[offs[1]:offs[2]], hop1.reshape(-1)) and np.array_equal(got[offs[2]:offs[3]], hop2.reshape(-1))
