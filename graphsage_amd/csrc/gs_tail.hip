@@ -198,7 +198,7 @@ __device__ __forceinline__ void tail_sync_done(const TailArgs& a, const int G, c
     }
 }
 
-template <int D, int O>
+template <int D, int O, int CW>
 __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
     // Co-scheduled gather: the tail occupies n/16 CUs for ~30 us of mostly waiting; the other ~220 CUs (one 8-wave
     // workgroup each: the launch's LDS size is uniform) stream a share of the NEXT step's gather+mean from HBM meanwhile.
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int C = a.C;
     const int Cp4 = (C + 3) & ~3, Cp32 = (C + 31) & ~31;
-    constexpr int lslabs = 2, nks = 4, GC = 64;       // logits (C <= 64): 2 column slabs x 4 K-slices = the 8 waves
+    // logits: CW = ceil(C / 64) class groups of 64 (one class of each group per lane); 2 CW column slabs of 32 x
+    // 4 / CW K-slices = the 8 waves
+    constexpr int lslabs = 2 * CW, nks = 8 / lslabs, GC = 64 * CW;
     constexpr int KL = Z / nks / 4;                   // k-steps (4 k each) per K-slice
     const int ldc = Cp32 + 4;
     float* Hs = lds;                                  // [16][ldh]   self rows of h0      (later: DIN [16][2D+8])
@@ -300,12 +302,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
 #pragma unroll
         for (int u = 0; u < KL; ++u) bl[u] = *reinterpret_cast<const f32x2*>(B + (4 * u) * ldw);
     }
-    // phase 4: bias / labels of this wave's two rows (one class per lane)
-    const int cl = min(lane, C - 1);
-    const float bias_l = a.bh ? a.bh[cl] : 0.f;
-    float lab2[2];
+    // phase 4: bias / labels of this wave's two rows (one class of every 64-class group per lane)
+    int cl[CW];
+    float bias_l[CW], lab2[2][CW];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) lab2[rr] = a.labels[min(r0 + wave * 2 + rr, n - 1) * (int)a.ldlab + cl];
+    for (int m = 0; m < CW; ++m) {
+        cl[m] = min(lane + 64 * m, C - 1);
+        bias_l[m] = a.bh ? a.bh[cl[m]] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) lab2[rr][m] = a.labels[min(r0 + wave * 2 + rr, n - 1) * (int)a.ldlab + cl[m]];
+    }
     // phase 7 ([d_self | d_means], NT form): DPW slabs of 32 weight rows, K = O
     f32x4 b7[DPW][M7][2];
     auto load_b7 = [&](const int sl) {
@@ -320,20 +326,22 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     };
     load_b7(0);
-    // phase 5 (d_y, NT form): rows n0 .. n0+31 of W_head, K = Cp32 <= 64 -> up to 4 macro steps x 2 tiles
-    f32x4 bh5[4][2];
+    // phase 5 (d_y, NT form): rows n0 .. n0+31 of W_head, K = Cp32 <= 64 CW -> up to 4 CW macro steps x 2 tiles
+    f32x4 bh5[4 * CW][2];
     {
         const int ldw = (int)a.ldwh;
         const int n0 = (wave < ZSLABS ? wave : 0) * 32;
         const float* B0 = a.Wh + (n0 + j) * ldw;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4 * CW; ++m) {
             const int kq = min(16 * m + 4 * q, Cp4 - 4);     // clamped: dlogits are zero beyond C
             bh5[m][0] = *reinterpret_cast<const f32x4*>(B0 + kq);
             bh5[m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + kq);
         }
     }
-    if (DPW > 1) load_b7(DPW - 1);
+    // (two class groups: the wider logits / d_y operands take the registers of the second input-gradient slab, which is
+    // requested after the loss phase instead -- phases 5-6 cover its round trip)
+    if (DPW > 1 && CW == 1) load_b7(DPW - 1);
     TAIL_STAMP(2);
 
     // ---------------- phase 1: pick up z from the helpers
@@ -412,41 +420,68 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
 
     const float inv_n = 1.0f / (float)n, inv_c = 1.0f / (float)C, inv_nc = inv_n * inv_c;
     // ---------------- phase 4: logits, loss rows, preds, dlogits   (supervised_models.py:111-126); two rows per wave,
-    // one class per lane (C <= 64).  __expf / __logf: v_exp_f32 / v_log_f32 based, ~1e-6 relative.
+    // one class of each 64-class group per lane (C <= 64 CW).  __expf / __logf: v_exp_f32 / v_log_f32 based, ~1e-6 relative.
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = wave * 2 + rr;
         const int i = r0 + row;
         const bool valid = i < n;
-        const bool in = lane < C;
-        float x = bias_l;
-        for (int ks = 0; ks < nks; ++ks) x += Ps[(ks * TAIL_ROWS + row) * GC + cl];
-        const float zl = (valid && in) ? lab2[rr] : 0.f;
-        if (!in) x = 0.f;
-        float gl, pr, loss;
+        bool in[CW];
+        float x[CW], zl[CW], gl[CW], pr[CW];
+#pragma unroll
+        for (int m = 0; m < CW; ++m) {
+            in[m] = lane + 64 * m < C;
+            float xv = bias_l[m];
+            for (int ks = 0; ks < nks; ++ks) xv += Ps[(ks * TAIL_ROWS + row) * GC + cl[m]];
+            x[m] = in[m] ? xv : 0.f;
+            zl[m] = (valid && in[m]) ? lab2[rr][m] : 0.f;
+        }
+        float loss;
         if (a.sigmoid) {
-            const float e = __expf(-fabsf(x));
-            const float term = in ? fmaxf(x, 0.f) - x * zl + __logf(1.0f + e) : 0.f;
-            const float r1 = __builtin_amdgcn_rcpf(1.0f + e);               // v_rcp_f32 (1 ulp)
-            pr = x >= 0.f ? r1 : e * r1;
-            gl = (pr - zl) * inv_nc;
+            float term = 0.f;
+#pragma unroll
+            for (int m = 0; m < CW; ++m) {
+                const float e = __expf(-fabsf(x[m]));
+                term += in[m] ? fmaxf(x[m], 0.f) - x[m] * zl[m] + __logf(1.0f + e) : 0.f;
+                const float r1 = __builtin_amdgcn_rcpf(1.0f + e);           // v_rcp_f32 (1 ulp)
+                pr[m] = x[m] >= 0.f ? r1 : e * r1;
+                gl[m] = (pr[m] - zl[m]) * inv_nc;
+            }
             loss = tail_wave_sum(term) * inv_c;
         } else {
-            const float mx = tail_wave_max(in ? x : -INFINITY);
-            const float ex = in ? __expf(x - mx) : 0.f;
-            const float se = tail_wave_sum(ex);
-            const float zs = tail_wave_sum(zl);
-            const float zx = tail_wave_sum(zl * x);
-            pr = ex * __builtin_amdgcn_rcpf(se);
-            gl = (pr * zs - zl) * inv_n;
+            float mxl = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < CW; ++m) mxl = fmaxf(mxl, in[m] ? x[m] : -INFINITY);
+            const float mx = tail_wave_max(mxl);
+            float ex[CW], sel = 0.f, zsl = 0.f, zxl = 0.f;
+#pragma unroll
+            for (int m = 0; m < CW; ++m) {
+                ex[m] = in[m] ? __expf(x[m] - mx) : 0.f;
+                sel += ex[m];
+                zsl += zl[m];
+                zxl += zl[m] * x[m];
+            }
+            const float se = tail_wave_sum(sel);
+            const float zs = tail_wave_sum(zsl);
+            const float zx = tail_wave_sum(zxl);
+            const float rse = __builtin_amdgcn_rcpf(se);
+#pragma unroll
+            for (int m = 0; m < CW; ++m) {
+                pr[m] = ex[m] * rse;
+                gl[m] = (pr[m] * zs - zl[m]) * inv_n;
+            }
             loss = zs * (mx + __logf(se)) - zx;
         }
-        const float gv = (valid && in) ? gl : 0.f;
-        if (lane < Cp32) DLs[row * ldc + lane] = gv;
-        if (valid && lane < Cp4) {
-            if (a.logits) a.logits[i * (int)a.ldlo + lane] = in ? x : 0.f;
-            if (a.preds) a.preds[i * (int)a.ldp + lane] = in ? pr : 0.f;
-            a.dlogits[i * (int)a.lddl + lane] = gv;
+#pragma unroll
+        for (int m = 0; m < CW; ++m) {
+            const int c = lane + 64 * m;
+            const float gv = (valid && in[m]) ? gl[m] : 0.f;
+            if (c < Cp32) DLs[row * ldc + c] = gv;
+            if (valid && c < Cp4) {
+                if (a.logits) a.logits[i * (int)a.ldlo + c] = in[m] ? x[m] : 0.f;
+                if (a.preds) a.preds[i * (int)a.ldp + c] = in[m] ? pr[m] : 0.f;
+                a.dlogits[i * (int)a.lddl + c] = gv;
+            }
         }
         if (valid && lane == 0) a.loss_rows[i] = loss;
     }
@@ -459,6 +494,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
         return;
     }
+    if (DPW > 1 && CW > 1) load_b7(DPW - 1);
     lds_barrier();
     TAIL_STAMP(6);
 
@@ -469,7 +505,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         const float* A = DLs + j * ldc + 4 * q;
         f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4 * CW; ++m) {
             if (16 * m < Cp32) {                                   // wave-uniform
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + 16 * m);
 #pragma unroll
@@ -590,25 +626,31 @@ static size_t tail_lds_bytes(int D, int O, int C) {
 }
 
 extern "C" int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C) {
-    const bool ok = (d_in == 128 || d_in == 256) && (out_dim == 64 || out_dim == 128) && C >= 1 && C <= 64 &&
+    const bool ok = (d_in == 128 || d_in == 256) && (out_dim == 64 || out_dim == 128) && C >= 1 && C <= 128 &&
                     tail_lds_bytes(d_in, out_dim, C) <= 160 * 1024;
     return ok ? 1 : 0;
 }
 
-template <int D, int O>
-static int launch_tail(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
+template <int D, int O, int CW>
+static int launch_tail_cw(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
     const size_t lds = tail_lds_bytes(a.D, a.O, a.C);
     static bool attr_done = false;
     if (!attr_done) {
-        GS_HIP(hipFuncSetAttribute((const void*)sage_tail_kernel<D, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GS_HIP(hipFuncSetAttribute((const void*)sage_tail_kernel<D, O, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + 1 main workgroup each
     const int64_t blocks = (int64_t)tail_blocks * (2 * O / 64 + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_fwd_bwd: grid too large");
-    hipLaunchKernelGGL((sage_tail_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
+    hipLaunchKernelGGL((sage_tail_kernel<D, O, CW>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
     GS_LAUNCH_CHECK("sage_tail_kernel");
     return GS_OK;
+}
+
+template <int D, int O>
+static int launch_tail(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
+    // C <= 64: one class per lane; 64 < C <= 128 (e.g. PPI's 121 sigmoid labels, example_supervised.sh): two
+    return a.C > 64 ? launch_tail_cw<D, O, 2>(a, J, gather_waves, st) : launch_tail_cw<D, O, 1>(a, J, gather_waves, st);
 }
 
 extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
@@ -622,7 +664,7 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     GS_REQUIRE((q->n + q->n * (int64_t)q->s) * std::max(q->ldh, std::max(q->lddh, (int64_t)1)) < (1ll << 31),
                "gs_sage_tail_fwd_bwd: (n + n*s) * ld must be < 2^31 (32-bit row offsets)");
     if (!gs_sage_tail_supported(q->d_in, q->out_dim, q->C)) {
-        gs_set_error("gs_sage_tail_fwd_bwd: unsupported shape d_in=%d out_dim=%d C=%d (d_in in {128,256}, out_dim in {64,128}, C <= 64)",
+        gs_set_error("gs_sage_tail_fwd_bwd: unsupported shape d_in=%d out_dim=%d C=%d (d_in in {128,256}, out_dim in {64,128}, C <= 128)",
                      q->d_in, q->out_dim, q->C);
         return GS_ENOTSUP;
     }

@@ -264,7 +264,10 @@ class SampleAndAggregate(object):
         optimizer then uses step_offset = 0 if the step counter has been advanced already."""
         e = self.engine
         advanced = False
-        if epilogue is not None:
+        # dropout masks are a function of the device clock and the backward pass regenerates them: with dropout on, the
+        # clock must not move before the backward pass has run (no sampler rides there: the prefetch pipeline is off)
+        early = epilogue is not None and self._dropout_rate() == 0.0
+        if early:
             self._epilogue_unsup(B, **epilogue)
             advanced = bool(epilogue.get("step"))
         e.begin_backward()
@@ -272,6 +275,8 @@ class SampleAndAggregate(object):
         # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
         e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
                           side_jobs=wgrad_jobs, step_offset=0 if advanced else 1)
+        if epilogue is not None and not early:
+            self._epilogue_unsup(B, **epilogue)
 
     def _epilogue_unsup(self, B, **counters):
         self.engine.advance(loss_rows=self._loss_rows, n=B, loss_out=self.loss_dev, accumulate=self._loss_accumulate,

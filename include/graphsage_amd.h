@@ -439,7 +439,7 @@ int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, flo
  *           [n, C], loss_rows [n]: written (inputs of the weight-gradient launch and model outputs)
  *   train != 0: dz [n, 2*out_dim] = dLoss/dz and d_h0 [n + n*s, d_in] = relu'(h0) * dLoss/dh0 are written too
  *   c0..c2 (nullable device counters) are advanced by d0..d2 at the end of the launch.
- * Supported: concat, no aggregator bias, s <= 11, d_in in {128, 256}, out_dim in {64, 128}, C <= 64
+ * Supported: concat, no aggregator bias, s <= 11, d_in in {128, 256}, out_dim in {64, 128}, C <= 128
  * (gs_sage_tail_supported);
  * anything else returns GS_ENOTSUP and the caller uses the per-operator entry points. */
 typedef struct gs_tail_desc {

@@ -738,11 +738,16 @@ def test_sage_dense_cogather_equals_separate_calls(dev):
 @pytest.mark.parametrize("n,s,D,O,C,sig,train", [(512, 10, 256, 128, 41, False, True), (37, 3, 128, 64, 7, True, True),
                                                  (100, 10, 256, 64, 33, True, True), (48, 5, 128, 128, 64, False, True),
                                                  (33, 4, 256, 128, 41, False, False),
+                                                 # two class groups (64 < C <= 128): PPI's 121 sigmoid labels at the
+                                                 # reference example's shapes (example_supervised.sh), softmax, ragged C
+                                                 (512, 10, 256, 128, 121, True, True), (70, 6, 128, 64, 100, False, True),
+                                                 (45, 3, 256, 64, 65, True, True), (90, 11, 128, 128, 128, False, True),
+                                                 (21, 2, 256, 128, 127, False, False),
                                                  (3000, 10, 256, 128, 41, False, True)])     # 940 workgroups > 256 CUs
 def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
     """gs_sage_tail_fwd_bwd (layer 1 + l2_normalize + head + loss + every input gradient, ONE launch) vs the oracle's
     MeanAggregator / head restatements (aggregators.py:43-64, supervised_models.py:85-126) in fp64; ragged n, both
-    losses, C above and below one 64-column group, device counters."""
+    losses, C inside one 64-class group and across two (C <= 128), device counters."""
     rng = np.random.default_rng(n + C)
     rows = n + n * s
     h0 = np.maximum(_asym(rng, (rows, D)), 0).astype(np.float32)            # relu outputs of layer 0 (zeros included)
@@ -750,7 +755,7 @@ def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
     Wh, bh = _asym(rng, (2 * O, C)) * 0.3, _asym(rng, (C,)) * 0.1
     lab = (rng.random((n, C)) > 0.5).astype(np.float32) if sig else np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]
     Z = 2 * O
-    assert ops.sage_tail_supported(D, O, C) and not ops.sage_tail_supported(D, O, 121) and not ops.sage_tail_supported(96, O, C)
+    assert ops.sage_tail_supported(D, O, C) and not ops.sage_tail_supported(D, O, 129) and not ops.sage_tail_supported(96, O, C)
     means, z, y = Mat.zeros(n, D, dev), Mat.zeros(n, Z, dev), Mat.zeros(n, Z, dev)
     lo, pr, dl = Mat.zeros(n, C, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
     lr = torch.zeros(n, device=dev)
