@@ -169,7 +169,7 @@ class MeanAggregator(_SageBase):
         d = neighs[0].shape3[2]
         k = len(self._saved)
         rate = _rate(self.dropout)
-        means = e.ws_mat((self.name, "mean", k, tag), n_total, d)
+        means = e.ws_mat((self.name, "mean", k, tag), n_total, d, ld_multiple=32)      # whole 128-byte lines per row
         r = row0 = 0
         for nv in neighs:
             n, s, _ = nv.shape3
@@ -187,7 +187,7 @@ class MeanAggregator(_SageBase):
         e = self.engine
         n_total = self_all.n
         d = neighs[0].shape3[2]
-        means = e.ws_mat((self.name, "mean", len(self._saved), tag), n_total, d)
+        means = e.ws_mat((self.name, "mean", len(self._saved), tag), n_total, d, ld_multiple=32)
         jobs, r = [], 0
         for nv in neighs:
             n, s, _ = nv.shape3
@@ -333,7 +333,7 @@ class GCNAggregator(_SageBase):
         self._no_dropout_here("the prefetch pipeline")
         e = self.engine
         d = neighs[0].shape3[2]
-        means = e.ws_mat((self.name, "mean", len(self._saved), tag), self_all.n, d)
+        means = e.ws_mat((self.name, "mean", len(self._saved), tag), self_all.n, d, ld_multiple=32)
         jobs, r = [], 0
         for nv in neighs:
             n, s, _ = nv.shape3
@@ -349,7 +349,7 @@ class GCNAggregator(_SageBase):
         d = neighs[0].shape3[2]
         k = len(self._saved)
         rate = _rate(self.dropout)
-        means = e.ws_mat((self.name, "mean", k, tag), n_total, d)
+        means = e.ws_mat((self.name, "mean", k, tag), n_total, d, ld_multiple=32)      # whole 128-byte lines per row
         self_in = self._drop_self(self_all, rate, k) if rate > 0 else self_all            # dropout(self_vecs) (:105)
         r = row0 = 0
         for nv in neighs:
