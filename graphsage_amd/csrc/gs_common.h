@@ -99,3 +99,40 @@ static inline int gs_drop_args(const gs_dropout* d, DropArgs* out) {
     return 0;
 }
 
+
+// Step epilogue body (one 256-thread workgroup): loss_out = scale * sum(loss_rows[0:n]) (+= if accumulate), optionally
+// aux_out = aux_scale * sum(aux_rows[0:n]), both in a fixed order, then the device counters advance.  Shared by
+// finalize_step_kernel (gs_runtime.hip) and the launches that carry the epilogue as an extra workgroup.
+struct StepEpilogue {
+    const float* loss_rows; int64_t n; float scale; float* loss_out; int accumulate;
+    const float* aux_rows; float aux_scale; float* aux_out;
+    uint64_t* c0; uint64_t d0; uint64_t* c1; uint64_t d1; uint64_t* c2; uint64_t d2;
+};
+__device__ __forceinline__ void gs_step_epilogue_block(const StepEpilogue& e, float* part, float* part2) {
+    if (e.aux_rows) {                          // a second mean in the same launch (unsupervised: mrr, models.py:404)
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < e.n; i += 256) s += e.aux_rows[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if ((threadIdx.x & 63) == 0) part2[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) e.aux_out[0] = ((part2[0] + part2[1]) + (part2[2] + part2[3])) * e.aux_scale;
+    }
+    if (e.loss_rows) {
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < e.n; i += 256) s += e.loss_rows[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = ((part[0] + part[1]) + (part[2] + part[3])) * e.scale;
+            e.loss_out[0] = e.accumulate ? e.loss_out[0] + tot : tot;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (e.c0) *e.c0 += e.d0;
+        if (e.c1) *e.c1 += e.d1;
+        if (e.c2) *e.c2 += e.d2;
+    }
+}

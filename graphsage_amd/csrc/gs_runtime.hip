@@ -164,32 +164,8 @@ __global__ __launch_bounds__(256) void finalize_step_kernel(const float* __restr
                                                             float* __restrict__ aux_out) {
     __shared__ float part[4];
     __shared__ float part2[4];
-    if (aux_rows) {                            // a second mean in the same launch (unsupervised: mrr, models.py:404)
-        float s = 0.f;
-        for (int64_t i = threadIdx.x; i < n; i += 256) s += aux_rows[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if ((threadIdx.x & 63) == 0) part2[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) aux_out[0] = ((part2[0] + part2[1]) + (part2[2] + part2[3])) * aux_scale;
-    }
-    if (loss_rows) {
-        float s = 0.f;
-        for (int64_t i = threadIdx.x; i < n; i += 256) s += loss_rows[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float tot = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
-            loss_out[0] = accumulate ? loss_out[0] + tot : tot;
-        }
-    }
-    if (threadIdx.x == 0) {
-        if (c0) *c0 += d0;
-        if (c1) *c1 += d1;
-        if (c2) *c2 += d2;
-    }
+    const StepEpilogue e = {loss_rows, n, scale, loss_out, accumulate, aux_rows, aux_scale, aux_out, c0, d0, c1, d1, c2, d2};
+    gs_step_epilogue_block(e, part, part2);
 }
 extern "C" int gs_finalize_step(const float* loss_rows, int64_t n, float scale, float* loss_out, int accumulate,
                                 uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2,

@@ -54,6 +54,72 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
+// One wave = one pair against all negatives.  o1 / o2: the pair's (normalised) rows, one 64-column group per register.
+// The n_neg affinities are formed 64 at a time with lane q holding negative q's, so that the sigmoid / softplus of the
+// whole block is ONE round of v_exp / v_log / v_rcp (the first version walked the negatives one by one with libm expf /
+// log1pf: 21 us for 512 pairs x 20 negatives); __expf / __logf are ~1e-6 relative like the supervised tail's.
+//   g1 += sum_q gq * neg_q;   mypart[q] = gq * o1   (the negatives' gradient contribution of this pair)
+template <int DJ>
+__device__ __forceinline__ void linkpred_pair(const float (&o1)[DJ], const float* __restrict__ negs, float* __restrict__ mypart,
+                                              const int n_neg, const float aff, const float neg_w, const float scale,
+                                              const bool live, const int lane, float (&g1)[DJ], float& loss, int& rank,
+                                              float* __restrict__ aff_row) {
+    constexpr int d = DJ * 64;
+    for (int qb = 0; qb < n_neg; qb += 64) {
+        const int nq = min(64, n_neg - qb);                       // wave-uniform
+        float nav = 0.f;
+        int q = 0;
+        for (; q + 4 <= nq; q += 4) {                             // four independent dot products / reductions in flight
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            const float* nr = negs + (size_t)(qb + q) * d + lane;
+#pragma unroll
+            for (int j = 0; j < DJ; ++j) {
+                p0 += o1[j] * nr[j * 64];
+                p1 += o1[j] * nr[d + j * 64];
+                p2 += o1[j] * nr[2 * d + j * 64];
+                p3 += o1[j] * nr[3 * d + j * 64];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                p0 += __shfl_xor(p0, off, 64);
+                p1 += __shfl_xor(p1, off, 64);
+                p2 += __shfl_xor(p2, off, 64);
+                p3 += __shfl_xor(p3, off, 64);
+            }
+            nav = lane == q ? p0 : nav;
+            nav = lane == q + 1 ? p1 : nav;
+            nav = lane == q + 2 ? p2 : nav;
+            nav = lane == q + 3 ? p3 : nav;
+        }
+        for (; q < nq; ++q) {
+            float p0 = 0.f;
+#pragma unroll
+            for (int j = 0; j < DJ; ++j) p0 += o1[j] * negs[(size_t)(qb + q) * d + j * 64 + lane];
+            p0 = wsum(p0);
+            nav = lane == q ? p0 : nav;
+        }
+        // lane q: negative qb + q
+        const bool in = lane < nq;
+        const float e = __expf(-fabsf(nav));
+        const float r1 = __builtin_amdgcn_rcpf(1.0f + e);
+        const float sg = nav >= 0.f ? r1 : e * r1;                // sigmoid(nav)
+        loss += neg_w * wsum(in ? fmaxf(nav, 0.f) + __logf(1.0f + e) : 0.f);
+        rank += __popcll(__ballot(in && nav >= aff));
+        const float gqv = (in && live) ? neg_w * scale * sg : 0.f;
+        if (aff_row && live && in) aff_row[qb + lane] = nav;
+        for (q = 0; q < nq; ++q) {
+            const float gq = __shfl(gqv, q, 64);
+            const float* nr = negs + (size_t)(qb + q) * d + lane;
+            float* mp = mypart + (size_t)(qb + q) * d + lane;
+#pragma unroll
+            for (int j = 0; j < DJ; ++j) {
+                g1[j] += gq * nr[j * 64];
+                mp[j * 64] = gq * o1[j];
+            }
+        }
+    }
+}
+
 // Y [2B + n_neg, d]: rows [0,B) = outputs1, [B,2B) = outputs2, [2B, 2B+n_neg) = neg_outputs (all l2-normalised).
 // Per pair i:  aff = <o1,o2>;  neg_aff_j = <o1, neg_j>;
 //   loss_i = xent(1, aff) + w * sum_j xent(0, neg_aff_j)                                  (prediction.py:102-110)
@@ -86,28 +152,17 @@ __global__ __launch_bounds__(256) void linkpred_fwd_bwd_kernel(const float* __re
         aff += o1[j] * o2[j];
     }
     aff = wsum(aff);
-    const float sa = 1.0f / (1.0f + expf(-aff));
+    const float ea = __expf(-fabsf(aff));
+    const float ra = __builtin_amdgcn_rcpf(1.0f + ea);
+    const float sa = aff >= 0.f ? ra : ea * ra;
     const float da = (sa - 1.0f) * scale;
-    float loss = fmaxf(aff, 0.f) - aff + log1pf(expf(-fabsf(aff)));
+    float loss = fmaxf(aff, 0.f) - aff + __logf(1.0f + ea);
     int rank = 0;
 #pragma unroll
     for (int j = 0; j < DJ; ++j) g1[j] = da * o2[j];
     float* mypart = part + (size_t)wave * n_neg * d;
-    for (int q = 0; q < n_neg; ++q) {
-        float na = 0.f;
-#pragma unroll
-        for (int j = 0; j < DJ; ++j) na += o1[j] * negs[q * d + j * 64 + lane];
-        na = wsum(na);
-        loss += neg_w * (fmaxf(na, 0.f) + log1pf(expf(-fabsf(na))));
-        rank += (na >= aff) ? 1 : 0;
-        const float gq = live ? neg_w * scale / (1.0f + expf(-na)) : 0.f;
-        if (aff_all && live && lane == 0) aff_all[i * ld_aff + q] = na;
-#pragma unroll
-        for (int j = 0; j < DJ; ++j) {
-            g1[j] += gq * negs[q * d + j * 64 + lane];
-            mypart[q * d + j * 64 + lane] = gq * o1[j];
-        }
-    }
+    linkpred_pair<DJ>(o1, negs, mypart, n_neg, aff, neg_w, scale, live, lane, g1, loss, rank,
+                      (aff_all && live) ? aff_all + i * ld_aff : nullptr);
     if (live) {
 #pragma unroll
         for (int j = 0; j < DJ; ++j) {
@@ -212,28 +267,17 @@ __global__ __launch_bounds__(256) void linkpred_norm_fwd_bwd_kernel(const float*
         aff += o1[j] * o2[j];
     }
     aff = wsum(aff);
-    const float sa = 1.0f / (1.0f + expf(-aff));
+    const float ea = __expf(-fabsf(aff));
+    const float ra = __builtin_amdgcn_rcpf(1.0f + ea);
+    const float sa = aff >= 0.f ? ra : ea * ra;
     const float da = (sa - 1.0f) * scale;
-    float loss = fmaxf(aff, 0.f) - aff + log1pf(expf(-fabsf(aff)));
+    float loss = fmaxf(aff, 0.f) - aff + __logf(1.0f + ea);
     int rank = 0;
 #pragma unroll
     for (int j = 0; j < DJ; ++j) g1[j] = da * o2[j];
     float* mypart = part + (size_t)wave * n_neg * d;
-    for (int q = 0; q < n_neg; ++q) {
-        float na = 0.f;
-#pragma unroll
-        for (int j = 0; j < DJ; ++j) na += o1[j] * negs[q * d + j * 64 + lane];
-        na = wsum(na);
-        loss += neg_w * (fmaxf(na, 0.f) + log1pf(expf(-fabsf(na))));
-        rank += (na >= aff) ? 1 : 0;
-        const float gq = live ? neg_w * scale / (1.0f + expf(-na)) : 0.f;
-        if (aff_all && live && lane == 0) aff_all[i * ld_aff + q] = na;
-#pragma unroll
-        for (int j = 0; j < DJ; ++j) {
-            g1[j] += gq * negs[q * d + j * 64 + lane];
-            mypart[q * d + j * 64 + lane] = gq * o1[j];
-        }
-    }
+    linkpred_pair<DJ>(o1, negs, mypart, n_neg, aff, neg_w, scale, live, lane, g1, loss, rank,
+                      (aff_all && live) ? aff_all + i * ld_aff : nullptr);
     if (live) {
         // back through y = z * inv:  dz = inv (g - y <g, y>);  clamped (sum z^2 < 1e-12, inv = 1e6): dz = g * inv
         float dot1 = 0.f, dot2 = 0.f;
@@ -265,55 +309,68 @@ __global__ __launch_bounds__(256) void linkpred_norm_fwd_bwd_kernel(const float*
         slab[t] = (part[t] + part[(size_t)n_neg * d + t]) + (part[2 * (size_t)n_neg * d + t] + part[3 * (size_t)n_neg * d + t]);
 }
 
-// One workgroup per negative row q: g = sum of the slabs (fixed order, 8 independent partial sums), then the
-// normalisation backward with the row's own inv (recomputed from Z) and y.
+// One workgroup per negative row q: g = sum of the n_slabs per-workgroup slabs in a fixed order, then the normalisation
+// backward with the row's own inv (recomputed from Z) and y.  The row's d/4 float4 columns x SG = 1024/d slab groups are
+// spread over the 256 threads; a group walks its slabs (sg, sg + SG, ...) with 16 independent 16-byte loads in flight
+// (the first version: 8 dword loads per batch, 16 dependent round trips for 128 slabs -- 8 us of pure latency), the
+// groups meet in LDS and are summed group 0, 1, ...  Block n_neg (when has_epi) is the step epilogue (mean loss / mrr +
+// device counters): it only needs the rows the previous launch wrote.
 __global__ __launch_bounds__(256) void linkpred_neg_bwd_kernel(const float* __restrict__ slabs, int32_t n_slabs, int32_t n_neg,
                                                                int32_t d, const float* __restrict__ Z, int64_t ldz,
-                                                               int64_t row0, float* __restrict__ dZ, int64_t lddz) {
+                                                               int64_t row0, float* __restrict__ dZ, int64_t lddz,
+                                                               const StepEpilogue epi) {
+    __shared__ f32x4 gpart[256];
     __shared__ float red[2][4];
+    if ((int)blockIdx.x == n_neg) {
+        gs_step_epilogue_block(epi, red[0], red[1]);
+        return;
+    }
     const int q = blockIdx.x, tid = threadIdx.x;
-    const float* zr = Z + (row0 + q) * ldz;
-    float g[2] = {0.f, 0.f}, z[2] = {0.f, 0.f};
+    const int d4 = d >> 2, SG = 256 / d4;                  // d in {64, 128, 256, 512}: d4 in {16 .. 128}, SG in {16 .. 2}
+    const int cg = tid % d4, sg = tid / d4;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(slabs + (size_t)q * d) + cg;
+    const size_t stride4 = (size_t)n_neg * d4;             // float4 per slab
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+    int sI = sg;
+    for (; sI + 15 * SG < n_slabs; sI += 16 * SG) {
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = sp[(size_t)(sI + u * SG) * stride4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u & 3] += v[u];
+    }
+    for (; sI < n_slabs; sI += SG) acc[0] += sp[(size_t)sI * stride4];
+    gpart[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    f32x4 g = zero4, z = zero4;
     float ss = 0.f;
-    for (int h = 0; h < 2; ++h) {
-        const int c = tid + 256 * h;
-        if (c < d) {
-            float acc[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-            const float* sp = slabs + (size_t)q * d + c;
-            const size_t stride = (size_t)n_neg * d;
-            int sI = 0;
-            for (; sI + 8 <= n_slabs; sI += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += sp[(size_t)(sI + u) * stride];
-            }
-            for (; sI < n_slabs; ++sI) acc[sI & 7] += sp[(size_t)sI * stride];
-            g[h] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-            z[h] = zr[c];
-            ss += z[h] * z[h];
-        }
+    if (tid < d4) {
+        g = gpart[tid];
+        for (int k = 1; k < SG; ++k) g += gpart[k * d4 + tid];
+        z = *reinterpret_cast<const f32x4*>(Z + (row0 + q) * ldz + 4 * tid);
+        ss = (z.x * z.x + z.y * z.y) + (z.z * z.z + z.w * z.w);
     }
     ss = wsum(ss);
     if ((tid & 63) == 0) red[0][tid >> 6] = ss;
     __syncthreads();
     ss = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-12f));
-    float dot = g[0] * z[0] * inv + g[1] * z[1] * inv;
+    float dot = ((g.x * z.x + g.y * z.y) + (g.z * z.z + g.w * z.w)) * inv;
     dot = wsum(dot);
     if ((tid & 63) == 0) red[1][tid >> 6] = dot;
     __syncthreads();
     dot = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const bool clamped = inv >= 1.0e6f;
-    for (int h = 0; h < 2; ++h) {
-        const int c = tid + 256 * h;
-        if (c < d) dZ[(row0 + q) * lddz + c] = clamped ? g[h] * inv : inv * (g[h] - z[h] * inv * dot);
+    if (tid < d4) {
+        const f32x4 o = clamped ? g * inv : (g - z * (inv * dot)) * inv;
+        *reinterpret_cast<f32x4*>(dZ + (row0 + q) * lddz + 4 * tid) = o;
     }
 }
 
-extern "C" int gs_linkpred_norm_fwd_bwd(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight,
-                                        float scale, float* Y, int64_t ldy, float* loss_rows, float* rr_rows, float* aff_all,
-                                        int64_t ld_aff, float* dZ, int64_t lddz, float* neg_slabs, void* stream) {
+static int linkpred_norm_launch(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight,
+                                float scale, float* Y, int64_t ldy, float* loss_rows, float* rr_rows, float* aff_all,
+                                int64_t ld_aff, float* dZ, int64_t lddz, float* neg_slabs, const StepEpilogue* epi, void* stream) {
     GS_REQUIRE(Z && Y && loss_rows && rr_rows && dZ && neg_slabs && B > 0 && n_neg > 0, "gs_linkpred_norm_fwd_bwd: bad args");
     GS_REQUIRE(d == 64 || d == 128 || d == 256 || d == 512, "gs_linkpred_norm_fwd_bwd: d must be 64/128/256/512 (got %d)", d);
     GS_REQUIRE(ldz >= d && ldy >= d && lddz >= d && (!aff_all || ld_aff >= n_neg + 1), "gs_linkpred_norm_fwd_bwd: ld too small");
@@ -334,8 +391,29 @@ extern "C" int gs_linkpred_norm_fwd_bwd(const float* Z, int64_t ldz, int64_t B, 
     if (d == 64) GS_LPN(1); else if (d == 128) GS_LPN(2); else if (d == 256) GS_LPN(4); else GS_LPN(8);
 #undef GS_LPN
     GS_LAUNCH_CHECK("linkpred_norm_fwd_bwd_kernel");
-    hipLaunchKernelGGL(linkpred_neg_bwd_kernel, dim3((unsigned)n_neg), dim3(256), 0, st, neg_slabs, (int32_t)blocks, n_neg, d, Z,
-                       ldz, 2 * B, dZ, lddz);
+    GS_REQUIRE(ldz % 4 == 0 && lddz % 4 == 0, "gs_linkpred_norm_fwd_bwd: ldz / lddz must be multiples of 4");
+    const StepEpilogue none = {};
+    hipLaunchKernelGGL(linkpred_neg_bwd_kernel, dim3((unsigned)(n_neg + (epi ? 1 : 0))), dim3(256), 0, st, neg_slabs,
+                       (int32_t)blocks, n_neg, d, Z, ldz, 2 * B, dZ, lddz, epi ? *epi : none);
     GS_LAUNCH_CHECK("linkpred_neg_bwd_kernel");
     return GS_OK;
+}
+
+extern "C" int gs_linkpred_norm_fwd_bwd(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight,
+                                        float scale, float* Y, int64_t ldy, float* loss_rows, float* rr_rows, float* aff_all,
+                                        int64_t ld_aff, float* dZ, int64_t lddz, float* neg_slabs, void* stream) {
+    return linkpred_norm_launch(Z, ldz, B, d, n_neg, neg_weight, scale, Y, ldy, loss_rows, rr_rows, aff_all, ld_aff, dZ, lddz,
+                                neg_slabs, nullptr, stream);
+}
+
+extern "C" int gs_linkpred_norm_fwd_bwd_step(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight,
+                                             float scale, float* Y, int64_t ldy, float* loss_rows, float* rr_rows,
+                                             float* aff_all, int64_t ld_aff, float* dZ, int64_t lddz, float* neg_slabs,
+                                             float* loss_out, int accumulate, float* mrr_out, uint64_t* c0, uint64_t d0,
+                                             uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream) {
+    GS_REQUIRE(loss_out && mrr_out, "gs_linkpred_norm_fwd_bwd_step: loss_out / mrr_out missing");
+    const float inv_b = B > 0 ? 1.0f / (float)B : 0.f;
+    const StepEpilogue epi = {loss_rows, B, inv_b, loss_out, accumulate, rr_rows, inv_b, mrr_out, c0, d0, c1, d1, c2, d2};
+    return linkpred_norm_launch(Z, ldz, B, d, n_neg, neg_weight, scale, Y, ldy, loss_rows, rr_rows, aff_all, ld_aff, dZ, lddz,
+                                neg_slabs, &epi, stream);
 }

@@ -200,7 +200,7 @@ class SampleAndAggregate(object):
         self._n_cdf = int(cdf.shape[0])
         # guide table of the inverse-cdf search: guide[b] = first index whose cdf exceeds b << (32 - bits); a draw r then
         # searches [guide[r >> s], guide[(r >> s) + 1]] only (same result, ~6 dependent loads instead of 18)
-        self._guide_bits = 12
+        self._guide_bits = 18          # 1 MB table; ~1 node per bucket: the search is 1-2 dependent loads
         thr = (np.arange((1 << self._guide_bits) + 1, dtype=np.uint64) << np.uint64(32 - self._guide_bits))
         guide = np.searchsorted(cdf.astype(np.uint64), thr, side="right")
         guide = np.minimum(guide, len(cdf) - 1).astype(np.int32)
@@ -222,7 +222,7 @@ class SampleAndAggregate(object):
                  ops.ptr(self._neg_cdf), self._n_cdf, self.neg_sample_size, self.neg_seed, ops.ptr(e.sample_clock_dev),
                  ops.ptr(roots), e.stream)
 
-    def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None):
+    def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None, epilogue=None):
         """_build (:347-370) + _loss (:385-391) + _accuracy (:393-405) and, when training, the gradient of the
         link-prediction head w.r.t. the normalised embeddings."""
         e = self.engine
@@ -244,38 +244,47 @@ class SampleAndAggregate(object):
         # l2_normalize (:368-370) + link-prediction loss / MRR ranks (:385-405) + their gradient carried back through the
         # normalisation: ONE launch (+ a 20-workgroup one for the negatives' rows); d_agg_out = dLoss/d(aggregator output)
         self._d_agg_out = e.ws_mat("d_agg_out", n_roots, d)
+        # `epilogue` (the step's device-counter increments): without dropout the loss / mrr means and the counters ride in
+        # the head's second launch (with dropout the clock must not move before the backward pass: separate launch later)
+        fold = epilogue is not None and self._dropout_rate() == 0.0
+        self._epilogue_folded = fold
+        epi = None
+        if fold:
+            epi = (self.loss_dev, False, self.mrr_dev,
+                   [(e.step_dev, epilogue.get("step", 0)), (e.sample_clock_dev, epilogue.get("clock", 0)),
+                    (epilogue.get("cursor"), epilogue.get("cursor_delta", 0))])
         self.link_pred_layer.loss_and_grads_fused(out, self.outputs_all, B, self.neg_sample_size, 1.0 / B, self._loss_rows,
-                                                  self._rr_rows, self.aff_all, self._d_agg_out)
+                                                  self._rr_rows, self.aff_all, self._d_agg_out, epilogue=epi)
         # loss = (sum_vars wd*l2_loss + xent) / batch_size  (:386-390, :378); the xent mean (and the mrr, :404) are formed
-        # by the epilogue launch
+        # by the epilogue (folded: the weight-decay terms are added behind it; separate launch: it adds to them)
         self._loss_accumulate = False
         if self.weight_decay != 0.0:
-            first = True
+            first = not fold
             for a in self.aggregators:
                 for v in a.vars.values():
                     ops.call("gs_sumsq_scaled", v.value.ptr, v.size, 0.5 * self.weight_decay / B, self.loss_dev.data_ptr(),
                              0 if first else 1, e.stream)
                     first = False
-            self._loss_accumulate = not first
+            self._loss_accumulate = not fold
 
     def _backward_unsup(self, B, n_roots, fuse_adam, wgrad_jobs=None, epilogue=None):
         """Reverse schedule.  The epilogue (loss / mrr means + device counters) runs FIRST: the fan-out sampler of a later
         step may ride in this pass's optimizer launch and must see the advanced sampler clock and pair cursor; the
         optimizer then uses step_offset = 0 if the step counter has been advanced already."""
         e = self.engine
-        advanced = False
         # dropout masks are a function of the device clock and the backward pass regenerates them: with dropout on, the
         # clock must not move before the backward pass has run (no sampler rides there: the prefetch pipeline is off)
-        early = epilogue is not None and self._dropout_rate() == 0.0
+        folded = epilogue is not None and getattr(self, "_epilogue_folded", False)     # already done by the forward pass
+        early = epilogue is not None and not folded and self._dropout_rate() == 0.0
         if early:
             self._epilogue_unsup(B, **epilogue)
-            advanced = bool(epilogue.get("step"))
+        advanced = (early or folded) and bool(epilogue.get("step"))
         e.begin_backward()
         self.aggregate_backward(self._d_agg_out)
         # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
         e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
                           side_jobs=wgrad_jobs, step_offset=0 if advanced else 1)
-        if epilogue is not None and not early:
+        if epilogue is not None and not early and not folded:
             self._epilogue_unsup(B, **epilogue)
 
     def _epilogue_unsup(self, B, **counters):
@@ -321,8 +330,9 @@ class SampleAndAggregate(object):
 
         def fwd_bwd():
             self._stage_negatives(roots, B)
-            self._forward_unsup(roots, B, n_roots, True)
-            self._backward_unsup(B, n_roots, fuse_adam=fused, epilogue=dict(step=1 if fused else 0, clock=1))
+            epilogue = dict(step=1 if fused else 0, clock=1)
+            self._forward_unsup(roots, B, n_roots, True, epilogue=epilogue)
+            self._backward_unsup(B, n_roots, fuse_adam=fused, epilogue=epilogue)
 
         self._run(("utrain" if fused else "utrain_fb", B, self._adj_version()), fwd_bwd)
         if not fused:
@@ -337,8 +347,9 @@ class SampleAndAggregate(object):
 
         def fwd():
             self._stage_negatives(roots, B)
-            self._forward_unsup(roots, B, n_roots, False)
-            self._epilogue_unsup(B, clock=1)
+            self._forward_unsup(roots, B, n_roots, False, epilogue=dict(clock=1))
+            if not self._epilogue_folded:
+                self._epilogue_unsup(B, clock=1)
 
         self._run(("ueval", B, self._adj_version()), fwd)
         loss, ranks, aff, mrr, outs = self._fetch_unsup(B)
@@ -501,9 +512,9 @@ class SampleAndAggregate(object):
                 if in_graph and self.cogather_dp_fork > 0:
                     left = max(1e-6, 1.0 - self.cogather_split)
                     wgrad_jobs, fork_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dp_fork / left))
-                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs)
-                self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs,
-                                     epilogue=dict(step=1 if local_adam else 0, clock=1, cursor=self._cursor, cursor_delta=B))
+                epilogue = dict(step=1 if local_adam else 0, clock=1, cursor=self._cursor, cursor_delta=B)
+                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue)
+                self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
                 if e._deferred_sampler is not None:
                     raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
                 if in_graph:

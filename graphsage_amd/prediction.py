@@ -45,7 +45,8 @@ class BipartiteEdgePredLayer(Layer):
         ops.call("gs_reduce_slabs", ops.ptr(slabs), n_slabs, n_neg * d, n_neg, d, d, 0.0, None, 0, dneg.ptr, dneg.ld, 0,
                  e.stream)
 
-    def loss_and_grads_fused(self, z_all, outputs_all, batch_size, n_neg, scale, loss_rows, rr_rows, aff_all, d_z_all):
+    def loss_and_grads_fused(self, z_all, outputs_all, batch_size, n_neg, scale, loss_rows, rr_rows, aff_all, d_z_all,
+                             epilogue=None):
         """z_all: Mat [2B + n_neg, d] RAW aggregator outputs.  One launch (+ a small one for the negatives' rows):
         outputs_all = l2_normalize(z_all) (models.py:368-370), loss_rows / rr_rows / aff_all as loss_and_grads, and
         d_z_all = scale * dLoss/d(z_all) (the gradient carried back through the normalisation)."""
@@ -54,7 +55,18 @@ class BipartiteEdgePredLayer(Layer):
         B = batch_size
         n_slabs = (B + 3) // 4
         slabs = e.ws_f32((self.name, "neg_slabs", B, n_neg, d), n_slabs * n_neg * d)
-        ops.call("gs_linkpred_norm_fwd_bwd", z_all.ptr, z_all.ld, B, d, n_neg, float(self.neg_sample_weights), float(scale),
-                 outputs_all.ptr, outputs_all.ld, ops.ptr(loss_rows), ops.ptr(rr_rows),
-                 aff_all.ptr if aff_all is not None else None, aff_all.ld if aff_all is not None else 0,
-                 d_z_all.ptr, d_z_all.ld, ops.ptr(slabs), e.stream)
+        args = (z_all.ptr, z_all.ld, B, d, n_neg, float(self.neg_sample_weights), float(scale),
+                outputs_all.ptr, outputs_all.ld, ops.ptr(loss_rows), ops.ptr(rr_rows),
+                aff_all.ptr if aff_all is not None else None, aff_all.ld if aff_all is not None else 0,
+                d_z_all.ptr, d_z_all.ld, ops.ptr(slabs))
+        if epilogue is None:
+            ops.call("gs_linkpred_norm_fwd_bwd", *args, e.stream)
+        else:
+            # `epilogue`: (loss_out, accumulate, mrr_out, [(counter, delta)] * 3) -- the step's loss / mrr means and device
+            # counters ride in the second launch
+            loss_out, accumulate, mrr_out, counters = epilogue
+            cargs = []
+            for c, dlt in counters:
+                cargs += [ops.ptr(c) if (c is not None and dlt) else None, int(dlt) if c is not None else 0]
+            ops.call("gs_linkpred_norm_fwd_bwd_step", *args, ops.ptr(loss_out), 1 if accumulate else 0, ops.ptr(mrr_out), *cargs,
+                     e.stream)

@@ -363,6 +363,14 @@ int gs_linkpred_fwd_bwd(const float* Y, int64_t ldy, int64_t B, int32_t d, int32
 int gs_linkpred_norm_fwd_bwd(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight, float scale,
                              float* Y, int64_t ldy, float* loss_rows, float* rr_rows, float* aff_all, int64_t ld_aff,
                              float* dZ, int64_t lddz, float* neg_slabs, void* stream);
+/* ... and the step epilogue of gs_finalize_step2 as one more workgroup of its second launch (it only needs loss_rows /
+ * rr_rows): loss_out[0] (+)= mean(loss_rows) (models.py:378), mrr_out[0] = mean(rr_rows) (models.py:404), then the device
+ * counters c0..c2 (nullable) advance by d0..d2 -- one launch less per unsupervised step. */
+int gs_linkpred_norm_fwd_bwd_step(const float* Z, int64_t ldz, int64_t B, int32_t d, int32_t n_neg, float neg_weight,
+                                  float scale, float* Y, int64_t ldy, float* loss_rows, float* rr_rows, float* aff_all,
+                                  int64_t ld_aff, float* dZ, int64_t lddz, float* neg_slabs, float* loss_out, int accumulate,
+                                  float* mrr_out, uint64_t* c0, uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2,
+                                  uint64_t d2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  optimizer               replaces supervised_models.py:95-99 (clip_by_value +-5, Adam) and the
