@@ -38,10 +38,6 @@ def main():
     r2.copy_(roots[:512])
     torch.cuda.synchronize()
     res["unsup_512_roots_prestaged_us"] = timeit(lambda: model._sample_phase(r2, 512, 1), s)
-    for law in ("iid",):
-        for smp in model._samplers():
-            smp.law = law
-        res["unsup_roots_prestaged_law_%s_us" % law] = timeit(lambda: model._sample_phase(roots, n_roots, 0), s)
     print(json.dumps(res))
 
 

@@ -234,3 +234,51 @@ def test_fullsize_training_steps_match_oracle(dev):
         for (name, g), (_, w) in zip(orc.flat_param_items(dev_g, "mean"), orc.flat_param_items(res["grads"], "mean")):
             np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
                                        err_msg="step %d %s" % (t, name))
+
+
+# ------------------------------------------------------------------------------------------------ configs[0]-shaped (PPI)
+def test_ppi_shaped_sigmoid_121_classes_takes_the_fused_tail(dev):
+    """The reference's own example (example_supervised.sh: graphsage_mean, --sigmoid, PPI: F = 50, C = 121 multi-label,
+    fan-out 25x10, dims 128/128, B = 512) on a PPI-sized synthetic graph through the device-epoch path: 121 classes = two
+    64-class groups of the fused tail launch, so the step is the 4-launch schedule; sampled ids bit-exact, then loss /
+    sigmoid preds / every gradient vs the oracle at 1e-4 for 4 steps (eager, eager, capture, replay)."""
+    Fp, Cp = 50, 121
+    G = reddit_shaped(avg_degree=28, seed=7, n_nodes=15000, feat_dim=Fp, num_classes=Cp)
+    it = NodeMinibatchIterator(G, None, {}, None, G.num_classes, batch_size=B, max_degree=128, build_padded=False)
+    rowptr, col = it.train_csr
+    rng = np.random.RandomState(3)
+    labels = (rng.rand(G.n_nodes + 1, Cp) < 0.3).astype(np.float32)         # multi-hot (PPI: 121 gene-ontology sets)
+    eng.reset_engine()
+    inits.set_seed(11)
+    e = eng.get_engine()
+    ph = {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'), 'dropout': Placeholder('dropout', 0.),
+          'batch_size': Placeholder('batch_size')}
+    adj_info = AdjInfo(CSRAdjacency(rowptr, col, G.n_nodes, e.device))
+    sampler = UniformNeighborSampler(adj_info, seed=123, law="reference", max_degree=MAXDEG)
+    layer_infos = [SAGEInfo("node", sampler, S1, DIM), SAGEInfo("node", sampler, S2, DIM)]
+    model = SupervisedGraphsage(Cp, ph, G.padded_features(), adj_info, it.deg, layer_infos, concat=True,
+                                aggregator_type="mean", sigmoid_loss=True, learning_rate=0.01, weight_decay=0.0)
+    order = np.random.RandomState(123).permutation(it.train_nodes).astype(np.int32)
+    model.attach_device_epoch(order, labels)
+    feats = G.padded_features()
+    for t in range(4):
+        before = {"agg": [{k: v.numpy().copy() for k, v in a.vars.items()} for a in model.aggregators],
+                  "node_pred": {"weights": model.node_pred.vars['weights'].numpy().copy(),
+                                "bias": model.node_pred.vars['bias'].numpy().reshape(-1).copy()}}
+        loss, preds = model.train_step_device(B, fetch=True)
+        assert model._tail_used, "C = 121 must take the fused tail launch"
+        batch = order[t * B:(t + 1) * B]
+        got = [s.cpu().numpy() for s in model.samples1]
+        _check_sampled_ids(got, batch, rowptr, col, G.n_nodes, [S2, S1], 123, t)
+        with orc.relu_ties_from(_layer0_ties(model, B, S2)):
+            res = orc.supervised_fwd_bwd(before, feats, got, [1, S2, S2 * S1], labels[batch], model.dims, [S1, S2], B, "mean",
+                                         True, True, weight_decay=0.0)
+        np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5, err_msg="step %d" % t)
+        assert preds.shape == (B, Cp)
+        np.testing.assert_allclose(preds, res["preds"], rtol=1e-4, atol=1e-4)
+        dev_g = {"agg": [{k: v.grad.numpy().copy() for k, v in a.vars.items()} for a in model.aggregators],
+                 "node_pred": {"weights": model.node_pred.vars['weights'].grad.numpy().copy(),
+                               "bias": model.node_pred.vars['bias'].grad.numpy().reshape(-1).copy()}}
+        for (name, g), (_, w) in zip(orc.flat_param_items(dev_g, "mean"), orc.flat_param_items(res["grads"], "mean")):
+            np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                       err_msg="step %d %s" % (t, name))
