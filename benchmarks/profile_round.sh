@@ -20,6 +20,9 @@ timeout 200 rocprofv3 --pmc FETCH_SIZE -d $O/cal -o cal -- python $R/benchmarks/
 python $R/benchmarks/pmc_traffic.py $(ls $O/pmc_fetch/*/*_results.db $O/pmc_fetch/*_results.db 2>/dev/null | head -1) \
        $(ls $O/pmc_write/*/*_results.db $O/pmc_write/*_results.db 2>/dev/null | head -1) \
        $(ls $O/cal/*/*_results.db $O/cal/*_results.db 2>/dev/null | head -1) $O/k2_pmc.json > $O/pmc_traffic.log 2>&1
+python $R/benchmarks/pmc_step_traffic.py $(ls $O/pmc_fetch/*/*_results.db $O/pmc_fetch/*_results.db 2>/dev/null | head -1) \
+       $(ls $O/pmc_write/*/*_results.db $O/pmc_write/*_results.db 2>/dev/null | head -1) \
+       $(ls $O/cal/*/*_results.db $O/cal/*_results.db 2>/dev/null | head -1) $O/step_traffic.json > $O/step_traffic.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o m -- python $R/bench.py --steps 16 --warmup 20 --no-cpu-baseline --no-aux > $O/pmc_mfma.log 2>&1
 python $R/benchmarks/pmc_mfma.py $(ls $O/pmc_mfma/*/*_results.db $O/pmc_mfma/*_results.db 2>/dev/null | head -1) $O/mfma_util.md > /dev/null 2>> $O/pmc_mfma.log
 # keep the merged-back payload small: the raw databases stay on the box

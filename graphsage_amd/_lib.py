@@ -14,7 +14,7 @@ ACT_IDENTITY = 0
 ACT_RELU = 1
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
 SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
-GS_ABI_VERSION = 3      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+GS_ABI_VERSION = 4      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -107,6 +107,7 @@ _PROTOS = {
     "gs_linkpred_norm_fwd_bwd_step": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, c_int64, _P, _P, _P, c_int64,
                                       _P, c_int64, _P, _P, c_int, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_sample_fanout_desc": [_P, _P],
+    "gs_build_padded_table": [_P, _P, c_int64, c_int32, c_int32, c_uint64, _P, _P],
     "gs_finalize_step2": [_P, c_int64, c_float, _P, c_int, _P, c_float, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_maxpool_sparse_wgrad": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, c_int32, c_int32, _P,
                                 c_int64, _P],
@@ -172,7 +173,7 @@ class FanoutDesc(ctypes.Structure):
                 ("law", c_int32), ("max_degree", c_int32),
                 ("pairs", c_void_p), ("n_pairs", c_int64), ("n_pair_roots", c_int64),
                 ("cdf", c_void_p), ("guide", c_void_p), ("n_cdf", c_int64),
-                ("n_neg", c_int32), ("guide_bits", c_int32), ("neg_seed", c_uint64)]
+                ("n_neg", c_int32), ("guide_bits", c_int32), ("neg_seed", c_uint64), ("padded_table", c_void_p)]
 
 
 class VarDesc(ctypes.Structure):

@@ -191,6 +191,38 @@ extern "C" int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, i
     return GS_OK;
 }
 
+// The virtual padded table of GS_LAW_REFERENCE, materialised: table[v][c] = col[rowptr[v] + gs_table_entry(key(seed, v), c,
+// deg, M)] (pad_id for deg == 0 and for the extra row n_nodes) -- what minibatch.py:227-245 builds on the host, entry for
+// entry the function the sampler evaluates per draw when it has no table.  One thread per entry.
+__global__ __launch_bounds__(256) void build_padded_table_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                 int64_t n_nodes, int32_t pad_id, int32_t M, uint64_t seed,
+                                                                 int32_t* __restrict__ table) {
+    const int64_t total = (n_nodes + 1) * (int64_t)M;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = t / M;
+        const uint32_t c = (uint32_t)(t - v * M);
+        int32_t pick = pad_id;
+        if (v < n_nodes) {
+            const int64_t b = rowptr[v];
+            const int32_t deg = (int32_t)(rowptr[v + 1] - b);
+            if (deg > 0) pick = col[b + (int64_t)gs_table_entry(gs_table_key(seed, (int32_t)v), c, (uint32_t)deg, (uint32_t)M)];
+        }
+        table[t] = pick;
+    }
+}
+
+extern "C" int gs_build_padded_table(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,
+                                     int32_t max_degree, uint64_t seed, int32_t* table_out, void* stream) {
+    GS_REQUIRE(rowptr && col && table_out && n_nodes > 0 && max_degree > 0, "gs_build_padded_table: bad args");
+    GS_REQUIRE(n_nodes < (1ll << 31) - 1, "gs_build_padded_table: node ids must fit int32");
+    const int64_t total = (n_nodes + 1) * (int64_t)max_degree;
+    const int blocks = (int)std::min<int64_t>(gs_ceil_div(total, 256), 1 << 16);
+    hipLaunchKernelGGL(build_padded_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, n_nodes, pad_id,
+                       max_degree, seed, table_out);
+    GS_LAUNCH_CHECK("build_padded_table_kernel");
+    return GS_OK;
+}
+
 // The same launch from a descriptor (what gs_flat_reduce_adam_sample takes as a rider), including the optional
 // unsupervised root staging (edge-pair batch + unigram negatives, see gs_fanout_desc).
 extern "C" int gs_sample_fanout_desc(const gs_fanout_desc* desc_host, void* stream) {

@@ -12,6 +12,8 @@ Two adjacency layouts:
   * CSRAdjacency     -- MI355X-native: rowptr/col on the device, counter-based per-slot draws
     (gs_sample_uniform_csr).  Default for training; hipGraph-replayable (no host RNG).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -87,6 +89,29 @@ class UniformNeighborSampler(Layer):
         self._call_index = 0          # sampler calls so far in this step = the `hop` stream id
         self.next_out = None          # optional destination of the next call (the model's contiguous id buffer)
         self.global_row_offset = 0    # first global row of this rank's slice (data-parallel invariance)
+        # law "reference": materialise the law's padded table once per adjacency (what minibatch.py:227-245 builds; 119 MB
+        # for Reddit at max_degree 128) so that a draw is one lookup -- same ids bit for bit, see padded_table()
+        self.use_table = os.environ.get("GS_SAMPLER_TABLE", "1") != "0"
+
+    def padded_table(self, adj):
+        """The reference law's padded table of `adj` ([N+1, max_degree] int32 on the device, gs_build_padded_table), built on
+        first use and cached on the adjacency object per (seed, max_degree); None for the other laws, when switched off, or
+        when it would exceed GS_SAMPLER_TABLE_MAX_GB (default 16): the sampler then evaluates the same entries per draw."""
+        if self.law != ops._lib.SAMPLER_LAWS["reference"] or not self.use_table or not isinstance(adj, CSRAdjacency):
+            return None
+        cache = adj.__dict__.setdefault("_padded_tables", {})
+        key = (self.seed, self.max_degree)
+        if key not in cache:
+            limit = float(os.environ.get("GS_SAMPLER_TABLE_MAX_GB", "16")) * (1 << 30)
+            if (adj.n_nodes + 1) * self.max_degree * 4 > limit:
+                cache[key] = None
+            else:
+                e = self.engine
+                e.sync()
+                cache[key] = ops.build_padded_table(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, self.max_degree, self.seed,
+                                                    stream=e.stream)
+                e.sync()
+        return cache[key]
 
     # -- step bookkeeping driven by the model -------------------------------------------------
     def new_step(self):
@@ -138,7 +163,8 @@ class UniformNeighborSampler(Layer):
             desc = ops.fanout_desc(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all, batch_size,
                                    self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,
                                    cursor_dev=cursor, law=self.law, max_degree=self.max_degree,
-                                   unsup=(pairs, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed))
+                                   unsup=(pairs, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed),
+                                   padded_table=self.padded_table(adj))
             if getattr(e, "_defer_sampler", False):
                 e._deferred_sampler = desc
             else:
@@ -147,13 +173,18 @@ class UniformNeighborSampler(Layer):
             return
         if stage is not None:
             order, cursor, table, labels_out = stage
-        if getattr(e, "_defer_sampler", False):
-            # not launched here: the descriptor rides in the step's optimizer launch (engine.finish_backward)
-            e._deferred_sampler = ops.fanout_desc(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all,
-                                                  batch_size, self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index,
-                                                  root_offset=root_offset, order=order, cursor_dev=cursor,
-                                                  label_table=table, labels_out=labels_out, law=self.law,
-                                                  max_degree=self.max_degree)
+        ptable = self.padded_table(adj)
+        if getattr(e, "_defer_sampler", False) or ptable is not None:
+            desc = ops.fanout_desc(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all,
+                                   batch_size, self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index,
+                                   root_offset=root_offset, order=order, cursor_dev=cursor,
+                                   label_table=table, labels_out=labels_out, law=self.law,
+                                   max_degree=self.max_degree, padded_table=ptable)
+            if getattr(e, "_defer_sampler", False):
+                # not launched here: the descriptor rides in the step's optimizer launch (engine.finish_backward)
+                e._deferred_sampler = desc
+            else:
+                ops.sample_fanout_desc(desc, stream=e.stream)
         else:
             ops.sample_fanout_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all, batch_size,
                                   self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,

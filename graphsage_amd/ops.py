@@ -113,7 +113,8 @@ def sample_fanout_csr(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, s
 
 
 def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, step_dev=None, hop0=0, root_offset=0,
-                order=None, cursor_dev=None, label_table=None, labels_out=None, law=0, max_degree=0, unsup=None):
+                order=None, cursor_dev=None, label_table=None, labels_out=None, law=0, max_degree=0, unsup=None,
+                padded_table=None):
     """unsup = (pairs [n_pairs, 2] int32, n_pair_roots, cdf (uint32 bits), guide or None, guide_bits, n_neg, neg_seed): the
     roots are staged by the launch itself as [pairs[:, 0] | pairs[:, 1] | negatives] (see gs_fanout_desc).
     The arguments of sample_fanout_csr as a struct gs_fanout_desc (for gs_flat_reduce_adam_sample).  The tensors are
@@ -133,13 +134,22 @@ def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, s
         q.label_table, q.ld_table, q.C = label_table.ptr, label_table.ld, label_table.d
     if labels_out is not None:
         q.labels_out, q.ld_out = labels_out.ptr, labels_out.ld
-    q._keep = (rowptr, col, ids_all, step_dev, order, cursor_dev, label_table, labels_out, unsup)
+    q.padded_table = ptr(padded_table)
+    q._keep = (rowptr, col, ids_all, step_dev, order, cursor_dev, label_table, labels_out, unsup, padded_table)
     if unsup is not None:
         pairs, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed = unsup
         q.pairs, q.n_pairs, q.n_pair_roots = ptr(pairs), pairs.shape[0], n_pair_roots
         q.cdf, q.guide, q.n_cdf = ptr(cdf), ptr(guide), cdf.numel()
         q.n_neg, q.guide_bits, q.neg_seed = n_neg, guide_bits, neg_seed & 0xFFFFFFFFFFFFFFFF
     return q
+
+
+def build_padded_table(rowptr, col, n_nodes, pad_id, max_degree, seed, stream=None):
+    """The reference law's padded table [n_nodes + 1, max_degree] (int32, device) from the CSR (gs_build_padded_table)."""
+    table = torch.empty((n_nodes + 1) * max_degree, dtype=torch.int32, device=rowptr.device)
+    call("gs_build_padded_table", ptr(rowptr), ptr(col), n_nodes, pad_id, max_degree, seed & 0xFFFFFFFFFFFFFFFF, ptr(table),
+         _s(stream))
+    return table
 
 
 def sample_fanout_desc(desc, stream=None):

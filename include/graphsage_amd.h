@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -441,8 +441,18 @@ typedef struct gs_fanout_desc {
     const uint32_t* cdf; const int32_t* guide; int64_t n_cdf;
     int32_t n_neg, guide_bits;
     uint64_t neg_seed;
+    /* GS_LAW_REFERENCE only, nullable: the law's virtual padded table materialised by gs_build_padded_table
+     * ([n_nodes + 1, max_degree] int32, same seed / max_degree): a draw becomes one lookup table[id][column].  Same ids,
+     * bit for bit, as without it. */
+    const int32_t* padded_table;
 } gs_fanout_desc;
-/* gs_sample_fanout_csr from a descriptor (incl. the unsupervised root staging). */
+/* The padded adjacency table of minibatch.py:227-245 under GS_LAW_REFERENCE's keyed law, built ON THE DEVICE from the CSR:
+ * table[v][c] = the c-th entry of node v's (frozen) padded row -- a keyed sample without replacement of max_degree
+ * neighbors when deg > max_degree, max_degree keyed draws with replacement when deg < max_degree, the list itself when
+ * equal; pad_id for degree-0 nodes and for row n_nodes.  table_out: [(n_nodes + 1) * max_degree] int32. */
+int gs_build_padded_table(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id, int32_t max_degree,
+                          uint64_t seed, int32_t* table_out, void* stream);
+/* gs_sample_fanout_csr from a descriptor (incl. the unsupervised root staging and the materialised table). */
 int gs_sample_fanout_desc(const gs_fanout_desc* desc_host, void* stream);
 int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
                                int64_t total, float weight_decay, int fuse_adam, float lr, float beta1, float beta2,

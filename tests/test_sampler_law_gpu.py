@@ -124,3 +124,43 @@ def test_reference_law_rejects_bad_arguments(dev):
         ops.sample_uniform_csr(rp, cl, 100, 100, ids, 9, 1, law=1, max_degree=8)
     with pytest.raises(ops._lib.GraphsageAmdError, match="unknown law"):
         ops.sample_uniform_csr(rp, cl, 100, 100, ids, 5, 1, law=7)
+
+
+def test_materialised_padded_table_matches_virtual_table_and_fanout(dev):
+    """gs_build_padded_table == oracle/sampler_hash.virtual_padded_table entry for entry (the table the reference builds in
+    minibatch.py:227-245 under the keyed law), and the fused fan-out sampler WITH the table (one lookup per draw) draws the
+    ids of the table-free path and of the oracle bit for bit -- batch staging from the epoch order included."""
+    rng = np.random.default_rng(12)
+    N, M, B, fans = 5000, 128, 300, [10, 25]
+    rowptr, col = _graph(rng, N, 600)
+    rp, cl = torch.from_numpy(rowptr).to(dev), _i32(col, dev)
+    table = ops.build_padded_table(rp, cl, N, N, M, 123)
+    torch.cuda.synchronize()
+    got_t = table.cpu().numpy().reshape(N + 1, M)
+    want_t = sampler_hash.virtual_padded_table(rowptr, col, N, N, 123, M)
+    assert np.array_equal(got_t[:N], want_t) and (got_t[N] == N).all()
+    order = rng.permutation(N).astype(np.int32)
+    sizes = [B, B * fans[0], B * fans[0] * fans[1]]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    cur = torch.tensor([17], dtype=torch.int64, device=dev)
+    clock = torch.tensor([3], dtype=torch.int64, device=dev)
+    outs = []
+    for tab in (None, table):
+        ids_all = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device=dev)
+        desc = ops.fanout_desc(rp, cl, N, N, fans, offs.tolist(), ids_all, B, 123, step_dev=clock, hop0=0, root_offset=64,
+                               order=_i32(order, dev), cursor_dev=cur, law=1, max_degree=M, padded_table=tab)
+        ops.sample_fanout_desc(desc)
+        torch.cuda.synchronize()
+        outs.append(ids_all.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    roots = order[(17 + np.arange(B)) % N]
+    assert np.array_equal(outs[1][:B], roots)
+    prev, support = roots, 1
+    for h, f in enumerate(fans):
+        want = sampler_hash.sample_uniform_csr(rowptr, col, N, N, prev, f, 123, 3, h, global_row_offset=64 * support, law=1,
+                                               max_degree=M)
+        assert np.array_equal(outs[1][offs[h + 1]:offs[h + 2]].reshape(-1, f), want), "hop %d" % h
+        prev, support = want.reshape(-1), support * f
+    with pytest.raises(ops._lib.GraphsageAmdError, match="padded_table"):
+        ids_all = torch.zeros(int(offs[-1]), dtype=torch.int32, device=dev)
+        ops.sample_fanout_desc(ops.fanout_desc(rp, cl, N, N, fans, offs.tolist(), ids_all, B, 123, law=0, padded_table=table))
