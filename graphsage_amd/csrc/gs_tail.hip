@@ -48,6 +48,9 @@ struct TailArgs {
     // flags (bit 0: a main workgroup gave up waiting, bit 1: a group saw a number of arrivals other than HP).  Nothing
     // is ever reset, so a launch does not depend on a reset store of the previous one.
     uint32_t* sync;
+    // split form: z (and the neighbor means) were written by a PREVIOUS launch (sage_tail_z_kernel): this launch has no
+    // helper workgroups, waits for nothing and touches no hand-over state
+    int32_t z_ready;
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -101,7 +104,7 @@ __device__ __forceinline__ float tail_wave_max(float v) {
 // summed in wave order through LDS, then published: stores -> device-scope release fence -> arrival counter.
 // The helper whose slab starts the neighbor term also writes the neighbor means (an input of the weight gradients).
 template <int D, int O>
-__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part) {
+__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part, const bool publish = true) {
     constexpr int ldh = D + 4;
     constexpr int D4 = D / 4;
     constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
@@ -181,6 +184,7 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (!publish) return;                                        // split form: the kernel boundary is the hand-over
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores are acknowledged ...
     __syncthreads();                                             // ... and everybody else's
     if (tid == 0) __hip_atomic_fetch_add(a.sync + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -212,17 +216,18 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     // (HP + 1) G workgroups are resident at once for n <= 816 (one 8-wave workgroup per CU).
     constexpr int HP = 2 * O / 64;
     const int G = tail_blocks;
-    if ((int)blockIdx.x >= (HP + 1) * G) {
+    const int hp = a.z_ready ? 0 : HP;                   // split form: no helper workgroups in this launch
+    if ((int)blockIdx.x >= (hp + 1) * G) {
         // (a rider wave walking 4 consecutive items with prefetched ids, and 25 loads in flight per lane, were measured:
         // 46 us / no change against 35 us -- with one 8-wave workgroup per CU the riders stream at ~4.6 TB/s either way)
-        run_gather_item<13>(J, ((int64_t)blockIdx.x - (HP + 1) * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+        run_gather_item<13>(J, ((int64_t)blockIdx.x - (hp + 1) * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
-    if ((int)blockIdx.x < HP * G) {
+    if ((int)blockIdx.x < hp * G) {
         tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP);
         return;
     }
-    const int grp = (int)blockIdx.x - HP * G;
+    const int grp = (int)blockIdx.x - hp * G;
     TAIL_STAMP(0);
     constexpr int Z = 2 * O;
     constexpr int ldh = D + 4, ldzs = Z + 4;
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     // dispatch order that starves them) the workgroup sets the error flag and goes on with whatever z holds -- the step's
     // numbers are then garbage but the stream does not hang, and the host raises on the flag at its next fetch.
     uint32_t sync_base = 0u;
-    if (tid == 0) {
+    if (tid == 0 && !a.z_ready) {
         sync_base = __hip_atomic_load(a.sync + G + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t spins = 0u;
         while (__hip_atomic_load(a.sync + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sync_base < (uint32_t)HP) {
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         if (valid && lane == 0) a.loss_rows[i] = loss;
     }
     if (!a.train) {
-        tail_sync_done<HP>(a, G, grp, sync_base);
+        if (!a.z_ready) tail_sync_done<HP>(a, G, grp, sync_base);
         if (grp == 0 && tid == 0) {
             if (a.c0) *a.c0 += a.d0;
             if (a.c1) *a.c1 += a.d1;
@@ -609,12 +614,38 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     }
     TAIL_STAMP(10);
-    tail_sync_done<HP>(a, G, grp, sync_base);
+    if (!a.z_ready) tail_sync_done<HP>(a, G, grp, sync_base);
     if (grp == 0 && tid == 0) {                       // device counters (sampler clock / epoch cursor / optimizer step)
         if (a.c0) *a.c0 += a.d0;
         if (a.c1) *a.c1 += a.d1;
         if (a.c2) *a.c2 += a.d2;
     }
+}
+
+// Split form, first launch: only the z helpers (+ gather riders).  A lean kernel -- no main-workgroup code path, so it
+// compiles to a fraction of the fused kernel's 246 VGPRs and 49 KB of LDS: two or three workgroups share a CU and the
+// riders stream at the full HBM rate from the first microsecond, also on the CUs that run helpers.
+template <int D, int O>
+__global__ __launch_bounds__(TAIL_THREADS, 4) void sage_tail_z_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
+    constexpr int HP = 2 * O / 64;
+    const int G = tail_blocks;
+    if ((int)blockIdx.x >= HP * G) {
+        run_gather_item<8>(J, ((int64_t)blockIdx.x - HP * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
+    tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP, false);
+}
+
+static size_t tail_z_lds_bytes(int D) { return ((size_t)TAIL_ROWS * (D + 4) + (size_t)TAIL_WAVES * TAIL_ROWS * 64) * sizeof(float); }
+
+template <int D, int O>
+static int launch_tail_z(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
+    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);
+    const int64_t blocks = (int64_t)tail_blocks * (2 * O / 64) + gs_ceil_div(gather_waves, TAIL_WAVES);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_z: grid too large");
+    hipLaunchKernelGGL((sage_tail_z_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), tail_z_lds_bytes(D), st, a, tail_blocks, J);
+    GS_LAUNCH_CHECK("sage_tail_z_kernel");
+    return GS_OK;
 }
 
 static size_t tail_lds_bytes(int D, int O, int C) {
@@ -640,7 +671,7 @@ static int launch_tail_cw(const TailArgs& a, const CoGatherS& J, int64_t gather_
         attr_done = true;
     }
     const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + 1 main workgroup each
-    const int64_t blocks = (int64_t)tail_blocks * (2 * O / 64 + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
+    const int64_t blocks = (int64_t)tail_blocks * ((a.z_ready ? 0 : 2 * O / 64) + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_fwd_bwd: grid too large");
     hipLaunchKernelGGL((sage_tail_kernel<D, O, CW>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
     GS_LAUNCH_CHECK("sage_tail_kernel");
@@ -696,8 +727,9 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     a.loss_rows = q->loss_rows; a.dz = q->dz; a.lddz = q->lddz; a.d_h0 = q->d_h0; a.lddh = q->lddh;
     a.c0 = q->c0; a.d0 = q->d0; a.c1 = q->c1; a.d1 = q->d1; a.c2 = q->c2; a.d2 = q->d2;
     a.train = q->train ? 1 : 0;
-    GS_REQUIRE(q->sync, "gs_sage_tail_fwd_bwd: sync (2 * ceil(n / 16) + 2 zero-initialised uint32 words, private to the "
-                        "caller's stream) missing");
+    a.z_ready = q->z_ready ? 1 : 0;
+    GS_REQUIRE(q->sync || q->z_ready, "gs_sage_tail_fwd_bwd: sync (2 * ceil(n / 16) + 2 zero-initialised uint32 words, private "
+                                      "to the caller's stream) missing");
     a.sync = q->sync;
     hipStream_t st = (hipStream_t)stream;
     CoGatherS J = {};
@@ -710,4 +742,46 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     if (D == 256 && O == 64) return launch_tail<256, 64>(a, J, gw, st);
     if (D == 128 && O == 128) return launch_tail<128, 128>(a, J, gw, st);
     return launch_tail<128, 64>(a, J, gw, st);
+}
+
+// Split form, first launch: z = [h_self . W_self | mean(h_neigh) . W_neigh] and the neighbor means of the descriptor (the
+// head / label / gradient fields are not touched), + gather riders.  Follow with gs_sage_tail_fwd_bwd on the same
+// descriptor with z_ready = 1.
+extern "C" int gs_sage_tail_z(const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    GS_REQUIRE(q, "gs_sage_tail_z: null descriptor");
+    if (q->n == 0) return GS_OK;
+    GS_REQUIRE(q->n > 0 && q->s > 0, "gs_sage_tail_z: bad sizes");
+    if (q->s > TAIL_NB) {
+        gs_set_error("gs_sage_tail_z: at most %d samples per node (got %d)", TAIL_NB, q->s);
+        return GS_ENOTSUP;
+    }
+    GS_REQUIRE((q->n + q->n * (int64_t)q->s) * std::max(q->ldh, (int64_t)1) < (1ll << 31),
+               "gs_sage_tail_z: (n + n*s) * ld must be < 2^31 (32-bit row offsets)");
+    if (!gs_sage_tail_supported(q->d_in, q->out_dim, q->C > 0 ? q->C : 1)) {
+        gs_set_error("gs_sage_tail_z: unsupported shape d_in=%d out_dim=%d", q->d_in, q->out_dim);
+        return GS_ENOTSUP;
+    }
+    const int D = q->d_in, O = q->out_dim, Z = 2 * O;
+    GS_CHECK_MAT(q->h0, q->ldh, "gs_sage_tail_z h0");
+    GS_CHECK_MAT(q->W_self, q->ldws, "gs_sage_tail_z W_self");
+    GS_CHECK_MAT(q->W_neigh, q->ldwn, "gs_sage_tail_z W_neigh");
+    GS_CHECK_MAT(q->means, q->ldm, "gs_sage_tail_z means");
+    GS_CHECK_MAT(q->z, q->ldz, "gs_sage_tail_z z");
+    GS_REQUIRE(q->ldh >= D && q->ldws >= O && q->ldwn >= O && q->ldm >= D && q->ldz >= Z, "gs_sage_tail_z: leading dimension too small");
+    TailArgs a = {};
+    a.h0 = q->h0; a.ldh = q->ldh; a.n = q->n; a.s = q->s; a.D = D;
+    a.Ws = q->W_self; a.ldws = q->ldws; a.Wn = q->W_neigh; a.ldwn = q->ldwn; a.O = O;
+    a.means = q->means; a.ldm = q->ldm; a.z = q->z; a.ldz = q->ldz;
+    a.z_ready = 1;
+    hipStream_t st = (hipStream_t)stream;
+    CoGatherS J = {};
+    int64_t gw = 0;
+    {
+        int rc = build_cojobs_s(jobs_host, n_jobs, &J, &gw);
+        if (rc != GS_OK) return rc;
+    }
+    if (D == 256 && O == 128) return launch_tail_z<256, 128>(a, J, gw, st);
+    if (D == 256 && O == 64) return launch_tail_z<256, 64>(a, J, gw, st);
+    if (D == 128 && O == 128) return launch_tail_z<128, 128>(a, J, gw, st);
+    return launch_tail_z<128, 64>(a, J, gw, st);
 }

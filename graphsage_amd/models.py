@@ -116,6 +116,9 @@ class SampleAndAggregate(object):
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         self.cogather_opt = float(os.environ.get("GS_COGATHER_OPT", 0.0))      # share riding in the optimizer launch
+        # fused tail as two launches (z helpers | row-group workgroups), and the part of the tail's share the first carries
+        self.tail_split = os.environ.get("GS_TAIL_SPLIT", "0") == "1"
+        self.cogather_tail_z = float(os.environ.get("GS_COGATHER_TAIL_Z", 0.35))
         # data-parallel with the all-reduce recorded in the step graph: share of the gather on a forked graph branch that
         # runs beside ncclAllReduce (the collective is latency-bound and leaves the chip idle).  OFF by default: measured
         # on one MI355X with a 30 us sleeping-wave stand-in for the collective (profiles/r03_dp_schedule.json), a fork/join
@@ -738,6 +741,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.cogather_opt,
+                self.tail_split, self.cogather_tail_z,
                 self.cogather_dp_fork, e.stream_gemm, str(getattr(self, "pipeline", None)), type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 

@@ -429,19 +429,23 @@ def tail_sync_error(sync, n):
 
 
 def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels, C, sigmoid_loss, means, z, y, logits,
-                      preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), jobs=(), stream=None, sync=None):
+                      preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), jobs=(), stream=None, sync=None,
+                      split=False, jobs_z=()):
     """gs_sage_tail_fwd_bwd: layer 1 + head (+ their input gradients when dz / d_h0 are given) in ONE launch.
     counters: up to three (device int64 tensor, delta) pairs advanced at the end of the launch.
     sync: int32 device tensor of tail_sync_words(n) words, zero-initialised once and owned by ONE caller / stream
-    (kernel-internal hand-over state + an error word, see tail_sync_error); a fresh one is allocated if not given."""
-    if sync is None:
+    (kernel-internal hand-over state + an error word, see tail_sync_error); a fresh one is allocated if not given.
+    split: two launches instead -- gs_sage_tail_z (lean z-helper kernel carrying the gather jobs `jobs_z`) and then this
+    entry with z_ready (no helpers, no hand-over state) carrying `jobs`; same results bit for bit."""
+    if sync is None and not split:
         import torch
         sync = torch.zeros(tail_sync_words(n), dtype=torch.int32, device=h0.buf.device)
         torch.cuda.synchronize()
-    assert sync.numel() >= tail_sync_words(n)
+    assert split or sync.numel() >= tail_sync_words(n)
     q = _lib.TailDesc()
     q._keep = sync
-    q.sync = ptr(sync)
+    q.sync = ptr(sync) if not split else None
+    q.z_ready = 1 if split else 0
     q.h0, q.ldh, q.n = h0.ptr, h0.ld, n
     q.W_self, q.ldws, q.W_neigh, q.ldwn = W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld
     q.W_head, q.ldwh, q.b_head = W_head.ptr, W_head.ld, ptr(b_head)
@@ -457,6 +461,10 @@ def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels
     cs += [(None, 0)] * (3 - len(cs))
     (q.c0, q.d0), (q.c1, q.d1), (q.c2, q.d2) = cs[:3]
     q.s, q.d_in, q.out_dim, q.C, q.sigmoid, q.train = s, h0.d, out_dim, C, 1 if sigmoid_loss else 0, 1 if train else 0
+    if split:
+        jz = list(jobs_z or ())
+        jzarr = (_lib.GatherDesc * max(len(jz), 1))(*jz)
+        call("gs_sage_tail_z", ctypes.addressof(q), ctypes.addressof(jzarr), len(jz), _s(stream))
     jobs = list(jobs or ())
     jarr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
     call("gs_sage_tail_fwd_bwd", ctypes.addressof(q), ctypes.addressof(jarr), len(jobs), _s(stream))

@@ -122,11 +122,17 @@ class SupervisedGraphsage(SampleAndAggregate):
                     counters.append((e.sample_clock_dev, epilogue["clock"]))
                 if epilogue.get("cursor") is not None and epilogue.get("cursor_delta"):
                     counters.append((epilogue["cursor"], epilogue["cursor_delta"]))
+            # split form: the z helpers as their own lean launch (its riders stream at the full HBM rate), then the
+            # row-group workgroups; the tail's gather share is divided between the two launches
+            jobs_z, jobs_m = [], tail_jobs
+            if self.tail_split and tail_jobs:
+                jobs_z, jobs_m = ops.split_gather_jobs(tail_jobs, self.cogather_tail_z)
             ops.sage_tail_fwd_bwd(h0, n, s, a1.vars['self_weights'].value, a1.vars['neigh_weights'].value, self.dims[2],
                                   self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels, C,
                                   self.sigmoid_loss, self._tail_means, self.agg_out, self.outputs1, self.node_preds,
                                   self.preds, self._dlogits, self._loss_rows, dz=self._tail_dz, d_h0=self._tail_dh0,
-                                  counters=counters, jobs=tail_jobs, stream=e.stream, sync=self._tail_sync)
+                                  counters=counters, jobs=jobs_m, stream=e.stream, sync=self._tail_sync,
+                                  split=self.tail_split, jobs_z=jobs_z)
         else:
             self.agg_out = out
             self.outputs1 = e.ws_mat("outputs1", n, out.d)

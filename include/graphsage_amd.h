@@ -496,9 +496,20 @@ typedef struct gs_tail_desc {
                               stream (in-kernel hand-over of the layer-1 pre-activations from the helper workgroups to the
                               row-group workgroups): monotonic arrival counters, consumed counts, and at index
                               2 * ceil(n / 16) an error word the caller should check when it fetches results (bit 0: a
-                              row-group workgroup gave up waiting (bounded wait), bit 1: unexpected arrival count). */
+                              row-group workgroup gave up waiting (bounded wait), bit 1: unexpected arrival count).
+                              May be NULL when z_ready != 0. */
+    int32_t z_ready;       /* != 0: z and means were written by gs_sage_tail_z on this stream (split form): the launch has no
+                              helper workgroups, no in-kernel hand-over and needs no sync buffer */
+    int32_t reserved_;
 } gs_tail_desc;
 int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
+/* Split form of the fused tail, first launch: the layer-1 pre-activations z = [h_self . W_self | mean(h_neigh) . W_neigh]
+ * and the neighbor means of the descriptor (its head / label / gradient fields are ignored) as a LEAN kernel -- 4 x 64-column
+ * helper workgroups per 16 rows, <= 128 VGPRs, 49 KB of LDS -- so that the gather jobs riding in the launch stream at the
+ * full HBM rate, also on the CUs that run helpers (in the one-launch form every workgroup inherits the row-group
+ * workgroups' 246 VGPRs / 88 KB and a CU holds one of them).  Follow with gs_sage_tail_fwd_bwd(desc with z_ready = 1).
+ * Results are bit-identical to the one-launch form. */
+int gs_sage_tail_z(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 /* jobs_host / n_jobs (0..6): gather+mean jobs of the NEXT step co-scheduled in the launch (as gs_sage_dense_fwd_cogather):
  * the tail keeps n/16 CUs busy, the rest of the chip streams the gather meanwhile. */
 int gs_sage_tail_fwd_bwd(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);

@@ -790,6 +790,41 @@ def test_fused_tail_fwd_bwd(dev, n, s, D, O, C, sig, train):
     np.testing.assert_allclose(dh0.numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("n,s,D,O,C,sig", [(512, 10, 256, 128, 41, False), (3000, 10, 256, 128, 41, False),
+                                           (200, 7, 128, 64, 121, True), (77, 3, 256, 64, 9, False)])
+def test_fused_tail_split_form_is_bit_identical(dev, n, s, D, O, C, sig):
+    """The split form of the fused tail (gs_sage_tail_z: lean z-helper launch, then gs_sage_tail_fwd_bwd with z_ready: no
+    helper workgroups, no in-kernel hand-over, no sync buffer) gives the bits of the one-launch form -- every output, with
+    gather riders in both launches -- and the device counters advance once."""
+    rng = np.random.default_rng(n + C)
+    rows, Z = n + n * s, 2 * O
+    h0 = Mat.from_numpy(np.maximum(_asym(rng, (rows, D)), 0).astype(np.float32), dev)
+    Ws, Wn = Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev), Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev)
+    Wh, bh = Mat.from_numpy(_asym(rng, (Z, C)) * 0.3, dev), torch.from_numpy(_asym(rng, (C,)) * 0.1).to(dev)
+    labn = (rng.random((n, C)) > 0.5).astype(np.float32) if sig else np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]
+    lab = Mat.from_numpy(labn, dev)
+    Xg = Mat.from_numpy(_asym(rng, (5000, 602)), dev, ld_multiple=32)
+    idx = _i32(rng.integers(0, 5000, size=1200 * 25), dev)
+    outs = []
+    for split in (False, True):
+        means, z, y = Mat.zeros(n, D, dev), Mat.zeros(n, Z, dev), Mat.zeros(n, Z, dev)
+        lo, pr, dl = Mat.zeros(n, C, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
+        lr, dz, dh0 = torch.zeros(n, device=dev), Mat.zeros(n, Z, dev), Mat.zeros(rows, D, dev)
+        g1, g2 = Mat.zeros(700, 602, dev), Mat.zeros(500, 602, dev)
+        c0 = torch.full((1,), 5, dtype=torch.int64, device=dev)
+        j1 = [ops.gather_job(Xg, idx[:700 * 25], 700, 25, g1)]
+        j2 = [ops.gather_job(Xg, idx[700 * 25:], 500, 25, g2)]
+        _sync()
+        ops.sage_tail_fwd_bwd(h0, n, s, Ws, Wn, O, Wh, bh, lab, C, sig, means, z, y, lo, pr, dl, lr, dz=dz, d_h0=dh0,
+                              counters=[(c0, 2)], jobs=j1 + ([] if split else j2), split=split, jobs_z=j2 if split else ())
+        _sync()
+        assert int(c0.item()) == 7
+        outs.append([m.numpy() for m in (means, z, y, lo, pr, dl, dz, dh0, g1, g2)] + [lr.cpu().numpy()])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert np.abs(outs[1][7]).max() > 0 and np.abs(outs[1][9]).max() > 0
+
+
 def test_fused_tail_handover_stress(dev):
     """The in-kernel hand-over of the fused tail (helper workgroups -> row-group workgroups through monotonic arrival
     counters, bounded wait, error word) under stress: 4000 rows = 1250 workgroups (far more than resident at once),
