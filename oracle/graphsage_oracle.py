@@ -9,8 +9,12 @@ nor installable in the build container, so the reference itself cannot be run
 to generate fixtures.  This file is therefore a *restatement* of the reference
 op sequence in NumPy; every function cites the reference file:line it follows
 (paths relative to /root/reference/graphsage/).  It is pinned only by
- (a) hand-computed integer fixtures in tests/golden/ (see tests/golden/make_golden.py),
- (b) finite-difference checks of every backward function (tests/test_oracle.py).
+ (a) hand-computed integer fixtures in tests/golden/ (see tests/golden/make_golden.py, make_golden_more.py) and the
+     big-int known answers of the sampler / dropout hashes (hash_kat.npz, law_kat.npz),
+ (b) finite-difference checks of every backward function (tests/test_oracle.py),
+ (c) an independent second restatement in torch whose gradients come from autograd (oracle/torch_port.py,
+     tests/test_oracle_port.py: forward values and hand-derived gradients must agree, fp64 1e-9 / fp32 1e-4),
+ (d) sklearn for micro/macro-F1.
 
 All arithmetic is done in the dtype of the inputs (float32 for parity runs,
 float64 for finite-difference checks).  Summation order inside TF's
