@@ -117,6 +117,8 @@ class SampleAndAggregate(object):
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         self.cogather_opt = float(os.environ.get("GS_COGATHER_OPT", 0.0))      # share riding in the optimizer launch
         # fused tail as two launches (z helpers | row-group workgroups), and the part of the tail's share the first carries
+        # unsupervised pipeline: share of the gather riding in the last layer's lean launch
+        self.cogather_z = float(os.environ.get("GS_COGATHER_Z", 0.04))        # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
         self.tail_split = os.environ.get("GS_TAIL_SPLIT", "0") == "1"
         self.cogather_tail_z = float(os.environ.get("GS_COGATHER_TAIL_Z", 0.35))
         # data-parallel with the all-reduce recorded in the step graph: share of the gather on a forked graph branch that
@@ -225,7 +227,7 @@ class SampleAndAggregate(object):
                  ops.ptr(self._neg_cdf), self._n_cdf, self.neg_sample_size, self.neg_seed, ops.ptr(e.sample_clock_dev),
                  ops.ptr(roots), e.stream)
 
-    def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None, epilogue=None):
+    def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None, epilogue=None, z_jobs=None):
         """_build (:347-370) + _loss (:385-391) + _accuracy (:393-405) and, when training, the gradient of the
         link-prediction head w.r.t. the normalised embeddings."""
         e = self.engine
@@ -235,7 +237,7 @@ class SampleAndAggregate(object):
         samples1, support_sizes1, means0 = prefetched
         out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n_roots,
                                 aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
-                                layer0_means=means0, layer0_side_jobs=side_jobs)
+                                layer0_means=means0, layer0_side_jobs=side_jobs, last_layer_side_jobs=z_jobs)
         self.samples1 = samples1
         self.agg_out = out
         d = out.d
@@ -511,12 +513,17 @@ class SampleAndAggregate(object):
                 roots, n_roots, pre = self._prefetched[(B, p)]
                 self._parity = p
                 fwd_jobs, wgrad_jobs = ops.split_gather_jobs(jobs, self.cogather_split)
+                z_jobs = []
+                if self.cogather_z > 0 and len(self.num_samples) > 1:
+                    # the last layer's lean launch (gs_sage_tail_z) leaves most of the chip idle: a share rides there at
+                    # the full HBM rate
+                    wgrad_jobs, z_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_z / max(1e-6, 1.0 - self.cogather_split)))
                 fork_jobs = []
                 if in_graph and self.cogather_dp_fork > 0:
                     left = max(1e-6, 1.0 - self.cogather_split)
                     wgrad_jobs, fork_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dp_fork / left))
                 epilogue = dict(step=1 if local_adam else 0, clock=1, cursor=self._cursor, cursor_delta=B)
-                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue)
+                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue, z_jobs=z_jobs)
                 self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
                 if e._deferred_sampler is not None:
                     raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
@@ -649,7 +656,7 @@ class SampleAndAggregate(object):
 
     def aggregate(self, samples, input_features, dims, num_samples, support_sizes, batch_size=None,
                   aggregators=None, name=None, concat=False, model_size="small", layer0_means=None,
-                  layer0_side_jobs=None, _stop_after_layer=None):
+                  layer0_side_jobs=None, _stop_after_layer=None, last_layer_side_jobs=None):
         from .aggregators import _contiguous
         if batch_size is None:
             batch_size = samples[0].numel()
@@ -669,7 +676,7 @@ class SampleAndAggregate(object):
                                                                dims, concat)
             if self_all is not None:
                 means = layer0_means if layer == 0 else None
-                jobs = layer0_side_jobs if layer == 0 else None
+                jobs = layer0_side_jobs if layer == 0 else (last_layer_side_jobs if layer == K - 1 else None)
                 h_all = aggregator.call_hops(self_all, neighs, means=means, side_jobs=jobs)   # all hops, one launch
                 outs = [h_all.rows_slice(offsets[h], offsets[h + 1]) for h in range(n_hops)]
                 tape.append(("batched", aggregator, rows, offsets, h_all))
@@ -741,7 +748,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.cogather_opt,
-                self.tail_split, self.cogather_tail_z,
+                self.tail_split, self.cogather_tail_z, self.cogather_z,
                 self.cogather_dp_fork, e.stream_gemm, str(getattr(self, "pipeline", None)), type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 

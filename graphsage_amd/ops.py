@@ -470,6 +470,21 @@ def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels
     call("gs_sage_tail_fwd_bwd", ctypes.addressof(q), ctypes.addressof(jarr), len(jobs), _s(stream))
 
 
+def sage_tail_z(h0, n, s, W_self, W_neigh, out_dim, means, z, jobs=(), stream=None):
+    """gs_sage_tail_z: z = [h0[:n] . W_self | mean_j(h0[n + i s + j]) . W_neigh] and the neighbor means of a LAST
+    mean-aggregator layer (concat, identity act, no bias) in one lean launch (+ gather jobs riding at the full HBM rate)."""
+    q = _lib.TailDesc()
+    q.h0, q.ldh, q.n = h0.ptr, h0.ld, n
+    q.W_self, q.ldws, q.W_neigh, q.ldwn = W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld
+    q.means, q.ldm, q.z, q.ldz = means.ptr, means.ld, z.ptr, z.ld
+    q.s, q.d_in, q.out_dim, q.C = s, h0.d, out_dim, 1
+    q.z_ready = 1
+    jobs = list(jobs or ())
+    jarr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_tail_z", ctypes.addressof(q), ctypes.addressof(jarr), len(jobs), _s(stream))
+    return z
+
+
 # ------------------------------------------------------------------------------------------ K6
 def reduce_slabs(slabs, n_slabs, slab_stride, rows, cols, ld_slab, weight_decay, w_ptr, ldw, grad_ptr, ldg,
                  accumulate=False, stream=None):
