@@ -87,6 +87,7 @@ _PROTOS = {
     "gs_sage_tail_supported": [c_int32, c_int32, c_int32],
     "gs_sage_tail_fwd_bwd": [_P, _P, c_int32, _P],
     "gs_sage_tail_z": [_P, _P, c_int32, _P],
+    "gs_sage_tail_dh0": [_P, _P, c_int32, _P],
     "gs_dropout_rows": [_P, c_int64, _P, c_int64, c_int32, _P, _P, c_int64, _P],
     "gs_gather_mean_dropout_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P, _P],
     "gs_scatter_add_rows": [_P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P, c_int64, _P],

@@ -224,7 +224,7 @@ class MeanAggregator(_SageBase):
             out = e.ws_mat((self.name, "out", k), n_total, 2 * self.output_dim)
             ops.sage_tail_z(h0, n_total, s, self.vars['self_weights'].value, self.vars['neigh_weights'].value, self.output_dim,
                             means, out, jobs=side_jobs, stream=e.stream)
-            self._push((self_all, neighs, means, out, rate, self_all))
+            self._push((self_all, neighs, means, out, rate, self_all, h0))
             return out
         if means is None:
             means = self.prefetch(self_all, neighs)
@@ -263,12 +263,12 @@ class MeanAggregator(_SageBase):
             ops.sage_dense_fwd(self_in.src, self_in.ids, means, None, n_total, self.vars['self_weights'].value,
                                self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
                                stream=e.stream)
-        self._push((self_all, neighs, means, out, rate, self_in))
+        self._push((self_all, neighs, means, out, rate, self_in, None))
         return out
 
     def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
-        self_all, neighs, means, out, rate, self_in = self._saved.pop()
+        self_all, neighs, means, out, rate, self_in, h0 = self._saved.pop()
         n_total = self_all.n
         k = len(self._saved)
         o = self.output_dim
@@ -298,6 +298,14 @@ class MeanAggregator(_SageBase):
         if d_prev is None:
             return
         d_in = self.input_dim
+        if (h0 is not None and rate == 0 and embed_sink is None and prev_mask is not None and prev_mask.ptr == h0.ptr
+                and prev_mask.ld == h0.ld and d_prev.rows == h0.rows and d_prev.d == h0.d
+                and list(prev_offsets[:3]) == [0, n_total, h0.rows] and os.environ.get("GS_LAYER1_DH0", "1") != "0"):
+            # the forward went through gs_sage_tail_z: the input gradients are its backward twin, ONE launch
+            # (dz . W^T for both terms + relu mask + 1/s broadcast) instead of a small GEMM and the pull
+            ops.sage_tail_dh0(h0, n_total, neighs[0].shape3[1], self.vars['self_weights'].value,
+                              self.vars['neigh_weights'].value, o, dz, d_prev, stream=e.stream)
+            return
         if self.neigh_input_dim == d_in and d_in % 4 == 0 and (not self.concat or o % 4 == 0):
             t2 = e.ws_mat((self.name, "dgrad2", k), n_total, 2 * d_in)       # [d_self | d_means] in one launch
             ops.sage_dense_dgrad(dz, n_total, o, self.concat, self.vars['self_weights'].value,

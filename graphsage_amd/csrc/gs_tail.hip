@@ -648,6 +648,160 @@ static int launch_tail_z(const TailArgs& a, const CoGatherS& J, int64_t gather_w
     return GS_OK;
 }
 
+// Split-off backward half (phases 7-8 of sage_tail_kernel as a launch of their own): given dLoss/dz of a LAST mean layer,
+//   [d_self | d_means] = [dz[:, :O] . W_self^T | dz[:, O:] . W_neigh^T]                       (aggregators.py:51-58 backward)
+//   d_h0 = relu'(h0) * (d_self on the self row, d_means / s on each of the s neighbor rows)    (aggregators.py:48, :64)
+// for models that do not take the fused tail (unsupervised, > 128 classes, ...): one launch instead of a small GEMM and
+// the input-gradient pull, with the same arithmetic as the fused kernel's phases.  Gather jobs may ride.
+template <int D, int O>
+__global__ __launch_bounds__(TAIL_THREADS) void sage_tail_dh0_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
+    const int G = tail_blocks;
+    if ((int)blockIdx.x >= G) {
+        run_gather_item<13>(J, ((int64_t)blockIdx.x - G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
+    const int grp = (int)blockIdx.x;
+    constexpr int Z = 2 * O;
+    constexpr int ldzs = Z + 4;
+    constexpr int D4 = D / 4, Z4 = Z / 4;
+    constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
+    constexpr int ZPASSES = (TAIL_ROWS * Z4 + TAIL_THREADS - 1) / TAIL_THREADS;
+    constexpr int DSLABS = 2 * D / 32;
+    constexpr int DPW = DSLABS / TAIL_WAVES;
+    constexpr int M7 = O / 16;
+    constexpr int ldi = 2 * D + 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* DZs = lds;                                  // [16][ldzs]
+    float* DIN = DZs + TAIL_ROWS * ldzs;               // [16][2D + 8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int r0 = grp * TAIL_ROWS;
+    const int n = (int)a.n;
+    const int s = a.s;
+    const int ldh0 = (int)a.ldh;
+    const float inv_s = 1.0f / (float)s;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // ---- everything this workgroup reads is an input: issue it all up front
+    f32x4 hself[PASSES], hnb[PASSES][TAIL_NB];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it / D4, c = (it % D4) * 4;
+        const int i = min(r0 + r, n - 1);
+        hself[p] = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
+        const float* nb = a.h0 + (n + i * s) * ldh0 + c;
+#pragma unroll
+        for (int u = 0; u < TAIL_NB; ++u) hnb[p][u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
+    }
+    f32x4 dzv[ZPASSES];
+#pragma unroll
+    for (int p = 0; p < ZPASSES; ++p) {
+        const int it = tid + p * TAIL_THREADS;
+        const int r = min(it / Z4, TAIL_ROWS - 1), c = (it % Z4) * 4;
+        dzv[p] = *reinterpret_cast<const f32x4*>(a.dz + (int64_t)min(r0 + r, n - 1) * a.lddz + c);
+    }
+    uint32_t mself[PASSES], mnb[PASSES][2];            // relu masks as bit flags: 4 bits per row
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        mnb[p][0] = mnb[p][1] = 0u;
+#pragma unroll
+        for (int u = 0; u < TAIL_NB; ++u) {
+            const f32x4 v = hnb[p][u];
+            const uint32_t bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            mnb[p][u >> 3] |= bits << (4 * (u & 7));
+        }
+        const f32x4 hs = hself[p];
+        mself[p] = (hs.x > 0.f ? 1u : 0u) | (hs.y > 0.f ? 2u : 0u) | (hs.z > 0.f ? 4u : 0u) | (hs.w > 0.f ? 8u : 0u);
+        asm volatile("" : "+v"(mself[p]), "+v"(mnb[p][0]), "+v"(mnb[p][1]));
+    }
+    f32x4 b7[DPW][M7][2];
+#pragma unroll
+    for (int sl = 0; sl < DPW; ++sl) {
+        const int col0 = (wave + sl * TAIL_WAVES) * 32;          // in [0, 2D)
+        const int term = col0 >= D ? 1 : 0;
+        const int ldw = (int)(term ? a.ldwn : a.ldws);
+        const float* B0 = (term ? a.Wn : a.Ws) + (col0 - term * D + j) * ldw + 4 * q;
+#pragma unroll
+        for (int m = 0; m < M7; ++m) {
+            b7[sl][m][0] = *reinterpret_cast<const f32x4*>(B0 + 16 * m);
+            b7[sl][m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + 16 * m);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < ZPASSES; ++p) {
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it / Z4, c = (it % Z4) * 4;
+        if (r < TAIL_ROWS) *reinterpret_cast<f32x4*>(DZs + r * ldzs + c) = (r0 + r < n) ? dzv[p] : zero4;
+    }
+    lds_barrier();
+    // ---- [d_self | d_means] -> DIN   (phase 7 of sage_tail_kernel)
+#pragma unroll
+    for (int sl = 0; sl < DPW; ++sl) {
+        const int col0 = (wave + sl * TAIL_WAVES) * 32;
+        const int term = col0 >= D ? 1 : 0;
+        const float* A = DZs + term * O + j * ldzs + 4 * q;
+        f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+        for (int m = 0; m < M7; ++m) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + 16 * m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = mfma16(a4[e], b7[sl][m][0][e], acc0);
+                acc1 = mfma16(a4[e], b7[sl][m][1][e], acc1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            DIN[(4 * q + i) * ldi + col0 + j] = acc0[i];
+            DIN[(4 * q + i) * ldi + col0 + 16 + j] = acc1[i];
+        }
+    }
+    lds_barrier();
+    // ---- d_h0   (phase 8 of sage_tail_kernel)
+    {
+        const int lddh0 = (int)a.lddh;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int it = tid + p * TAIL_THREADS;
+            const int r = it / D4, c = (it % D4) * 4;
+            const int i = r0 + r;
+            if (i < n) {
+                const f32x4 g_self = *reinterpret_cast<const f32x4*>(DIN + r * ldi + c);
+                const f32x4 g_mean = *reinterpret_cast<const f32x4*>(DIN + r * ldi + D + c) * inv_s;
+                f32x4 o;
+                o.x = (mself[p] & 1u) ? g_self.x : 0.f;
+                o.y = (mself[p] & 2u) ? g_self.y : 0.f;
+                o.z = (mself[p] & 4u) ? g_self.z : 0.f;
+                o.w = (mself[p] & 8u) ? g_self.w : 0.f;
+                *reinterpret_cast<f32x4*>(a.d_h0 + i * lddh0 + c) = o;
+                float* dst = a.d_h0 + (n + i * s) * lddh0 + c;
+#pragma unroll
+                for (int u = 0; u < TAIL_NB; ++u) {
+                    if (u < s) {
+                        const uint32_t bits = mnb[p][u >> 3] >> (4 * (u & 7));
+                        o.x = (bits & 1u) ? g_mean.x : 0.f;
+                        o.y = (bits & 2u) ? g_mean.y : 0.f;
+                        o.z = (bits & 4u) ? g_mean.z : 0.f;
+                        o.w = (bits & 8u) ? g_mean.w : 0.f;
+                        *reinterpret_cast<f32x4*>(dst + u * lddh0) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int D, int O>
+static int launch_tail_dh0(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
+    const size_t lds = ((size_t)TAIL_ROWS * (2 * O + 4) + (size_t)TAIL_ROWS * (2 * D + 8)) * sizeof(float);
+    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);
+    const int64_t blocks = (int64_t)tail_blocks + gs_ceil_div(gather_waves, TAIL_WAVES);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_dh0: grid too large");
+    hipLaunchKernelGGL((sage_tail_dh0_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
+    GS_LAUNCH_CHECK("sage_tail_dh0_kernel");
+    return GS_OK;
+}
+
 static size_t tail_lds_bytes(int D, int O, int C) {
     const int Z = 2 * O, ldh = D + 4, ldzs = Z + 4;
     const int Cp32 = (C + 31) & ~31;
@@ -784,4 +938,45 @@ extern "C" int gs_sage_tail_z(const gs_tail_desc* q, const gs_gather_desc* jobs_
     if (D == 256 && O == 64) return launch_tail_z<256, 64>(a, J, gw, st);
     if (D == 128 && O == 128) return launch_tail_z<128, 128>(a, J, gw, st);
     return launch_tail_z<128, 64>(a, J, gw, st);
+}
+
+// The input gradients of a LAST mean layer from dLoss/dz (see sage_tail_dh0_kernel): desc fields used: h0, W_self, W_neigh,
+// dz (in), d_h0 (out), n, s, d_in, out_dim.
+extern "C" int gs_sage_tail_dh0(const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    GS_REQUIRE(q, "gs_sage_tail_dh0: null descriptor");
+    if (q->n == 0) return GS_OK;
+    GS_REQUIRE(q->n > 0 && q->s > 0, "gs_sage_tail_dh0: bad sizes");
+    if (q->s > TAIL_NB) {
+        gs_set_error("gs_sage_tail_dh0: at most %d samples per node (got %d)", TAIL_NB, q->s);
+        return GS_ENOTSUP;
+    }
+    GS_REQUIRE((q->n + q->n * (int64_t)q->s) * std::max(q->ldh, std::max(q->lddh, (int64_t)1)) < (1ll << 31),
+               "gs_sage_tail_dh0: (n + n*s) * ld must be < 2^31 (32-bit row offsets)");
+    if (!gs_sage_tail_supported(q->d_in, q->out_dim, 1)) {
+        gs_set_error("gs_sage_tail_dh0: unsupported shape d_in=%d out_dim=%d", q->d_in, q->out_dim);
+        return GS_ENOTSUP;
+    }
+    const int D = q->d_in, O = q->out_dim, Z = 2 * O;
+    GS_CHECK_MAT(q->h0, q->ldh, "gs_sage_tail_dh0 h0");
+    GS_CHECK_MAT(q->W_self, q->ldws, "gs_sage_tail_dh0 W_self");
+    GS_CHECK_MAT(q->W_neigh, q->ldwn, "gs_sage_tail_dh0 W_neigh");
+    GS_CHECK_MAT(q->dz, q->lddz, "gs_sage_tail_dh0 dz");
+    GS_CHECK_MAT(q->d_h0, q->lddh, "gs_sage_tail_dh0 d_h0");
+    GS_REQUIRE(q->ldh >= D && q->ldws >= O && q->ldwn >= O && q->lddz >= Z && q->lddh >= D, "gs_sage_tail_dh0: leading dimension too small");
+    TailArgs a = {};
+    a.h0 = q->h0; a.ldh = q->ldh; a.n = q->n; a.s = q->s; a.D = D;
+    a.Ws = q->W_self; a.ldws = q->ldws; a.Wn = q->W_neigh; a.ldwn = q->ldwn; a.O = O;
+    a.dz = q->dz; a.lddz = q->lddz; a.d_h0 = q->d_h0; a.lddh = q->lddh;
+    a.z_ready = 1;
+    hipStream_t st = (hipStream_t)stream;
+    CoGatherS J = {};
+    int64_t gw = 0;
+    {
+        int rc = build_cojobs_s(jobs_host, n_jobs, &J, &gw);
+        if (rc != GS_OK) return rc;
+    }
+    if (D == 256 && O == 128) return launch_tail_dh0<256, 128>(a, J, gw, st);
+    if (D == 256 && O == 64) return launch_tail_dh0<256, 64>(a, J, gw, st);
+    if (D == 128 && O == 128) return launch_tail_dh0<128, 128>(a, J, gw, st);
+    return launch_tail_dh0<128, 64>(a, J, gw, st);
 }

@@ -485,6 +485,21 @@ def sage_tail_z(h0, n, s, W_self, W_neigh, out_dim, means, z, jobs=(), stream=No
     return z
 
 
+def sage_tail_dh0(h0, n, s, W_self, W_neigh, out_dim, dz, d_h0, jobs=(), stream=None):
+    """gs_sage_tail_dh0: d_h0 = relu'(h0) * ([dz[:, :O] . W_self^T on the self rows | dz[:, O:] . W_neigh^T / s on the
+    neighbor rows]) of a last mean layer, one launch (+ gather jobs)."""
+    q = _lib.TailDesc()
+    q.h0, q.ldh, q.n = h0.ptr, h0.ld, n
+    q.W_self, q.ldws, q.W_neigh, q.ldwn = W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld
+    q.dz, q.lddz, q.d_h0, q.lddh = dz.ptr, dz.ld, d_h0.ptr, d_h0.ld
+    q.s, q.d_in, q.out_dim, q.C = s, h0.d, out_dim, 1
+    q.z_ready = 1
+    jobs = list(jobs or ())
+    jarr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_tail_dh0", ctypes.addressof(q), ctypes.addressof(jarr), len(jobs), _s(stream))
+    return d_h0
+
+
 # ------------------------------------------------------------------------------------------ K6
 def reduce_slabs(slabs, n_slabs, slab_stride, rows, cols, ld_slab, weight_decay, w_ptr, ldw, grad_ptr, ldg,
                  accumulate=False, stream=None):

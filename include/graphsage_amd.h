@@ -510,6 +510,12 @@ int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
  * workgroups' 246 VGPRs / 88 KB and a CU holds one of them).  Follow with gs_sage_tail_fwd_bwd(desc with z_ready = 1).
  * Results are bit-identical to the one-launch form. */
 int gs_sage_tail_z(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
+/* The matching backward half as a launch of its own (the fused kernel's last two phases): from dz = dLoss/dz [n, 2*out_dim],
+ *   [d_self | d_means] = [dz[:, :out_dim] . W_self^T | dz[:, out_dim:] . W_neigh^T]      (aggregators.py:51-58 backward)
+ *   d_h0 [n + n*s, d_in] = relu'(h0) * (d_self on row i, d_means / s on rows n + i*s + j)  (aggregators.py:48, :64)
+ * instead of a small GEMM + gs_input_grad_pull.  Descriptor fields used: h0, W_self, W_neigh, dz, d_h0, n, s, d_in,
+ * out_dim.  gs_sage_tail_z / gs_sage_tail_dh0 serve last mean layers of models that do not take the fused tail. */
+int gs_sage_tail_dh0(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 /* jobs_host / n_jobs (0..6): gather+mean jobs of the NEXT step co-scheduled in the launch (as gs_sage_dense_fwd_cogather):
  * the tail keeps n/16 CUs busy, the rest of the chip streams the gather meanwhile. */
 int gs_sage_tail_fwd_bwd(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);

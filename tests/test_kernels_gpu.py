@@ -825,6 +825,41 @@ def test_fused_tail_split_form_is_bit_identical(dev, n, s, D, O, C, sig):
     assert np.abs(outs[1][7]).max() > 0 and np.abs(outs[1][9]).max() > 0
 
 
+@pytest.mark.parametrize("n,s,D,O", [(1044, 10, 256, 128), (37, 3, 128, 64), (3000, 11, 256, 64), (100, 5, 128, 128)])
+def test_last_layer_z_and_dh0_launches(dev, n, s, D, O):
+    """gs_sage_tail_z (neighbor mean + both contractions + concat of a last mean layer, aggregators.py:48-58) and its
+    backward twin gs_sage_tail_dh0 (dz . W^T for both terms + relu mask + 1/s broadcast) as stand-alone launches vs the
+    oracle's MeanAggregator forward / backward in fp64 -- ragged n, a gather job riding in each launch."""
+    rng = np.random.default_rng(n + D + O)
+    rows, Z = n + n * s, 2 * O
+    h0n = np.maximum(_asym(rng, (rows, D)), 0).astype(np.float32)
+    h0 = Mat.from_numpy(h0n, dev)
+    Wsn, Wnn = _asym(rng, (D, O)) * 0.2, _asym(rng, (D, O)) * 0.2
+    Ws, Wn = Mat.from_numpy(Wsn, dev), Mat.from_numpy(Wnn, dev)
+    Xg = Mat.from_numpy(_asym(rng, (3000, 602)), dev, ld_multiple=32)
+    idx = rng.integers(0, 3000, size=(400, 25)).astype(np.int32)
+    idx_d = _i32(idx.reshape(-1), dev)
+    g1, g2 = Mat.zeros(400, 602, dev), Mat.zeros(400, 602, dev)
+    means, z = Mat.zeros(n, D, dev, 32), Mat.zeros(n, Z, dev)
+    ops.sage_tail_z(h0, n, s, Ws, Wn, O, means, z, jobs=[ops.gather_job(Xg, idx_d, 400, 25, g1)])
+    _sync()
+    h64 = h0n.astype(np.float64)
+    self_v, neigh = h64[:n], h64[n:].reshape(n, s, D)
+    zz, cache = orc.mean_aggregator_fwd(self_v, neigh, Wsn.astype(np.float64), Wnn.astype(np.float64), True, "id")
+    np.testing.assert_allclose(means.numpy(), neigh.mean(1), **TOL)
+    np.testing.assert_allclose(z.numpy(), zz, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(g1.numpy(), Xg.numpy()[idx].mean(axis=1), **TOL)
+    dzn = _asym(rng, (n, Z)).astype(np.float32)
+    dz, dh0 = Mat.from_numpy(dzn, dev), Mat.zeros(rows, D, dev)
+    dh0.buf.fill_(float("nan"))                                             # every row must be written
+    ops.sage_tail_dh0(h0, n, s, Ws, Wn, O, dz, dh0, jobs=[ops.gather_job(Xg, idx_d, 400, 25, g2)])
+    _sync()
+    d_self, d_neigh, _ = orc.mean_aggregator_bwd(dzn.astype(np.float64), cache, Wsn.astype(np.float64), Wnn.astype(np.float64), True, "id")
+    want = np.concatenate([d_self, d_neigh.reshape(n * s, D)], axis=0) * (h64 > 0)
+    np.testing.assert_allclose(dh0.numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+    assert np.array_equal(g1.numpy(), g2.numpy())
+
+
 def test_fused_tail_handover_stress(dev):
     """The in-kernel hand-over of the fused tail (helper workgroups -> row-group workgroups through monotonic arrival
     counters, bounded wait, error word) under stress: 4000 rows = 1250 workgroups (far more than resident at once),
