@@ -269,6 +269,9 @@ class MeanAggregator(_SageBase):
     def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
         self_all, neighs, means, out, rate, self_in, h0 = self._saved.pop()
+        if getattr(self, "bwd_jobs", None) and not (h0 is not None and d_prev is not None and rate == 0):
+            e.launch_gather_jobs(self.bwd_jobs)          # no launch of this pass can carry them: issue them on their own
+            self.bwd_jobs = None
         n_total = self_all.n
         k = len(self._saved)
         o = self.output_dim
@@ -303,8 +306,9 @@ class MeanAggregator(_SageBase):
                 and list(prev_offsets[:3]) == [0, n_total, h0.rows] and os.environ.get("GS_LAYER1_DH0", "1") != "0"):
             # the forward went through gs_sage_tail_z: the input gradients are its backward twin, ONE launch
             # (dz . W^T for both terms + relu mask + 1/s broadcast) instead of a small GEMM and the pull
+            jobs, self.bwd_jobs = getattr(self, "bwd_jobs", None), None      # a gather share of the next step may ride here
             ops.sage_tail_dh0(h0, n_total, neighs[0].shape3[1], self.vars['self_weights'].value,
-                              self.vars['neigh_weights'].value, o, dz, d_prev, stream=e.stream)
+                              self.vars['neigh_weights'].value, o, dz, d_prev, jobs=jobs, stream=e.stream)
             return
         if self.neigh_input_dim == d_in and d_in % 4 == 0 and (not self.concat or o % 4 == 0):
             t2 = e.ws_mat((self.name, "dgrad2", k), n_total, 2 * d_in)       # [d_self | d_means] in one launch

@@ -119,6 +119,7 @@ class SampleAndAggregate(object):
         # fused tail as two launches (z helpers | row-group workgroups), and the part of the tail's share the first carries
         # unsupervised pipeline: share of the gather riding in the last layer's lean launch
         self.cogather_z = float(os.environ.get("GS_COGATHER_Z", 0.04))        # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
+        self.cogather_dh0 = float(os.environ.get("GS_COGATHER_DH0", 0.0))     # ... and in its backward twin's launch
         self.tail_split = os.environ.get("GS_TAIL_SPLIT", "0") == "1"
         self.cogather_tail_z = float(os.environ.get("GS_COGATHER_TAIL_Z", 0.35))
         # data-parallel with the all-reduce recorded in the step graph: share of the gather on a forked graph branch that
@@ -518,6 +519,10 @@ class SampleAndAggregate(object):
                     # the last layer's lean launch (gs_sage_tail_z) leaves most of the chip idle: a share rides there at
                     # the full HBM rate
                     wgrad_jobs, z_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_z / max(1e-6, 1.0 - self.cogather_split)))
+                if self.cogather_dh0 > 0 and len(self.num_samples) > 1 and isinstance(self.aggregators[-1], MeanAggregator):
+                    left = max(1e-6, 1.0 - self.cogather_split - (self.cogather_z if z_jobs else 0.0))
+                    wgrad_jobs, bj = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dh0 / left))
+                    self.aggregators[-1].bwd_jobs = bj or None
                 fork_jobs = []
                 if in_graph and self.cogather_dp_fork > 0:
                     left = max(1e-6, 1.0 - self.cogather_split)
@@ -748,7 +753,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.cogather_opt,
-                self.tail_split, self.cogather_tail_z, self.cogather_z,
+                self.tail_split, self.cogather_tail_z, self.cogather_z, self.cogather_dh0,
                 self.cogather_dp_fork, e.stream_gemm, str(getattr(self, "pipeline", None)), type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 
