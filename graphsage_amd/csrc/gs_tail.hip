@@ -652,139 +652,97 @@ static int launch_tail_z(const TailArgs& a, const CoGatherS& J, int64_t gather_w
 //   [d_self | d_means] = [dz[:, :O] . W_self^T | dz[:, O:] . W_neigh^T]                       (aggregators.py:51-58 backward)
 //   d_h0 = relu'(h0) * (d_self on the self row, d_means / s on each of the s neighbor rows)    (aggregators.py:48, :64)
 // for models that do not take the fused tail (unsupervised, > 128 classes, ...): one launch instead of a small GEMM and
-// the input-gradient pull, with the same arithmetic as the fused kernel's phases.  Gather jobs may ride.
+// the input-gradient pull.  LEAN like the z helpers: 2D / 128 workgroups per 16-row group, one per 128-column slab of
+// [d_self | d_means] (a slab lies in ONE term: 128 divides D), each of its 8 waves one 16-column MFMA tile with its 16
+// weight rows (K = O: 8 float4) in registers; ~100 VGPRs and 17 KB of LDS, so several workgroups share a CU and gather
+// jobs riding in the launch stream at the full rate.  (A first version gave a whole group to one workgroup, as the fused
+// kernel does: 66 workgroups for 1044 rows each pulling both weight matrices through one CU -- 20 us.)
 template <int D, int O>
-__global__ __launch_bounds__(TAIL_THREADS) void sage_tail_dh0_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
+__global__ __launch_bounds__(TAIL_THREADS, 4) void sage_tail_dh0_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
+    constexpr int NWG = 2 * D / 128;
     const int G = tail_blocks;
-    if ((int)blockIdx.x >= G) {
-        run_gather_item<13>(J, ((int64_t)blockIdx.x - G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+    if ((int)blockIdx.x >= NWG * G) {
+        run_gather_item<8>(J, ((int64_t)blockIdx.x - NWG * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
-    const int grp = (int)blockIdx.x;
-    constexpr int Z = 2 * O;
-    constexpr int ldzs = Z + 4;
-    constexpr int D4 = D / 4, Z4 = Z / 4;
-    constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
-    constexpr int ZPASSES = (TAIL_ROWS * Z4 + TAIL_THREADS - 1) / TAIL_THREADS;
-    constexpr int DSLABS = 2 * D / 32;
-    constexpr int DPW = DSLABS / TAIL_WAVES;
+    const int grp = (int)blockIdx.x / NWG, part = (int)blockIdx.x % NWG;
+    const int colbase = part * 128;                    // in [0, 2D)
+    const int term = colbase >= D ? 1 : 0;             // workgroup-uniform
+    const int cb = colbase - term * D;                 // first of this slab's 128 columns inside the term's D columns
     constexpr int M7 = O / 16;
-    constexpr int ldi = 2 * D + 8;
+    constexpr int ldzs = O + 4, ldi = 128 + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* DZs = lds;                                  // [16][ldzs]
-    float* DIN = DZs + TAIL_ROWS * ldzs;               // [16][2D + 8]
+    float* DZs = lds;                                  // [16][ldzs]   the term's half of dz
+    float* DIN = DZs + TAIL_ROWS * ldzs;               // [16][ldi]    this slab of [d_self | d_means]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int r0 = grp * TAIL_ROWS;
     const int n = (int)a.n;
     const int s = a.s;
     const int ldh0 = (int)a.ldh;
-    const float inv_s = 1.0f / (float)s;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // ---- everything this workgroup reads is an input: issue it all up front
-    f32x4 hself[PASSES], hnb[PASSES][TAIL_NB];
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int it = tid + p * TAIL_THREADS;
-        const int r = it / D4, c = (it % D4) * 4;
-        const int i = min(r0 + r, n - 1);
-        hself[p] = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
-        const float* nb = a.h0 + (n + i * s) * ldh0 + c;
-#pragma unroll
-        for (int u = 0; u < TAIL_NB; ++u) hnb[p][u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
-    }
-    f32x4 dzv[ZPASSES];
-#pragma unroll
-    for (int p = 0; p < ZPASSES; ++p) {
-        const int it = tid + p * TAIL_THREADS;
-        const int r = min(it / Z4, TAIL_ROWS - 1), c = (it % Z4) * 4;
-        dzv[p] = *reinterpret_cast<const f32x4*>(a.dz + (int64_t)min(r0 + r, n - 1) * a.lddz + c);
-    }
-    uint32_t mself[PASSES], mnb[PASSES][2];            // relu masks as bit flags: 4 bits per row
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        mnb[p][0] = mnb[p][1] = 0u;
-#pragma unroll
-        for (int u = 0; u < TAIL_NB; ++u) {
-            const f32x4 v = hnb[p][u];
-            const uint32_t bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
-            mnb[p][u >> 3] |= bits << (4 * (u & 7));
-        }
-        const f32x4 hs = hself[p];
-        mself[p] = (hs.x > 0.f ? 1u : 0u) | (hs.y > 0.f ? 2u : 0u) | (hs.z > 0.f ? 4u : 0u) | (hs.w > 0.f ? 8u : 0u);
-        asm volatile("" : "+v"(mself[p]), "+v"(mnb[p][0]), "+v"(mnb[p][1]));
-    }
-    f32x4 b7[DPW][M7][2];
-#pragma unroll
-    for (int sl = 0; sl < DPW; ++sl) {
-        const int col0 = (wave + sl * TAIL_WAVES) * 32;          // in [0, 2D)
-        const int term = col0 >= D ? 1 : 0;
+    // (1) the term's half of dz: 16 rows x O columns
+    const int zr = min(tid / (O / 4), TAIL_ROWS - 1), zc = (tid % (O / 4)) * 4;
+    const f32x4 dzv = *reinterpret_cast<const f32x4*>(a.dz + (int64_t)min(r0 + zr, n - 1) * a.lddz + term * O + zc);
+    // (2) this wave's 16 weight rows cb + 16 wave + j, all K = O columns (NT form, as phase 7 of the fused kernel)
+    f32x4 b7[M7];
+    {
         const int ldw = (int)(term ? a.ldwn : a.ldws);
-        const float* B0 = (term ? a.Wn : a.Ws) + (col0 - term * D + j) * ldw + 4 * q;
+        const float* B0 = (term ? a.Wn : a.Ws) + (cb + 16 * wave + j) * ldw + 4 * q;
 #pragma unroll
-        for (int m = 0; m < M7; ++m) {
-            b7[sl][m][0] = *reinterpret_cast<const f32x4*>(B0 + 16 * m);
-            b7[sl][m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + 16 * m);
-        }
+        for (int m = 0; m < M7; ++m) b7[m] = *reinterpret_cast<const f32x4*>(B0 + 16 * m);
     }
+    // (3) the h0 values behind this thread's output float4s (their signs are the relu mask): thread = (row, float4 column)
+    const int hr = tid >> 5, hc = cb + 4 * (tid & 31);
+    const int hi = min(r0 + hr, n - 1);
+    f32x4 hv[TAIL_NB];
+    if (term == 0) {
+        hv[0] = *reinterpret_cast<const f32x4*>(a.h0 + hi * ldh0 + hc);
+    } else {
+        const float* nb = a.h0 + (n + hi * s) * ldh0 + hc;
 #pragma unroll
-    for (int p = 0; p < ZPASSES; ++p) {
-        const int it = tid + p * TAIL_THREADS;
-        const int r = it / Z4, c = (it % Z4) * 4;
-        if (r < TAIL_ROWS) *reinterpret_cast<f32x4*>(DZs + r * ldzs + c) = (r0 + r < n) ? dzv[p] : zero4;
+        for (int u = 0; u < TAIL_NB; ++u) hv[u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
     }
+    if (tid < TAIL_ROWS * (O / 4)) *reinterpret_cast<f32x4*>(DZs + zr * ldzs + zc) = (r0 + zr < n) ? dzv : zero4;
     lds_barrier();
-    // ---- [d_self | d_means] -> DIN   (phase 7 of sage_tail_kernel)
-#pragma unroll
-    for (int sl = 0; sl < DPW; ++sl) {
-        const int col0 = (wave + sl * TAIL_WAVES) * 32;
-        const int term = col0 >= D ? 1 : 0;
-        const float* A = DZs + term * O + j * ldzs + 4 * q;
-        f32x4 acc0 = zero4, acc1 = zero4;
+    // ---- the slab of [d_self | d_means]: one 16 x 16 tile per wave
+    {
+        const float* A = DZs + j * ldzs + 4 * q;
+        f32x4 acc = zero4;
 #pragma unroll
         for (int m = 0; m < M7; ++m) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + 16 * m);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = mfma16(a4[e], b7[sl][m][0][e], acc0);
-                acc1 = mfma16(a4[e], b7[sl][m][1][e], acc1);
-            }
+            for (int e = 0; e < 4; ++e) acc = mfma16(a4[e], b7[m][e], acc);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            DIN[(4 * q + i) * ldi + col0 + j] = acc0[i];
-            DIN[(4 * q + i) * ldi + col0 + 16 + j] = acc1[i];
-        }
+        for (int i = 0; i < 4; ++i) DIN[(4 * q + i) * ldi + 16 * wave + j] = acc[i];
     }
     lds_barrier();
-    // ---- d_h0   (phase 8 of sage_tail_kernel)
-    {
+    // ---- d_h0: relu mask (+ the 1/s broadcast over the row's s neighbor rows for the d_means slabs)
+    if (r0 + hr < n) {
         const int lddh0 = (int)a.lddh;
+        f32x4 g = *reinterpret_cast<const f32x4*>(DIN + hr * ldi + 4 * (tid & 31));
+        if (term == 0) {
+            f32x4 o;
+            o.x = hv[0].x > 0.f ? g.x : 0.f;
+            o.y = hv[0].y > 0.f ? g.y : 0.f;
+            o.z = hv[0].z > 0.f ? g.z : 0.f;
+            o.w = hv[0].w > 0.f ? g.w : 0.f;
+            *reinterpret_cast<f32x4*>(a.d_h0 + (r0 + hr) * lddh0 + hc) = o;
+        } else {
+            g *= 1.0f / (float)s;
+            float* dst = a.d_h0 + (n + (r0 + hr) * s) * lddh0 + hc;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int it = tid + p * TAIL_THREADS;
-            const int r = it / D4, c = (it % D4) * 4;
-            const int i = r0 + r;
-            if (i < n) {
-                const f32x4 g_self = *reinterpret_cast<const f32x4*>(DIN + r * ldi + c);
-                const f32x4 g_mean = *reinterpret_cast<const f32x4*>(DIN + r * ldi + D + c) * inv_s;
-                f32x4 o;
-                o.x = (mself[p] & 1u) ? g_self.x : 0.f;
-                o.y = (mself[p] & 2u) ? g_self.y : 0.f;
-                o.z = (mself[p] & 4u) ? g_self.z : 0.f;
-                o.w = (mself[p] & 8u) ? g_self.w : 0.f;
-                *reinterpret_cast<f32x4*>(a.d_h0 + i * lddh0 + c) = o;
-                float* dst = a.d_h0 + (n + i * s) * lddh0 + c;
-#pragma unroll
-                for (int u = 0; u < TAIL_NB; ++u) {
-                    if (u < s) {
-                        const uint32_t bits = mnb[p][u >> 3] >> (4 * (u & 7));
-                        o.x = (bits & 1u) ? g_mean.x : 0.f;
-                        o.y = (bits & 2u) ? g_mean.y : 0.f;
-                        o.z = (bits & 4u) ? g_mean.z : 0.f;
-                        o.w = (bits & 8u) ? g_mean.w : 0.f;
-                        *reinterpret_cast<f32x4*>(dst + u * lddh0) = o;
-                    }
+            for (int u = 0; u < TAIL_NB; ++u) {
+                if (u < s) {
+                    f32x4 o;
+                    o.x = hv[u].x > 0.f ? g.x : 0.f;
+                    o.y = hv[u].y > 0.f ? g.y : 0.f;
+                    o.z = hv[u].z > 0.f ? g.z : 0.f;
+                    o.w = hv[u].w > 0.f ? g.w : 0.f;
+                    *reinterpret_cast<f32x4*>(dst + u * lddh0) = o;
                 }
             }
         }
@@ -793,9 +751,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_dh0_kernel(const TailA
 
 template <int D, int O>
 static int launch_tail_dh0(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
-    const size_t lds = ((size_t)TAIL_ROWS * (2 * O + 4) + (size_t)TAIL_ROWS * (2 * D + 8)) * sizeof(float);
+    const size_t lds = ((size_t)TAIL_ROWS * (O + 4) + (size_t)TAIL_ROWS * (128 + 4)) * sizeof(float);
     const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);
-    const int64_t blocks = (int64_t)tail_blocks + gs_ceil_div(gather_waves, TAIL_WAVES);
+    const int64_t blocks = (int64_t)tail_blocks * (2 * D / 128) + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_dh0: grid too large");
     hipLaunchKernelGGL((sage_tail_dh0_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
     GS_LAUNCH_CHECK("sage_tail_dh0_kernel");
