@@ -108,6 +108,9 @@ _PROTOS = {
                                  _P, c_int64, _P, _P],
     "gs_linkpred_norm_fwd_bwd_step": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, c_int64, _P, _P, _P, c_int64,
                                       _P, c_int64, _P, _P, c_int, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
+    "gs_unique_ids": [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
+    "gs_dense_fwd_rows_dev": [_P, c_int64, _P, c_int32, c_int64, _P, _P, c_int64, c_int32, c_int, _P, _P, c_int64, _P],
+    "gs_segment_max_gather_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P],
     "gs_sample_fanout_desc": [_P, _P],
     "gs_build_padded_table": [_P, _P, c_int64, c_int32, c_int32, c_uint64, _P, _P],
     "gs_finalize_step2": [_P, c_int64, c_float, _P, c_int, _P, c_float, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],

@@ -540,8 +540,35 @@ class _PoolingAggregator(_SageBase):
             argmax = e.ws_i32((self.name, "argmax", k), n_total * self.hidden_dim).view(n_total, self.hidden_dim)
         fused_pool = (self.POOL == "max" and rate == 0 and getattr(self, "fuse_pool", True)
                       and all(nv.shape3[1] <= 64 for nv in neighs))
+        # layer 0 (rows gathered from the feature table through the model's contiguous id buffer): the MLP of a node does
+        # not depend on who sampled it -- run it once per DISTINCT id of the step and let the reduce_max pick rows
+        # through an index (37 % fewer GEMM rows at Reddit's degree)
+        dedup = (fused_pool and x_all is not None and x_all.ids is not None and rows_total > 2048
+                 and x_all.src.rows < (1 << 31) and getattr(self, "dedup_pool", os.environ.get("GS_POOL_DEDUP", "1") != "0"))
         H = None
-        if fused_pool:
+        if dedup:
+            X, ids, nv_rows = x_all.src, x_all.ids, x_all.src.rows
+            rank_ws = e.ws_i32((self.name, "dd_rank", k), nv_rows)
+            sums_ws = e.ws_i32((self.name, "dd_sums", k), 256)
+            uniq = e.ws_i32((self.name, "dd_uniq", k), rows_total)
+            inv = e.ws_i32((self.name, "dd_inv", k), rows_total)
+            cnt = e.ws_i32((self.name, "dd_count", k), 1)
+            ops.call("gs_unique_ids", ops.ptr(ids), rows_total, nv_rows, ops.ptr(rank_ws), ops.ptr(sums_ws), ops.ptr(uniq),
+                     ops.ptr(inv), ops.ptr(cnt), e.stream)
+            Hu = e.ws_mat((self.name, "H_unique", k), rows_total, self.hidden_dim)
+            W, bmlp = mlp.vars['weights'].value, mlp.vars['bias'].value.buf
+            ops.call("gs_dense_fwd_rows_dev", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt), W.ptr, W.ld,
+                     self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld, e.stream)
+            r = hr = 0
+            for nv in neighs:
+                n, s, _ = nv.shape3
+                pr, ar = pooled.rows_slice(r, r + n), argmax[r:r + n]
+                ops.call("gs_segment_max_gather_fwd", Hu.ptr, Hu.ld, inv.data_ptr() + 4 * hr, n, s, self.hidden_dim, pr.ptr, pr.ld,
+                         ar.data_ptr(), argmax.stride(0), e.stream)
+                r += n
+                hr += n * s
+            self.last_unique = (cnt, rows_total)
+        elif fused_pool:
             # Dense (:176-179) + reduce_max (:181) in ONE launch per hop: the GEMM tiles hold whole neighbor groups and
             # reduce them in the epilogue, so the [n*s, hidden] activations never exist in HBM
             r = 0

@@ -49,6 +49,7 @@ struct GemmArgs {
     int64_t pool_ld;
     int32_t* pool_arg;
     int64_t pool_lda;
+    const int32_t* m_dev;  // nullable: the row count lives on the device (rows >= *m_dev do not exist); M is its upper bound
 };
 
 #define GS_IDXCAP 1024  // gather indices cached in LDS per k-chunk (row-gathered TN operand)
@@ -67,7 +68,7 @@ __device__ __forceinline__ int gs_xcd_swizzle(int bid, int nwg) {
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, const int zslice, float* smem) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, const int zslice, float* smem, const int64_t gM) {
     constexpr int BK = 32;
     constexpr int KP = BK + 4;  // padded k stride for k-contiguous tiles (conflict-free ds_read_b128)
     constexpr int PA = BM / 32;  // float4 loads per thread per stage
@@ -96,6 +97,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
     }
     const int64_t m0 = (int64_t)tile_m * (g.pool_s > 0 ? g.pool_rows : BM);
     const int n0 = tile_n * BN;
+    if (m0 >= gM) return;                       // (only with a device-side row count: the grid covers its upper bound)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -123,7 +125,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int64_t r = m0 + p * 32 + (tid >> 3);
-                a_ok[p] = r < g.M;
+                a_ok[p] = r < gM;
                 const int64_t src = a_ok[p] ? (T.a_idx ? (int64_t)T.a_idx[r] : r) : 0;
                 a_row[p] = T.A + src * T.lda + (tid & 7) * 4;
             }
@@ -166,13 +168,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
                     const int64_t r = m0 + (u - kk * UPR) * 4;
                     const int k = k0 + kk;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (k < k_end && r < g.M) {
+                    if (k < k_end && r < gM) {
                         const int64_t src = T.a_idx ? (int64_t)idx_lds[k - idx_base] : (int64_t)k;
                         v = *reinterpret_cast<const f32x4*>(T.A + src * T.lda + r);
-                        if (r + 3 >= g.M) {
-                            if (r + 1 >= g.M) v.y = 0.f;
-                            if (r + 2 >= g.M) v.z = 0.f;
-                            if (r + 3 >= g.M) v.w = 0.f;
+                        if (r + 3 >= gM) {
+                            if (r + 1 >= gM) v.y = 0.f;
+                            if (r + 2 >= gM) v.z = 0.f;
+                            if (r + 3 >= gM) v.w = 0.f;
                         }
                     }
                     ra[p] = v;
@@ -341,7 +343,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
         __syncthreads();
         const int s = g.pool_s;
         const int groups = g.pool_rows / s;
-        const int64_t n_groups = g.M / s;
+        const int64_t n_groups = gM / s;
         for (int item = tid; item < groups * BN; item += 256) {
             const int gi = item / BN, lc = item - gi * BN;
             const int64_t node = (int64_t)tile_m * groups + gi;
@@ -373,7 +375,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = m0 + wm * (BM / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row < g.M) {
+                if (row < gM) {
                     if (col_ok) {
                         float v = acc[tm][tn][e] + bv;
                         float* dst = C + row * g.ldc + gcol;
@@ -388,12 +390,25 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
         }
 }
 
+__device__ __forceinline__ int64_t gs_ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmArgs g_in) {
     constexpr int AS_FLOATS = A_KC ? BM * 36 : 32 * BM;
     constexpr int BS_FLOATS = B_KC ? BN * 36 : 32 * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * (AS_FLOATS + BS_FLOATS) + (A_KC ? 0 : GS_IDXCAP)];
-    gemm_tile<BM, BN, A_KC, B_KC>(g, gs_xcd_swizzle(blockIdx.x, gridDim.x), blockIdx.z, smem);
+    if (g_in.m_dev) {
+        // the row count lives on the device (rows >= *m_dev do not exist; M is the grid's upper bound): the XCD swizzle runs
+        // over the tiles that exist -- swizzled over the whole grid, the first XCDs would own all the work (measured: 30 % of
+        // the rows took 88 % of the full time)
+        const int64_t gM = min(g_in.M, (int64_t)max(*g_in.m_dev, 0));
+        const int tiles_n_total = g_in.tiles_n * ((g_in.nterms == 2 && g_in.concat) ? 2 : 1);
+        const int nwg = (int)gs_ceil_div_dev(gM, (int64_t)(g_in.pool_s > 0 ? g_in.pool_rows : BM)) * tiles_n_total;
+        if ((int)blockIdx.x >= nwg) return;
+        gemm_tile<BM, BN, A_KC, B_KC>(g_in, gs_xcd_swizzle(blockIdx.x, nwg), blockIdx.z, smem, gM);
+        return;
+    }
+    gemm_tile<BM, BN, A_KC, B_KC>(g_in, gs_xcd_swizzle(blockIdx.x, gridDim.x), blockIdx.z, smem, g_in.M);
 }
 
 // Grouped weight-gradient launch: every dW = A^T·dZ of one backward pass (all layers, all variables, the bias
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedArgs 
     const int local = bid - G.block_start[p];
     const int tiles = g.tiles_m * g.tiles_n;
     const int z = local / tiles;
-    gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem);
+    gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem, g.M);
 }
 
 // Small-M contraction (M <= 2048: the layer-1 / head-sized GEMMs, which are pure latency with 64x64 tiles because
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(256) void sage_dense_cogather_kernel(const GemmArgs
     constexpr int BS_FLOATS = 32 * 64;
     __shared__ __attribute__((aligned(16))) float smem[2 * (AS_FLOATS + BS_FLOATS)];
     if ((int)blockIdx.x < gemm_blocks) {
-        gemm_tile<64, 64, true, false>(g, gs_xcd_swizzle(blockIdx.x, gemm_blocks), 0, smem);
+        gemm_tile<64, 64, true, false>(g, gs_xcd_swizzle(blockIdx.x, gemm_blocks), 0, smem, g.M);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_cogather_kernel(const Gro
         const int local = bid - G.block_start[p];
         const int tiles = g.tiles_m * g.tiles_n;
         const int z = local / tiles;
-        gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem);
+        gemm_tile<64, 64, false, false>(g, local - z * tiles, z, smem, g.M);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -771,6 +786,25 @@ extern "C" int gs_sage_dense_fwd(const float* self, int64_t ld_self, const int32
         g.nterms = 1;
     }
     g.M = n; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
+    return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
+}
+
+// out[i] = act(X[idx[i]] . W + bias) for i < min(n_max, *n_dev): the row count is a device word (e.g. the number of
+// distinct sampled ids of this step, gs_unique_ids), the grid covers n_max.  Rows >= *n_dev of `out` are not written.
+extern "C" int gs_dense_fwd_rows_dev(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max,
+                                     const int32_t* n_dev, const float* W, int64_t ldw, int32_t out_dim, int act,
+                                     const float* bias, float* out, int64_t ldo, void* stream) {
+    if (n_max == 0) return GS_OK;
+    GS_CHECK_MAT(X, ldx, "gs_dense_fwd_rows_dev X");
+    GS_CHECK_MAT(W, ldw, "gs_dense_fwd_rows_dev W");
+    GS_CHECK_MAT(out, ldo, "gs_dense_fwd_rows_dev out");
+    GS_REQUIRE(idx && n_dev && n_max > 2048 && d > 0 && out_dim > 0 && ldx >= rup4(d) && ldw >= out_dim && ldo >= rup4(out_dim),
+               "gs_dense_fwd_rows_dev: bad args (n_max must be > 2048: the tiled kernels)");
+    GemmArgs g = {};
+    g.t[0] = GemmTerm{X, idx, W, ldx, ldw, d};
+    g.nterms = 1;
+    g.M = n_max; g.N = out_dim; g.C = out; g.ldc = ldo; g.bias = bias; g.act = act;
+    g.m_dev = n_dev;
     return dispatch_gemm<true, false>(g, 1, (hipStream_t)stream);
 }
 

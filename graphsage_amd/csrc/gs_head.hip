@@ -60,6 +60,79 @@ extern "C" int gs_segment_max_fwd(const float* H, int64_t ldh, int64_t n, int32_
     return GS_OK;
 }
 
+// reduce_max over rows picked through an index (the MLP ran on the step's UNIQUE ids): one wave per (group, 64-float4
+// column chunk); the group's s row indices are loaded once and broadcast with v_readlane, U rows in flight; rows are
+// compared in j order, so pooled / argmax are those of segment_max_fwd on the expanded [n*s, hidden] matrix, bit for bit.
+template <int U>
+__global__ __launch_bounds__(256) void segment_max_gather_kernel(const float* __restrict__ H, int64_t ldh,
+                                                                 const int32_t* __restrict__ inv, int64_t n, int32_t s,
+                                                                 int32_t hidden, float* __restrict__ pooled, int64_t ldp,
+                                                                 int32_t* __restrict__ argmax, int64_t lda) {
+    const int lane = threadIdx.x & 63;
+    const int c4 = (hidden + 3) / 4, chunks = (c4 + 63) / 64;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n * chunks) return;
+    const int64_t i = w / chunks;
+    const int col = ((int)(w - i * chunks) * 64 + lane) * 4;
+    const bool active = col < hidden;
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int ax = 0, ay = 0, az = 0, aw = 0;
+    for (int jb = 0; jb < s; jb += 64) {
+        const int cnt = min(64, s - jb);
+        int32_t my = 0;
+        if (lane < cnt) my = inv[i * s + jb + lane];
+        if (active) {
+            for (int j = 0; j < cnt; j += U) {
+                f32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int32_t r = __builtin_amdgcn_readlane(my, min(j + u, cnt - 1));
+                    v[u] = *reinterpret_cast<const f32x4*>(H + (int64_t)r * ldh + col);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (j + u < cnt) {                      // wave-uniform
+                        const int jj = jb + j + u;
+                        if (v[u].x > best.x) { best.x = v[u].x; ax = jj; }
+                        if (v[u].y > best.y) { best.y = v[u].y; ay = jj; }
+                        if (v[u].z > best.z) { best.z = v[u].z; az = jj; }
+                        if (v[u].w > best.w) { best.w = v[u].w; aw = jj; }
+                    }
+                }
+            }
+        }
+    }
+    if (!active) return;
+    if (col + 1 >= hidden) best.y = 0.f;
+    if (col + 2 >= hidden) best.z = 0.f;
+    if (col + 3 >= hidden) best.w = 0.f;
+    *reinterpret_cast<f32x4*>(pooled + i * ldp + col) = best;
+    int32_t* a = argmax + i * lda + col;
+    a[0] = ax;
+    if (col + 1 < hidden) a[1] = ay;
+    if (col + 2 < hidden) a[2] = az;
+    if (col + 3 < hidden) a[3] = aw;
+}
+
+extern "C" int gs_segment_max_gather_fwd(const float* H, int64_t ldh, const int32_t* inv, int64_t n, int32_t s, int32_t hidden,
+                                         float* pooled, int64_t ldp, int32_t* argmax, int64_t lda, void* stream) {
+    if (n == 0) return GS_OK;
+    GS_CHECK_MAT(H, ldh, "gs_segment_max_gather_fwd H");
+    GS_CHECK_MAT(pooled, ldp, "gs_segment_max_gather_fwd pooled");
+    GS_REQUIRE(inv && argmax && n > 0 && s > 0 && hidden > 0 && lda >= hidden && ldh >= ((hidden + 3) & ~3) && ldp >= ((hidden + 3) & ~3),
+               "gs_segment_max_gather_fwd: bad args");
+    const int64_t waves = n * (int64_t)((((hidden + 3) / 4) + 63) / 64);
+    GS_REQUIRE(gs_ceil_div(waves, 4) < (1ll << 31), "gs_segment_max_gather_fwd: grid too large");
+    if (s >= 13)
+        hipLaunchKernelGGL(segment_max_gather_kernel<13>, dim3((unsigned)gs_ceil_div(waves, 4)), dim3(256), 0, (hipStream_t)stream, H, ldh,
+                           inv, n, s, hidden, pooled, ldp, argmax, lda);
+    else
+        hipLaunchKernelGGL(segment_max_gather_kernel<5>, dim3((unsigned)gs_ceil_div(waves, 4)), dim3(256), 0, (hipStream_t)stream, H, ldh,
+                           inv, n, s, hidden, pooled, ldp, argmax, lda);
+    GS_LAUNCH_CHECK("segment_max_gather_kernel");
+    return GS_OK;
+}
+
 __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __restrict__ d_pooled, int64_t ldd,
                                                               const float* __restrict__ pooled, int64_t ldp,
                                                               const int32_t* __restrict__ argmax, int64_t lda,

@@ -276,6 +276,22 @@ int gs_dense_pool_max_fwd(const float* X, int64_t ldx, const int32_t* idx, int32
                           const float* W, int64_t ldw, int32_t hidden, const float* bias, float* pooled, int64_t ldp,
                           int32_t* argmax, int64_t lda, void* stream);
 
+/* The pooling MLP on the step's DISTINCT sampled ids (its output depends on the node id only; at Reddit's degree 37 % of a
+ * step's 133 k sampled ids are duplicates):
+ *   gs_unique_ids            ids [m] in [0, n_values) -> uniq [count] (ascending), inv [m] (position of ids[j] in uniq) and the
+ *                            device word count, by flag array + prefix sum (deterministic, static launch shapes);
+ *                            rank_ws: n_values int32 words, sums_ws: 256
+ *   gs_dense_fwd_rows_dev    out[i] = act(X[idx[i]] . W + bias) for i < min(n_max, *n_dev): the row count is a device word
+ *   gs_segment_max_gather_fwd  pooled[i, c] = max_j H[inv[i*s + j], c], argmax = first j attaining it: the bits of
+ *                            gs_dense_pool_max_fwd on the expanded rows */
+int gs_unique_ids(const int32_t* ids, int64_t m, int64_t n_values, int32_t* rank_ws, int32_t* sums_ws, int32_t* uniq_out,
+                  int32_t* inv_out, int32_t* count_out, void* stream);
+int gs_dense_fwd_rows_dev(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
+                          const float* W, int64_t ldw, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+                          void* stream);
+int gs_segment_max_gather_fwd(const float* H, int64_t ldh, const int32_t* inv, int64_t n, int32_t s, int32_t hidden,
+                              float* pooled, int64_t ldp, int32_t* argmax, int64_t lda, void* stream);
+
 /* H[n*s, hidden] = relu(X[idx] · W_mlp + b_mlp)  (Dense, layers.py:104-116) is produced by
  * gs_sage_dense_fwd(self=NULL, agg=X, agg_idx=idx, ...).  This reduces it:
  *   pooled[i, c] = max_j H[i*s+j, c];  argmax[i, c] = first j attaining it   (reduce_max, :181) */

@@ -348,6 +348,71 @@ def test_dense_pool_max_fwd(dev, n, s, d, hid, gathered):
     assert not got[allzero].any()
 
 
+@pytest.mark.parametrize("m,nv", [(133120, 232966), (5000, 3001), (2049, 70000), (300000, 1000)])
+def test_unique_ids(dev, m, nv):
+    """gs_unique_ids (flag array + prefix sum: distinct ids ascending, inverse map, count as a device word) vs np.unique --
+    heavy duplication, sparse occupancy, the pad id, more ids than values."""
+    rng = np.random.default_rng(m + nv)
+    ids = rng.integers(0, nv, size=m).astype(np.int32)
+    ids[:7] = [nv - 1, 0, nv - 1, 5 % nv, 5 % nv, 0, nv - 1]
+    ids_d = _i32(ids, dev)
+    rank = torch.full((nv,), -5, dtype=torch.int32, device=dev)
+    sums = torch.zeros(256, dtype=torch.int32, device=dev)
+    uniq = torch.full((m,), -1, dtype=torch.int32, device=dev)
+    inv = torch.full((m,), -1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    for _ in range(2):                                    # reusable without host-side resets
+        ops.call("gs_unique_ids", ops.ptr(ids_d), m, nv, ops.ptr(rank), ops.ptr(sums), ops.ptr(uniq), ops.ptr(inv), ops.ptr(cnt), None)
+        _sync()
+        want_u, want_inv = np.unique(ids, return_inverse=True)
+        U = int(cnt.item())
+        assert U == len(want_u)
+        assert np.array_equal(uniq.cpu().numpy()[:U], want_u)
+        assert np.array_equal(inv.cpu().numpy(), want_inv.astype(np.int32))
+
+
+@pytest.mark.parametrize("groups,d,hid", [([(5120, 25), (512, 10)], 602, 512), ([(700, 10)], 50, 130), ([(90, 64), (30, 3)], 33, 64)])
+def test_pool_max_on_unique_ids_equals_fused_launch(dev, groups, d, hid):
+    """The de-duplicated pooling path (gs_unique_ids -> gs_dense_fwd_rows_dev on the distinct ids -> gs_segment_max_gather_fwd)
+    gives the pooled values and arg-max rows of gs_dense_pool_max_fwd on the expanded rows, bit for bit."""
+    rng = np.random.default_rng(d + hid)
+    Nn = 4000
+    X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
+    m = sum(n * s for n, s in groups)
+    idx = rng.integers(0, Nn + 1, size=m).astype(np.int32)
+    idx[rng.random(m) < 0.3] = idx[0]                                     # heavy duplication
+    W, b = _asym(rng, (d, hid)) * 0.2, _asym(rng, (hid,)) * 0.1
+    Xd, idx_d = Mat.from_numpy(X, dev, 32), _i32(idx, dev)
+    Wd, bd = Mat.from_numpy(W, dev), torch.from_numpy(b).to(dev)
+    n_total = sum(n for n, _ in groups)
+    p1, a1 = Mat.zeros(n_total, hid, dev), torch.full((n_total, hid), -1, dtype=torch.int32, device=dev)
+    p2, a2 = Mat.zeros(n_total, hid, dev), torch.full((n_total, hid), -1, dtype=torch.int32, device=dev)
+    r = hr = 0
+    for n, s in groups:
+        ops.dense_pool_max_fwd(Xd, idx_d[hr:hr + n * s], n, s, Wd, bd, p1.rows_slice(r, r + n), a1[r:r + n])
+        r, hr = r + n, hr + n * s
+    nv = Nn + 1
+    rank, sums = torch.zeros(nv, dtype=torch.int32, device=dev), torch.zeros(256, dtype=torch.int32, device=dev)
+    uniq, inv = torch.zeros(m, dtype=torch.int32, device=dev), torch.zeros(m, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.call("gs_unique_ids", ops.ptr(idx_d), m, nv, ops.ptr(rank), ops.ptr(sums), ops.ptr(uniq), ops.ptr(inv), ops.ptr(cnt), None)
+    Hu = Mat.zeros(max(m, 2049), hid, dev)
+    Hu.buf.fill_(float("nan"))
+    ops.call("gs_dense_fwd_rows_dev", Xd.ptr, Xd.ld, ops.ptr(uniq), d, max(m, 2049), ops.ptr(cnt), Wd.ptr, Wd.ld, hid, ops.ACT_RELU,
+             ops.ptr(bd), Hu.ptr, Hu.ld, None)
+    r = hr = 0
+    for n, s in groups:
+        pr = p2.rows_slice(r, r + n)
+        ops.call("gs_segment_max_gather_fwd", Hu.ptr, Hu.ld, inv.data_ptr() + 4 * hr, n, s, hid, pr.ptr, pr.ld,
+                 a2[r:r + n].data_ptr(), a2.stride(0), None)
+        r, hr = r + n, hr + n * s
+    _sync()
+    U = int(cnt.item())
+    assert U == len(np.unique(idx)) and np.isfinite(Hu.numpy()[:U]).all()
+    assert np.array_equal(p1.numpy(), p2.numpy())
+    assert np.array_equal(a1.cpu().numpy(), a2.cpu().numpy())
+
+
 @pytest.mark.parametrize("n,s,d,hid,k", [(203, 25, 602, 512, 7), (37, 10, 50, 128, 5), (9, 3, 70, 100, 2),
                                           (64, 16, 33, 64, 3), (21, 25, 40, 1100, 2)])
 def test_maxpool_sparse_wgrad(dev, n, s, d, hid, k):
