@@ -10,6 +10,10 @@
 
 #define DD_BLOCKS 256
 
+__global__ __launch_bounds__(256) void dd_clear_kernel(int32_t* __restrict__ flags, int64_t nv) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += (int64_t)gridDim.x * blockDim.x) flags[t] = 0;
+}
+
 __global__ __launch_bounds__(256) void dd_mark_kernel(const int32_t* __restrict__ ids, int64_t m, int32_t* __restrict__ flags,
                                                       int64_t nv) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += (int64_t)gridDim.x * blockDim.x) {
@@ -97,9 +101,10 @@ extern "C" int gs_unique_ids(const int32_t* ids, int64_t m, int64_t n_values, in
     GS_REQUIRE(ids && rank_ws && sums_ws && uniq_out && inv_out && count_out && m > 0 && n_values > 0, "gs_unique_ids: bad args");
     GS_REQUIRE(n_values < (1ll << 31), "gs_unique_ids: ids must fit int32");
     hipStream_t st = (hipStream_t)stream;
-    GS_HIP(hipMemsetAsync(rank_ws, 0, (size_t)n_values * sizeof(int32_t), st));
     const int64_t chunk = gs_ceil_div(n_values, DD_BLOCKS);
     const int mblocks = (int)std::min<int64_t>(gs_ceil_div(m, 256), 2048);
+    // (a kernel, not hipMemsetAsync: a memset node inside a captured step graph faulted at replay for some batch sizes)
+    hipLaunchKernelGGL(dd_clear_kernel, dim3((unsigned)std::min<int64_t>(gs_ceil_div(n_values, 256), 2048)), dim3(256), 0, st, rank_ws, n_values);
     hipLaunchKernelGGL(dd_mark_kernel, dim3(mblocks), dim3(256), 0, st, ids, m, rank_ws, n_values);
     hipLaunchKernelGGL(dd_count_kernel, dim3(DD_BLOCKS), dim3(256), 0, st, rank_ws, n_values, chunk, sums_ws);
     hipLaunchKernelGGL(dd_scan_sums_kernel, dim3(1), dim3(DD_BLOCKS), 0, st, sums_ws, count_out);
