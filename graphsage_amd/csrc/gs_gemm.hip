@@ -363,6 +363,37 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int wgid, con
     float* C = g.C + (g.kchunk > 0 ? (int64_t)zslice * g.slab_stride : 0);
     const int n_total = g.N * ((g.nterms == 2 && g.concat) ? 2 : 1);
     const int n_pad = (n_total + 3) & ~3;
+    if (BM * BN <= 2 * STAGE_FLOATS && !g.accumulate && g.kchunk == 0 && (g.N & 3) == 0 && (g.ldc & 3) == 0) {
+        // plain output, whole float4 columns: the tile goes through LDS (the stage buffers are free now) and leaves as
+        // 16-byte row-contiguous stores -- 16 per thread instead of 64 dword stores behind per-row branches (the unfused
+        // pooling GEMM that writes H: 949 -> see DESIGN.md).  Same values, bit for bit.
+        __syncthreads();
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int lc = wn * (BN / 2) + tn * 32 + l31;
+                const int col = n0 + lc;
+                const float bv = (g.bias && col < g.N) ? g.bias[col_off + col] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = wm * (BM / 2) + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    float v = acc[tm][tn][e] + bv;
+                    if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                    smem[lr * BN + lc] = v;
+                }
+            }
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+        for (int item = tid; item < BM * C4; item += 256) {
+            const int r = item / C4, c4 = item - r * C4;
+            const int64_t row = m0 + r;
+            const int col = n0 + 4 * c4;
+            if (row < gM && col < g.N)
+                *reinterpret_cast<f32x4*>(C + row * g.ldc + col_off + col) = *reinterpret_cast<const f32x4*>(smem + r * BN + 4 * c4);
+        }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
