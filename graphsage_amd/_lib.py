@@ -14,7 +14,7 @@ ACT_IDENTITY = 0
 ACT_RELU = 1
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
 SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
-GS_ABI_VERSION = 4      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+GS_ABI_VERSION = 5      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -178,7 +178,8 @@ class FanoutDesc(ctypes.Structure):
                 ("law", c_int32), ("max_degree", c_int32),
                 ("pairs", c_void_p), ("n_pairs", c_int64), ("n_pair_roots", c_int64),
                 ("cdf", c_void_p), ("guide", c_void_p), ("n_cdf", c_int64),
-                ("n_neg", c_int32), ("guide_bits", c_int32), ("neg_seed", c_uint64), ("padded_table", c_void_p)]
+                ("n_neg", c_int32), ("guide_bits", c_int32), ("neg_seed", c_uint64), ("padded_table", c_void_p),
+                ("seg_begin", c_int64 * 2)]
 
 
 class VarDesc(ctypes.Structure):

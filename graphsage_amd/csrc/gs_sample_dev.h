@@ -134,6 +134,10 @@ struct FanoutArgs {
     // by gs_build_padded_table from the same gs_table_entry): a draw is then ONE lookup table[id][column] -- no rowptr
     // pair, no permutation arithmetic, 4 cache lines per parent instead of ~16 scattered ones.  Same ids bit for bit.
     const int32_t* table;
+    // GS_LAW_REFERENCE only: roots [0, seg1) | [seg1, seg2) | [seg2, B) belong to DIFFERENT sampler calls of the reference
+    // (models.py:347-357: sample(batch1), sample(batch2), sample(neg_samples) each shuffle their own columns), so segment g
+    // uses the call ids hop0 + g * n_hops + h.  seg1 == seg2 == B (one segment) otherwise.
+    int64_t seg1, seg2;
 };
 
 #define GS_LAW_COLS 128      // per-call columns kept in LDS up to this fan-out (larger fan-outs compute them per slot)
@@ -155,7 +159,8 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
                 const uint64_t t = (uint64_t)(i - 2 * a.n_pair_roots);
                 const uint64_t stc = a.step + (a.step_dev ? *a.step_dev : 0ull);
                 const uint64_t nkey = gs_mix64(a.neg_seed ^ (stc * 0x9E3779B97F4A7C15ull) ^ (0xFFull << 56));
-                const uint32_t r = (uint32_t)(gs_mix64(nkey + t) >> 32);
+                // keyed by the GLOBAL slot: data-parallel ranks draw different negatives
+                const uint32_t r = (uint32_t)(gs_mix64(nkey + t + (uint64_t)a.root_offset) >> 32);
                 int64_t lo = 0, hi = a.n_cdf - 1;  // first index with cdf[idx] > r
                 if (a.guide) {
                     const uint32_t b = r >> (32 - a.guide_bits);
@@ -189,7 +194,9 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
     for (int h = 0; h < a.n_hops; ++h) {
         const int s = a.fan[h];
         const int64_t count = count_prev * s;
-        const uint64_t key = gs_mix64(a.seed ^ (st * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(a.hop0 + h) << 56));
+        const uint32_t seg = a.law.law == GS_LAW_REFERENCE ? (uint32_t)(i >= a.seg1) + (uint32_t)(i >= a.seg2) : 0u;
+        const uint64_t key = gs_mix64(a.seed ^ (st * 0x9E3779B97F4A7C15ull) ^
+                                      ((uint64_t)(a.hop0 + seg * (uint32_t)a.n_hops + h) << 56));
         const int32_t* prev = lvl[h & 1];
         int32_t* next = lvl[(h + 1) & 1];
         const bool keep = (h + 1 < a.n_hops);  // the last hop is only written to global memory
@@ -271,6 +278,7 @@ static inline int gs_fanout_args(const int64_t* rowptr, const int32_t* col, int6
     for (int h = 0; h <= n_hops; ++h) a.offsets[h] = offsets_host[h];
     a.ids_all = ids_all; a.B = B; a.seed = seed; a.step = step; a.step_dev = step_dev; a.hop0 = hop0;
     a.root_offset = root_offset;
+    a.seg1 = a.seg2 = B;
     a.order = order; a.n_order = n_order; a.cursor = cursor_dev;
     a.label_table = label_table; a.ldt = ld_table; a.C = C; a.labels_out = labels_out; a.ldo = ld_out;
     GS_REQUIRE(B < (1ll << 31), "gs_sample_fanout_csr: batch too large");
@@ -297,6 +305,16 @@ static inline int gs_fanout_args_desc(const gs_fanout_desc* s, FanoutArgs* out, 
         out->pairs = s->pairs; out->n_pairs = s->n_pairs; out->n_pair_roots = s->n_pair_roots;
         out->cdf = s->cdf; out->guide = s->guide; out->n_cdf = s->n_cdf; out->n_neg = s->n_neg; out->guide_bits = s->guide_bits;
         out->neg_seed = s->neg_seed;
+        out->seg1 = s->n_pair_roots; out->seg2 = 2 * s->n_pair_roots;
     }
+    if (s->seg_begin[0] > 0 || s->seg_begin[1] > 0) {
+        GS_REQUIRE(s->seg_begin[0] >= 0 && s->seg_begin[0] <= s->seg_begin[1] && s->seg_begin[1] <= s->B,
+                   "gs_fanout_desc: need 0 <= seg_begin[0] <= seg_begin[1] <= B");
+        GS_REQUIRE(!s->pairs || (s->seg_begin[0] == s->n_pair_roots && s->seg_begin[1] == 2 * s->n_pair_roots),
+                   "gs_fanout_desc: seg_begin must match the pair staging");
+        out->seg1 = s->seg_begin[0]; out->seg2 = s->seg_begin[1];
+    }
+    GS_REQUIRE(s->law != GS_LAW_REFERENCE || out->seg1 >= s->B || s->hop0 + 3u * (uint32_t)s->n_hops <= 256u,
+               "gs_fanout_desc: call ids must be < 256");
     return GS_OK;
 }

@@ -228,6 +228,22 @@ class SampleAndAggregate(object):
                  ops.ptr(self._neg_cdf), self._n_cdf, self.neg_sample_size, self.neg_seed, ops.ptr(e.sample_clock_dev),
                  ops.ptr(roots), e.stream)
 
+    def inject_negatives(self, neg):
+        """Parity tests: the negatives of the next host-fed step (the reference draws them from TF's candidate sampler,
+        models.py:336-343; like the sampler's permutations they are injected so both sides see the same ids)."""
+        self._injected_neg = None if neg is None else np.ascontiguousarray(neg, dtype=np.int32)
+        self.use_graphs = False if neg is not None else self.use_graphs
+
+    def _stage_negatives_or_injected(self, roots, B):
+        neg = getattr(self, "_injected_neg", None)
+        if neg is None:
+            return self._stage_negatives(roots, B)
+        assert neg.shape[0] == self.neg_sample_size
+        self._injected_neg = None
+        self.engine.sync()
+        roots[2 * B: 2 * B + self.neg_sample_size].copy_(torch.from_numpy(neg))
+        torch.cuda.current_stream().synchronize()
+
     def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None, epilogue=None, z_jobs=None):
         """_build (:347-370) + _loss (:385-391) + _accuracy (:393-405) and, when training, the gradient of the
         link-prediction head w.r.t. the normalised embeddings."""
@@ -335,7 +351,7 @@ class SampleAndAggregate(object):
         fused = self.grad_hook is None
 
         def fwd_bwd():
-            self._stage_negatives(roots, B)
+            self._stage_negatives_or_injected(roots, B)
             epilogue = dict(step=1 if fused else 0, clock=1)
             self._forward_unsup(roots, B, n_roots, True, epilogue=epilogue)
             self._backward_unsup(B, n_roots, fuse_adam=fused, epilogue=epilogue)
@@ -352,7 +368,7 @@ class SampleAndAggregate(object):
         roots, B, n_roots = self._stage_feed_unsup(feed_dict)
 
         def fwd():
-            self._stage_negatives(roots, B)
+            self._stage_negatives_or_injected(roots, B)
             self._forward_unsup(roots, B, n_roots, False, epilogue=dict(clock=1))
             if not self._epilogue_folded:
                 self._epilogue_unsup(B, clock=1)
@@ -619,6 +635,9 @@ class SampleAndAggregate(object):
             support_size *= layer_infos[t].num_samples
             if contiguous:
                 sampler.next_out = buf[offsets[k + 1]: offsets[k + 2]]
+            if sampler.root_segments is not None:
+                rows_per_root = samples[k].numel() // batch_size
+                sampler.call_segments = tuple(b * rows_per_root for b in sampler.root_segments)
             node = sampler((samples[k], layer_infos[t].num_samples))
             samples.append(node.reshape(support_size * batch_size))
             support_sizes.append(support_size)
@@ -730,8 +749,22 @@ class SampleAndAggregate(object):
         self.reset_tapes()      # a forward-only step (eval) leaves saved activations behind: buffer keys count them
         for s in self._samplers():
             s.new_step()
+            # the unsupervised model's one pass over [batch1 | batch2 | negatives] stands for three sample() calls of the
+            # reference (:347-357), each with its own column permutations
+            s.root_segments = self._root_segments(n)
+            s.calls_per_sample = len(self.layer_infos)
         self._pending_stage = stage
-        return self.sample(batch, self.layer_infos, n)
+        try:
+            return self.sample(batch, self.layer_infos, n)
+        finally:
+            for s in self._samplers():
+                s.root_segments = None
+
+    def _root_segments(self, n_roots):
+        """(start of batch2, start of the negatives) inside the roots [batch1 | batch2 | negatives] of the unsupervised
+        pass (this class); the supervised subclass has one sample() call per step and returns None."""
+        B = (n_roots - self.neg_sample_size) // 2
+        return (B, 2 * B)
 
     def _layer0_inputs(self, samples, support_sizes, n):
         hidden = [Rows(self.features, sm, requires_grad=False) for sm in samples]

@@ -89,6 +89,13 @@ class UniformNeighborSampler(Layer):
         self._call_index = 0          # sampler calls so far in this step = the `hop` stream id
         self.next_out = None          # optional destination of the next call (the model's contiguous id buffer)
         self.global_row_offset = 0    # first global row of this rank's slice (data-parallel invariance)
+        # unsupervised model: the roots [batch1 | batch2 | negatives] of ONE pass stand for the reference's THREE sample()
+        # calls (models.py:347-357), each with its own column permutation per hop (neigh_samplers.py:27).  root_segments =
+        # (start of batch2, start of the negatives) in roots; calls_per_sample = K.  Under law "reference" (and on the
+        # padded table) segment g of call k then uses the reference's call id g * K + k.
+        self.root_segments = None
+        self.call_segments = None     # the same boundaries in rows of the NEXT hop-by-hop call (set by model.sample)
+        self.calls_per_sample = 1
         # law "reference": materialise the law's padded table once per adjacency (what minibatch.py:227-245 builds; 119 MB
         # for Reddit at max_degree 128) so that a draw is one lookup -- same ids bit for bit, see padded_table()
         self.use_table = os.environ.get("GS_SAMPLER_TABLE", "1") != "0"
@@ -118,8 +125,19 @@ class UniformNeighborSampler(Layer):
         self._call_index = 0
 
     def inject_perms(self, perms):
-        """Parity tests: column permutations to use for the next calls (padded layout only)."""
+        """Parity tests: column permutations to use for the next calls (padded layout only).  With root segments (the
+        unsupervised model) the list is indexed by the reference's call id g * K + k instead of being consumed in order."""
         self._injected_perms = list(perms) if perms is not None else None
+
+    def _segment_slices(self, n):
+        """[(segment, row_begin, row_end)] of the next hop-by-hop call."""
+        segs = self.call_segments
+        self.call_segments = None
+        if segs is None:
+            return [(0, 0, n)]
+        b1, b2 = int(segs[0]), int(segs[1])
+        assert 0 <= b1 <= b2 <= n
+        return [(g, lo, hi) for g, lo, hi in ((0, 0, b1), (1, b1, b2), (2, b2, n)) if hi > lo]
 
     def _call(self, inputs):
         ids, num_samples = inputs
@@ -130,17 +148,30 @@ class UniformNeighborSampler(Layer):
                                                                         n * num_samples)
         self.next_out = None
         assert out.numel() >= n * num_samples
+        segmented = self.call_segments is not None
+        slices = self._segment_slices(n)
         if isinstance(adj, PaddedAdjacency):
             if num_samples > adj.max_degree:
                 raise ops._lib.GraphsageAmdError("num_samples %d > max_degree %d" % (num_samples, adj.max_degree))
-            if self._injected_perms:
-                perm = np.asarray(self._injected_perms.pop(0))[:num_samples]
-            else:
-                perm = self._rng.permutation(adj.max_degree)[:num_samples]
-            perm_dev = e.ws_i32((self.name, "perm", self._call_index), num_samples)
-            perm_dev.copy_(torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int32)))
-            torch.cuda.current_stream().synchronize()
-            ops.sample_padded(adj.table, ids, perm_dev, num_samples, out=out, stream=e.stream)
+            for g, lo, hi in slices:
+                if self._injected_perms and segmented:
+                    perm = np.asarray(self._injected_perms[g * self.calls_per_sample + self._call_index])[:num_samples]
+                elif self._injected_perms:
+                    perm = np.asarray(self._injected_perms.pop(0))[:num_samples]
+                else:
+                    perm = self._rng.permutation(adj.max_degree)[:num_samples]
+                perm_dev = e.ws_i32((self.name, "perm", self._call_index, g), num_samples)
+                perm_dev.copy_(torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int32)))
+                torch.cuda.current_stream().synchronize()
+                ops.sample_padded(adj.table, ids[lo:hi], perm_dev, num_samples, out=out[lo * num_samples: hi * num_samples],
+                                  stream=e.stream)
+        elif segmented and self.law == ops._lib.SAMPLER_LAWS["reference"]:
+            for g, lo, hi in slices:
+                ops.sample_uniform_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, ids[lo:hi], num_samples, self.seed,
+                                       step=0, step_dev=e.sample_clock_dev, hop=g * self.calls_per_sample + self._call_index,
+                                       global_row_offset=self.global_row_offset + lo,
+                                       out=out[lo * num_samples: hi * num_samples], stream=e.stream, law=self.law,
+                                       max_degree=self.max_degree)
         else:
             ops.sample_uniform_csr(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, ids, num_samples, self.seed,
                                    step=0, step_dev=e.sample_clock_dev, hop=self._call_index,
@@ -164,7 +195,7 @@ class UniformNeighborSampler(Layer):
                                    self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index, root_offset=root_offset,
                                    cursor_dev=cursor, law=self.law, max_degree=self.max_degree,
                                    unsup=(pairs, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed),
-                                   padded_table=self.padded_table(adj))
+                                   padded_table=self.padded_table(adj), segments=self.root_segments)
             if getattr(e, "_defer_sampler", False):
                 e._deferred_sampler = desc
             else:
@@ -174,12 +205,12 @@ class UniformNeighborSampler(Layer):
         if stage is not None:
             order, cursor, table, labels_out = stage
         ptable = self.padded_table(adj)
-        if getattr(e, "_defer_sampler", False) or ptable is not None:
+        if getattr(e, "_defer_sampler", False) or ptable is not None or self.root_segments is not None:
             desc = ops.fanout_desc(adj.rowptr, adj.col, adj.n_nodes, adj.n_nodes, fans, offsets, ids_all,
                                    batch_size, self.seed, step_dev=e.sample_clock_dev, hop0=self._call_index,
                                    root_offset=root_offset, order=order, cursor_dev=cursor,
                                    label_table=table, labels_out=labels_out, law=self.law,
-                                   max_degree=self.max_degree, padded_table=ptable)
+                                   max_degree=self.max_degree, padded_table=ptable, segments=self.root_segments)
             if getattr(e, "_defer_sampler", False):
                 # not launched here: the descriptor rides in the step's optimizer launch (engine.finish_backward)
                 e._deferred_sampler = desc

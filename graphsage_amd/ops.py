@@ -114,7 +114,7 @@ def sample_fanout_csr(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, s
 
 def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, step_dev=None, hop0=0, root_offset=0,
                 order=None, cursor_dev=None, label_table=None, labels_out=None, law=0, max_degree=0, unsup=None,
-                padded_table=None):
+                padded_table=None, segments=None):
     """unsup = (pairs [n_pairs, 2] int32, n_pair_roots, cdf (uint32 bits), guide or None, guide_bits, n_neg, neg_seed): the
     roots are staged by the launch itself as [pairs[:, 0] | pairs[:, 1] | negatives] (see gs_fanout_desc).
     The arguments of sample_fanout_csr as a struct gs_fanout_desc (for gs_flat_reduce_adam_sample).  The tensors are
@@ -135,6 +135,8 @@ def fanout_desc(rowptr, col, n_nodes, pad_id, fans, offsets, ids_all, B, seed, s
     if labels_out is not None:
         q.labels_out, q.ld_out = labels_out.ptr, labels_out.ld
     q.padded_table = ptr(padded_table)
+    if segments is not None:       # root boundaries of the reference's three sample() calls (gs_fanout_desc.seg_begin)
+        q.seg_begin[0], q.seg_begin[1] = int(segments[0]), int(segments[1])
     q._keep = (rowptr, col, ids_all, step_dev, order, cursor_dev, label_table, labels_out, unsup, padded_table)
     if unsup is not None:
         pairs, n_pair_roots, cdf, guide, guide_bits, n_neg, neg_seed = unsup

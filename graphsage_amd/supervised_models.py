@@ -42,6 +42,9 @@ class SupervisedGraphsage(SampleAndAggregate):
                   "_tail_step_advanced")
 
     # ------------------------------------------------------------------------------ build (:78-100)
+    def _root_segments(self, n_roots):
+        return None           # one sample() call per step (supervised_models.py:79)
+
     def build(self):
         e = self.engine
         self.num_samples = [layer_info.num_samples for layer_info in self.layer_infos]

@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -461,6 +461,13 @@ typedef struct gs_fanout_desc {
      * ([n_nodes + 1, max_degree] int32, same seed / max_degree): a draw becomes one lookup table[id][column].  Same ids,
      * bit for bit, as without it. */
     const int32_t* padded_table;
+    /* GS_LAW_REFERENCE only: the roots [0, seg_begin[0]) | [seg_begin[0], seg_begin[1]) | [seg_begin[1], B) come from
+     * DIFFERENT sampler calls of the reference -- SampleAndAggregate._build runs sample(batch1), sample(batch2) and
+     * sample(neg_samples) (models.py:347-357), each with its own tf.random_shuffle per hop (neigh_samplers.py:27) -- so
+     * segment g uses the call ids hop0 + g * n_hops + h: six independent column permutations per unsupervised step.
+     * {0, 0} = one call (supervised); with pair staging the boundaries default to {n_pair_roots, 2 * n_pair_roots}.
+     * The staged negatives are keyed by root_offset + t, so data-parallel ranks draw different negatives. */
+    int64_t seg_begin[2];
 } gs_fanout_desc;
 /* The padded adjacency table of minibatch.py:227-245 under GS_LAW_REFERENCE's keyed law, built ON THE DEVICE from the CSR:
  * table[v][c] = the c-th entry of node v's (frozen) padded row -- a keyed sample without replacement of max_degree

@@ -161,6 +161,26 @@ def sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, ste
     return out
 
 
+def sample_uniform_csr_segments(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, step, hop, n_hops, seg_rows,
+                                global_row_offset=0, law=LAW_REFERENCE, max_degree=0):
+    """One hop of the UNSUPERVISED pass over the roots [batch1 | batch2 | negatives] under GS_LAW_REFERENCE: the reference
+    makes three sample() calls per step (models.py:347-357) and every sampler call shuffles its own columns
+    (neigh_samplers.py:27), so the rows of segment g (row boundaries `seg_rows` = (start of batch2's rows, start of the
+    negatives' rows) at THIS hop) use the call id g * n_hops + hop -- six independent permutations per step
+    (gs_fanout_desc.seg_begin).  The other laws draw per row and ignore the segments."""
+    ids = np.asarray(ids)
+    if law != LAW_REFERENCE or seg_rows is None:
+        return sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids, num_samples, seed, step, hop, global_row_offset, law,
+                                  max_degree)
+    bounds = [0, int(seg_rows[0]), int(seg_rows[1]), len(ids)]
+    parts = []
+    for g in range(3):
+        lo, hi = bounds[g], bounds[g + 1]
+        parts.append(sample_uniform_csr(rowptr, col, n_nodes, pad_id, ids[lo:hi], num_samples, seed, step, g * n_hops + hop,
+                                        global_row_offset + lo, law, max_degree))
+    return np.concatenate(parts, axis=0)
+
+
 def unigram_cdf_u32(degrees, distortion=0.75):
     """Fixed-point CDF of tf.nn.fixed_unigram_candidate_sampler(unigrams=degrees, distortion=0.75)
     (models.py:336-343): cdf[i] = floor(2^32 * P(node <= i)), last entry forced to 2^32-1."""
@@ -171,11 +191,13 @@ def unigram_cdf_u32(degrees, distortion=0.75):
     return cdf
 
 
-def sample_unigram(cdf, n_neg, seed, clock):
-    """Restatement of the negative draw of gs_unsup_stage: slot t -> first index whose cdf exceeds a 32-bit hash."""
+def sample_unigram(cdf, n_neg, seed, clock, slot_offset=0):
+    """Restatement of the negative draw of gs_unsup_stage: slot t -> first index whose cdf exceeds a 32-bit hash.
+    `slot_offset`: the fan-out sampler's staging keys slot t by root_offset + t (data-parallel ranks draw different
+    negatives); 0 on one GPU."""
     with np.errstate(over="ignore"):
         key = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (np.uint64(clock) * _G) ^ (np.uint64(0xFF) << np.uint64(56)))
-        r = (mix64(key + np.arange(n_neg, dtype=np.uint64)) >> np.uint64(32)).astype(np.uint64)
+        r = (mix64(key + np.arange(n_neg, dtype=np.uint64) + np.uint64(slot_offset)) >> np.uint64(32)).astype(np.uint64)
     idx = np.searchsorted(cdf.astype(np.uint64), r, side="right")
     return np.minimum(idx, len(cdf) - 1).astype(np.int32)
 

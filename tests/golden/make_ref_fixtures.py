@@ -480,6 +480,10 @@ SUP_CASES = {
     "sup_mean_identity": dict(aggregator_type="mean", concat=True, sigmoid=False, num_samples=[4, 3], dim=16,
                               max_degree=8, batch_size=16, batches=[list(range(5, 17)), list(range(33, 44))],
                               weight_decay=0.01, learning_rate=0.01, seed=8, np_seed=108, identity_dim=6),
+    # the headline model's own widths (dim_1 = dim_2 = 128, concat, fan-out <= 11): the device takes its fused-tail launch
+    "sup_mean_tail": dict(aggregator_type="mean", concat=True, sigmoid=False, num_samples=[4, 3], dim=128, max_degree=8,
+                          batch_size=32, batches=[list(range(8, 32)) + [40, 41, 42, 43, 44, 45, 46, 47, 48]],
+                          weight_decay=0.001, learning_rate=0.01, seed=13, np_seed=113),
     "sup_mean_dropout": dict(aggregator_type="mean", concat=True, sigmoid=False, num_samples=[4, 3], dim=16, max_degree=8,
                              batch_size=16, batches=[list(range(22, 35)), list(range(44, 52))], weight_decay=0.01,
                              learning_rate=0.01, seed=11, np_seed=111, dropout=0.3),

@@ -52,11 +52,16 @@ def _layer0_ties(model, n_roots, s2):
 LAW, MAXDEG = sampler_hash.LAW_REFERENCE, 128          # bench.py's default sampling law (--sampler_law reference)
 
 
-def _check_sampled_ids(got, roots, rowptr, col, N, fans, seed, t):
+def _check_sampled_ids(got, roots, rowptr, col, N, fans, seed, t, segments=None):
+    """`segments` = (start of batch2, start of the negatives) in the roots: the unsupervised pass, whose three root groups
+    are three sample() calls of the reference (models.py:347-357) with their own column permutations."""
     assert np.array_equal(got[0], roots)
     prev, hop = roots, 0
     for f, g in zip(fans, got[1:]):
-        want = sampler_hash.sample_uniform_csr(rowptr, col, N, N, prev, f, seed, t, hop, law=LAW, max_degree=MAXDEG)
+        rows_per_root = len(prev) // len(roots)
+        seg = None if segments is None else tuple(b * rows_per_root for b in segments)
+        want = sampler_hash.sample_uniform_csr_segments(rowptr, col, N, N, prev, f, seed, t, hop, len(fans), seg, law=LAW,
+                                                        max_degree=MAXDEG)
         assert np.array_equal(g, want.reshape(-1)), "hop %d ids differ from the hash restatement" % (hop + 1)
         prev, hop = want.reshape(-1), hop + 1
 
@@ -93,7 +98,10 @@ def test_unsupervised_benched_shapes_match_oracle(dev):
         neg = sampler_hash.sample_unigram(cdf, NEG, 123, t)
         roots = np.concatenate([sel[:, 0], sel[:, 1], neg]).astype(np.int32)
         got = [s.cpu().numpy() for s in model.samples1]
-        _check_sampled_ids(got, roots, rowptr, col, G.n_nodes, [S2, S1], 123, t)
+        _check_sampled_ids(got, roots, rowptr, col, G.n_nodes, [S2, S1], 123, t, segments=(B, 2 * B))
+        # batch1, batch2 and the negatives do NOT share their column permutations (six tf.random_shuffle per step)
+        for h, f in ((1, S2), (2, S1)):
+            assert len({tuple(sampler_hash.call_columns(123, t, g * 2 + h - 1, f, MAXDEG).tolist()) for g in range(3)}) == 3
         # ---- the oracle on exactly these ids
         with orc.relu_ties_from(_layer0_ties(model, n_roots, S2)):
             res = orc.unsupervised_fwd_bwd(before, feats, got, [1, S2, S2 * S1], model.dims, [S1, S2], B, NEG, "mean", True,

@@ -311,6 +311,45 @@ def test_reference_law_is_the_padded_table_law():
     assert len(seen_cols) == 8
 
 
+def test_reference_law_unsupervised_pass_is_three_reference_sample_calls():
+    """models.py:347-357: sample(batch1), sample(batch2), sample(neg_samples) -- three calls of models.py:254-275, i.e.
+    2 sampler calls each = SIX independent column permutations per step.  The one-pass restatement over the roots
+    [batch1 | batch2 | negatives] with segment call ids g * K + hop equals three orc.sample() runs on the padded table,
+    each fed its own permutations, and the six permutations are pairwise different."""
+    rng = np.random.default_rng(21)
+    N, M, fans, B, NEG = 250, 12, [4, 3], 9, 5
+    deg = rng.integers(0, 40, size=N)
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = np.concatenate([rng.permutation(N)[:d] for d in deg]).astype(np.int32)
+    padded = np.vstack([sampler_hash.virtual_padded_table(rowptr, col, N, N, 123, M), np.full((1, M), N, np.int32)])
+    roots = [rng.integers(0, N, size=B), rng.integers(0, N, size=B), rng.integers(0, N, size=NEG)]
+    allroots = np.concatenate(roots).astype(np.int32)
+    step, K = 3, len(fans)
+    # one pass, segmented call ids
+    prev, rows_per_root, got = allroots, 1, []
+    for hop, f in enumerate(fans):
+        seg = (B * rows_per_root, 2 * B * rows_per_root)
+        out = sampler_hash.sample_uniform_csr_segments(rowptr, col, N, N, prev, f, 123, step, hop, K, seg, law=1, max_degree=M)
+        got.append(out.reshape(-1))
+        prev, rows_per_root = out.reshape(-1), rows_per_root * f
+    # three reference sample() calls, each with its own permutations
+    perms = {}
+    per_group = []
+    for g, r in enumerate(roots):
+        pg = []
+        for hop, f in enumerate(fans):
+            cols = sampler_hash.call_columns(123, step, g * K + hop, f, M)
+            perms[(g, hop)] = tuple(cols.tolist())
+            pg.append(np.concatenate([cols, np.setdiff1d(np.arange(M), cols)]))
+        smp, _ = orc.sample(padded, r, fans[::-1], pg)        # num_samples_per_layer: call k uses layer K-1-k
+        per_group.append(smp)
+    for hop in range(K):
+        want = np.concatenate([per_group[g][hop + 1] for g in range(3)])
+        assert np.array_equal(got[hop], want), hop
+    assert len(set(perms.values())) == 6
+
+
 def test_distinct_law_properties():
     rng = np.random.default_rng(12)
     N, s = 200, 6

@@ -1,0 +1,181 @@
+"""-m gpu: the HIP path (through the C ABI) == the REFERENCE'S OWN CODE.
+
+tests/golden/ref_*.npz were computed by /root/reference/graphsage/*.py executed unmodified on the TF1 stand-in
+(tests/golden/make_ref_fixtures.py); the reference's padded adjacency tables, initial weights, batches, labels, column
+permutations and negatives are fed to the device model, and every step of the reference run is compared: sampled ids
+bit-exact; loss, predictions, embeddings, every gradient and the parameters after clip + Adam within north_star's 1e-4
+(fp32 run of the reference; gradients relative to the tensor's largest entry)."""
+import numpy as np
+import pytest
+import torch
+
+from graphsage_amd import engine as eng
+from graphsage_amd import inits
+from graphsage_amd.models import Placeholder, SAGEInfo, SampleAndAggregate
+from graphsage_amd.neigh_samplers import AdjInfo, PaddedAdjacency, UniformNeighborSampler
+from graphsage_amd.supervised_models import SupervisedGraphsage
+from ref_fixtures import SUP, UNSUP, Fixture, flat_items
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def close(got, want, msg, atol_rel=1e-4):
+    want = np.asarray(want)
+    np.testing.assert_allclose(np.asarray(got).reshape(want.shape), want, rtol=RTOL,
+                               atol=atol_rel * max(1e-2, float(np.abs(want).max())), err_msg=msg)
+
+
+def model_variables(model, supervised=True):
+    """name -> engine Variable in the fixture's naming."""
+    out = {}
+    for i, a in enumerate(model.aggregators):
+        for k, v in a.vars.items():
+            out["agg%d/%s" % (i, k)] = v
+        for l in getattr(a, "mlp_layers", []):
+            out["agg%d/mlp_weights" % i] = l.vars['weights']
+            out["agg%d/mlp_bias" % i] = l.vars['bias']
+    if supervised:
+        out["node_pred/weights"] = model.node_pred.vars['weights']
+        out["node_pred/bias"] = model.node_pred.vars['bias']
+    if model.embeds is not None:
+        out["embeds"] = model.embeds
+    return out
+
+
+def load_weights(model, fx, prefix, supervised=True):
+    mv = model_variables(model, supervised)
+    assert sorted(mv) == sorted(k[len(prefix):] for k in fx.z.files if k.startswith(prefix))
+    for k, v in mv.items():
+        v.assign(fx[prefix + k].astype(np.float32).reshape(v.numpy().shape))
+    if model.embeds is not None:
+        model._refresh_embeds()
+    eng.get_engine().sync()
+    return mv
+
+
+def build_supervised(fx):
+    c = fx.cfg
+    eng.reset_engine()
+    inits.set_seed(1)
+    e = eng.get_engine()
+    ph = {'labels': Placeholder('labels'), 'batch': Placeholder('batch1'), 'dropout': Placeholder('dropout', 0.),
+          'batch_size': Placeholder('batch_size')}
+    adj_info = AdjInfo(PaddedAdjacency(fx["graph/adj_train"], e.device))
+    sampler = UniformNeighborSampler(adj_info)
+    layer_infos = [SAGEInfo("node", sampler, s, fx.out_dim) for s in c["num_samples"]]
+    model = SupervisedGraphsage(fx["graph/labels"].shape[1], ph, fx["graph/feats"], adj_info, fx["graph/deg"], layer_infos,
+                                concat=c["concat"], aggregator_type=fx.agg, sigmoid_loss=c["sigmoid"],
+                                learning_rate=c["learning_rate"], weight_decay=c["weight_decay"],
+                                identity_dim=fx.identity_dim)
+    model.use_graphs = False                      # the padded sampler takes a host permutation per call
+    return e, ph, adj_info, sampler, model
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("name", SUP)
+def test_supervised_steps_equal_reference_run(dev, name, fuse):
+    fx = Fixture(name)
+    c = fx.cfg
+    e, ph, adj_info, sampler, model = build_supervised(fx)
+    model.fuse_head = model.fuse_sampler = model.fuse_tail = fuse
+    mv = load_weights(model, fx, "init/")
+    for s in range(fx.n_steps):
+        p = "s%d/" % s
+        batch, labels = fx[p + "batch"], fx[p + "labels"]
+        sampler.inject_perms(fx.perms(p, fx.K))
+        loss, preds = model.train_step({ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)})
+        if name == "sup_mean_tail":
+            assert bool(getattr(model, "_tail_used", False)) == fuse     # the headline step's fused-tail launch
+        for k in range(fx.K):                                           # S1/S2: bit-exact
+            assert np.array_equal(model.samples1[k + 1].cpu().numpy(), fx[p + "sampled%d" % k].reshape(-1)), (s, k)
+        close(loss, fx[p + "32/loss"], "loss step %d" % s)
+        close(preds, fx[p + "32/preds"], "preds step %d" % s)
+        close(model.outputs1.numpy(), fx[p + "32/outputs1"], "outputs1 step %d" % s)
+        for k, v in mv.items():
+            close(v.grad.numpy(), fx[p + "32/grad/" + k], "grad/%s step %d" % (k, s))
+        for k, v in mv.items():
+            want, g = fx[p + "32/after/" + k], fx[p + "32/grad/" + k]
+            got = v.numpy().reshape(want.shape)
+            # Adam's first steps move every entry by ~lr * sign(g): entries whose gradient is numerically zero on one
+            # side (|g| below fp32 noise) are decided by that noise -- compare the rest
+            solid = np.abs(g) > 1e-6 * max(1e-2, np.abs(g).max())
+            np.testing.assert_allclose(got[solid], want[solid], rtol=RTOL, atol=2e-5, err_msg="after/%s step %d" % (k, s))
+            assert solid.mean() > 0.5 or np.abs(g).max() == 0, k
+        # continue from the reference's parameters (each step is pinned by itself; Adam moments stay the device's)
+        for k, v in mv.items():
+            v.assign(fx[p + "32/after/" + k].astype(np.float32).reshape(v.numpy().shape))
+        if model.embeds is not None:
+            model._refresh_embeds()
+        e.sync()
+
+
+@pytest.mark.parametrize("name", ["sup_mean", "sup_gcn"])
+def test_evaluation_on_the_test_adjacency_equals_reference(dev, name):
+    """supervised_train.py:280-285: tf.assign(adj_info, test_adj) -> AdjInfo.assign; forward only."""
+    fx = Fixture(name)
+    e, ph, adj_info, sampler, model = build_supervised(fx)
+    load_weights(model, fx, "s%d/32/after/" % (fx.n_steps - 1))
+    adj_info.assign(PaddedAdjacency(fx["graph/adj_test"], e.device))
+    batch, labels = fx["eval/batch"], fx["eval/labels"]
+    sampler.inject_perms(fx.perms("eval/", fx.K))
+    loss, preds = model.eval_step({ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)})
+    for k in range(fx.K):
+        assert np.array_equal(model.samples1[k + 1].cpu().numpy(), fx["eval/sampled%d" % k].reshape(-1))
+    close(loss, fx["eval/32/loss"], "loss")
+    close(preds, fx["eval/32/preds"], "preds")
+
+
+@pytest.mark.parametrize("name", UNSUP)
+def test_unsupervised_steps_equal_reference_run(dev, name):
+    """models.py:332-405: three sample() calls with their OWN permutations (perm index g * K + k), the reference's
+    negatives, loss / MRR / affinities / embeddings / gradients / parameters after Adam."""
+    fx = Fixture(name)
+    c = fx.cfg
+    K, n_neg = fx.K, c["neg_sample_size"]
+    eng.reset_engine()
+    inits.set_seed(1)
+    e = eng.get_engine()
+    ph = {'batch1': Placeholder('batch1'), 'batch2': Placeholder('batch2'), 'neg_samples': Placeholder('neg'),
+          'dropout': Placeholder('dropout', 0.), 'batch_size': Placeholder('batch_size')}
+    adj_info = AdjInfo(PaddedAdjacency(fx["graph/adj_train"], e.device))
+    sampler = UniformNeighborSampler(adj_info)
+    layer_infos = [SAGEInfo("node", sampler, s, fx.out_dim) for s in c["num_samples"]]
+    model = SampleAndAggregate(ph, fx["graph/feats"], adj_info, fx["graph/deg"], layer_infos, concat=c["concat"],
+                               aggregator_type=fx.agg, learning_rate=c["learning_rate"], weight_decay=c["weight_decay"],
+                               neg_sample_size=n_neg)
+    model.use_graphs = False
+    mv = load_weights(model, fx, "init/", supervised=False)
+    for s in range(fx.n_steps):
+        p = "s%d/" % s
+        b1, b2, neg = fx[p + "batch1"], fx[p + "batch2"], fx[p + "neg_samples"]
+        B = len(b1)
+        sampler.inject_perms(fx.perms(p, 3 * K))
+        model.inject_negatives(neg)
+        loss, ranks, aff_all, mrr, outputs1 = model.train_step({ph['batch1']: b1, ph['batch2']: b2, ph['batch_size']: B})
+        roots = np.concatenate([b1, b2, neg])
+        assert np.array_equal(model.samples1[0].cpu().numpy(), roots)
+        for k in range(K):
+            want = np.concatenate([fx[p + "sampled%d" % (g * K + k)].reshape(-1) for g in range(3)])
+            assert np.array_equal(model.samples1[k + 1].cpu().numpy(), want), (s, k)
+        close(loss, fx[p + "32/loss"], "loss step %d" % s)
+        close(aff_all, fx[p + "32/aff_all"], "aff_all")
+        close(outputs1, fx[p + "32/outputs1"], "outputs1")
+        full = model.outputs_all.numpy()
+        close(full[B:2 * B], fx[p + "32/outputs2"], "outputs2")
+        close(full[2 * B:2 * B + n_neg], fx[p + "32/neg_outputs"], "neg_outputs")
+        ref_aff = fx[p + "32/aff_all"]
+        margin = np.abs(ref_aff[:, :-1] - ref_aff[:, -1:]).min(axis=1) > 1e-4           # float near-ties aside
+        assert np.array_equal(np.asarray(ranks)[margin], fx[p + "32/ranks"][:, -1][margin])
+        if margin.all():
+            close(mrr, fx[p + "32/mrr"], "mrr")
+        for k, v in mv.items():
+            close(v.grad.numpy(), fx[p + "32/grad/" + k], "grad/%s step %d" % (k, s))
+        for k, v in mv.items():
+            want, g = fx[p + "32/after/" + k], fx[p + "32/grad/" + k]
+            solid = np.abs(g) > 1e-6 * max(1e-2, np.abs(g).max())
+            np.testing.assert_allclose(v.numpy().reshape(want.shape)[solid], want[solid], rtol=RTOL, atol=2e-5,
+                                       err_msg="after/%s step %d" % (k, s))
+        for k, v in mv.items():
+            v.assign(fx[p + "32/after/" + k].astype(np.float32).reshape(v.numpy().shape))
+        e.sync()

@@ -312,3 +312,40 @@ def test_fanout_unsup_staging_bit_exact(dev):
     hop1 = sampler_hash.sample_uniform_csr(rowptr, col, N, N, roots, fans[0], 123, 7, 0)
     hop2 = sampler_hash.sample_uniform_csr(rowptr, col, N, N, hop1.reshape(-1), fans[1], 123, 7, 1)
     assert np.array_equal(got[offs[1]:offs[2]], hop1.reshape(-1)) and np.array_equal(got[offs[2]:offs[3]], hop2.reshape(-1))
+    # law "reference": batch1 | batch2 | negatives are three sample() calls of the reference (models.py:347-357), each
+    # with its own column permutation per hop -> segment call ids g * K + hop; virtual and materialised table agree
+    M = 32
+    table = ops.build_padded_table(rp, cl, N, N, M, 123)
+    hop1 = sampler_hash.sample_uniform_csr_segments(rowptr, col, N, N, roots, fans[0], 123, 7, 0, 2, (B, 2 * B), law=1,
+                                                    max_degree=M)
+    hop2 = sampler_hash.sample_uniform_csr_segments(rowptr, col, N, N, hop1.reshape(-1), fans[1], 123, 7, 1, 2,
+                                                    (B * fans[0], 2 * B * fans[0]), law=1, max_degree=M)
+    shared = sampler_hash.sample_uniform_csr(rowptr, col, N, N, roots, fans[0], 123, 7, 0, law=1, max_degree=M)
+    assert not np.array_equal(shared, hop1) and np.array_equal(shared[:B], hop1[:B])   # ONE shared permutation is not it
+    for tbl in (None, table):
+        ids_all = torch.full((int(offs[-1]),), -3, dtype=torch.int32, device=dev)
+        desc = ops.fanout_desc(rp, cl, N, N, fans, offs.tolist(), ids_all, n_roots, 123, step_dev=clk, cursor_dev=cur,
+                               unsup=(pairs_dev, B, cdf_dev, None, bits, nn, 123), law=1, max_degree=M, padded_table=tbl)
+        ops.sample_fanout_desc(desc)
+        _sync()
+        got = ids_all.cpu().numpy()
+        assert np.array_equal(got[:n_roots], roots)
+        assert np.array_equal(got[offs[1]:offs[2]], hop1.reshape(-1)) and np.array_equal(got[offs[2]:offs[3]], hop2.reshape(-1))
+    # roots already in the buffer (host-fed batches): explicit seg_begin, same ids
+    ids_all = torch.full((int(offs[-1]),), -3, dtype=torch.int32, device=dev)
+    ids_all[:n_roots] = torch.from_numpy(roots).to(dev)
+    desc = ops.fanout_desc(rp, cl, N, N, fans, offs.tolist(), ids_all, n_roots, 123, step_dev=clk, law=1, max_degree=M,
+                           padded_table=table, segments=(B, 2 * B))
+    ops.sample_fanout_desc(desc)
+    _sync()
+    got = ids_all.cpu().numpy()
+    assert np.array_equal(got[offs[1]:offs[2]], hop1.reshape(-1)) and np.array_equal(got[offs[2]:offs[3]], hop2.reshape(-1))
+    # data-parallel: rank r's negatives are keyed by its global root offset -> different ranks, different negatives
+    ids_all = torch.full((int(offs[-1]),), -3, dtype=torch.int32, device=dev)
+    desc = ops.fanout_desc(rp, cl, N, N, fans, offs.tolist(), ids_all, n_roots, 123, step_dev=clk, cursor_dev=cur,
+                           unsup=(pairs_dev, B, cdf_dev, None, bits, nn, 123), root_offset=n_roots)
+    ops.sample_fanout_desc(desc)
+    _sync()
+    neg1 = ids_all.cpu().numpy()[2 * B:n_roots]
+    assert np.array_equal(neg1, sampler_hash.sample_unigram(cdf, nn, 123, 7, slot_offset=n_roots))
+    assert not np.array_equal(neg1, roots[2 * B:])
