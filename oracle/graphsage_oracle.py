@@ -3,12 +3,15 @@
 TEST INFRASTRUCTURE ONLY.  Nothing under graphsage_amd/ may import this module.
 Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
 
-PARITY UNPINNED: the reference (williamleif/GraphSAGE, TF 1.x) ships no tests,
-no golden vectors and no recorded outputs, and TensorFlow is neither installed
-nor installable in the build container, so the reference itself cannot be run
-to generate fixtures.  This file is therefore a *restatement* of the reference
-op sequence in NumPy; every function cites the reference file:line it follows
-(paths relative to /root/reference/graphsage/).  It is pinned only by
+PARITY PINNED (round 4) to the reference's OWN source: tests/golden/make_ref_fixtures.py puts /root/reference on sys.path and
+executes graphsage/{minibatch,neigh_samplers,models,aggregators,layers,supervised_models,prediction}.py UNMODIFIED on
+tests/tf1_shim (a torch-backed stand-in for the ~70 TensorFlow 1.x entry points they use; TF 1.8 itself is not installable
+here) and commits what they computed as tests/golden/ref_*.npz: padded tables, sampled ids, loss, predictions, embeddings,
+MRR, every gradient and the parameters after clip + Adam for 14 runs (mean / GCN / max-pool / mean-pool, softmax and sigmoid,
+2 and 3 layers, identity features, dropout, unsupervised, evaluation on the test adjacency, short last batch,
+num_samples == max_degree, degree-0 and val/test nodes).  tests/test_ref_pin.py: THIS FILE == those fixtures, float64 twin
+at 1e-9, float32 at 1e-4, integer outputs bit-exact.  Every function still cites the reference file:line it follows
+(paths relative to /root/reference/graphsage/).  Further pins:
  (a) hand-computed integer fixtures in tests/golden/ (see tests/golden/make_golden.py, make_golden_more.py) and the
      big-int known answers of the sampler / dropout hashes (hash_kat.npz, law_kat.npz),
  (b) finite-difference checks of every backward function (tests/test_oracle.py),

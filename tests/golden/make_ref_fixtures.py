@@ -492,9 +492,10 @@ SUP_CASES = {
                                 learning_rate=0.01, seed=12, np_seed=112, dropout=0.25),
 }
 UNSUP_CASES = {
-    "unsup_mean": dict(aggregator_type="mean", concat=True, num_samples=[4, 3], dim=16, max_degree=8, batch_size=12,
+    # embedding widths of 64 (the device's link-prediction launch takes d in {64, 128, 256, 512})
+    "unsup_mean": dict(aggregator_type="mean", concat=True, num_samples=[4, 3], dim=32, max_degree=8, batch_size=12,
                        n_pairs=30, neg_sample_size=6, weight_decay=0.01, learning_rate=0.01, seed=9, np_seed=109),
-    "unsup_gcn": dict(aggregator_type="gcn", concat=False, num_samples=[3, 3], dim=8, max_degree=6, batch_size=10,
+    "unsup_gcn": dict(aggregator_type="gcn", concat=False, num_samples=[3, 3], dim=32, max_degree=6, batch_size=10,
                       n_pairs=18, neg_sample_size=5, weight_decay=0.0, learning_rate=0.02, seed=10, np_seed=110),
 }
 

@@ -101,7 +101,9 @@ def test_supervised_steps_equal_reference_run(dev, name, fuse):
             # side (|g| below fp32 noise) are decided by that noise -- compare the rest
             solid = np.abs(g) > 1e-6 * max(1e-2, np.abs(g).max())
             np.testing.assert_allclose(got[solid], want[solid], rtol=RTOL, atol=2e-5, err_msg="after/%s step %d" % (k, s))
-            assert solid.mean() > 0.5 or np.abs(g).max() == 0, k
+            dead = (g == 0) & (v.grad.numpy().reshape(g.shape) == 0)       # e.g. weights behind units that never fire:
+            np.testing.assert_allclose(got[dead], want[dead], rtol=0, atol=1e-6,     # only Adam's decaying moments move them
+                                       err_msg="after/%s step %d (zero gradient)" % (k, s))
         # continue from the reference's parameters (each step is pinned by itself; Adam moments stay the device's)
         for k, v in mv.items():
             v.assign(fx[p + "32/after/" + k].astype(np.float32).reshape(v.numpy().shape))

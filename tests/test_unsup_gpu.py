@@ -109,6 +109,16 @@ def build(agg_type="mean", concat=True, csr=False, wd=0.0, dim=32, nn=6, n_nodes
     return G, it, ph, sampler, model, ns
 
 
+def sample_three_calls(adj, b1, b2, neg, ns, perms):
+    """models.py:347-357: sample(batch1), sample(batch2), sample(neg_samples) -- each call of models.py:254-275 shuffles its
+    own columns; perms[g * K + k] is the permutation of group g's k-th sampler call.  Returns the per-hop id vectors of the
+    concatenated roots [batch1 | batch2 | negatives] (rows are independent, so one pass over them is the same computation)."""
+    K = len(ns)
+    groups = [orc.sample(adj, r, ns, perms[g * K:(g + 1) * K]) for g, r in enumerate((b1, b2, neg))]
+    samples = [np.concatenate([grp[0][h] for grp in groups]) for h in range(K + 1)]
+    return samples, groups[0][1]
+
+
 def oracle_agg_params(model, agg_type):
     out = []
     for a in model.aggregators:
@@ -128,7 +138,7 @@ def test_unsup_train_step_matches_oracle(dev, agg_type, concat):
     rng = np.random.RandomState(3)
     edges = it.train_edges[:29]                                  # ragged batch
     B = len(edges)
-    perms = [rng.permutation(it.max_degree) for _ in ns]
+    perms = [rng.permutation(it.max_degree) for _ in range(3 * len(ns))]     # six tf.random_shuffle per step
     params = oracle_agg_params(model, agg_type)
     sampler.inject_perms(perms)
     feed = {ph['batch1']: edges[:, 0], ph['batch2']: edges[:, 1], ph['batch_size']: B}
@@ -136,7 +146,7 @@ def test_unsup_train_step_matches_oracle(dev, agg_type, concat):
     neg = sampler_hash.sample_unigram(sampler_hash.unigram_cdf_u32(it.deg), nn, 123, 0)
     roots = np.concatenate([edges[:, 0], edges[:, 1], neg]).astype(np.int32)
     assert np.array_equal(model.samples1[0].cpu().numpy(), roots)            # same negatives as the oracle hash
-    samples, support = orc.sample(it.adj, roots, ns, perms)
+    samples, support = sample_three_calls(it.adj, edges[:, 0], edges[:, 1], neg, ns, perms)
     for got, want in zip(model.samples1, samples):
         assert np.array_equal(got.cpu().numpy(), want)
     res = orc.unsupervised_fwd_bwd(params, G.padded_features(), samples, support, model.dims, ns, B, nn, agg_type, concat,
@@ -161,14 +171,14 @@ def test_unsup_dropout_matches_oracle(dev):
     rng = np.random.RandomState(5)
     edges = it.train_edges[:21]
     B = len(edges)
-    perms = [rng.permutation(it.max_degree) for _ in ns]
+    perms = [rng.permutation(it.max_degree) for _ in range(3 * len(ns))]
     params = oracle_agg_params(model, "mean")
     sampler.inject_perms(perms)
     feed = {ph['batch1']: edges[:, 0], ph['batch2']: edges[:, 1], ph['batch_size']: B, ph['dropout']: rate}
     loss, ranks, aff_all, mrr, outputs1 = model.train_step(feed)
     neg = sampler_hash.sample_unigram(sampler_hash.unigram_cdf_u32(it.deg), nn, 123, 0)
     roots = np.concatenate([edges[:, 0], edges[:, 1], neg]).astype(np.int32)
-    samples, support = orc.sample(it.adj, roots, ns, perms)
+    samples, support = sample_three_calls(it.adj, edges[:, 0], edges[:, 1], neg, ns, perms)
     masks, _ = _device_masks(model, "mean", rate, 0, ns, len(roots))
     res = orc.unsupervised_fwd_bwd(params, G.padded_features(), samples, support, model.dims, ns, B, nn, "mean", True,
                                    weight_decay=wd, masks=masks)
