@@ -188,3 +188,25 @@ def test_bench_multistep_graphs_equal_single_steps(dev, agg_type, opt_share):
         assert np.array_equal(outs[0][1], other[1])
         assert np.array_equal(outs[0][2], other[2])
     assert np.isfinite(outs[0][0])
+
+
+def test_bench_timed_graph_lengths_equal_single_steps(dev):
+    """The graph lengths the bench itself times: `bench.py` on one GPU replays 32 steps per launch, and the driver's command
+    (--steps 20) is ONE 20-step graph.  Both give the bits of one-step launches: 32 + 32 + 32 (eager, capture, replay of the
+    32-step graph) + 20 + 20 + 20 (the same for the 20-step graph) = 156 steps."""
+    outs = []
+    for mode in ("multi", "single"):
+        G, it, model, order = build("mean")
+        if mode == "multi":
+            for _ in range(3):
+                model.train_steps_device(B, 32, steps_per_launch=32)
+            for _ in range(3):
+                model.train_steps_device(B, 20, steps_per_launch=32)
+        else:
+            for _ in range(156):
+                model.train_step_device(B)
+        loss, preds = model._fetch(B)
+        outs.append((loss, preds.copy(), model.engine.params.cpu().numpy().copy()))
+    assert outs[0][0] == outs[1][0] and np.isfinite(outs[0][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])

@@ -223,3 +223,35 @@ def test_negatives_follow_the_degree_law_support():
     deg = fx["graph/deg"]
     for s in range(fx.n_steps):
         assert (deg[fx["s%d/neg_samples" % s]] > 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the TIMED CPU baseline (oracle/cpu_baseline.py, bench.py's cpu_baseline leg) is the same computation
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["sup_mean", "sup_mean_3layer", "sup_mean_add_sigmoid", "sup_mean_tail"])
+def test_cpu_baseline_port_steps_equal_reference_run(name):
+    """The torch-CPU port whose step time bench.py reports as `cpu_baseline` trains exactly like the reference run:
+    sampled ids, loss, logits and the parameters after every clip + Adam step (its own Adam, moments carried)."""
+    import torch
+    from oracle.cpu_baseline import CpuSupervisedMean
+    fx = Fixture(name)
+    c = fx.cfg
+    port = CpuSupervisedMean(fx["graph/feats"], fx["graph/adj_train"], fx.dims, fx["graph/labels"].shape[1], c["num_samples"],
+                             concat=c["concat"], sigmoid_loss=c["sigmoid"], lr=c["learning_rate"],
+                             weight_decay=c["weight_decay"], threads=1)
+    port.set_params_from_oracle(fx.params("init/", np.float32))
+    for s in range(fx.n_steps):
+        p = "s%d/" % s
+        batch, labels = fx[p + "batch"], fx[p + "labels"]
+        samples, _ = port.sample(batch, fx.perms(p, fx.K))
+        for k in range(fx.K):
+            assert np.array_equal(samples[k + 1].numpy(), fx[p + "sampled%d" % k].reshape(-1))
+        loss, logits, _ = port.train_step(batch, labels, fx.perms(p, fx.K))
+        close(loss, fx[p + "32/loss"], "32", "loss")
+        close(logits, fx[p + "32/node_preds"], "32", "logits")
+        after = fx.params(p + "32/after/", np.float32)
+        for (wn, ws), a in zip(port.params, after["agg"]):
+            np.testing.assert_allclose(wn.detach().numpy(), a["neigh_weights"], rtol=1e-4, atol=2e-5)
+            np.testing.assert_allclose(ws.detach().numpy(), a["self_weights"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(port.W.detach().numpy(), after["node_pred"]["weights"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(port.b.detach().numpy(), after["node_pred"]["bias"], rtol=1e-4, atol=2e-5)
