@@ -41,7 +41,7 @@ def placeholders(unsup=False):
             'batch_size': Placeholder('batch_size')}
 
 
-def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_seed=123, sampler_law=None):
+def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_seed=123, sampler_law=None, sigmoid=False):
     """A fresh engine + model on the device-resident graph DG (features / CSR / labels are shared, not copied)."""
     from graphsage_amd import engine as eng
     from graphsage_amd.models import SAGEInfo, SampleAndAggregate
@@ -64,7 +64,7 @@ def build_model(DG, args, world, rank, model_name, unsupervised=False, sampler_s
     layer_infos = [SAGEInfo("node", sampler, args.samples_1, mult * args.dim_1),
                    SAGEInfo("node", sampler, args.samples_2, mult * args.dim_2)]
     model = SupervisedGraphsage(DG.num_classes, ph, DG.feats, adj_info, DG.deg, layer_infos,
-                                concat=(agg != "gcn"), aggregator_type=agg, sigmoid_loss=False,
+                                concat=(agg != "gcn"), aggregator_type=agg, sigmoid_loss=sigmoid,
                                 learning_rate=0.01, weight_decay=0.0, world_size=world, rank=rank)
     model.row_offset = rank * args.batch_size
     return e, model, ph, adj_info
@@ -187,6 +187,12 @@ def pmc_profile_path(args):
     return os.path.join(ROOT, "profiles", "k2_pmc_%s.json" % tag)
 
 
+def lib_digest():
+    """Source digest of the loaded library (graphsage_amd/_C/build.stamp, written by graphsage_amd.build)."""
+    p = os.path.join(ROOT, "graphsage_amd", "_C", "build.stamp")
+    return open(p).read().strip() if os.path.exists(p) else None
+
+
 def step_traffic_profile(args):
     """Per-step fabric-side bytes from the newest committed whole-step PMC profile (profiles/r*_step_traffic.json,
     benchmarks/profile_step_traffic.sh) -- only for the headline configuration it was taken on."""
@@ -208,7 +214,7 @@ def step_traffic_profile(args):
         if k not in by or l["launches_seen"] > by[k]["launches_seen"]:
             by[k] = l
     total = sum((l["hbm_read_MB"] + l["hbm_write_MB"]) * 1e6 for l in by.values())
-    return {"bytes_per_step": total, "path": os.path.relpath(paths[-1], ROOT)}
+    return {"bytes_per_step": total, "path": os.path.relpath(paths[-1], ROOT), "lib_digest": d.get("lib_digest")}
 
 
 def timed_events(e, fn, iters, between=None):
@@ -379,10 +385,15 @@ def main():
     achieved = alg_bytes / (k2_us * 1e-6) / 1e9
     unique_bytes = float(np.mean(uniq)) * F * 4 + n2 * s1 * 4 + n2 * F * 4
     traffic = traffic_src = None
+    traffic_stale = None
     pmc = pmc_profile_path(args)
     if os.path.exists(pmc) and args.workload == "reddit" and not args.unsupervised:
         with open(pmc) as fpm:
-            traffic = json.load(fpm)["traffic_bytes_per_launch"]
+            prof = json.load(fpm)
+        traffic = prof["traffic_bytes_per_launch"]
+        # the counters were collected on the library whose source digest the profile carries: a different library running
+        # now (kernels edited since) makes them stale -> `frac` falls back to the live unique-row bound below
+        traffic_stale = prof.get("lib_digest") != lib_digest()
         traffic_src = ("PROFILE-SOURCED, not measured by this run: %s (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of "
                        "this command on this graph; FETCH_SIZE calibrated on a known-byte gather, MI355X_MICROARCH.md HBM). "
                        "FETCH_SIZE counts at the L2's FABRIC side: reads served by the Infinity Cache (MALL) are included, so "
@@ -397,16 +408,18 @@ def main():
             "unique_row_bytes_per_launch": unique_bytes,
             "unique_rows_frac": float(np.mean(uniq)) / float(n2 * s1),
             "frac_unique_lower": min(achieved, unique_gbs) / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+            "lib_digest": lib_digest(),
             "traffic_basis": "L2 fabric-side bytes (Infinity-Cache hits included): upper bound on HBM bytes"}
-    if traffic is not None:
+    if traffic is not None and not traffic_stale:
         roof["frac"] = traffic / (k2_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         roof["frac_basis"] = ("L2 fabric-side bytes (traffic, upper bound on HBM bytes) / avg_launch_us / peak; the true HBM "
                               "fraction lies in [frac_unique_lower, frac]")
     else:
         roof["frac"] = min(achieved, unique_gbs) / HBM_PEAK_GBS
         roof["frac_basis"] = ("unique-row bytes (live lower bound of the HBM-side traffic: duplicate rows of a launch can be "
-                              "served by L2/MALL) / avg_launch_us / peak; no committed PMC profile for this configuration")
+                              "served by L2/MALL) / avg_launch_us / peak; no committed PMC profile of THIS library "
+                              "(source digest) for this configuration")
     result["roofline"] = roof
     # ---------------- the WHOLE step against the same roof: algorithmic bytes of a step (rows*F*4 + ids +
     # mean writes, all hops) / ms_per_step, and the fabric-side counter bytes of the step's launches from the committed
@@ -422,6 +435,7 @@ def main():
         step["frac_counter"] = stp["bytes_per_step"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
         step["wasted_traffic_ratio"] = stp["bytes_per_step"] / alg_step
         step["counter_source"] = "PROFILE-SOURCED: %s (L2 fabric-side bytes, upper bound on HBM bytes)" % stp["path"]
+        step["counter_stale"] = stp.get("lib_digest") != lib_digest()
     result["roofline_step"] = step
 
     # ---------------- roofline of the launch that dominates the step: the layer-0 contraction with the next step's
@@ -593,6 +607,94 @@ def f1_legs(DG, args, B, s1, s2, F, spl, seeds=5, steps=100, n_val=4096):
     return f1, cb
 
 
+def toy_ppi_leg(args):
+    """BASELINE configs[0]: `python -m graphsage.supervised_train --train_prefix ./example_data/ppi --model graphsage_mean
+    --sigmoid` (example_supervised.sh:1) on a toy-PPI-SHAPED synthetic graph (N = 14,755 from example_data/toy-ppi-id_map.json,
+    F = 50, C = 121 multi-hot; the reference's G / feats / class_map blobs are stripped), the driver's defaults: 10 epochs,
+    B = 512, fan-out 25x10, dims 128/128, max_degree 128, lr 0.01.  Two legs FROM THE SAME INITIAL WEIGHTS on the same epoch
+    orders: the torch-CPU port (the configuration's own device in BASELINE.json: 'reference TF-CPU path') and the MI355X engine
+    (CSR sampler, reference law, device epoch + hipGraphs); validation micro-F1 (sigmoid, threshold 0.5) on the test adjacency."""
+    from graphsage_amd import engine as eng
+    from graphsage_amd.models import SAGEInfo
+    from graphsage_amd.neigh_samplers import AdjInfo, CSRAdjacency, UniformNeighborSampler
+    from graphsage_amd.supervised_models import SupervisedGraphsage
+    from graphsage_amd.utils import build_csr, padded_from_csr, synthetic_graph
+    from oracle import graphsage_oracle as orc
+    from oracle.cpu_baseline import CpuSupervisedMean, port_micro_f1
+    N, F, C, B, s1, s2, D, MAXD, EPOCHS = 14755, 50, 121, 512, 25, 10, 128, 128, 10
+    G = synthetic_graph(n_nodes=N, feat_dim=F, num_classes=C, avg_degree=28, seed=123, multilabel=True)
+    nt = G.val_mask | G.test_mask
+    rp, col = build_csr(N, G.src, G.dst, keep=~(nt[G.src] | nt[G.dst]))
+    rp_t, col_t = build_csr(N, G.src, G.dst)
+    rng = np.random.RandomState(123)
+    adj, deg = padded_from_csr(rp, col, N, MAXD, rng)
+    test_adj, _ = padded_from_csr(rp_t, col_t, N, MAXD, rng)
+    feats, labels = G.padded_features(), G.label_matrix()
+    train_nodes = np.nonzero(~nt & (deg[:N] > 0))[0].astype(np.int32)
+    val = np.nonzero(G.val_mask)[0].astype(np.int32)
+    per_epoch = len(train_nodes) // B
+    order = np.concatenate([rng.permutation(train_nodes)[: per_epoch * B] for _ in range(EPOCHS)]).astype(np.int32)
+    steps = per_epoch * EPOCHS
+    # ---- CPU port: timed while it trains
+    t0 = time.time()
+    init = CpuSupervisedMean(feats[:1], adj[:1], [F, D, D], C, [s1, s2], seed=123)        # the port's initial weights
+    port = CpuSupervisedMean(feats, adj, [F, D, D], C, [s1, s2], sigmoid_loss=True, seed=123)
+    ts = []
+    for i in range(steps):
+        b = order[i * B:(i + 1) * B]
+        t1 = time.time()
+        port.train_step(b, labels[b])
+        ts.append(time.time() - t1)
+    cpu_f1 = port_micro_f1(port, test_adj, labels, val, batch_size=B, sigmoid=True)
+    cpu_s = float(np.median(ts[2:]))
+    cpu_wall = time.time() - t0
+    # ---- MI355X
+    eng.reset_engine()
+    e = eng.get_engine()
+    adj_info = AdjInfo(CSRAdjacency(rp, col, N, e.device))
+    sampler = UniformNeighborSampler(adj_info, seed=123, law=args.sampler_law, max_degree=MAXD)
+    ph = placeholders()
+    layer_infos = [SAGEInfo("node", sampler, s1, D), SAGEInfo("node", sampler, s2, D)]
+    model = SupervisedGraphsage(C, ph, feats, adj_info, deg, layer_infos, concat=True, aggregator_type="mean",
+                                sigmoid_loss=True, learning_rate=0.01, weight_decay=0.0)
+    for agg, (wn, ws) in zip(model.aggregators, init.params):
+        agg.vars['neigh_weights'].assign(wn.detach().numpy())
+        agg.vars['self_weights'].assign(ws.detach().numpy())
+    model.node_pred.vars['weights'].assign(init.W.detach().numpy())
+    model.node_pred.vars['bias'].assign(init.b.detach().numpy())
+    e.snapshot_initial_parameters()
+    model.attach_device_epoch(order, labels)
+    spl = min(args.steps_per_launch or 32, 32)
+    model.train_steps_device(B, steps, steps_per_launch=spl)
+    e.sync()
+    train_adj = adj_info.current
+    adj_info.assign(CSRAdjacency(rp_t, col_t, N, e.device))                 # supervised_train.py:280
+    preds = []
+    for a in range(0, len(val), B):
+        b = val[a:a + B]
+        _, p = model.eval_step({ph['batch']: b, ph['labels']: labels[b], ph['batch_size']: len(b)})
+        preds.append(p)
+    adj_info.assign(train_adj)
+    gpu_f1 = orc.calc_f1_micro(labels[val], np.vstack(preds), True)
+    K = 64
+    for _ in range(2):
+        model.train_steps_device(B, K, steps_per_launch=spl)
+    e.sync()
+    t0 = time.time()
+    model.train_steps_device(B, K, steps_per_launch=spl)
+    e.sync()
+    gpu_s = (time.time() - t0) / K
+    edges = B * (s2 + s2 * s1)
+    return {"config": "configs[0]: toy-PPI-shaped (N=%d, F=%d, C=%d multi-hot, avg degree 28) supervised graphsage_mean --sigmoid, "
+                      "B=%d, fan-out %dx%d, dims %d/%d, %d epochs = %d steps (example_supervised.sh:1 semantics; synthetic "
+                      "data: the reference's toy-ppi blobs are stripped)" % (N, F, C, B, s1, s2, D, D, EPOCHS, steps),
+            "cpu_port": {"s_per_step": cpu_s, "value": edges / cpu_s, "unit": "sampled-edges/s", "cores": int(port.threads),
+                         "kind": "port", "val_micro_f1": float(cpu_f1), "wall_s": cpu_wall},
+            "mi355x": {"ms_per_step": gpu_s * 1e3, "value": edges / gpu_s, "unit": "sampled-edges/s",
+                       "val_micro_f1": float(gpu_f1), "sampler_law": args.sampler_law},
+            "val_nodes": int(len(val)), "train_steps": int(steps)}
+
+
 def run_aux(DG, args, B, s1, s2):
     """Short timed runs of the other BASELINE configurations so that the driver's record carries them:
     configs[2] maxpool, configs[3] unsupervised (one GPU's share), configs[4] RMAT (one GPU's share)."""
@@ -622,6 +724,17 @@ def run_aux(DG, args, B, s1, s2):
     except Exception as ex:            # an aux failure must not lose the headline line
         out["graphsage_maxpool"] = {"error": repr(ex)}
     try:
+        e, model, ph, _ = build_model(DG, args, 1, 0, "gcn")
+        model.attach_device_epoch(np.random.RandomState(123).permutation(DG.train_nodes), DG.label_table)
+        r = timed(model, e, B, s1)
+        r["config"] = ("configs[1]-shaped: Reddit-shaped supervised gcn (GCNAggregator, dims 2x%d, concat off: "
+                       "supervised_train.py:175-185), fan-out %dx%d, batch %d" % (args.dim_1, s1, s2, B))
+        r["loss_after"] = model._fetch(B)[0]
+        out["gcn"] = r
+        del model
+    except Exception as ex:
+        out["gcn"] = {"error": repr(ex)}
+    try:
         e, model, ph, _ = build_model(DG, args, 1, 0, "graphsage_mean", unsupervised=True)
         pairs = random_walk_pairs_device(DG.train_csr[0], DG.train_csr[1], DG.train_nodes, max_pairs=1000000, seed=123)
         model.attach_device_pairs(pairs.cpu().numpy())
@@ -644,6 +757,14 @@ def run_aux(DG, args, B, s1, s2):
         out["rmat"] = r
     except Exception as ex:
         out["rmat"] = {"error": repr(ex)}
+    try:
+        del e, model
+    except Exception:
+        pass
+    try:
+        out["toy_ppi"] = toy_ppi_leg(args)
+    except Exception as ex:
+        out["toy_ppi"] = {"error": repr(ex)}
     return out
 
 

@@ -40,6 +40,11 @@ def main():
         dur = float(np.mean([d for _, d in fv])) / 1e3 if fv else float("nan")
         res["launches"].append({"kernel": key[0], "grid": key[1], "launches_seen": len(fv), "hbm_read_MB": rd / 1e6, "hbm_write_MB": wr / 1e6,
                                 "avg_us_under_pmc": dur, "TBps": (rd + wr) / (dur * 1e-6) / 1e12 if dur == dur and dur > 0 else None})
+    # the kernels these counters belong to: digest of the library's sources (graphsage_amd/_C/build.stamp); bench.py marks the
+    # profile stale when it differs from the library it runs
+    import os
+    stamp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "graphsage_amd", "_C", "build.stamp")
+    res["lib_digest"] = open(stamp).read().strip() if os.path.exists(stamp) else None
     json.dump(res, open(out, "w"), indent=1)
     for r in res["launches"]:
         print("%-28s grid %8d  x%3d  read %7.1f MB  write %6.1f MB  %6.1f us  %s TB/s" % (

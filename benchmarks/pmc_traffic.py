@@ -41,6 +41,11 @@ def main():
         "avg_duration_us_under_pmc": float(np.mean([d for _, d in f])) / 1e3,
     }
     res["traffic_over_algorithmic"] = res["traffic_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+    # the kernels these counters belong to: digest of the library's sources (graphsage_amd/_C/build.stamp); bench.py marks the
+    # profile stale when it differs from the library it runs
+    import os
+    stamp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "graphsage_amd", "_C", "build.stamp")
+    res["lib_digest"] = open(stamp).read().strip() if os.path.exists(stamp) else None
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
