@@ -1,0 +1,96 @@
+"""Micro-benchmark: the layer-0 contraction at the Reddit / unsupervised / GCN step shapes -- fp32-MFMA stream kernel
+(gs_sage_dense_fwd_stream) vs the split-MFMA kernel (gs_sage_dense_fwd_split: fp32 operands as three bf16 pieces), alone
+(hot operands, back-to-back launches) and with a share of the next step's gather co-scheduled.
+    python benchmarks/micro_split.py"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphsage_amd import ops  # noqa: E402
+from graphsage_amd.ops import Mat  # noqa: E402
+
+
+def timeit(fn, stream, iters=40, warmup=8):
+    for _ in range(warmup):
+        fn()
+    e0, e1 = ops.Event(), ops.Event()
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    return e0.elapsed_ms(e1) / iters * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    st = ops.Stream()
+    s = st.handle
+    N, F, B, s1, s2, D = 232965, 602, 512, 25, 10, 128
+    g = torch.Generator(device="cpu").manual_seed(0)
+    X = Mat(torch.randn((N + 1, 608), generator=g).to(dev), F)
+    X.buf[:, F:] = 0
+    res = {}
+    for tag, roots in (("reddit", B), ("unsup", 2 * B + 20)):
+        n = roots * (1 + s2)
+        ids_self = torch.randint(0, N, (n,), generator=g, dtype=torch.int32).to(dev)
+        idx2 = torch.randint(0, N, (roots * s2 * s1,), generator=g, dtype=torch.int32).to(dev)
+        means = Mat.zeros(n, F, dev, 32)
+        means.buf[:, :F].normal_()
+        Ws = Mat(torch.randn((F, D), generator=g).to(dev) * 0.05, D)
+        Wn = Mat(torch.randn((F, D), generator=g).to(dev) * 0.05, D)
+        W3s, W3n = ops.split_rows(Ws, stream=s), ops.split_rows(Wn, stream=s)
+        out = Mat.zeros(n, 2 * D, dev)
+        m2 = Mat.zeros(roots * s2, F, dev, 32)
+        job = [ops.gather_job(X, idx2, roots * s2, s1, m2)]
+        r = {}
+        r["split_rows_us"] = timeit(lambda: ops.split_rows(Ws, out=W3s, stream=s), s)
+        r["fp32_stream_alone_us"] = timeit(lambda: ops.sage_dense_fwd_stream(X, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s), s)
+        r["split_alone_us"] = timeit(lambda: ops.sage_dense_fwd_split(X, ids_self, means, n, W3s, W3n, D, ops.ACT_RELU, None, out, [], stream=s), s)
+        r["gather_alone_us"] = timeit(lambda: ops.gather_mean_fwd(X, idx2, roots * s2, s1, out=m2, stream=s), s)
+        for frac in (0.15, 0.5, 1.0):
+            head, _ = ops.split_gather_jobs(job, frac)
+            r["fp32_stream_cogather_%.2f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_stream(X, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, head, stream=s), s)
+            r["split_cogather_%.2f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_split(X, ids_self, means, n, W3s, W3n, D, ops.ACT_RELU, None, out, head, stream=s), s)
+        # GCN form: one term, N = 256
+        Wg = Mat(torch.randn((F, 2 * D), generator=g).to(dev) * 0.05, 2 * D)
+        W3g = ops.split_rows(Wg, stream=s)
+        r["gcn_fp32_stream_alone_us"] = timeit(lambda: ops.sage_dense_fwd_stream(None, None, means, n, None, Wg, 2 * D, ops.ACT_RELU, None, out, [], stream=s), s)
+        r["gcn_split_alone_us"] = timeit(lambda: ops.sage_dense_fwd_split(None, None, means, n, None, W3g, 2 * D, ops.ACT_RELU, None, out, [], stream=s), s)
+        res[tag] = r
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__" and len(sys.argv) == 1:
+    main()
+
+
+def pool():
+    """The pooling MLP GEMM of the max-pool step at its real shape: 83 k distinct rows x 602 -> 512."""
+    dev = torch.device("cuda:0")
+    st = ops.Stream()
+    s = st.handle
+    N, F, H = 232965, 602, 512
+    g = torch.Generator(device="cpu").manual_seed(0)
+    X = Mat(torch.randn((N + 1, 608), generator=g).to(dev), F)
+    X.buf[:, F:] = 0
+    rows = 133120
+    ids = torch.sort(torch.randperm(N, generator=g)[:83000]).values.to(torch.int32).to(dev)
+    cnt = torch.tensor([83000], dtype=torch.int32, device=dev)
+    W = Mat(torch.randn((F, H), generator=g).to(dev) * 0.05, H)
+    b = torch.zeros(H, device=dev)
+    W3 = ops.split_rows(W, stream=s)
+    out = Mat.zeros(rows, H, dev)
+    r = {}
+    r["pool_fp32_tiled_us"] = timeit(lambda: ops.call("gs_dense_fwd_rows_dev", X.ptr, X.ld, ops.ptr(ids), F, rows, ops.ptr(cnt), W.ptr, W.ld,
+                                                       H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, s), s, iters=10, warmup=3)
+    r["pool_split_tiled_us"] = timeit(lambda: ops.call("gs_dense_fwd_rows_split", X.ptr, X.ld, ops.ptr(ids), F, rows, ops.ptr(cnt), ops.ptr(W3),
+                                                        H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, s), s, iters=10, warmup=3)
+    r["GF"] = 2.0 * 83000 * F * H / 1e9
+    print(json.dumps(r, indent=1))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pool":
+    pool()

@@ -238,8 +238,15 @@ class MeanAggregator(_SageBase):
         if side_jobs or stream_fwd:
             # horizontally fused launch: the contraction workgroups + the NEXT step's gather-mean waves share the CUs.
             # Stream form (gs_stream.hip): split-K workgroups without LDS staging, the self rows gathered in the A loads.
+            split_fwd = stream_fwd and e.split_gemm
+
             def launch(jobs=list(side_jobs or ())):
-                if stream_fwd:
+                if split_fwd:
+                    # the same contraction on the bf16 matrix pipe, operands cut into three bf16 pieces (fp32 accuracy)
+                    ops.sage_dense_fwd_split(self_all.src, self_all.ids, means, n_total, e.split_of(self.vars['self_weights']),
+                                             e.split_of(self.vars['neigh_weights']), self.output_dim, self.act_code, b, out,
+                                             jobs, stream=e.stream)
+                elif stream_fwd:
                     ops.sage_dense_fwd_stream(self_all.src, self_all.ids, means, n_total, self.vars['self_weights'].value,
                                               self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, jobs,
                                               stream=e.stream)
@@ -252,9 +259,12 @@ class MeanAggregator(_SageBase):
             d_in = self_all.src.d
             jobs_ = list(side_jobs or ())
             self.last_fused_launch = (launch, {
-                "kernel": "%s: [%d x %d|%d] . [%d x %d] x2 (fp32 MFMA) + %d co-scheduled "
-                          "gather+mean jobs of the next step" % ("sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
-                                                                 n_total, d_in, means.d, d_in, self.output_dim, len(jobs_)),
+                "kernel": "%s: [%d x %d|%d] . [%d x %d] x2 (%s) + %d co-scheduled "
+                          "gather+mean jobs of the next step" % ("sage_split_fwd_kernel" if split_fwd else
+                                                                 "sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
+                                                                 n_total, d_in, means.d, d_in, self.output_dim,
+                                                                 "fp32 as 3 bf16 pieces, 6 bf16 MFMAs per product" if split_fwd
+                                                                 else "fp32 MFMA", len(jobs_)),
                 "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in jobs_),
                 "gemm_bytes": n_total * (d_in + means.d) * 4 + (d_in + means.d) * self.output_dim * 4 + n_total * n_out * 4,
                 "flops": 2.0 * n_total * (d_in + means.d) * self.output_dim,
@@ -408,7 +418,11 @@ class GCNAggregator(_SageBase):
             means = self.prefetch(self_all, neighs)
         out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
-        if e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
+        if e.stream_gemm and e.split_gemm and n_total > 2048 and rate == 0:
+            # split-MFMA form (gs_split.hip): fp32 operands as three bf16 pieces on the bf16 matrix pipe
+            ops.sage_dense_fwd_split(None, None, means, n_total, None, e.split_of(self.vars['weights']), self.output_dim,
+                                     self.act_code, b, out, side_jobs, stream=e.stream)
+        elif e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
             # stream form: LDS-free contraction waves (+ the next step's gather jobs) in one launch
             ops.sage_dense_fwd_stream(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
                                       b, out, side_jobs, stream=e.stream)
@@ -557,8 +571,14 @@ class _PoolingAggregator(_SageBase):
                      ops.ptr(inv), ops.ptr(cnt), e.stream)
             Hu = e.ws_mat((self.name, "H_unique", k), rows_total, self.hidden_dim)
             W, bmlp = mlp.vars['weights'].value, mlp.vars['bias'].value.buf
-            ops.call("gs_dense_fwd_rows_dev", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt), W.ptr, W.ld,
-                     self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld, e.stream)
+            if e.split_pool:
+                # the 51 GF of the pooling MLP on the bf16 matrix pipe, operands as three bf16 pieces (fp32 accuracy)
+                ops.call("gs_dense_fwd_rows_split", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt),
+                         ops.ptr(e.split_of(mlp.vars['weights'])), self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld,
+                         e.stream)
+            else:
+                ops.call("gs_dense_fwd_rows_dev", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt), W.ptr, W.ld,
+                         self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld, e.stream)
             r = hr = 0
             for nv in neighs:
                 n, s, _ = nv.shape3

@@ -1,0 +1,524 @@
+// fp32 contractions on the bf16 matrix pipe, EXACTLY: every fp32 operand is cut into three bf16 pieces
+//     x = h + m + l,   h = top 8 significant bits of x, m = the next 8, l = the last 8   (24 = 8 + 8 + 8: no bit is lost)
+// and a product of two fp32 numbers is the sum of piece products, each of which the bf16 MFMA forms exactly (8 x 8 bits) and
+// accumulates in fp32.  Six of the nine piece products are kept -- hh, hm, mh, mm, hl, lh; the dropped ml, lm, ll are
+// <= 3 * 2^-24 |x y|, the size of ONE fp32 rounding -- so a K-term dot product carries the error of an fp32 FMA chain
+// (measured against fp64: tests/test_split_gemm_gpu.py), while v_mfma_f32_32x32x16_bf16 issues every 32 cycles for 32 x 32 x
+// 16 MACs against 64 cycles for 32 x 32 x 2 on the fp32 form: 6 / 16 of the matrix-pipe time.  (MI355X_MICROARCH.md: fp32 MFMA
+// = the fp32 VECTOR rate, 1/16 of bf16; there is no xf32 on gfx950.)  dtype stays f32: inputs, outputs and accumulation are
+// fp32, no value is rounded to bf16 anywhere.
+//
+//   gs_split_rows             W [K, N] fp32 -> W3 [2 ceil(K/16)][3][N][8] bf16: per group of 8 k and piece, the N columns side by
+//                             side (16 bytes each), so that the 32 lanes of a B-fragment load read 512 contiguous bytes (a
+//                             first version kept a column's pieces together -- 48-byte records 3.6 KB apart between lanes:
+//                             64 cache lines per wave load, and the kernel ran at the texture addresser's pace, 40 us)
+//   gs_sage_dense_fwd_split   the layer-0 contraction of a mean / GCN step (aggregators.py:51-58 / :110), drop-in for
+//                             gs_sage_dense_fwd_stream: A operands (gathered self rows, neighbor means) are read as fp32
+//                             and cut in registers (11 VALU per 2 elements, in the shadow of the MFMAs), B operands come
+//                             pre-cut from W3.  One WAVE per 32 x 64 output tile over the whole K: no LDS, no barrier, no
+//                             split-K epilogue; gather jobs of the next step ride as extra workgroups like before.
+#include "gs_common.h"
+#include "gs_gather_dev.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t gs_hi16_pair(const float x, const float y) {   // bf16 bits of x (low half) and y (high half)
+    return __builtin_amdgcn_perm(__float_as_uint(y), __float_as_uint(x), 0x07060302u);
+}
+__device__ __forceinline__ float gs_top16(const float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+
+// two fp32 values -> their three bf16 pieces, packed pairwise.  Truncation, not rounding: every subtraction is exact.
+__device__ __forceinline__ void gs_split2(const float x, const float y, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const float rx = x - gs_top16(x), ry = y - gs_top16(y);       // <= 16 significant bits
+    const float sx = rx - gs_top16(rx), sy = ry - gs_top16(ry);   // <= 8 significant bits: exact in bf16
+    h = gs_hi16_pair(x, y);
+    m = gs_hi16_pair(rx, ry);
+    l = gs_hi16_pair(sx, sy);
+}
+__device__ __forceinline__ void gs_split8(const f32x4 a0, const f32x4 a1, u32x4& h, u32x4& m, u32x4& l) {
+#ifdef GS_DIAG_SPLIT_NOCUT    // diagnostics builds only (benchmarks/probes/build_variant.sh): wrong values, the kernel's time without the cut
+    h = u32x4{__float_as_uint(a0.x), __float_as_uint(a0.y), __float_as_uint(a0.z), __float_as_uint(a0.w)};
+    m = u32x4{__float_as_uint(a1.x), __float_as_uint(a1.y), __float_as_uint(a1.z), __float_as_uint(a1.w)};
+    l = h;
+    return;
+#endif
+    uint32_t hh[4], mm[4], ll[4];
+    gs_split2(a0.x, a0.y, hh[0], mm[0], ll[0]);
+    gs_split2(a0.z, a0.w, hh[1], mm[1], ll[1]);
+    gs_split2(a1.x, a1.y, hh[2], mm[2], ll[2]);
+    gs_split2(a1.z, a1.w, hh[3], mm[3], ll[3]);
+    h = u32x4{hh[0], hh[1], hh[2], hh[3]};
+    m = u32x4{mm[0], mm[1], mm[2], mm[3]};
+    l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+}
+
+__device__ __forceinline__ f32x16 gs_mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ W -> W3
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ W, int64_t ldw, int32_t K, int32_t N,
+                                                         u32x4* __restrict__ W3) {
+    const int KG = ((K + 15) / 16) * 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // t = kg * N + n: consecutive lanes, consecutive n
+    if (t >= (int64_t)KG * N) return;
+    const int kg = (int)(t / N), n = (int)(t - (int64_t)kg * N);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * kg + j;
+        v[j] = k < K ? W[(int64_t)k * ldw + n] : 0.f;
+    }
+    u32x4 h, m, l;
+    gs_split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, h, m, l);
+    u32x4* dst = W3 + (int64_t)kg * 3 * N + n;
+    dst[0] = h; dst[(int64_t)N] = m; dst[2 * (int64_t)N] = l;
+}
+
+static inline int64_t split_rows_bytes(int32_t K, int32_t N) { return (int64_t)N * (((K + 15) / 16) * 2) * 48; }
+
+extern "C" int gs_split_rows_bytes(int32_t K, int32_t N, int64_t* bytes_out_host) {
+    GS_REQUIRE(K > 0 && N > 0 && bytes_out_host, "gs_split_rows_bytes: bad args");
+    *bytes_out_host = split_rows_bytes(K, N);
+    return GS_OK;
+}
+
+extern "C" int gs_split_rows(const float* W, int64_t ldw, int32_t K, int32_t N, void* W3, void* stream) {
+    GS_REQUIRE(W && W3 && K > 0 && N > 0 && ldw >= N, "gs_split_rows: bad args");
+    GS_REQUIRE(gs_aligned16(W3), "gs_split_rows: W3 must be 16-byte aligned");
+    const int64_t total = (int64_t)N * (((K + 15) / 16) * 2);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)gs_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, K, N,
+                       (u32x4*)W3);
+    GS_LAUNCH_CHECK("split_rows_kernel");
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct SplitTerm {
+    const float* A;        // [*, lda] fp32; row i of the term is A[a_idx ? a_idx[i] : i]
+    const int32_t* a_idx;  // nullable row gather (layer 0: the self rows of the feature table)
+    const u32x4* W3;       // gs_split_rows(W [K, N])
+    int32_t lda;
+};
+struct SplitFwdArgs {
+    SplitTerm t[2];
+    int32_t nterms;        // 1, or 2 (concat: term i writes columns [i*N, (i+1)*N))
+    int32_t M, N, K;
+    float* C;
+    int32_t ldc;
+    const float* bias;     // indexed by output column (incl. the concat offset), nullable
+    int32_t act;
+    int32_t tiles_n;       // 64-column tiles per term
+    int32_t n_waves;       // contraction waves = tiles_m * tiles_n * nterms
+};
+
+// One WAVE: C[m0 .. m0+31][n0 .. n0+63] of one term over the whole K.
+//   step s (16 k): lane (r = lane & 31, g = lane >> 5) holds A[row r][16 s + 8 g .. + 7] (two 16-byte loads, cut into pieces
+//   in registers) and, for both 32-column halves, the three pre-cut pieces of W[16 s + 8 g .. + 7][column r] (three 16-byte
+//   loads each: 32 lanes x 16 contiguous bytes); 12 MFMAs.  Both operand streams run D steps ahead of their use (vmcnt
+//   retires loads in order, so a deeper A ring would only wait behind the B loads issued after it).
+template <int D>
+__device__ __forceinline__ void split_fwd_wave(const SplitFwdArgs& g, const int item, const int lane) {
+    constexpr int DA = D, DB = D, U = (D % 2) ? 2 * D : D;     // ring depth; unrolled group (even: the piece buffers alternate)
+    const int l31 = lane & 31, lh = lane >> 5;
+    // The four waves of a workgroup = four ROW tiles of the same (term, column tile): they read the same B fragments at about
+    // the same time, so three of four B loads hit in the CU's L1 -- register-streaming contractions are bound by the L2 -> CU
+    // bandwidth of the operand re-reads (measured: 218 MB per launch at the Reddit shape when every wave streams its own B).
+    const int tiles_m = g.n_waves / (g.nterms * g.tiles_n);
+    const int combo = item / tiles_m, tile_m = item - combo * tiles_m;
+    const int term = combo / g.tiles_n, tile_n = combo - term * g.tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 64;
+    const SplitTerm& T = g.t[term];
+    const int K = g.K, N = g.N;
+    const int S = (K + 15) >> 4;                       // steps; the last one may hold k >= K (A masked, W3 zero-padded)
+    const int KG = 2 * S;
+    const int arow = min(m0 + l31, g.M - 1);
+    const int64_t srow = T.a_idx ? (int64_t)T.a_idx[arow] : (int64_t)arow;
+    const float* ap = T.A + srow * T.lda + 8 * lh;
+    const int c0 = min(n0 + l31, N - 1), c1 = min(n0 + 32 + l31, N - 1);     // clamped: never stored if >= N
+    const char* __restrict__ Wb = (const char*)T.W3;   // uniform base + 32-bit byte offsets (one VALU add per stream and step)
+    const uint32_t plane = (uint32_t)N * 16u;          // bytes between the pieces of a group
+    uint32_t bo0 = ((uint32_t)lh * 3u * (uint32_t)N + (uint32_t)c0) * 16u, bo1 = ((uint32_t)lh * 3u * (uint32_t)N + (uint32_t)c1) * 16u;
+    // the last step is handled apart when K % 16 != 0 (A columns >= K are masked; pad columns up to round_up(K, 4) readable)
+    const int Sfull = (K & 15) ? S - 1 : S;
+    // Two accumulators per column half: the bf16 MFMA adds into its accumulator with truncation, a bias that grows with the
+    // number of additions into a LARGE sum (measured: one accumulator for all six piece products = 228 additions over K = 602
+    // -> 4.7e-6 of the row's rms against 1.9e-6 for the fp32 FMA chain).  The h h products (38 additions) get their own; the
+    // five small products (<= 2^-8 of it) meet in a second one whose truncation is 2^-8 smaller; they are added once at the end.
+    f32x16 acc0, acc1, sml0, sml1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; sml0[e] = 0.f; sml1[e] = 0.f; }
+    f32x4 a[DA][2];
+    u32x4 b[DB][6];
+    int a_left = Sfull - 1, b_left = Sfull - 1;        // pointer advances still allowed (a refill past the end re-reads the
+                                                       // last full step: valid address, value never used)
+    auto load_a = [&](const int slot) {
+#ifdef GS_DIAG_SPLIT_NOA
+        a[slot][0] = f32x4{__int_as_float((int)(uintptr_t)ap), 0.f, 1.f, 2.f}; a[slot][1] = a[slot][0];
+#else
+        a[slot][0] = *reinterpret_cast<const f32x4*>(ap);
+        a[slot][1] = *reinterpret_cast<const f32x4*>(ap + 4);
+#endif
+        ap += a_left > 0 ? 16 : 0;
+        --a_left;
+    };
+    auto load_b = [&](const int slot) {
+#ifdef GS_DIAG_SPLIT_NOB
+        b[slot][0] = b[slot][1] = b[slot][2] = u32x4{bo0, 1u, 2u, 3u}; b[slot][3] = b[slot][4] = b[slot][5] = u32x4{bo1, 1u, 2u, 3u};
+        { const uint32_t adv = b_left > 0 ? 6u * plane : 0u; bo0 += adv; bo1 += adv; --b_left; }
+        return;
+#endif
+        b[slot][0] = *reinterpret_cast<const u32x4*>(Wb + bo0);
+        b[slot][1] = *reinterpret_cast<const u32x4*>(Wb + bo0 + plane);
+        b[slot][2] = *reinterpret_cast<const u32x4*>(Wb + bo0 + 2u * plane);
+        b[slot][3] = *reinterpret_cast<const u32x4*>(Wb + bo1);
+        b[slot][4] = *reinterpret_cast<const u32x4*>(Wb + bo1 + plane);
+        b[slot][5] = *reinterpret_cast<const u32x4*>(Wb + bo1 + 2u * plane);
+        const uint32_t adv = b_left > 0 ? 6u * plane : 0u;     // two groups of 8 k per step
+        bo0 += adv; bo1 += adv;
+        --b_left;
+    };
+    // 12 MFMAs of one step from ready-made A pieces P[0..2] = (h, m, l): small terms first, the two column halves alternate so
+    // that consecutive MFMAs never wait on each other
+    auto mfma12 = [&](const u32x4* P, const u32x4* bb) {
+        sml0 = gs_mfma_bf16(P[0], bb[2], sml0); sml1 = gs_mfma_bf16(P[0], bb[5], sml1);     // h l
+        sml0 = gs_mfma_bf16(P[2], bb[0], sml0); sml1 = gs_mfma_bf16(P[2], bb[3], sml1);     // l h
+        sml0 = gs_mfma_bf16(P[1], bb[1], sml0); sml1 = gs_mfma_bf16(P[1], bb[4], sml1);     // m m
+        sml0 = gs_mfma_bf16(P[0], bb[1], sml0); sml1 = gs_mfma_bf16(P[0], bb[4], sml1);     // h m
+        sml0 = gs_mfma_bf16(P[1], bb[0], sml0); sml1 = gs_mfma_bf16(P[1], bb[3], sml1);     // m h
+        acc0 = gs_mfma_bf16(P[0], bb[0], acc0); acc1 = gs_mfma_bf16(P[0], bb[3], acc1);     // h h
+    };
+    // Software pipeline: while the 12 MFMAs of step s run (384 matrix-pipe cycles), the VALU cuts the A operand of step s + 1
+    // (44 instructions) and the refills of the ring slots step s has freed are issued: one MFMA, then <= 5 other instructions
+    // (an MFMA gap hides 5 single-issue instructions, MI355X_MICROARCH.md).  The scheduler is told the pattern explicitly --
+    // left alone it lumps the 44 VALU in front of the 12 MFMAs.
+    u32x4 P[2][3];
+    if (Sfull > 0) {
+#pragma unroll
+        for (int st = 0; st < DA; ++st) load_a(st);
+#pragma unroll
+        for (int st = 0; st < DB; ++st) load_b(st);
+        gs_split8(a[0][0], a[0][1], P[0][0], P[0][1], P[0][2]);
+        int s = 0;
+#pragma unroll 1
+        for (; s + U < Sfull; s += U) {
+#pragma unroll
+            for (int st = 0; st < U; ++st) {
+                mfma12(P[st & 1], b[st % DB]);
+                load_a(st % DA);                       // slot st was cut one step ago
+                gs_split8(a[(st + 1) % DA][0], a[(st + 1) % DA][1], P[(st + 1) & 1][0], P[(st + 1) & 1][1], P[(st + 1) & 1][2]);
+                load_b(st % DB);                       // (register dependences keep it behind the MFMAs that read the slot)
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);            // four VALU
+                    if (q % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a load behind 8 of the 12
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the last (possibly partial) group: the rings hold steps s .. s+D-1 and are refilled as long as steps remain
+#pragma unroll
+        for (int st = 0; st < U; ++st) {
+            if (s + st < Sfull) {                      // wave-uniform
+                mfma12(P[st & 1], b[st % DB]);
+                if (s + st + DA < Sfull) load_a(st % DA);
+                if (s + st + 1 < Sfull)
+                    gs_split8(a[(st + 1) % DA][0], a[(st + 1) % DA][1], P[(st + 1) & 1][0], P[(st + 1) & 1][1], P[(st + 1) & 1][2]);
+                if (s + st + DB < Sfull) load_b(st % DB);
+            }
+        }
+    }
+    if (Sfull != S) {
+        const int k0 = 16 * Sfull + 8 * lh;
+        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+        const float* p = T.A + srow * T.lda + k0;
+        if (k0 < K) x0 = *reinterpret_cast<const f32x4*>(p);
+        if (k0 + 4 < K) x1 = *reinterpret_cast<const f32x4*>(p + 4);
+        if (k0 + 1 >= K) x0.y = 0.f;
+        if (k0 + 2 >= K) x0.z = 0.f;
+        if (k0 + 3 >= K) x0.w = 0.f;
+        if (k0 + 5 >= K) x1.y = 0.f;
+        if (k0 + 6 >= K) x1.z = 0.f;
+        if (k0 + 7 >= K) x1.w = 0.f;
+        u32x4 bb[6];
+        const u32x4* q0 = T.W3 + (int64_t)(2 * Sfull + lh) * 3 * N + c0;
+        const u32x4* q1 = T.W3 + (int64_t)(2 * Sfull + lh) * 3 * N + c1;
+        bb[0] = q0[0]; bb[1] = q0[N]; bb[2] = q0[2 * N]; bb[3] = q1[0]; bb[4] = q1[N]; bb[5] = q1[2 * N];
+        gs_split8(x0, x1, P[0][0], P[0][1], P[0][2]);
+        mfma12(P[0], bb);
+    }
+    // bias + activation + store (C/D layout of the 32x32 MFMA: row = (e&3) + 8 (e>>2) + 4 (lane>>5), column = lane & 31)
+    const int col_off = term * N;
+    const int ca = n0 + l31, cb = n0 + 32 + l31;
+    float bias0 = 0.f, bias1 = 0.f;
+    if (g.bias) {
+        if (ca < N) bias0 = g.bias[col_off + ca];
+        if (cb < N) bias1 = g.bias[col_off + cb];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v0 = (acc0[e] + sml0[e]) + bias0, v1 = (acc1[e] + sml1[e]) + bias1;
+        if (g.act == GS_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (row < g.M) {
+            float* dst = g.C + (int64_t)row * g.ldc + col_off;
+            if (ca < N) dst[ca] = v0;
+            if (cb < N) dst[cb] = v1;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void sage_split_fwd_kernel(const SplitFwdArgs g, const CoGatherS J) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int host_wgs = (g.n_waves + 3) >> 2;
+    if ((int)blockIdx.x < host_wgs) {
+        const int item = (int)blockIdx.x * 4 + wave;
+        if (item < g.n_waves) split_fwd_wave<D>(g, item, lane);
+        return;
+    }
+    run_gather_item(J, ((int64_t)blockIdx.x - host_wgs) * 4 + wave, lane);
+}
+
+extern "C" int gs_sage_dense_fwd_split(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg, int64_t ld_agg,
+                                       int32_t d, int64_t n, const void* W3_self, const void* W3_neigh, int32_t out_dim, int act,
+                                       const float* bias, float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs,
+                                       void* stream) {
+    if (n == 0 && n_jobs == 0) return GS_OK;
+    GS_REQUIRE(agg && W3_neigh && out && d > 0 && out_dim > 0 && n >= 0, "gs_sage_dense_fwd_split: bad args");
+    GS_REQUIRE(!self || W3_self, "gs_sage_dense_fwd_split: W3_self missing");
+    GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_split agg");
+    if (self) GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_split self");
+    const int d4 = ((d + 3) / 4) * 4;
+    GS_REQUIRE(ld_agg >= d4 && (!self || ld_self >= d4), "gs_sage_dense_fwd_split: ld must be >= round_up(d, 4)");
+    GS_REQUIRE(gs_aligned16(W3_neigh) && (!self || gs_aligned16(W3_self)), "gs_sage_dense_fwd_split: W3 must be 16-byte aligned");
+    GS_REQUIRE(n < (1ll << 26) && ldo >= out_dim * (self ? 2 : 1), "gs_sage_dense_fwd_split: bad sizes");
+    GS_REQUIRE(split_rows_bytes(d, out_dim) < (1ll << 32), "gs_sage_dense_fwd_split: W3 must stay below 4 GB");
+    SplitFwdArgs g = {};
+    g.nterms = self ? 2 : 1;
+    if (self) {
+        g.t[0] = SplitTerm{self, self_idx, (const u32x4*)W3_self, (int32_t)ld_self};
+        g.t[1] = SplitTerm{agg, nullptr, (const u32x4*)W3_neigh, (int32_t)ld_agg};
+    } else {
+        g.t[0] = SplitTerm{agg, nullptr, (const u32x4*)W3_neigh, (int32_t)ld_agg};
+    }
+    g.M = (int32_t)n; g.N = out_dim; g.K = d; g.C = out; g.ldc = (int32_t)ldo; g.bias = bias; g.act = act;
+    g.tiles_n = (out_dim + 63) / 64;
+    // a workgroup's four waves = (term, column tile) combinations of the same rows first
+    const int tiles_m = (int)((n + 31) / 32);
+    g.n_waves = tiles_m * g.tiles_n * g.nterms;
+    CoGatherS J = {};
+    int64_t waves = 0;
+    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
+    if (rc != GS_OK) return rc;
+    const int64_t blocks = (g.n_waves + 3) / 4 + gs_ceil_div(waves, 4);
+    GS_REQUIRE(blocks > 0 && blocks < (1ll << 31), "gs_sage_dense_fwd_split: grid too large");
+    // ring depth: 3 steps keep the kernel at <= 256 registers (two waves per SIMD: a contraction wave and a rider, or two
+    // contraction waves); GS_SPLIT_DEPTH=4 is the diagnostics variant (one wave per SIMD)
+    static const int depth = getenv("GS_SPLIT_DEPTH") ? atoi(getenv("GS_SPLIT_DEPTH")) : 3;
+    if (depth >= 4)
+        hipLaunchKernelGGL((sage_split_fwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
+    else
+        hipLaunchKernelGGL((sage_split_fwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
+    GS_LAUNCH_CHECK("sage_split_fwd_kernel");
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-tiled form
+// out[i] = act(X[idx[i]] . W + bias), i < min(n_max, *n_dev)  -- the pooling MLP of the max-pool aggregator on the step's
+// distinct sampled ids (aggregators.py:176-179 via layers.py:104-116; 51 GF per Reddit step: the one contraction of the path
+// that is bound by the matrix pipe, 564 us on the fp32 MFMA = 0.58 of its peak).  Same three-piece arithmetic as above.
+//   workgroup (8 waves) = 128 rows x 128 columns, wave = 32 x 64 (two MFMA tiles, an h-h and a small-terms accumulator each);
+//   stage = 32 k: every thread loads 8 floats of one gathered row and 3 x 16 bytes of W3, cuts the A values ONCE per
+//   workgroup (44 VALU per 24 MFMAs) and writes the pieces to LDS; the MFMA fragments are ds_read_b128.  Two LDS buffers, one
+//   barrier per stage, the global loads of stage s + 2 in flight under the MFMAs of stage s.
+#define ST_LDA 40                      // bf16 per LDS row of an A plane: 32 + 8 pad (80 bytes: the 32 lanes of a fragment read
+                                       // 16 bytes each at a 20-dword stride -> all 64 banks in use)
+struct SplitTiledArgs {
+    const float* X; const int32_t* idx; const u32x4* W3; const float* bias; float* out; const int32_t* n_dev;
+    int64_t ldx, ldo;
+    int32_t n_max, K, N, act;
+};
+
+__global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_PLANE = 128 * ST_LDA * 2;                 // bytes
+    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 12 * 128 * 16, BUF = A_BYTES + B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
+    const int tiles_n = (g.N + 127) >> 7, tiles_m = (count + 127) >> 7;
+    const int nwg = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nwg) return;
+    // XCD-aware: block b runs on XCD b % 8; consecutive LOGICAL tiles (the column tiles of one row tile) share an XCD's L2
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int K = g.K, N = g.N;
+    const int stages = (K + 31) >> 5;
+    // ---- global -> register roles (512 threads)
+    const int arow = tid >> 2, aq = tid & 3;                   // A: row of the tile, 8-float quarter of the stage
+    const int grow = min(m0 + arow, count - 1);
+    const int64_t srow = g.idx ? (int64_t)g.idx[grow] : (int64_t)grow;
+    const int bcol = tid & 127, bch = tid >> 7;                // B: column of the tile, chunks bch, bch + 4, bch + 8 (12 per stage)
+    const int bc = min(n0 + bcol, N - 1);
+    f32x4 ra[2][2];                                            // two register sets: stage s + 2 is requested while stage s
+    u32x4 rb[2][3];                                            // computes and stage s + 1 is cut and written to LDS
+    const int KG = ((K + 15) >> 4) * 2;
+    const int K4 = ((K + 3) >> 2) << 2;                        // readable columns of a row
+    // Requests are straight-line code with clamped addresses (always valid memory); what lies beyond K / beyond W3 is zeroed
+    // when the registers are USED (lds_store) -- a branch or a select at request time would make the compiler wait for every
+    // outstanding load there.
+    auto gload = [&](const int set, const int s) {
+#ifdef GS_DIAG_TILED_NOG      // diagnostics builds only: no global loads
+#pragma unroll
+        for (int v = 0; v < 2; ++v) ra[set][v] = f32x4{(float)s, 1.f, 2.f, (float)tid};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rb[set][j] = u32x4{(unsigned)s, 1u, 2u, (unsigned)tid};
+        return;
+#endif
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int k = min(32 * s + 8 * aq + 4 * v, K4 - 4);
+            ra[set][v] = *reinterpret_cast<const f32x4*>(g.X + srow * g.ldx + k);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = bch + 4 * j;                         // chunk = (k-group of the stage) * 3 + piece
+            const int kg = min(4 * s + c / 3, KG - 1), p = c - (c / 3) * 3;
+            rb[set][j] = g.W3[((int64_t)kg * 3 + p) * N + bc];
+        }
+    };
+    auto lds_store = [&](const int set, const int s, unsigned char* buf) {
+        f32x4 x[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int k = 32 * s + 8 * aq + 4 * v;
+            // selects, not branches (a branch would end the scheduling region the MFMAs are in): zero beyond K -- the stage
+            // that holds K, and the all-zero stage behind an odd stage count
+            x[v].x = k < K ? ra[set][v].x : 0.f;
+            x[v].y = k + 1 < K ? ra[set][v].y : 0.f;
+            x[v].z = k + 2 < K ? ra[set][v].z : 0.f;
+            x[v].w = k + 3 < K ? ra[set][v].w : 0.f;
+        }
+        u32x4 h0, m0_, l0;
+        gs_split8(x[0], x[1], h0, m0_, l0);
+        unsigned char* pa = buf + (arow * ST_LDA + 8 * aq) * 2;
+        *reinterpret_cast<u32x4*>(pa) = h0;
+        *reinterpret_cast<u32x4*>(pa + A_PLANE) = m0_;
+        *reinterpret_cast<u32x4*>(pa + 2 * A_PLANE) = l0;
+        unsigned char* pb = buf + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = bch + 4 * j;
+            const bool live = 4 * s + c / 3 < KG;              // groups beyond W3 are zero
+            u32x4 w = rb[set][j];
+            w.x = live ? w.x : 0u; w.y = live ? w.y : 0u; w.z = live ? w.z : 0u; w.w = live ? w.w : 0u;
+            *reinterpret_cast<u32x4*>(pb + (c * 128 + bcol) * 16) = w;
+        }
+    };
+    // 8 waves = 4 (rows of 32) x 2 (columns of 64): two waves per SIMD, so that one wave's LDS round trips and barrier waits
+    // are covered by the other's MFMAs (4 waves of 64 x 64 -- half the LDS reads per MFMA -- left the matrix pipe idle two
+    // thirds of the time: 465 us, of which 300 without a single MFMA)
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2], sml[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[j][e] = 0.f; sml[j][e] = 0.f; }
+    auto compute = [&](const unsigned char* buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 fa[3], fb[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                fa[p] = *reinterpret_cast<const u32x4*>(buf + p * A_PLANE + ((32 * wm + l31) * ST_LDA + 16 * q + 8 * lh) * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fb[j][p] = *reinterpret_cast<const u32x4*>(buf + A_BYTES + (((2 * q + lh) * 3 + p) * 128 + 64 * wn + 32 * j + l31) * 16);
+            // piece product outermost, the two column halves innermost: an MFMA that accumulates into the result of the one
+            // issued right before it waits for that result
+#ifdef GS_DIAG_TILED_NOMFMA   // diagnostics builds only: the kernel's time without the matrix pipe
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) asm volatile("" :: "v"(fa[p]), "v"(fb[0][p]), "v"(fb[1][p]));
+#else
+#define GS_PP(dst, pa, pb) _Pragma("unroll") for (int j = 0; j < 2; ++j) dst[j] = gs_mfma_bf16(fa[pa], fb[j][pb], dst[j]);
+            GS_PP(sml, 0, 2)     // h l
+            GS_PP(sml, 2, 0)     // l h
+            GS_PP(sml, 1, 1)     // m m
+            GS_PP(sml, 0, 1)     // h m
+            GS_PP(sml, 1, 0)     // m h
+            GS_PP(acc, 0, 0)     // h h
+#undef GS_PP
+#endif
+        }
+    };
+    // ---- pipeline: stage s computes from LDS buffer s & 1 while stage s + 1 (register set (s + 1) & 1) is cut and written to
+    // the other buffer in the shadow of the MFMAs, and stage s + 2 is requested into the register set stage s has left.
+    // An odd stage count is padded with one all-zero stage (the loop body is unrolled by two and free of branches).
+    const int stages2 = (stages + 1) & ~1;
+    gload(0, 0);
+    gload(1, 1);
+    lds_store(0, 0, smem);
+    __syncthreads();
+    for (int s = 0; s < stages2; s += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {                    // the register sets are indexed statically
+            const int ss = s + par;
+            unsigned char* cur = smem + par * BUF;
+            unsigned char* nxt = smem + (par ^ 1) * BUF;
+            gload(par, ss + 2);                                // (past the end: clamped addresses, values zeroed or unused)
+            compute(cur);
+            lds_store(par ^ 1, ss + 1, nxt);
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                    // three VALU (the cut of stage s + 1)
+                __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                    // an LDS read or write
+            }
+            __syncthreads();
+        }
+    }
+    // ---- bias + activation + store (C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5), column = lane & 31)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + 64 * wn + 32 * j + l31;
+        const float bv = (g.bias && col < N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            float v = (acc[j][e] + sml[j][e]) + bv;
+            if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+#ifdef GS_DIAG_TILED_NOSTORE
+            if (row < count && col < N && v == 12345.678f) g.out[(int64_t)row * g.ldo + col] = v;
+#else
+            if (row < count && col < N) g.out[(int64_t)row * g.ldo + col] = v;
+#endif
+        }
+    }
+}
+
+extern "C" int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
+                                       const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+                                       void* stream) {
+    if (n_max == 0) return GS_OK;
+    GS_REQUIRE(X && W3 && out && d > 0 && out_dim > 0 && n_max > 0 && n_max < (1ll << 30), "gs_dense_fwd_rows_split: bad args");
+    GS_CHECK_MAT(X, ldx, "gs_dense_fwd_rows_split X");
+    GS_REQUIRE(ldx >= ((d + 3) / 4) * 4 && ldo >= out_dim && gs_aligned16(W3), "gs_dense_fwd_rows_split: bad leading dimensions");
+    SplitTiledArgs g = {X, idx, (const u32x4*)W3, bias, out, n_dev, ldx, ldo, (int32_t)n_max, d, out_dim, act};
+    const int64_t blocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 128);
+    const size_t lds = 2 * (3 * 128 * ST_LDA * 2 + 12 * 128 * 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GS_HIP(hipFuncSetAttribute((const void*)split_tiled_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(split_tiled_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
+    GS_LAUNCH_CHECK("split_tiled_fwd_kernel");
+    return GS_OK;
+}

@@ -38,6 +38,10 @@ class Variable(object):
         self.grad = None    # Mat view into engine.grads
         self.slabs = None   # flat tensor [MAX_SLABS * rows * ld]
         self.n_slabs = 0    # slabs written so far in the current backward pass
+        # three-piece bf16 copy of value^T for the split-MFMA contractions (gs_split_rows); made by Engine.split_of on first
+        # use, re-made after every update of the value
+        self.split3 = None
+        self.split_dirty = True
 
     @property
     def size(self):
@@ -49,6 +53,7 @@ class Variable(object):
     def assign(self, a):
         a = np.asarray(a, dtype=np.float32).reshape(self.rows, self.cols)
         self.value.buf[:, : self.cols].copy_(torch.from_numpy(a))
+        self.split_dirty = True
 
     def slab_ptr(self, k):
         return self.slabs.data_ptr() + 4 * k * self.size
@@ -74,6 +79,13 @@ class Engine(object):
         self._n_sites = 0
         # "stream" contraction kernels (gs_stream.hip) for the layer-0 forward and the grouped weight gradients
         self.stream_gemm = os.environ.get("GS_STREAM_GEMM", "1") == "1"
+        # ... and their split-MFMA form (gs_split.hip): fp32 operands cut into three bf16 pieces, six bf16 MFMAs per product
+        # tile -- fp32 accuracy at 6/16 of the fp32 MFMA's matrix-pipe time
+        # Default: the LDS-tiled pooling MLP (matrix-pipe bound: 564 -> measured below) takes it; the register-streaming layer-0
+        # contraction does not (bound by the L2 -> CU operand traffic in either form: 24.7 vs 24.6 us alone, and the per-step
+        # re-cut of its weights costs two launches)
+        self.split_gemm = os.environ.get("GS_SPLIT_GEMM", "0") == "1"
+        self.split_pool = os.environ.get("GS_SPLIT_POOL", "1") == "1"
         # split-K policy knobs (tuning hooks, benchmarks/slab_sweep.sh), read ONCE
         self._wgrad_blocks = int(os.environ.get("GS_WGRAD_BLOCKS", 768))
         self._wgrad_max_slabs = int(os.environ.get("GS_WGRAD_MAX_SLABS", 32))
@@ -339,8 +351,22 @@ class Engine(object):
 
     def _params_updated(self):
         """Launches that must follow every optimizer step (e.g. refreshing a materialised copy of a variable)."""
+        for v in self.variables:
+            v.split_dirty = True
         for hook in self.post_update_hooks:
             hook()
+
+    def split_of(self, var):
+        """The current three-piece copy of var.value^T (gs_split_rows), re-made on the engine stream when the value has
+        changed since the last call -- inside a captured step that launch is part of the step's graph."""
+        if var.split3 is None:
+            K, N = var.rows, var.cols
+            var.split3 = torch.empty(N * ((K + 15) // 16) * 2 * 12, dtype=torch.int32, device=self.device)
+            var.split_dirty = True
+        if var.split_dirty:
+            ops.split_rows(var.value, out=var.split3, stream=self.stream)
+            var.split_dirty = False
+        return var.split3
 
     def advance(self, step=0, clock=0, cursor=None, cursor_delta=0, loss_rows=None, n=0, loss_out=None, accumulate=False,
                 aux_rows=None, aux_out=None):

@@ -787,7 +787,7 @@ class SampleAndAggregate(object):
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.cogather_opt,
                 self.tail_split, self.cogather_tail_z, self.cogather_z, self.cogather_dh0,
-                self.cogather_dp_fork, e.stream_gemm, str(getattr(self, "pipeline", None)), type(self.grad_hook).__name__,
+                self.cogather_dp_fork, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)), type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 
     def _run(self, key, fn):

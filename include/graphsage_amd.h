@@ -243,6 +243,28 @@ int gs_sage_dense_fwd_stream_form(int32_t d, int64_t n, int32_t out_dim, int32_t
  * its gather riders; 3 is 7 % faster as a stand-alone launch).  Environment: GS_STREAM_FWD_V3=1. */
 int gs_set_stream_fwd_form(int32_t form);
 
+/* The same contraction on the bf16 matrix pipe WITHOUT giving up fp32: every fp32 operand x is cut into three bf16 pieces
+ * x = h + m + l (top / middle / low 8 significant bits: nothing is lost), a product is the sum of piece products -- each formed
+ * exactly by v_mfma_f32_32x32x16_bf16 and accumulated in fp32 -- and six of the nine are kept (hh, hm, mh, mm, hl, lh; the
+ * dropped ml, lm, ll are <= 3 * 2^-24 |x y|, one fp32 rounding).  Accuracy of an fp32 FMA chain at 6/16 of the fp32 MFMA's
+ * matrix-pipe time (fp32 MFMA runs at the vector rate on gfx950, 1/16 of bf16).  Inputs, outputs, accumulation: fp32.
+ *   gs_split_rows: W [K, ldw >= N] fp32 -> W3 [2 * ceil(K / 16)][3][N][8] bf16 (per group of 8 k and piece: the N columns
+ *     side by side, 16 bytes each -- a B-fragment load of 32 lanes reads 512 contiguous bytes; zero for k >= K); gs_split_rows_bytes gives the size.  Call it after every update of W.
+ *   gs_sage_dense_fwd_split: gs_sage_dense_fwd_stream with W3_self / W3_neigh in place of the weights; A operands are read
+ *     as fp32 and cut in registers in the shadow of the MFMAs.  One wave per 32 x 64 output tile over the whole K (no LDS,
+ *     no barrier, no split-K epilogue); pad columns [d, round_up(d, 4)) of self / agg must be readable.  Deterministic.
+ *   gs_dense_fwd_rows_split: gs_dense_fwd_rows_dev in the same arithmetic, LDS-tiled (128 x 128 per workgroup, A rows gathered
+ *     through idx and cut once per workgroup): the pooling MLP of the max-pool aggregator on the step's distinct ids.
+ */
+int gs_split_rows_bytes(int32_t K, int32_t N, int64_t* bytes_out_host);
+int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
+                            const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo, void* stream);
+int gs_split_rows(const float* W, int64_t ldw, int32_t K, int32_t N, void* W3, void* stream);
+int gs_sage_dense_fwd_split(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg, int64_t ld_agg,
+                            int32_t d, int64_t n, const void* W3_self, const void* W3_neigh, int32_t out_dim, int act,
+                            const float* bias, float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs,
+                            void* stream);
+
 /* Input gradient:  dX[n, d] (+)= dZ[:, col0:col0+out_dim] · W[d, out_dim]^T */
 int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,
                    const float* W, int64_t ldw, int32_t d, float* dX, int64_t ldx, int accumulate,

@@ -1,0 +1,200 @@
+"""-m gpu: the split-MFMA contractions (graphsage_amd/csrc/gs_split.hip): fp32 operands cut into three bf16 pieces, six bf16
+MFMAs per product tile, fp32 accumulation.  Claims checked here:
+  * the cut is EXACT: h + m + l == x bit for bit, for every fp32 value (normal range), in the layout the kernel reads;
+  * the contraction has the accuracy of an fp32 FMA chain: its error against fp64 is of the size of the fp32 MFMA kernel's
+    own error against fp64 (both ~1e-7 of the row's rms at K = 602), five hundred times below north_star's 1e-4;
+  * shapes: the Reddit / unsupervised / RMAT layer-0 shapes, ragged M, K with a masked last step, N not a multiple of the
+    64-column tile, gathered and dense self rows, bias + relu / identity, NaN in every pad column, co-scheduled gather jobs;
+  * run to run bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from graphsage_amd import ops
+from graphsage_amd.ops import Mat
+
+pytestmark = pytest.mark.gpu
+
+
+def _i32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+
+def _pieces(w3, K, N):
+    """int32 device tensor of gs_split_rows -> float64 arrays h, m, l of shape [N, Kp] (the pieces of W^T)."""
+    KG = ((K + 15) // 16) * 2
+    raw = w3.cpu().numpy().view(np.uint16).reshape(KG, 3, N, 8)
+    as_f32 = (raw.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    return [as_f32[:, p].transpose(1, 0, 2).reshape(N, KG * 8) for p in range(3)]
+
+
+def test_split_rows_pieces_are_exact(dev):
+    rng = np.random.default_rng(0)
+    K, N = 602, 128
+    W = rng.normal(size=(K, N)).astype(np.float32)
+    W[0, :8] = [0.0, -0.0, 1.0, -1.0, 2.0 ** -100, -3.0e38, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24]    # edge values
+    W[1] = np.ldexp(rng.normal(size=N), rng.integers(-60, 60, size=N)).astype(np.float32)       # wide exponent range
+    Wd = Mat.from_numpy(W, dev)
+    w3 = ops.split_rows(Wd)
+    torch.cuda.synchronize()
+    h, m, l = _pieces(w3, K, N)
+    total = h + m + l                                               # float64: exact sum of three bf16 values
+    assert np.array_equal(total[:, :K], W.T.astype(np.float64))     # nothing is lost
+    assert np.all(total[:, K:] == 0)                                # zero padding up to the next multiple of 16
+    # the pieces are what the header says: top / middle / low 8 significant bits (truncation: same sign, decreasing size)
+    assert np.all(np.abs(m) <= np.abs(h) * 2.0 ** -7) and np.all(np.abs(l) <= np.abs(h) * 2.0 ** -15)
+    assert np.all((np.sign(m) == np.sign(h)) | (m == 0)) and np.all((np.sign(l) == np.sign(h)) | (l == 0))
+
+
+CASES = [
+    # n, d, out, two, act, bias, gathered, riders
+    (5632, 602, 128, True, ops.ACT_RELU, False, True, True),        # the Reddit step's layer 0
+    (11484, 602, 128, True, ops.ACT_RELU, False, True, False),      # the unsupervised step's
+    (5632, 256, 128, True, ops.ACT_RELU, False, True, False),       # RMAT's F = 256 (16 whole steps)
+    (5633, 601, 128, True, ops.ACT_IDENTITY, True, False, True),    # ragged rows, 9 valid k in the masked last step
+    (17000, 608, 64, False, ops.ACT_RELU, True, False, False),      # one term (GCN form), one column tile, K = 608 exactly
+    (4100, 250, 192, True, ops.ACT_RELU, True, True, False),        # three column tiles per term, K tail of 10
+    (2050, 50, 100, True, ops.ACT_RELU, True, True, False),         # PPI's F = 50; N = 100: second tile has 36 live columns
+    (33, 7, 8, False, ops.ACT_IDENTITY, False, False, False),       # one partial step only
+    (5632, 602, 256, False, ops.ACT_RELU, False, False, False),     # GCN at Reddit's shape (dims 2 x 128)
+]
+
+
+@pytest.mark.parametrize("n,d,out,two,act,bias,gathered,riders", CASES)
+def test_sage_dense_fwd_split(dev, n, d, out, two, act, bias, gathered, riders):
+    rng = np.random.default_rng(n + d + out)
+    Nn = 6000
+    X = rng.normal(size=(Nn + 1, d)).astype(np.float32); X[Nn] = 0
+    self_m, mean = rng.normal(size=(n, d)).astype(np.float32), rng.normal(size=(n, d)).astype(np.float32)
+    self_ids = rng.integers(0, Nn + 1, size=n).astype(np.int32)
+    if gathered:
+        self_m = X[self_ids]
+    Ws, Wn = (rng.normal(size=(d, out)) * 0.1).astype(np.float32), (rng.normal(size=(d, out)) * 0.1).astype(np.float32)
+    b = (rng.normal(size=((2 if two else 1) * out,)) * 0.1).astype(np.float32) if bias else None
+    Xd = Mat.from_numpy(X, dev, 32)
+    sd, md = Mat.from_numpy(self_m, dev, 32), Mat.from_numpy(mean, dev, 4)      # the means: ld = round_up(d, 4) only
+    for mat in (Xd, sd, md):
+        if mat.ld > d:
+            mat.buf[:, d:] = float("nan")                   # nothing beyond K may leak
+    Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
+    w3s, w3n = ops.split_rows(Wsd), ops.split_rows(Wnd)
+    bd = torch.from_numpy(b).to(dev) if bias else None
+    idx = rng.integers(0, Nn + 1, size=(700, 25)).astype(np.int32)
+    idx_d, sid_d = _i32(idx.reshape(-1), dev), _i32(self_ids, dev)
+    Xclean = Mat.from_numpy(X, dev, 32)                      # the riders' table (NaN pads would enter their float4 sums)
+    outs = []
+    for rep in range(2):
+        outm = Mat.zeros(n, (2 if two else 1) * out, dev)
+        outm.buf.fill_(float("nan"))
+        g_out = Mat.zeros(700, d, dev)
+        jobs = [ops.gather_job(Xclean, idx_d, 700, 25, g_out)] if riders else []
+        if two:
+            ops.sage_dense_fwd_split(Xd if gathered else sd, sid_d if gathered else None, md, n, w3s, w3n, out, act, bd, outm, jobs)
+        else:
+            ops.sage_dense_fwd_split(None, None, md, n, None, w3n, out, act, bd, outm, jobs)
+        torch.cuda.synchronize()
+        outs.append(outm.numpy())
+        if riders:
+            np.testing.assert_allclose(g_out.numpy(), X[idx].mean(axis=1), rtol=1e-4, atol=1e-4)
+    assert np.array_equal(outs[0], outs[1])                  # deterministic
+    want_n = mean.astype(np.float64) @ Wn.astype(np.float64)
+    want = np.concatenate([self_m.astype(np.float64) @ Ws.astype(np.float64), want_n], axis=1) if two else want_n
+    if bias:
+        want = want + b
+    pre = want.copy()
+    if act == ops.ACT_RELU:
+        want = np.maximum(want, 0)
+    got = outs[0].astype(np.float64)
+    assert np.isfinite(got).all()
+    # fp32 accuracy: the error is a few fp32 roundings of the row's scale, like a float32 NumPy matmul's
+    rms = np.sqrt((pre * pre).mean())
+    err = np.abs(got - want).max() / rms
+    f32 = mean @ Wn
+    f32 = np.concatenate([self_m @ Ws, f32], axis=1) if two else f32
+    if bias:
+        f32 = f32 + b
+    if act == ops.ACT_RELU:
+        f32 = np.maximum(f32, 0)
+    err32 = np.abs(f32.astype(np.float64) - want).max() / rms
+    assert err <= max(4 * err32, 4e-7), (err, err32)
+    assert err < 4e-6, err
+
+
+def test_split_fwd_is_as_accurate_as_the_fp32_mfma_kernel(dev):
+    """Same operands through gs_sage_dense_fwd_stream (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains) and through the split
+    form: both errors against fp64 are fp32 rounding noise of the same size."""
+    rng = np.random.default_rng(9)
+    n, d, out = 5632, 602, 128
+    Xs, Mn = rng.normal(size=(n, d)).astype(np.float32), rng.normal(size=(n, d)).astype(np.float32)
+    Ws, Wn = (rng.normal(size=(d, out)) * 0.1).astype(np.float32), (rng.normal(size=(d, out)) * 0.1).astype(np.float32)
+    sd, md = Mat.from_numpy(Xs, dev, 32), Mat.from_numpy(Mn, dev, 32)
+    Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
+    a, b = Mat.zeros(n, 2 * out, dev), Mat.zeros(n, 2 * out, dev)
+    ops.sage_dense_fwd_stream(sd, None, md, n, Wsd, Wnd, out, ops.ACT_IDENTITY, None, a, [])
+    ops.sage_dense_fwd_split(sd, None, md, n, ops.split_rows(Wsd), ops.split_rows(Wnd), out, ops.ACT_IDENTITY, None, b, [])
+    torch.cuda.synchronize()
+    want = np.concatenate([Xs.astype(np.float64) @ Ws, Mn.astype(np.float64) @ Wn], axis=1)
+    rms = np.sqrt((want * want).mean())
+    e_fp32 = np.abs(a.numpy() - want).max() / rms
+    e_split = np.abs(b.numpy() - want).max() / rms
+    print("max error / rms vs fp64: fp32 MFMA kernel %.3g, split kernel %.3g" % (e_fp32, e_split))
+    assert e_split <= 2 * e_fp32 and e_split < 4e-6
+
+
+@pytest.mark.parametrize("n_max,count,d,out,act,bias", [
+    (6000, 5000, 602, 512, ops.ACT_RELU, True),      # the pooling MLP's shape (fewer rows), device-side row count
+    (300, 300, 602, 512, ops.ACT_RELU, True),        # three row tiles, the last one ragged
+    (1000, 777, 50, 512, ops.ACT_RELU, True),        # PPI's F = 50: two stages, the second with a 2-k tail
+    (700, 700, 40, 100, ops.ACT_IDENTITY, False),    # ceil(K/16) odd: the last stage reads two k-groups only; N = 100
+    (260, 130, 256, 1024, ops.ACT_RELU, True)])      # model_size "big": hidden 1024
+def test_dense_fwd_rows_split(dev, n_max, count, d, out, act, bias):
+    """gs_dense_fwd_rows_split (LDS-tiled split-MFMA GEMM on gathered rows with a device-side row count) vs fp64 and vs the
+    fp32 MFMA kernel gs_dense_fwd_rows_dev: same accuracy class; rows beyond the count are not written; deterministic."""
+    rng = np.random.default_rng(n_max + d + out)
+    Nn = 5000
+    X = rng.normal(size=(Nn + 1, d)).astype(np.float32); X[Nn] = 0
+    ids = rng.integers(0, Nn + 1, size=n_max).astype(np.int32)
+    W = (rng.normal(size=(d, out)) * 0.1).astype(np.float32)
+    b = (rng.normal(size=(out,)) * 0.1).astype(np.float32) if bias else None
+    Xd, Wd = Mat.from_numpy(X, dev, 32), Mat.from_numpy(W, dev)
+    if Xd.ld > d:
+        Xd.buf[:, d:] = float("nan")
+    w3 = ops.split_rows(Wd)
+    ids_d = _i32(ids, dev)
+    cnt = _i32(np.asarray([count]), dev)
+    bd = torch.from_numpy(b).to(dev) if bias else None
+    outs = []
+    for rep in range(2):
+        o = Mat.zeros(n_max, out, dev)
+        o.buf.fill_(-7.0)
+        ops.call("gs_dense_fwd_rows_split", Xd.ptr, Xd.ld, ops.ptr(ids_d), d, n_max, ops.ptr(cnt), ops.ptr(w3), out, act,
+                 ops.ptr(bd), o.ptr, o.ld, ops.current_stream())
+        torch.cuda.synchronize()
+        outs.append(o.numpy())
+    assert np.array_equal(outs[0], outs[1])
+    if n_max > 2048:                                         # the fp32 MFMA kernel of the same call (tiled kernels: n_max > 2048)
+        ref = Mat.zeros(n_max, out, dev)
+        Xc = Mat.from_numpy(X, dev, 32)
+        ops.call("gs_dense_fwd_rows_dev", Xc.ptr, Xc.ld, ops.ptr(ids_d), d, n_max, ops.ptr(cnt), Wd.ptr, Wd.ld, out, act,
+                 ops.ptr(bd), ref.ptr, ref.ld, ops.current_stream())
+        torch.cuda.synchronize()
+        ref = ref.numpy()
+    else:                                                    # a float32 NumPy matmul as the fp32 yardstick
+        ref = X[ids] @ W
+        if bias:
+            ref = ref + b
+        if act == ops.ACT_RELU:
+            ref = np.maximum(ref, 0)
+    want = X[ids].astype(np.float64) @ W.astype(np.float64)
+    if bias:
+        want = want + b
+    pre = want.copy()
+    if act == ops.ACT_RELU:
+        want = np.maximum(want, 0)
+    got = outs[0].astype(np.float64)
+    assert np.all(outs[0][count:] == -7.0)                                    # rows beyond the device-side count untouched
+    rms = np.sqrt((pre[:count] ** 2).mean())
+    err = np.abs(got[:count] - want[:count]).max() / rms
+    err32 = np.abs(ref[:count].astype(np.float64) - want[:count]).max() / rms
+    print("d=%d: max error / rms vs fp64: fp32 MFMA kernel %.3g, split kernel %.3g" % (d, err32, err))
+    assert err <= max(2.5 * err32, 5e-7) and err < 4e-6
