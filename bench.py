@@ -285,7 +285,7 @@ def main():
         # number of microseconds (0 = no-op hook); GS_COGATHER_DP_FORK=0 gives the schedule without the forked gather branch
         model.grad_hook = gsd.SpinHook(e, float(os.environ["GS_PROBE_DP_SCHEDULE"]))
     if model.grad_hook is not None:
-        dp_info = model.calibrate_dp_fork(n_gather_rows=(roots_of(args) * (1 + args.samples_2)), log=log if rank == 0 else None) or {}
+        dp_info = model.measure_dp_allreduce(log=log if rank == 0 else None) or {}
         dp_info["allreduce"] = type(model.grad_hook).__name__
         dp_info["in_graph"] = bool(model._dp_in_graph())
         if hasattr(model.grad_hook, "ranks"):

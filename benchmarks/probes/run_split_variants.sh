@@ -1,3 +1,3 @@
-for v in nomfma nog nocut nostore mfmaonly; do
+for v in nomfma nog nostore mfmaonly nothing; do
   echo "== $v"; GS_LIB=benchmarks/probes/_lib/libgs_tiled_$v.so timeout 100 python benchmarks/micro_split.py pool 2>/dev/null | grep "split_tiled"
 done

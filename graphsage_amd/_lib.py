@@ -85,8 +85,6 @@ _PROTOS = {
     "gs_dense_fwd_rows_split": [_P, c_int64, _P, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P],
     "gs_sage_dense_fwd_split": [_P, c_int64, _P, _P, c_int64, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P,
                                 c_int32, _P],
-    "gs_sage_dense_fwd_stream_form": [c_int32, c_int64, c_int32, c_int32, c_int64, c_int64],
-    "gs_set_stream_fwd_form": [c_int32],
     "gs_flat_reduce_adam_sample": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
                                    c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P, c_int32, _P],
     "gs_sage_tail_supported": [c_int32, c_int32, c_int32],

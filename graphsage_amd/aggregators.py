@@ -279,9 +279,6 @@ class MeanAggregator(_SageBase):
     def backward_hops(self, d_out, pre_masked=False, d_prev=None, prev_mask=None, prev_offsets=None, embed_sink=None):
         e = self.engine
         self_all, neighs, means, out, rate, self_in, h0 = self._saved.pop()
-        if getattr(self, "bwd_jobs", None) and not (h0 is not None and d_prev is not None and rate == 0):
-            e.launch_gather_jobs(self.bwd_jobs)          # no launch of this pass can carry them: issue them on their own
-            self.bwd_jobs = None
         n_total = self_all.n
         k = len(self._saved)
         o = self.output_dim
@@ -313,12 +310,11 @@ class MeanAggregator(_SageBase):
         d_in = self.input_dim
         if (h0 is not None and rate == 0 and embed_sink is None and prev_mask is not None and prev_mask.ptr == h0.ptr
                 and prev_mask.ld == h0.ld and d_prev.rows == h0.rows and d_prev.d == h0.d
-                and list(prev_offsets[:3]) == [0, n_total, h0.rows] and os.environ.get("GS_LAYER1_DH0", "1") != "0"):
+                and list(prev_offsets[:3]) == [0, n_total, h0.rows]):
             # the forward went through gs_sage_tail_z: the input gradients are its backward twin, ONE launch
             # (dz . W^T for both terms + relu mask + 1/s broadcast) instead of a small GEMM and the pull
-            jobs, self.bwd_jobs = getattr(self, "bwd_jobs", None), None      # a gather share of the next step may ride here
             ops.sage_tail_dh0(h0, n_total, neighs[0].shape3[1], self.vars['self_weights'].value,
-                              self.vars['neigh_weights'].value, o, dz, d_prev, jobs=jobs, stream=e.stream)
+                              self.vars['neigh_weights'].value, o, dz, d_prev, jobs=None, stream=e.stream)
             return
         if self.neigh_input_dim == d_in and d_in % 4 == 0 and (not self.concat or o % 4 == 0):
             t2 = e.ws_mat((self.name, "dgrad2", k), n_total, 2 * d_in)       # [d_self | d_means] in one launch
@@ -557,8 +553,12 @@ class _PoolingAggregator(_SageBase):
         # layer 0 (rows gathered from the feature table through the model's contiguous id buffer): the MLP of a node does
         # not depend on who sampled it -- run it once per DISTINCT id of the step and let the reduce_max pick rows
         # through an index (37 % fewer GEMM rows at Reddit's degree)
+        # gs_unique_ids makes three passes over a flag word per TABLE row (independent of the batch): worth it while the table
+        # is within a small multiple of the step's sampled rows (Reddit: 233 k rows for 133 k ids), not for 10^7-node graphs
         dedup = (fused_pool and x_all is not None and x_all.ids is not None and rows_total > 2048
-                 and x_all.src.rows < (1 << 31) and getattr(self, "dedup_pool", os.environ.get("GS_POOL_DEDUP", "1") != "0"))
+                 and x_all.src.rows < (1 << 31)
+                 and x_all.src.rows <= int(os.environ.get("GS_POOL_DEDUP_MAX_RATIO", "16")) * rows_total
+                 and getattr(self, "dedup_pool", os.environ.get("GS_POOL_DEDUP", "1") != "0"))
         H = None
         if dedup:
             X, ids, nv_rows = x_all.src, x_all.ids, x_all.src.rows

@@ -65,9 +65,7 @@ struct FwdArgs {
     const float* bias;    // indexed by output column (incl. the concat offset), nullable
     int32_t act;
     int32_t tiles_n;      // 64-column tiles per term
-    int32_t n_tiles;      // contraction workgroups (v2: tiles_m * tiles_n * nterms; v3: msets * tiles_n * nterms)
-    int32_t tiles_m, msets;   // v3: 32-row tiles, and how many persistent M-sets walk them
-    int32_t rider_prio;   // v3: gather riders raise their issue priority
+    int32_t n_tiles;      // contraction workgroups: tiles_m * tiles_n * nterms
 };
 
 // One WORKGROUP (4 waves) owns one 32 x 64 output tile; wave w contracts a QUARTER of K (split-K inside the workgroup,
@@ -230,187 +228,6 @@ __global__ __launch_bounds__(256) void sage_stream_fwd_kernel(const FwdArgs g, c
     GS_STAMP(1);
 #endif
     run_gather_item(J, ((int64_t)blockIdx.x - g.n_tiles) * 4 + wave, lane);
-#ifdef GS_TIMELINE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GS_STAMP(2);
-    GS_STAMP(3);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------ forward, weight-stationary
-// Third form of the layer-0 contraction (v3).  What the per-wave timelines of the v2 launch WITH gather riders showed
-// (benchmarks/timeline_riders.py, profiles/r03_rider_timeline.txt): (1) a SIMD issues for its oldest waves first and the
-// 2-3 contraction waves it holds always have an MFMA ready, so rider waves resident from t = 1 us finish their first item
-// at t = 13-17 us (4 us when alone) -- nothing of the gather is hidden; (2) with s_setprio 3 the riders do progress, but
-// the contraction waves -- five dependent loads per 8 MFMAs, ~1 us of ring coverage -- then stall on the loaded memory
-// system and the launch gets no shorter.  With the operand loads compiled out the same launch does overlap (riders end
-// at 19.7 us against 17.4 us for the contraction alone).  So the host has to be insensitive to memory latency:
-//   * persistent workgroups, ONE per CU (4 waves = the 4 K-quarters of a 64-column slab of one term), each walking
-//     M-tiles mt = mset, mset + msets, ...; the wave's whole W slice ([8 KQ k] x 64 columns, 8 KQ VGPRs as MFMA B
-//     operands) is loaded ONCE and stays in registers;
-//   * per macro step (8 k, 8 MFMAs = 512 matrix-pipe cycles) a lane issues ONE 16-byte A load (immediate offset against a
-//     per-lane row pointer: no address arithmetic) -- 10 x fewer load instructions per MFMA than v2;
-//   * A runs through a statically indexed ring with >= R macro steps (R x 512 cycles) between a load and its use,
-//     ACROSS tile boundaries: stages [0, FULL) (FULL = KQ rounded down to a multiple of R) use slot st % R, the
-//     remaining EXTRA = KQ - FULL stages have a slot each; after computing stage st < FULL - R the slot takes stage
-//     st + R of the same tile, after FULL - R <= st < FULL stage st % R of the NEXT tile, after st >= FULL stage st of
-//     the next tile (distances R, KQ - R, KQ);
-//   * split-K partials meet in LDS once per tile (double-buffered: one barrier per tile).
-// 245 VGPRs -> two waves per SIMD: one contraction wave + one rider wave (25 loads in flight), riders at s_setprio 3.
-#define FWD3_MAXT 8      // tiles per persistent workgroup
-template <int KQ, int R>
-__device__ __forceinline__ void stream_fwd3_host(const FwdArgs& g, const int L, const int wave, const int lane,
-                                                 float (*red)[4][32][64]) {
-    constexpr int FULL = (KQ / R) * R, EXTRA = KQ - FULL, SLOTS = R + EXTRA;
-    static_assert(KQ >= R, "ring of R macro steps");
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int tl_item = L * 4 + wave; (void)tl_item;
-    GS_STAMP(0);
-    const int combos = g.nterms * g.tiles_n;
-    const int mset = L / combos, combo = L - mset * combos;          // the combos of an M-set are neighbours (same XCD)
-    const int term = combo / g.tiles_n, tile_n = combo - term * g.tiles_n;
-    const int n0 = tile_n * 64;
-    const FwdTerm& T = g.t[term];
-    const int K = g.K, N = g.N, M = g.M;
-    // The host guarantees ceil(K / 8) == 4 KQ: every wave has exactly KQ macro steps (the tile loop is straight-line code:
-    // a branch inside it would make the compiler wait for ALL outstanding loads at every stage); only the very last
-    // macro step (wave 3, stage KQ - 1) may be partial.
-    const int s0 = wave * KQ;                                          // this wave's first macro step
-    // ---- the wave's W slice, resident for the whole kernel: b[st][e] = W[8 (s0 + st) + 4 lh + e][cl, cl + 1]
-    const int cl = min(n0 + 2 * l31, N - 2);                           // the lane's column pair (never stored if >= N)
-    f32x2 b[KQ][4];
-    {
-        const float* Wp = T.W + cl;
-#pragma unroll
-        for (int st = 0; st < KQ; ++st)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = 8 * (s0 + st) + 4 * lh + e;
-                if (st < KQ - 1) {
-                    b[st][e] = *reinterpret_cast<const f32x2*>(Wp + (int64_t)k * T.ldw);
-                } else {                                                // rows k >= K: zero (the load stays in range)
-                    const f32x2 w = *reinterpret_cast<const f32x2*>(Wp + (int64_t)min(k, K - 1) * T.ldw);
-                    b[st][e] = k < K ? w : f32x2{0.f, 0.f};
-                }
-            }
-    }
-    // elements of the last macro step whose k >= K are zeroed on the A side too (pad columns may hold anything)
-    const int kp = 8 * (s0 + KQ - 1) + 4 * lh;
-    const bool pm0 = kp + 0 < K, pm1 = kp + 1 < K, pm2 = kp + 2 < K, pm3 = kp + 3 < K;
-    const int koff = 8 * s0 + 4 * lh;
-    // Source rows of this lane's A row in each of the workgroup's tiles (<= FWD3_MAXT, checked on the host), all requested
-    // up front: a vector load inside the tile loop would sit between the ring loads and the epilogue's stores in the
-    // in-order vmcnt queue, and waiting for it would drain the ring.  srow[0] is always the NEXT tile's (rotated per tile).
-    int srow[FWD3_MAXT];
-#pragma unroll
-    for (int j = 0; j < FWD3_MAXT; ++j) {
-        const int mtj = min(mset + j * g.msets, g.tiles_m - 1);
-        const int arow = min(mtj * 32 + l31, M - 1);
-        srow[j] = T.a_idx ? T.a_idx[arow] : arow;
-    }
-    auto row_ptr = [&](const int sr) -> const float* { return T.A + (int64_t)sr * T.lda + koff; };
-    f32x4 a[SLOTS];
-    int mt = mset;                                                     // (msets <= tiles_m: every workgroup has a tile)
-    const float* ap = row_ptr(srow[0]);
-#pragma unroll
-    for (int j = 0; j + 1 < FWD3_MAXT; ++j) srow[j] = srow[j + 1];
-    // prologue: the first tile's ring
-#pragma unroll
-    for (int st = 0; st < R; ++st) a[st] = *reinterpret_cast<const f32x4*>(ap + 8 * st);
-#pragma unroll
-    for (int x = 0; x < EXTRA; ++x) a[R + x] = *reinterpret_cast<const f32x4*>(ap + 8 * (FULL + x));
-    const int col_off = term * N;
-    const int c = n0 + 2 * l31;
-    f32x2 bias2 = {0.f, 0.f};
-    if (g.bias && c < N) bias2 = *reinterpret_cast<const f32x2*>(g.bias + col_off + c);
-    int buf = 0;
-#ifdef GS_TIMELINE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    GS_STAMP(1);
-#pragma unroll 1
-    for (; mt < g.tiles_m; mt += g.msets) {
-        // the next tile's rows (past the last tile: a clamped tile -- valid addresses, values never used)
-        const float* ap_next = row_ptr(srow[0]);
-#pragma unroll
-        for (int j = 0; j + 1 < FWD3_MAXT; ++j) srow[j] = srow[j + 1];
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int st = 0; st < KQ; ++st) {
-            const int slot = st < FULL ? (st % R) : R + (st - FULL);
-            f32x4 av = a[slot];
-            if (st == KQ - 1) {                                        // (all true except in a partial last macro step)
-                av.x = pm0 ? av.x : 0.f; av.y = pm1 ? av.y : 0.f; av.z = pm2 ? av.z : 0.f; av.w = pm3 ? av.w : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (st == 0 && e == 0) {
-                    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc0 = mfma32(av[e], b[st][e].x, zero16);
-                    acc1 = mfma32(av[e], b[st][e].y, zero16);
-                } else {
-                    acc0 = mfma32(av[e], b[st][e].x, acc0);
-                    acc1 = mfma32(av[e], b[st][e].y, acc1);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);                         // the refill stays below the MFMAs that free its slot
-#ifdef GS_DIAG_FWD_NOA
-            a[slot] = f32x4{__int_as_float((int)(uintptr_t)ap_next + st), 0.f, 1.f, 2.f};
-#else
-            if (st + R < FULL) {
-                a[slot] = *reinterpret_cast<const f32x4*>(ap + 8 * (st + R));
-            } else {
-                const int nst = st < FULL ? (st % R) : st;             // stage of the next tile that takes this slot
-                a[slot] = *reinterpret_cast<const f32x4*>(ap_next + 8 * nst);
-            }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // split-K sum in a fixed order + bias + activation + store: wave w finishes elements e = 4w .. 4w+3 of both n-tiles
-        GS_STAMP(2);
-#ifdef GS_DIAG_FWD3_NOEPI
-        if (mt + g.msets < g.tiles_m) { asm volatile("" :: "v"(acc0), "v"(acc1)); ap = ap_next; continue; }
-#endif
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            red[buf][wave][e][lane] = acc0[e];
-            red[buf][wave][16 + e][lane] = acc1[e];
-        }
-        __syncthreads();
-        const int m0 = mt * 32;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = 4 * wave + q;
-            f32x2 v;
-            v.x = ((red[buf][0][e][lane] + red[buf][1][e][lane]) + red[buf][2][e][lane]) + red[buf][3][e][lane] + bias2.x;
-            v.y = ((red[buf][0][16 + e][lane] + red[buf][1][16 + e][lane]) + red[buf][2][16 + e][lane]) + red[buf][3][16 + e][lane] + bias2.y;
-            if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-            const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;      // C/D layout of the 32x32 MFMA
-            if (row < M && c < N) *reinterpret_cast<f32x2*>(g.C + (int64_t)row * g.ldc + col_off + c) = v;
-        }
-        // (no second barrier: the next tile writes the OTHER buffer, and nobody writes this one again before having passed
-        // the next tile's barrier, which every wave reaches only after these reads)
-        buf ^= 1;
-        ap = ap_next;
-        GS_STAMP(3);
-    }
-}
-
-template <int KQ, int R>
-__global__ __launch_bounds__(256, 2) void sage_stream_fwd3_kernel(const FwdArgs g, const CoGatherS J) {
-    __shared__ float red[2][4][32][64];                    // split-K partial tiles, double-buffered by tile parity
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.x < g.n_tiles) {                     // n_tiles: the persistent contraction workgroups
-        stream_fwd3_host<KQ, R>(g, stream_xcd_swizzle(blockIdx.x, g.n_tiles), wave, lane, red);
-        return;
-    }
-    if (g.rider_prio) __builtin_amdgcn_s_setprio(3);       // see the note above: riders must not wait behind ready MFMAs
-#ifdef GS_TIMELINE
-    const int tl_item = g.n_tiles * 4 + ((int)blockIdx.x - g.n_tiles) * 4 + wave;
-    GS_STAMP(0);
-    GS_STAMP(1);
-#endif
-    run_gather_item<10, 25>(J, ((int64_t)blockIdx.x - g.n_tiles) * 4 + wave, lane);
 #ifdef GS_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GS_STAMP(2);
@@ -626,43 +443,6 @@ __global__ __launch_bounds__(256) void stream_wgrad_kernel(const WgradArgs G, co
 // ------------------------------------------------------------------------------------------ host side
 static inline int rup4s(int x) { return (x + 3) & ~3; }
 
-// The weight-stationary form applies when K fills one of the instantiated slice lengths exactly (ceil(K / 8) == 4 KQ, KQ in
-// {19, 8}: F in 601..608 or 249..256), every A row is readable up to the 8-aligned K, there are at least two M-tiles per
-// persistent workgroup and at most FWD3_MAXT.
-// Form 3 is OFF by default (measured, profiles/r03_fwd_forms.json: 22.8 us alone against 24.6 for form 2, no difference
-// inside the training step, where the launch is bound by its riders); GS_STREAM_FWD_V3=1 or gs_set_stream_fwd_form(3)
-// turn it on.
-static int g_fwd_form = -1;
-extern "C" int gs_set_stream_fwd_form(int32_t form) {
-    GS_REQUIRE(form == 2 || form == 3, "gs_set_stream_fwd_form: form must be 2 or 3");
-    g_fwd_form = form;
-    return GS_OK;
-}
-static int fwd3_cus() {
-    static int n_cus = 0;
-    if (!n_cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
-        if (n_cus <= 0) n_cus = 256;
-    }
-    return n_cus;
-}
-static bool fwd3_applies(int32_t d, int64_t n, int32_t out_dim, int32_t nterms, int64_t ld_self, int64_t ld_agg) {
-    if (g_fwd_form < 0) g_fwd_form = getenv("GS_STREAM_FWD_V3") && atoi(getenv("GS_STREAM_FWD_V3")) ? 3 : 2;
-    if (g_fwd_form != 3 || d <= 0 || n <= 0 || out_dim <= 0) return false;
-    const int nm = (d + 7) / 8, kq = (nm + 3) / 4;
-    const int64_t tiles_m = gs_ceil_div(n, 32);
-    const int combos = nterms * (int)gs_ceil_div(out_dim, 64);
-    const int msets = std::max(1, fwd3_cus() / combos);
-    return (kq == 19 || kq == 8) && nm == 4 * kq && ld_agg >= 8 * nm && ld_self >= 8 * nm && tiles_m >= 2 * msets &&
-           gs_ceil_div(tiles_m, msets) <= FWD3_MAXT;
-}
-
-extern "C" int gs_sage_dense_fwd_stream_form(int32_t d, int64_t n, int32_t out_dim, int32_t two_terms, int64_t ld_self, int64_t ld_agg) {
-    return fwd3_applies(d, n, out_dim, two_terms ? 2 : 1, two_terms ? ld_self : ld_agg, ld_agg) ? 3 : 2;
-}
-
 extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg,
                                         int64_t ld_agg, int32_t d, int64_t n, const float* W_self, int64_t ldw_self,
                                         const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias,
@@ -693,32 +473,13 @@ extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, cons
     const int tiles_m = (int)gs_ceil_div(n, 32);
     g.tiles_n = (int)gs_ceil_div(out_dim, 64);
     g.n_tiles = tiles_m * g.tiles_n * g.nterms;
-    g.tiles_m = tiles_m;
     CoGatherS J = {};
     int64_t waves = 0;
     int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
     if (rc != GS_OK) return rc;
-    // weight-stationary persistent form (v3), where it applies
-    static const int v3_prio = getenv("GS_RIDER_PRIO") ? atoi(getenv("GS_RIDER_PRIO")) : 1;
-    const int n_cus = fwd3_cus();
-    const int combos = g.nterms * g.tiles_n;
-    if (fwd3_applies(d, n, out_dim, g.nterms, self ? ld_self : ld_agg, ld_agg)) {
-        g.msets = std::max(1, n_cus / combos);
-        g.n_tiles = g.msets * combos;
-        g.rider_prio = v3_prio;
-        const int64_t blocks3 = g.n_tiles + gs_ceil_div(waves, 4);
-        GS_REQUIRE(blocks3 < (1ll << 31), "gs_sage_dense_fwd_stream: grid too large");
-        if ((d + 7) / 8 == 4 * 19) hipLaunchKernelGGL((sage_stream_fwd3_kernel<19, 8>), dim3((unsigned)blocks3), dim3(256), 0, (hipStream_t)stream, g, J);
-        else hipLaunchKernelGGL((sage_stream_fwd3_kernel<8, 8>), dim3((unsigned)blocks3), dim3(256), 0, (hipStream_t)stream, g, J);
-        GS_LAUNCH_CHECK("sage_stream_fwd3_kernel");
-        return GS_OK;
-    }
     const int64_t blocks = g.n_tiles + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_dense_fwd_stream: grid too large");
-    static const int ring = getenv("GS_STREAM_FWD_P") ? atoi(getenv("GS_STREAM_FWD_P")) : 4;   // tuning hook
-    if (ring >= 8) hipLaunchKernelGGL(sage_stream_fwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
-    else if (ring >= 6) hipLaunchKernelGGL(sage_stream_fwd_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
-    else hipLaunchKernelGGL(sage_stream_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
+    hipLaunchKernelGGL(sage_stream_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);   // ring of 4 (6, 8: measured slower)
     GS_LAUNCH_CHECK("sage_stream_fwd_kernel");
     return GS_OK;
 }

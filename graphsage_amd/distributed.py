@@ -140,8 +140,11 @@ class NativeAllReduce(object):
         th.start()
         th.join(timeout)
         if th.is_alive():
-            raise RuntimeError("ncclCommInitRank did not return within %.0f s on rank %d (a peer failed before entering it?)"
-                               % (timeout, self.rank))
+            # FATAL for this process: the abandoned thread still sits inside ncclCommInitRank with a half-built communicator on
+            # this device and may write `h` later; any further collective on the device (the NCCL-backend fallback included)
+            # could hang behind it.  make_grad_hook does not fall back from this one.
+            raise RcclInitTimeout("ncclCommInitRank did not return within %.0f s on rank %d (a peer failed before entering it?)"
+                                  % (timeout, self.rank))
         if "err" in box:
             raise box["err"]
         self._comm = h.value
@@ -207,6 +210,10 @@ class SpinHook(object):
             ops.call("gs_spin_us", self.us, self.engine.stream)
 
 
+class RcclInitTimeout(RuntimeError):
+    """ncclCommInitRank hung past the watchdog: the process must not issue further GPU collectives."""
+
+
 def make_grad_hook(engine, log=None):
     """The gradient all-reduce hook of a data-parallel run: the in-graph RCCL binding of the C ABI when it initialises
     and passes its self test on EVERY rank (each stage's outcome is agreed collectively, so no rank is left inside a
@@ -219,7 +226,14 @@ def make_grad_hook(engine, log=None):
         try:
             hook = NativeAllReduce(engine)
             ok = 1
-        except Exception as ex:      # RCCL missing / id / init failure / watchdog
+        except RcclInitTimeout as ex:
+            # a bootstrap abandoned in flight: falling back to another collective on the same device is only safe when that
+            # collective runs on the host (gloo); otherwise stop this rank -- its peers time out in _agree
+            if log:
+                log("FATAL on rank %d: %r" % (rank, ex))
+            if not (dist.is_initialized() and dist.get_backend() == "gloo"):
+                raise
+        except Exception as ex:      # RCCL missing / id / init failure
             if log:
                 log("native RCCL hook unavailable on rank %d: %r" % (rank, ex))
         ok = _agree(ok, engine)      # every rank constructed it -- only then is the (collective) self test entered

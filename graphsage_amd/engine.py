@@ -92,13 +92,8 @@ class Engine(object):
         self._wgrad_big_n = int(os.environ.get("GS_WGRAD_BIG_N", 16384))
         self._stream_max_slabs = int(os.environ.get("GS_STREAM_MAX_SLABS", 32))
         self._stream_slice_rows = float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))
-        self._pending_stream_ok = True
-        # second stream for the data chain (sampling + gathers of the NEXT step overlap this step's compute)
-        self._stream2_obj = None
-        self.stream2 = None
         self._defer_sampler = False       # neigh_samplers.fanout: hand the launch to the next optimizer launch instead
         self._deferred_sampler = None
-        self._ev_fork = self._ev_join = None
 
     # -------------------------------------------------------------------------------- variables
     def add_variable(self, name, init, decay=False, scatter=False):
@@ -200,7 +195,6 @@ class Engine(object):
         for v in self.variables:
             v.n_slabs = 1 if v.scatter else 0
         self._pending = []
-        self._pending_stream_ok = True
 
     def pick_slabs(self, n_rows, tiles):
         """Split-K slices for a weight gradient.  The kernel is latency-bound per workgroup (one global round trip
@@ -228,36 +222,46 @@ class Engine(object):
         big = n >= self._wgrad_big_n and var.rows >= 128 and var.cols >= 128   # throughput-bound: own launch with 128x128 tiles
         t = 128 if big else 64
         tiles = ((var.rows + t - 1) // t) * ((var.cols + t - 1) // t)
-        k = self.pick_slabs(n, tiles)
-        if self.stream_gemm and not big and self._pending_stream_ok:
-            # stream kernel: one WAVE per (64x64 tile, slice); ~1 contraction wave per SIMD over the whole launch
-            # (~900 items for the Reddit step) with >= 256 reduction rows per slice.  Eligibility is decided HERE, per
-            # problem, so that a problem the stream kernel cannot take keeps the slab count tuned for the tiled kernel.
-            ks = int(max(1, min(self._stream_max_slabs, MAX_SLABS - var.n_slabs, round(n / self._stream_slice_rows))))
-            lda, ldz = A.ld, dZ.ld
-            if a_idx is not None:
-                ok = (n + ks - 1) // ks <= 510 and (A.rows + 1) * lda * 4 < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
-            else:
-                ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
-            if ok:
-                k = ks
-            else:
-                self._pending_stream_ok = False      # the whole grouped launch takes the tiled kernel
-        if var.n_slabs + k > MAX_SLABS:
-            raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
         if big:
+            k = self.pick_slabs(n, tiles)
+            if var.n_slabs + k > MAX_SLABS:
+                raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
             ops.call("gs_dense_wgrad", A.ptr, A.ld, ops.ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, var.cols, n, k,
                      var.slab_ptr(var.n_slabs), var.ld, self.stream)
             var.n_slabs += k
             return
-        d = ops._lib.WgradDesc()
-        d.A, d.a_idx, d.dZ = A.ptr, ops.ptr(a_idx), dZ.ptr
-        d.slabs = var.slab_ptr(var.n_slabs)
-        d.lda, d.ldz, d.ld_slab, d.n = A.ld, dZ.ld, var.ld, n
-        d.d, d.col0, d.out_dim, d.n_slabs = var.rows, col0, var.cols, k
-        d.a_rows = A.rows if a_idx is not None else 0
-        self._pending.append(d)
-        var.n_slabs += k
+        # queued: slab counts are assigned in launch_wgrads(), once it is known whether EVERY problem of the pass can take the
+        # stream kernel (its slab count is tuned differently from the tiled kernel's)
+        self._pending.append((var, A, a_idx, dZ, col0, n, tiles))
+
+    def _stream_slabs(self, var, A, a_idx, dZ, n, reserved=0):
+        """(eligible for the stream kernel, its slab count): one WAVE per (64x64 tile, slice), ~1 contraction wave per SIMD over
+        the whole launch (~900 items for the Reddit step) with >= 256 reduction rows per slice."""
+        ks = int(max(1, min(self._stream_max_slabs, MAX_SLABS - var.n_slabs - reserved, round(n / self._stream_slice_rows))))
+        lda, ldz = A.ld, dZ.ld
+        if a_idx is not None:
+            ok = (n + ks - 1) // ks <= 510 and (A.rows + 1) * lda * 4 < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
+        else:
+            ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
+        return ok, ks
+
+    def _assign_slabs(self, stream):
+        """Pending problems -> gs_wgrad_desc list with slabs assigned behind what each variable already holds."""
+        descs = []
+        for var, A, a_idx, dZ, col0, n, tiles in self._pending:
+            k = self._stream_slabs(var, A, a_idx, dZ, n)[1] if stream else self.pick_slabs(n, tiles)
+            if var.n_slabs + k > MAX_SLABS:
+                raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
+            d = ops._lib.WgradDesc()
+            d.A, d.a_idx, d.dZ = A.ptr, ops.ptr(a_idx), dZ.ptr
+            d.slabs = var.slab_ptr(var.n_slabs)
+            d.lda, d.ldz, d.ld_slab, d.n = A.ld, dZ.ld, var.ld, n
+            d.d, d.col0, d.out_dim, d.n_slabs = var.rows, col0, var.cols, k
+            d.a_rows = A.rows if a_idx is not None else 0
+            descs.append(d)
+            var.n_slabs += k
+        self._pending = []
+        return descs
 
     def bgrad(self, var, dZ, n, n_cols, col0=0):
         """Bias gradient = column sums of dZ[:, col0:col0+n_cols] = ones^T · dZ (one more grouped problem)."""
@@ -285,26 +289,27 @@ class Engine(object):
         if not self._pending:
             self.launch_gather_jobs(side_jobs)
             return
-        if self.stream_gemm and self._pending_stream_ok:
-            # (eligibility was decided per problem in wgrad(); the kernel takes up to 12 problems per launch)
+        # the whole pass takes the stream kernel, or the tiled one: decided here, over every queued problem, BEFORE any slab
+        # count is assigned (each kernel has its own slab policy)
+        stream = self.stream_gemm and all(self._stream_slabs(v, A, ai, dZ, n)[0] for v, A, ai, dZ, _, n, _ in self._pending)
+        pending = self._assign_slabs(stream)
+        if stream:
             jobs = list(side_jobs or ())
-            for a in range(0, len(self._pending), 12):
-                chunk = self._pending[a:a + 12]
+            for a in range(0, len(pending), 12):       # the kernel takes up to 12 problems per launch
+                chunk = pending[a:a + 12]
                 arr = (ops._lib.WgradDesc * len(chunk))(*chunk)
                 jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
                 ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(arr), len(chunk), ctypes.addressof(jarr),
                          len(jobs), self.stream)
                 jobs = []
-            self._pending = []
             return
-        arr = (ops._lib.WgradDesc * len(self._pending))(*self._pending)
+        arr = (ops._lib.WgradDesc * len(pending))(*pending)
         if side_jobs:
             jarr = (ops._lib.GatherDesc * len(side_jobs))(*side_jobs)
-            ops.call("gs_dense_wgrad_grouped_cogather", ctypes.addressof(arr), len(self._pending), ctypes.addressof(jarr),
+            ops.call("gs_dense_wgrad_grouped_cogather", ctypes.addressof(arr), len(pending), ctypes.addressof(jarr),
                      len(side_jobs), self.stream)
         else:
-            ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr), len(self._pending), self.stream)
-        self._pending = []
+            ops.call("gs_dense_wgrad_grouped", ctypes.addressof(arr), len(pending), self.stream)
 
     def _var_descs(self):
         arr = (ops._lib.VarDesc * len(self.variables))()
@@ -316,12 +321,12 @@ class Engine(object):
         return arr
 
     def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0, side_jobs=None,
-                        loss=None, step_offset=1, opt_jobs=None):
+                        loss=None, step_offset=1):
         """One grouped launch for every queued weight gradient, then ONE launch that sums the slabs into the
         flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass.
         loss = (loss_rows, n, scale, loss_out, accumulate): the step's scalar loss is formed by that launch too;
         step_offset = 0 when an earlier launch of the step has already advanced the optimizer step counter.
-        side_jobs / opt_jobs: gather+mean descriptors of the next step riding in the weight-gradient / optimizer launch."""
+        side_jobs: gather+mean descriptors of the next step riding in the weight-gradient launch."""
         self.launch_wgrads(side_jobs)
         arr = self._var_descs()
         lr_, ln, lscale, lout, lacc = loss if loss is not None else (None, 0, 0.0, None, False)
@@ -331,13 +336,10 @@ class Engine(object):
                 ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
                 1 if lacc else 0)
         rider = getattr(self, "_deferred_sampler", None)
-        if rider is not None or opt_jobs:
+        if rider is not None:
             # a later mini-batch's fan-out sampler rides in this launch (neigh_samplers.fanout under _defer_sampler)
             self._deferred_sampler = None
-            jobs = list(opt_jobs or ())
-            jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
-            ops.call("gs_flat_reduce_adam_sample", *args, ctypes.addressof(rider) if rider is not None else None,
-                     ctypes.addressof(jarr), len(jobs), self.stream)
+            ops.call("gs_flat_reduce_adam_sample", *args, ctypes.addressof(rider), None, 0, self.stream)
         else:
             ops.call("gs_flat_reduce_adam", *args, self.stream)
         if fuse_adam:
@@ -384,33 +386,6 @@ class Engine(object):
                  ops.ptr(self.step_dev) if step else None, step,
                  ops.ptr(self.sample_clock_dev) if clock else None, clock,
                  ops.ptr(cursor) if (cursor is not None and cursor_delta) else None, cursor_delta, self.stream)
-
-    def ensure_stream2(self):
-        if self.stream2 is None:
-            self._stream2_obj = ops.Stream()
-            self.stream2 = self._stream2_obj.handle
-            self._ev_fork, self._ev_join = ops.Event(), ops.Event()
-        return self.stream2
-
-    def fork_join(self, main_fn, side_fn, main_first=False):
-        """Run side_fn on the second stream concurrently with main_fn on the engine stream (fork after what is
-        already queued, join before what comes next).  Works eagerly and inside a hipGraph capture.  main_first: enqueue
-        main_fn before side_fn (a collective's kernel should reach the chip before the work that fills it)."""
-        s2 = self.ensure_stream2()
-        s1 = self.stream
-        self._ev_fork.record(s1)
-        self._ev_fork.wait(s2)
-        if main_first:
-            main_fn()
-        self.stream = s2
-        try:
-            side_fn()
-        finally:
-            self.stream = s1
-        if not main_first:
-            main_fn()
-        self._ev_join.record(s2)
-        self._ev_join.wait(s1)
 
     def launch_gather_jobs(self, jobs):
         """Stand-alone gather+mean launches (K2) of a list of gs_gather_desc jobs on the current stream."""

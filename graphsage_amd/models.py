@@ -115,29 +115,23 @@ class SampleAndAggregate(object):
         self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.5 if self.engine.stream_gemm else 0.7))
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
-        self.cogather_opt = float(os.environ.get("GS_COGATHER_OPT", 0.0))      # share riding in the optimizer launch
-        # fused tail as two launches (z helpers | row-group workgroups), and the part of the tail's share the first carries
         # unsupervised pipeline: share of the gather riding in the last layer's lean launch
         self.cogather_z = float(os.environ.get("GS_COGATHER_Z", 0.04))        # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
-        self.cogather_dh0 = float(os.environ.get("GS_COGATHER_DH0", 0.0))     # ... and in its backward twin's launch
+        # DIAGNOSTIC (one test pins it bit-identical): the fused tail as two launches (z helpers | row-group workgroups) --
+        # no dependency between workgroups of a launch, the safe form under tools that serialise workgroups; +11 us per step
         self.tail_split = os.environ.get("GS_TAIL_SPLIT", "0") == "1"
-        self.cogather_tail_z = float(os.environ.get("GS_COGATHER_TAIL_Z", 0.35))
-        # data-parallel with the all-reduce recorded in the step graph: share of the gather on a forked graph branch that
-        # runs beside ncclAllReduce (the collective is latency-bound and leaves the chip idle).  OFF by default: measured
-        # on one MI355X with a 30 us sleeping-wave stand-in for the collective (profiles/r03_dp_schedule.json), a fork/join
-        # inside the step hipGraph costs ~8 us by itself and the two branches overlap only partly, so the forked schedule
-        # (149.9 / 157.5 us at 35 % / 62 %) loses against the plain in-graph one (147.9 us).  GS_COGATHER_DP_FORK=<share>
-        # or GS_DP_FORK_AUTO=1 (calibrate_dp_fork sizes the share from the measured collective) turn it on.
-        self.cogather_dp_fork = float(os.environ.get("GS_COGATHER_DP_FORK", 0.0))
+        self.cogather_tail_z = 0.35           # part of the tail's gather share the z launch carries in that form
+        # (Removed in round 4 after losing their measurements -- sources and numbers in benchmarks/variants/README.md: a gather
+        #  share in the optimizer launch, one in the last layer's backward launch, a forked gather branch beside the in-graph
+        #  all-reduce, the second-stream pipeline, the weight-stationary form of the layer-0 forward.)
         # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
         self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
         self.grad_hook = None
         if self.identity_dim == 0:
-            # True / "fused": next-step gather co-scheduled inside this step's big launches (one stream);
-            # "streams": the data chain of the next step on a second stream (fork/join inside the step graph)
-            self.pipeline = os.environ.get("GS_PIPELINE", "fused") if os.environ.get("GS_PIPELINE") else True
+            # next-step gather co-scheduled inside this step's launches (one stream); False = sequential schedule
+            self.pipeline = os.environ.get("GS_PIPELINE", "1") != "0"
         self._primed = None
         self._prefetched = {}
         self._pending_stage = None
@@ -427,10 +421,10 @@ class SampleAndAggregate(object):
         """Data-parallel AND the all-reduce hook can be recorded inside the step's hipGraph (NativeAllReduce)."""
         return self.grad_hook is not None and getattr(self.grad_hook, "capturable", False)
 
-    def calibrate_dp_fork(self, n_gather_rows=None, log=None):
-        """Size the gather share that runs beside the in-graph all-reduce from measurements: the collective's duration
-        (HIP events around eager calls of the hook on the gradient buffer -- every rank calls this, it is a collective)
-        against the duration of the step's whole layer-0 gather as a stand-alone launch.  Returns the measurements."""
+    def measure_dp_allreduce(self, log=None):
+        """Duration of the gradient all-reduce as a stand-alone call (HIP events around eager calls of the hook on the
+        gradient buffer -- every rank calls this, it is a collective): what the in-graph data-parallel step exposes per
+        step, echoed by bench.py (dp_schedule)."""
         e = self.engine
         if not self._dp_in_graph():
             return None
@@ -443,29 +437,9 @@ class SampleAndAggregate(object):
         ar_us = float(np.median([a.elapsed_ms(b) for a, b in evs[2:]])) * 1e3
         e.grads.zero_()
         torch.cuda.synchronize()
-        # the gather: what one step prefetches for the next (all hops of layer 0)
-        n_rows = int(n_gather_rows) if n_gather_rows else 5632
-        s = self.num_samples[0]
-        F = self.features
-        idx = torch.randint(0, F.rows, (n_rows * s,), device=e.device, dtype=torch.int64).to(torch.int32)
-        out = Mat.zeros(n_rows, F.d, e.device)
-        torch.cuda.synchronize()
-        evs = [(ops.Event(), ops.Event()) for _ in range(8)]
-        for a, b in evs:
-            a.record(e.stream)
-            ops.gather_mean_fwd(F, idx, n_rows, s, out=out, stream=e.stream)
-            b.record(e.stream)
-        e.sync()
-        k2_us = float(np.median([a.elapsed_ms(b) for a, b in evs[2:]])) * 1e3
-        share = max(0.0, min(0.85, ar_us / max(k2_us, 1e-3)))
-        if os.environ.get("GS_COGATHER_DP_FORK") is None and os.environ.get("GS_DP_FORK_AUTO", "0") == "1":
-            self.cogather_dp_fork = round(share, 2)
-        res = {"allreduce_us_standalone": ar_us, "layer0_gather_us_standalone": k2_us, "fork_share": self.cogather_dp_fork,
-               "fork_share_suggested": round(share, 2)}
         if log:
-            log("data-parallel schedule: all-reduce %.1f us, layer-0 gather %.1f us stand-alone; %.0f %% of the gather runs "
-                "beside the collective" % (ar_us, k2_us, 100 * self.cogather_dp_fork))
-        return res
+            log("data-parallel schedule: all-reduce %.1f us stand-alone, recorded in the step graph behind the backward pass" % ar_us)
+        return {"allreduce_us_standalone": ar_us}
 
     def _pipelined_steps_unsup(self, B, k):
         e = self.engine
@@ -535,25 +509,14 @@ class SampleAndAggregate(object):
                     # the last layer's lean launch (gs_sage_tail_z) leaves most of the chip idle: a share rides there at
                     # the full HBM rate
                     wgrad_jobs, z_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_z / max(1e-6, 1.0 - self.cogather_split)))
-                if self.cogather_dh0 > 0 and len(self.num_samples) > 1 and isinstance(self.aggregators[-1], MeanAggregator):
-                    left = max(1e-6, 1.0 - self.cogather_split - (self.cogather_z if z_jobs else 0.0))
-                    wgrad_jobs, bj = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dh0 / left))
-                    self.aggregators[-1].bwd_jobs = bj or None
-                fork_jobs = []
-                if in_graph and self.cogather_dp_fork > 0:
-                    left = max(1e-6, 1.0 - self.cogather_split)
-                    wgrad_jobs, fork_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dp_fork / left))
                 epilogue = dict(step=1 if local_adam else 0, clock=1, cursor=self._cursor, cursor_delta=B)
                 self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue, z_jobs=z_jobs)
                 self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
                 if e._deferred_sampler is not None:
                     raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
                 if in_graph:
-                    # backward | ncclAllReduce (recorded in the graph; a gather share may run beside it) | clip + Adam
-                    if fork_jobs:
-                        e.fork_join(lambda: self.grad_hook(self), lambda: e.launch_gather_jobs(fork_jobs), main_first=True)
-                    else:
-                        self.grad_hook(self)
+                    # backward | ncclAllReduce (recorded in the graph) | clip + Adam
+                    self.grad_hook(self)
                     self._optimize()
                 p = q
 
@@ -785,9 +748,9 @@ class SampleAndAggregate(object):
         e = self.engine
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
-                self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.cogather_opt,
-                self.tail_split, self.cogather_tail_z, self.cogather_z, self.cogather_dh0,
-                self.cogather_dp_fork, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)), type(self.grad_hook).__name__,
+                self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
+                self.cogather_z, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
+                type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 
     def _run(self, key, fn):

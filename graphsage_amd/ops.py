@@ -427,17 +427,6 @@ def head_fwd_bwd(x, n, W, bias, labels, C, sigmoid_loss, y, logits, preds, dlogi
          dx.ptr if dx is not None else None, dx.ld if dx is not None else 0, _s(stream))
 
 
-def sage_dense_fwd_stream_form(d, n, out_dim, two_terms, ld_self, ld_agg):
-    """2 or 3: the form of gs_sage_dense_fwd_stream a call of this shape takes (3 = weight-stationary persistent)."""
-    return int(_lib.load().gs_sage_dense_fwd_stream_form(int(d), int(n), int(out_dim), 1 if two_terms else 0, int(ld_self),
-                                                         int(ld_agg)))
-
-
-def set_stream_fwd_form(form):
-    """Process-wide: 3 = the weight-stationary persistent form of the layer-0 contraction where it applies, 2 = default."""
-    call("gs_set_stream_fwd_form", int(form))
-
-
 def sage_tail_supported(d_in, out_dim, C):
     return bool(_lib.load().gs_sage_tail_supported(int(d_in), int(out_dim), int(C)))
 

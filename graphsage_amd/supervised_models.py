@@ -164,7 +164,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                     first = False
             self._loss_accumulate = not first
 
-    def _backward(self, n, fuse_adam, wgrad_jobs=None, epilogue=None, opt_jobs=None):
+    def _backward(self, n, fuse_adam, wgrad_jobs=None, epilogue=None):
         """Reverse of _forward.  Every weight gradient of the pass is ONE grouped launch; the slab reduction
         (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
@@ -183,9 +183,8 @@ class SupervisedGraphsage(SampleAndAggregate):
             e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
                               side_jobs=wgrad_jobs,
                               loss=(self._loss_rows, n, 1.0 / n, self.loss_dev, self._loss_accumulate) if epilogue is not None else None,
-                              step_offset=0 if self._tail_step_advanced else 1, opt_jobs=opt_jobs)
+                              step_offset=0 if self._tail_step_advanced else 1)
             return
-        assert not opt_jobs, "optimizer-launch gather riders need the fused-tail schedule"
         if self._head_fused:
             e.wgrad(self.node_pred.vars['weights'], self.outputs1, None, self._dlogits, 0, n)
             e.bgrad(self.node_pred.vars['bias'], self._dlogits, n, self.num_classes)
@@ -361,13 +360,13 @@ class SupervisedGraphsage(SampleAndAggregate):
     def _pipelined_steps(self, n, k, data, fused):
         """k consecutive pipelined steps as ONE hipGraph launch (k even, or 1).
 
-        pipeline == "fused" (default): single stream.  Step t first samples step t+1 (one small launch), then its
-        layer-0 dense launch carries step t+1's gather+mean waves along (horizontal fusion), so the HBM-bound
-        gather overlaps the MFMA-bound contraction without any cross-stream dependency.
-        pipeline == "streams": the whole data chain of step t+1 runs on a second stream (fork/join graph)."""
+        Single stream: step t first samples step t+1 (one small launch, or riding in an optimizer launch), then its
+        launches carry step t+1's gather+mean waves along (horizontal fusion): no cross-stream dependency.  (A second-stream
+        fork/join pipeline and a forked gather branch beside the all-reduce were built and measured in rounds 2-3 -- 152-162 us
+        against 118, 149.9 against 147.9 -- and removed in round 4: benchmarks/variants/README.md.)"""
         e = self.engine
         p0 = self._pipe_parity
-        mode = "streams" if self.pipeline == "streams" else "fused"
+        mode = "fused"
         in_graph = self._dp_in_graph()          # `fused` is then True as well: the whole DP step is one graph
         local_adam = self.grad_hook is None
 
@@ -376,40 +375,19 @@ class SupervisedGraphsage(SampleAndAggregate):
             self._parity = p
             # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
-            opt_jobs, fork_jobs = [], []
             if side_jobs and self.cogather_tail > 0 and self._tail_ok():
                 # the fused tail launch keeps only n/16 CUs busy: the rest of the chip streams a share of the gather
                 f_fwd, f_tail = self.cogather_split3, self.cogather_tail
-                f_fork = min(self.cogather_dp_fork, 1.0 - f_fwd) if in_graph else 0.0
-                if f_fork > 0:
-                    # data-parallel: the collective is latency-bound and leaves the chip idle -- that share of the gather
-                    # runs on a forked branch concurrently with ncclAllReduce; the tail launch keeps what is left
-                    f_tail = max(0.0, min(f_tail, 1.0 - f_fwd - f_fork))
                 fwd_jobs, rest = ops.split_gather_jobs(side_jobs, f_fwd)
-                tail_jobs, rest = ops.split_gather_jobs(rest, min(1.0, f_tail / max(1e-6, 1.0 - f_fwd)))
-                if f_fork > 0:
-                    left = max(1e-6, 1.0 - f_fwd - f_tail)
-                    wgrad_jobs, fork_jobs = ops.split_gather_jobs(rest, max(0.0, 1.0 - f_fork / left))
-                else:
-                    wgrad_jobs = rest
-                if self.cogather_opt > 0 and local_adam:
-                    left = max(1e-6, 1.0 - f_fwd - f_tail)
-                    wgrad_jobs, opt_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_opt / left))
+                tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, f_tail / max(1e-6, 1.0 - f_fwd)))
             else:
                 fwd_jobs, wgrad_jobs = ops.split_gather_jobs(side_jobs, self.cogather_split)
                 tail_jobs = []
-                if side_jobs and in_graph and self.cogather_dp_fork > 0:
-                    left = max(1e-6, 1.0 - self.cogather_split)
-                    wgrad_jobs, fork_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_dp_fork / left))
             self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue,
                           tail_jobs=tail_jobs)
-            self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue, opt_jobs=opt_jobs)
+            self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
             if in_graph:
-                # ncclAllReduce on the engine stream, recorded in the graph; the forked gather share runs beside it
-                if fork_jobs:
-                    e.fork_join(lambda: self.grad_hook(self), lambda: e.launch_gather_jobs(fork_jobs), main_first=True)
-                else:
-                    self.grad_hook(self)
+                self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
                 self._optimize(advanced=True)
 
         def sample_into(parity):
@@ -429,11 +407,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             p = p0
             staged = None
             for j in range(k):
-                if mode == "streams":
-                    def main(p=p):
-                        compute(p, epilogue=dict(step=1 if fused else 0))
-                    e.fork_join(main, lambda p=p: data(1 - p))
-                else:
+                if True:
                     q = 1 - p
                     if staged is None:
                         staged = sample_into(q)                    # standalone sampler launch (first step of a graph)

@@ -230,19 +230,6 @@ int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const int32_t* 
                              const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);
-/* Which form of gs_sage_dense_fwd_stream a call of this shape takes: 3 = weight-stationary persistent workgroups (one per
- * CU: the wave's whole W slice lives in registers, the A rows stream through a statically indexed register ring with >= 8
- * macro steps between a load and its use across tile boundaries, gather riders run at raised issue priority -- the
- * contraction is then insensitive to the memory latency the riders cause), 2 = one workgroup per 32 x 64 tile.  Form 3
- * needs ceil(d / 8) == 4 * 19 or 4 * 8 (d in 601..608 or 249..256), ld_self / ld_agg >= 8 * ceil(d / 8) (pad columns may
- * hold anything: the partial last macro step is masked), 2..8 M-tiles of 32 rows per persistent workgroup.  Same maths;
- * each form sums in its own fixed order (deterministic run to run); the two forms cut K into quarters at different macro
- * steps, so they agree to fp32 rounding, not bitwise. */
-int gs_sage_dense_fwd_stream_form(int32_t d, int64_t n, int32_t out_dim, int32_t two_terms, int64_t ld_self, int64_t ld_agg);
-/* Process-wide choice of the form (2 = default: measured equal inside the training step, where the launch is bound by
- * its gather riders; 3 is 7 % faster as a stand-alone launch).  Environment: GS_STREAM_FWD_V3=1. */
-int gs_set_stream_fwd_form(int32_t form);
-
 /* The same contraction on the bf16 matrix pipe WITHOUT giving up fp32: every fp32 operand x is cut into three bf16 pieces
  * x = h + m + l (top / middle / low 8 significant bits: nothing is lost), a product is the sum of piece products -- each formed
  * exactly by v_mfma_f32_32x32x16_bf16 and accumulated in fp32 -- and six of the nine are kept (hh, hm, mh, mm, hl, lh; the

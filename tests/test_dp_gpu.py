@@ -108,29 +108,25 @@ def test_native_rccl_hook_in_graph_single_rank(dev):
     np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7)
 
 
-def test_dp_fork_schedule_single_rank_matches_and_unsup_in_graph(dev):
-    """(a) supervised: the data-parallel in-graph schedule WITH the forked gather branch beside the collective (here the
-    1-rank RCCL all-reduce, and a sleeping-wave stand-in) gives the same parameters as the single-GPU fused schedule;
-    (b) unsupervised: the in-graph data-parallel schedule (backward | all-reduce | clip+Adam in ONE graph, several steps
-    per launch) == the single-GPU schedule."""
+def test_dp_in_graph_schedule_single_rank_matches_and_unsup_in_graph(dev):
+    """(a) supervised: the data-parallel in-graph schedule (backward | all-reduce | clip + Adam in ONE graph; here the 1-rank
+    RCCL all-reduce, and a sleeping-wave stand-in for a slow collective) gives the same parameters as the single-GPU fused
+    schedule; (b) unsupervised: the same for SampleAndAggregate, several steps per launch."""
     import numpy as np
     from graphsage_amd import engine as eng
     from graphsage_amd.distributed import NativeAllReduce, SpinHook
     from test_model_gpu import build
     outs = []
-    for mode in ("single", "rccl_fork", "spin_fork", "rccl_nofork"):
+    for mode in ("single", "rccl", "spin"):
         G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True)
         hook = None
         if mode != "single":
-            hook = NativeAllReduce(eng.get_engine(), world_size=1, rank=0) if mode.startswith("rccl") else SpinHook(eng.get_engine(), 20.0)
+            hook = NativeAllReduce(eng.get_engine(), world_size=1, rank=0) if mode == "rccl" else SpinHook(eng.get_engine(), 20.0)
             model.grad_hook = hook
-            model.cogather_dp_fork = 0.0 if mode == "rccl_nofork" else 0.4
             assert model._dp_in_graph()
-            if mode == "rccl_fork":
-                info = model.calibrate_dp_fork(n_gather_rows=32 * 4)
-                assert info["allreduce_us_standalone"] > 0 and 0.0 <= model.cogather_dp_fork <= 0.85
-                assert hook.ranks() == 1
-                model.cogather_dp_fork = 0.4
+            if mode == "rccl":
+                info = model.measure_dp_allreduce()
+                assert info["allreduce_us_standalone"] > 0 and hook.ranks() == 1
         model.attach_device_epoch(it.train_nodes[:320], it.label_matrix)
         model.train_steps_device(32, 9, steps_per_launch=2)
         loss, preds = model._fetch(32)
@@ -140,7 +136,7 @@ def test_dp_fork_schedule_single_rank_matches_and_unsup_in_graph(dev):
     for o in outs[1:]:
         np.testing.assert_allclose(outs[0][0], o[0], rtol=1e-5)
         np.testing.assert_allclose(outs[0][1], o[1], rtol=1e-5, atol=1e-7)
-    assert np.array_equal(outs[1][1], outs[2][1]) and np.array_equal(outs[1][1], outs[3][1])   # schedules differ, bits do not
+    assert np.array_equal(outs[1][1], outs[2][1])               # the collective's duration does not change the bits
     # ---- unsupervised
     from test_unsup_gpu import build as build_unsup
     res = []
@@ -149,7 +145,6 @@ def test_dp_fork_schedule_single_rank_matches_and_unsup_in_graph(dev):
         if dp:
             hook = NativeAllReduce(eng.get_engine(), world_size=1, rank=0)
             model.grad_hook = hook
-            model.cogather_dp_fork = 0.3
         model.attach_device_pairs(it.train_edges[:320])
         model.train_steps_device(32, 9, steps_per_launch=2)
         eng.get_engine().sync()
@@ -183,7 +178,7 @@ def _rccl_worker(rank, world, port, q):
         model.grad_hook = gsd.make_grad_hook(e)
         if mode == "native":
             assert type(model.grad_hook).__name__ == "NativeAllReduce" and model.grad_hook.ranks() == world
-            model.calibrate_dp_fork(n_gather_rows=B * 4)
+            model.measure_dp_allreduce()
         model.attach_device_epoch(gsd.shard_order(order, rank, world, B), it.label_matrix)
         model.train_steps_device(B, 7, steps_per_launch=2)
         e.sync()

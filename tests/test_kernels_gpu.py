@@ -1015,77 +1015,6 @@ def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias, gathered):
     assert np.array_equal(c_out.numpy(), X[ids1])
 
 
-@pytest.mark.parametrize("n,d,out,two,act,bias,gathered,riders", [
-    (5632, 602, 128, True, ops.ACT_RELU, False, True, True),        # the Reddit step's layer 0 (3 tiles per workgroup)
-    (11484, 602, 128, True, ops.ACT_RELU, False, True, True),       # the unsupervised step's (6 tiles)
-    (5632, 256, 128, True, ops.ACT_RELU, False, True, False),       # RMAT's F = 256: slice length 8
-    (5633, 601, 128, True, ops.ACT_IDENTITY, True, False, False),   # ragged rows, one valid k in the last macro step
-    (17000, 608, 64, False, ops.ACT_RELU, True, False, True),       # one term, one column tile, K = 608 exactly
-    (4100, 250, 192, True, ops.ACT_RELU, True, True, False)])       # three column tiles per term, K tail of 2
-def test_sage_dense_fwd_stream_weight_stationary(dev, n, d, out, two, act, bias, gathered, riders):
-    """The weight-stationary persistent form of gs_sage_dense_fwd_stream (W slice resident in registers, A through a static
-    register ring across tile boundaries, riders at raised priority) vs NumPy fp64: operands with 128-byte aligned rows whose
-    pad columns hold NaN (nothing beyond K may leak), gathered / dense self rows, the co-scheduled gather jobs, and -- run
-    twice -- bit-identical results."""
-    rng = np.random.default_rng(n + d)
-    Nn = 6000
-    X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
-    self_m, mean = _asym(rng, (n, d)), _asym(rng, (n, d))
-    self_ids = rng.integers(0, Nn + 1, size=n).astype(np.int32)
-    if gathered:
-        self_m = X[self_ids]
-    Ws, Wn = _asym(rng, (d, out)) * 0.1, _asym(rng, (d, out)) * 0.1
-    b = (_asym(rng, ((2 if two else 1) * out,)) * 0.1) if bias else None
-    idx = rng.integers(0, Nn + 1, size=(1500, 25)).astype(np.int32)
-    idx10 = rng.integers(0, Nn + 1, size=(300, 10)).astype(np.int32)
-    Xd = Mat.from_numpy(X, dev, 32)
-    sd, md = Mat.from_numpy(self_m, dev, 32), Mat.from_numpy(mean, dev, 32)
-    for m in (Xd, sd, md):
-        if m.ld > d:
-            m.buf[:, d:] = float("nan")
-    assert ops.sage_dense_fwd_stream_form(d, n, out, two, Xd.ld if gathered else sd.ld, md.ld) == 2       # off by default
-    ops.set_stream_fwd_form(3)
-    try:
-        _fwd3_case(dev, rng, n, d, out, two, act, bias, gathered, riders, Nn, X, self_m, mean, self_ids, Ws, Wn, b, idx, idx10,
-                   Xd, sd, md)
-    finally:
-        ops.set_stream_fwd_form(2)
-
-
-def _fwd3_case(dev, rng, n, d, out, two, act, bias, gathered, riders, Nn, X, self_m, mean, self_ids, Ws, Wn, b, idx, idx10, Xd, sd,
-               md):
-    assert ops.sage_dense_fwd_stream_form(d, n, out, two, Xd.ld if gathered else sd.ld, md.ld) == 3
-    assert ops.sage_dense_fwd_stream_form(d, n, out, two, Xd.ld, (d + 3) & ~3) == (3 if d % 8 == 0 else 2)   # unreadable pads
-    assert ops.sage_dense_fwd_stream_form(100, n, out, two, 128, 128) == 2 and ops.sage_dense_fwd_stream_form(d, 200, out, two, 640, 640) == 2
-    idx_d, idx10_d = _i32(idx.reshape(-1), dev), _i32(idx10.reshape(-1), dev)
-    Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
-    bd = torch.from_numpy(b).to(dev) if bias else None
-    sid_d = _i32(self_ids, dev)
-    outs = []
-    for rep in range(2):
-        outm = Mat.zeros(n, (2 if two else 1) * out, dev)
-        g_out, g10 = Mat.zeros(1500, d, dev), Mat.zeros(300, d, dev)
-        jobs = [ops.gather_job(Xd, idx_d, 1500, 25, g_out), ops.gather_job(Xd, idx10_d, 300, 10, g10)] if riders else []
-        if gathered:
-            ops.sage_dense_fwd_stream(Xd if two else None, sid_d if two else None, md, n, Wsd if two else None, Wnd, out, act, bd, outm, jobs)
-        else:
-            ops.sage_dense_fwd_stream(sd if two else None, None, md, n, Wsd if two else None, Wnd, out, act, bd, outm, jobs)
-        _sync()
-        outs.append(outm.numpy())
-        if riders:
-            np.testing.assert_allclose(g_out.numpy(), X[idx].mean(axis=1), **TOL)
-            np.testing.assert_allclose(g10.numpy(), X[idx10].mean(axis=1), **TOL)
-    want_n = mean.astype(np.float64) @ Wn
-    want = np.concatenate([self_m.astype(np.float64) @ Ws, want_n], axis=1) if two else want_n
-    if bias:
-        want = want + b
-    if act == ops.ACT_RELU:
-        want = np.maximum(want, 0)
-    assert np.isfinite(outs[0]).all()
-    assert_close_rownorm(outs[0], want)
-    assert np.array_equal(outs[0], outs[1])
-
-
 @pytest.mark.parametrize("slices0", [22, 11, 45])
 def test_dense_wgrad_grouped_stream(dev, slices0):
     """gs_dense_wgrad_grouped_stream: the weight gradients of a mean step (layer 0: 602x128 x2 over 5632 rows, layer 1:

@@ -345,7 +345,7 @@ def test_csr_training_graph_replay_equals_eager(dev):
     outs = []
     # (hipGraph?, fused kernels?, cross-step pipeline?)
     for use_graphs, fuse, pipe in ((False, True, False), (True, True, True), (False, False, False), (True, True, False),
-                                   (False, True, True), (True, True, "streams"), (False, True, "streams")):
+                                   (False, True, True)):
         G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True, fuse=fuse)
         model.use_graphs = use_graphs
         model.pipeline = pipe
