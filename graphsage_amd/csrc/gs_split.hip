@@ -61,7 +61,7 @@ __device__ __forceinline__ f32x16 gs_mfma_bf16(const u32x4 a, const u32x4 b, con
 // ------------------------------------------------------------------------------------------------ W -> W3
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ W, int64_t ldw, int32_t K, int32_t N,
                                                          u32x4* __restrict__ W3) {
-    const int KG = ((K + 15) / 16) * 2;
+    const int KG = 4 * ((((K + 31) / 32) + 1) & ~1);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // t = kg * N + n: consecutive lanes, consecutive n
     if (t >= (int64_t)KG * N) return;
     const int kg = (int)(t / N), n = (int)(t - (int64_t)kg * N);
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     dst[0] = h; dst[(int64_t)N] = m; dst[2 * (int64_t)N] = l;
 }
 
-static inline int64_t split_rows_bytes(int32_t K, int32_t N) { return (int64_t)N * (((K + 15) / 16) * 2) * 48; }
+// groups of 8 k in W3: the k16 steps of the streaming kernel (2 ceil(K/16)), rounded up to the tiled kernel's even count of 32-k
+// stages -- everything beyond K is zero, so neither kernel masks or clamps its B loads
+static inline int split_groups(int32_t K) { return 4 * ((((K + 31) / 32) + 1) & ~1); }
+static inline int64_t split_rows_bytes(int32_t K, int32_t N) { return (int64_t)N * split_groups(K) * 48; }
 
 extern "C" int gs_split_rows_bytes(int32_t K, int32_t N, int64_t* bytes_out_host) {
     GS_REQUIRE(K > 0 && N > 0 && bytes_out_host, "gs_split_rows_bytes: bad args");
@@ -88,7 +91,7 @@ extern "C" int gs_split_rows_bytes(int32_t K, int32_t N, int64_t* bytes_out_host
 extern "C" int gs_split_rows(const float* W, int64_t ldw, int32_t K, int32_t N, void* W3, void* stream) {
     GS_REQUIRE(W && W3 && K > 0 && N > 0 && ldw >= N, "gs_split_rows: bad args");
     GS_REQUIRE(gs_aligned16(W3), "gs_split_rows: W3 must be 16-byte aligned");
-    const int64_t total = (int64_t)N * (((K + 15) / 16) * 2);
+    const int64_t total = (int64_t)N * split_groups(K);
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)gs_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, K, N,
                        (u32x4*)W3);
     GS_LAUNCH_CHECK("split_rows_kernel");
@@ -364,11 +367,13 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledAr
     const int arow = tid >> 2, aq = tid & 3;                   // A: row of the tile, 8-float quarter of the stage
     const int grow = min(m0 + arow, count - 1);
     const int64_t srow = g.idx ? (int64_t)g.idx[grow] : (int64_t)grow;
-    const int bcol = tid & 127, bch = tid >> 7;                // B: column of the tile, chunks bch, bch + 4, bch + 8 (12 per stage)
-    const int bc = min(n0 + bcol, N - 1);
+    const int bcol = tid & 127, bch = wave >> 1;               // B: column of the tile, chunks bch, bch + 4, bch + 8 (12 per stage;
+    const int bc = min(n0 + bcol, N - 1);                      //    bch is wave-uniform: the group arithmetic stays scalar)
+    const char* __restrict__ W3b = (const char*)g.W3;
+    const uint32_t bcol_off = (uint32_t)bc * 16u, plane_b = (uint32_t)N * 16u;
     f32x4 ra[2][2];                                            // two register sets: stage s + 2 is requested while stage s
     u32x4 rb[2][3];                                            // computes and stage s + 1 is cut and written to LDS
-    const int KG = ((K + 15) >> 4) * 2;
+    const int stages2 = (stages + 1) & ~1;                     // an odd stage count is padded with one all-zero stage
     const int K4 = ((K + 3) >> 2) << 2;                        // readable columns of a row
     // Requests are straight-line code with clamped addresses (always valid memory); what lies beyond K / beyond W3 is zeroed
     // when the registers are USED (lds_store) -- a branch or a select at request time would make the compiler wait for every
@@ -388,9 +393,9 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledAr
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int c = bch + 4 * j;                         // chunk = (k-group of the stage) * 3 + piece
-            const int kg = min(4 * s + c / 3, KG - 1), p = c - (c / 3) * 3;
-            rb[set][j] = g.W3[((int64_t)kg * 3 + p) * N + bc];
+            const int c = bch + 4 * j;                         // chunk = (k-group of the stage) * 3 + piece: W3's own order
+            const uint32_t off = (uint32_t)(12 * min(s, stages2 - 1) + c) * plane_b + bcol_off;     // (zero beyond K: no mask)
+            rb[set][j] = *reinterpret_cast<const u32x4*>(W3b + off);
         }
     };
     auto lds_store = [&](const int set, const int s, unsigned char* buf) {
@@ -413,13 +418,7 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledAr
         *reinterpret_cast<u32x4*>(pa + 2 * A_PLANE) = l0;
         unsigned char* pb = buf + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c = bch + 4 * j;
-            const bool live = 4 * s + c / 3 < KG;              // groups beyond W3 are zero
-            u32x4 w = rb[set][j];
-            w.x = live ? w.x : 0u; w.y = live ? w.y : 0u; w.z = live ? w.z : 0u; w.w = live ? w.w : 0u;
-            *reinterpret_cast<u32x4*>(pb + (c * 128 + bcol) * 16) = w;
-        }
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4*>(pb + ((bch + 4 * j) * 128 + bcol) * 16) = rb[set][j];
     };
     // 8 waves = 4 (rows of 32) x 2 (columns of 64): two waves per SIMD, so that one wave's LDS round trips and barrier waits
     // are covered by the other's MFMAs (4 waves of 64 x 64 -- half the LDS reads per MFMA -- left the matrix pipe idle two
@@ -460,8 +459,7 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledAr
     };
     // ---- pipeline: stage s computes from LDS buffer s & 1 while stage s + 1 (register set (s + 1) & 1) is cut and written to
     // the other buffer in the shadow of the MFMAs, and stage s + 2 is requested into the register set stage s has left.
-    // An odd stage count is padded with one all-zero stage (the loop body is unrolled by two and free of branches).
-    const int stages2 = (stages + 1) & ~1;
+    // (the loop body is unrolled by two and free of branches: see stages2)
     gload(0, 0);
     gload(1, 1);
     lds_store(0, 0, smem);
@@ -475,31 +473,57 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledAr
             gload(par, ss + 2);                                // (past the end: clamped addresses, values zeroed or unused)
             compute(cur);
             lds_store(par ^ 1, ss + 1, nxt);
+            // the first 8 MFMAs run beside LDS reads only; the cut of stage s + 1 (whose loads then had a stage and a third to
+            // arrive) and its LDS writes follow behind the other 16
 #pragma unroll
             for (int q = 0; q < 24; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                    // three VALU (the cut of stage s + 1)
-                __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                    // an LDS read or write
+                if (q < 8) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // two LDS reads
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                // five VALU
+                    __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                // an LDS read or write
+                }
             }
             __syncthreads();
         }
     }
-    // ---- bias + activation + store (C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5), column = lane & 31)
+    // ---- bias + activation, then through LDS (free after the last barrier) so that a lane stores 16 contiguous bytes of a row:
+    // 8 dwordx4 stores per wave instead of 32 dword stores (H is 170 MB per Reddit step: the store phase was 61 of 428 us).
+    // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5), column = lane & 31.
+    float* otile = reinterpret_cast<float*>(smem) + wave * (32 * 68);          // [32 rows][64 + 4 pad] per wave
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + 64 * wn + 32 * j + l31;
         const float bv = (g.bias && col < N) ? g.bias[col] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int row = m0 + 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * lh;
             float v = (acc[j][e] + sml[j][e]) + bv;
             if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
-#ifdef GS_DIAG_TILED_NOSTORE
-            if (row < count && col < N && v == 12345.678f) g.out[(int64_t)row * g.ldo + col] = v;
-#else
-            if (row < count && col < N) g.out[(int64_t)row * g.ldo + col] = v;
-#endif
+            otile[((e & 3) + 8 * (e >> 2) + 4 * lh) * 68 + 32 * j + l31] = v;
         }
+    }
+    // (wave-private region: no barrier, the wave's own LDS writes are ordered before its reads by lgkmcnt)
+    const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+    const int colg = n0 + 64 * wn + c4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = 4 * it + r0;
+        const int row = m0 + 32 * wm + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(otile + r * 68 + c4);
+#ifdef GS_DIAG_TILED_NOSTORE
+        if (row < count && colg < N && v.x == 12345.678f) g.out[(int64_t)row * g.ldo + colg] = v.x;
+#else
+        if (row < count) {
+            float* dst = g.out + (int64_t)row * g.ldo + colg;
+            if (colg + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+            else {
+                if (colg < N) dst[0] = v.x;
+                if (colg + 1 < N) dst[1] = v.y;
+                if (colg + 2 < N) dst[2] = v.z;
+            }
+        }
+#endif
     }
 }
 
@@ -510,6 +534,8 @@ extern "C" int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_
     GS_REQUIRE(X && W3 && out && d > 0 && out_dim > 0 && n_max > 0 && n_max < (1ll << 30), "gs_dense_fwd_rows_split: bad args");
     GS_CHECK_MAT(X, ldx, "gs_dense_fwd_rows_split X");
     GS_REQUIRE(ldx >= ((d + 3) / 4) * 4 && ldo >= out_dim && gs_aligned16(W3), "gs_dense_fwd_rows_split: bad leading dimensions");
+    GS_REQUIRE(ldo % 4 == 0 && gs_aligned16(out), "gs_dense_fwd_rows_split: out must be 16-byte aligned with ldo % 4 == 0");
+    GS_REQUIRE(split_rows_bytes(d, out_dim) < (1ll << 32), "gs_dense_fwd_rows_split: W3 must stay below 4 GB");
     SplitTiledArgs g = {X, idx, (const u32x4*)W3, bias, out, n_dev, ldx, ldo, (int32_t)n_max, d, out_dim, act};
     const int64_t blocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 128);
     const size_t lds = 2 * (3 * 128 * ST_LDA * 2 + 12 * 128 * 16);

@@ -363,7 +363,7 @@ class Engine(object):
         changed since the last call -- inside a captured step that launch is part of the step's graph."""
         if var.split3 is None:
             K, N = var.rows, var.cols
-            var.split3 = torch.empty(N * ((K + 15) // 16) * 2 * 12, dtype=torch.int32, device=self.device)
+            var.split3 = torch.empty(ops.split_rows_words(K, N), dtype=torch.int32, device=self.device)
             var.split_dirty = True
         if var.split_dirty:
             ops.split_rows(var.value, out=var.split3, stream=self.stream)

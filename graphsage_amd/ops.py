@@ -311,12 +311,20 @@ def sage_dense_fwd_stream(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, ac
     return out
 
 
+def split_rows_words(K, N):
+    """int32 words of gs_split_rows' output (gs_split_rows_bytes / 4): groups of 8 k up to an even count of 32-k stages."""
+    import ctypes
+    n = ctypes.c_int64()
+    call("gs_split_rows_bytes", int(K), int(N), ctypes.byref(n))
+    return int(n.value) // 4
+
+
 def split_rows(W, out=None, stream=None):
-    """gs_split_rows: the three bf16 pieces of W^T ([2 ceil(K/16)][3][N][8] bf16, as an int32 tensor) for the split-MFMA
+    """gs_split_rows: the three bf16 pieces of W^T ([groups of 8 k][3][N][8] bf16, as an int32 tensor) for the split-MFMA
     contractions; W is a Mat [K, N]."""
     K, N = W.rows, W.d
     if out is None:
-        out = torch.empty(N * ((K + 15) // 16) * 2 * 12, dtype=torch.int32, device=W.buf.device)
+        out = torch.empty(split_rows_words(K, N), dtype=torch.int32, device=W.buf.device)
     call("gs_split_rows", W.ptr, W.ld, K, N, ptr(out), _s(stream))
     return out
 

@@ -235,8 +235,9 @@ int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_des
  * exactly by v_mfma_f32_32x32x16_bf16 and accumulated in fp32 -- and six of the nine are kept (hh, hm, mh, mm, hl, lh; the
  * dropped ml, lm, ll are <= 3 * 2^-24 |x y|, one fp32 rounding).  Accuracy of an fp32 FMA chain at 6/16 of the fp32 MFMA's
  * matrix-pipe time (fp32 MFMA runs at the vector rate on gfx950, 1/16 of bf16).  Inputs, outputs, accumulation: fp32.
- *   gs_split_rows: W [K, ldw >= N] fp32 -> W3 [2 * ceil(K / 16)][3][N][8] bf16 (per group of 8 k and piece: the N columns
- *     side by side, 16 bytes each -- a B-fragment load of 32 lanes reads 512 contiguous bytes; zero for k >= K); gs_split_rows_bytes gives the size.  Call it after every update of W.
+ *   gs_split_rows: W [K, ldw >= N] fp32 -> W3 [G][3][N][8] bf16 (per group of 8 k and piece: the N columns side by side,
+ *     16 bytes each -- a B-fragment load of 32 lanes reads 512 contiguous bytes; G = groups up to an even count of 32-k
+ *     stages, zero for k >= K: the kernels neither mask nor clamp their B loads); gs_split_rows_bytes gives the size.  Call it after every update of W.
  *   gs_sage_dense_fwd_split: gs_sage_dense_fwd_stream with W3_self / W3_neigh in place of the weights; A operands are read
  *     as fp32 and cut in registers in the shadow of the MFMAs.  One wave per 32 x 64 output tile over the whole K (no LDS,
  *     no barrier, no split-K epilogue); pad columns [d, round_up(d, 4)) of self / agg must be readable.  Deterministic.

@@ -374,7 +374,7 @@ def test_csr_training_graph_replay_equals_eager(dev):
             model.train_step_device(32)
     eng.get_engine().sync()
     assert np.array_equal(multi, eng.get_engine().params.cpu().numpy())
-    for other in (1, 3, 4, 5, 6):     # eager == hipGraph replay == fused / two-stream pipelines, bitwise
+    for other in (1, 3, 4):           # eager == hipGraph replay == fused pipeline, bitwise
         assert outs[0][0] == outs[other][0]
         assert np.array_equal(outs[0][1], outs[other][1])
     # fused sampler/head kernels vs the per-hop / unfused kernels: same maths, different summation order

@@ -22,7 +22,8 @@ def _i32(a, dev):
 
 def _pieces(w3, K, N):
     """int32 device tensor of gs_split_rows -> float64 arrays h, m, l of shape [N, Kp] (the pieces of W^T)."""
-    KG = ((K + 15) // 16) * 2
+    KG = w3.numel() // (12 * N)                           # groups of 8 k (zero-padded beyond K)
+    assert KG >= ((K + 15) // 16) * 2 and KG % 4 == 0
     raw = w3.cpu().numpy().view(np.uint16).reshape(KG, 3, N, 8)
     as_f32 = (raw.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
     return [as_f32[:, p].transpose(1, 0, 2).reshape(N, KG * 8) for p in range(3)]
