@@ -29,8 +29,8 @@ def _digest():
     incl = os.path.join(HERE, "..", "include", "graphsage_amd.h")
     for p in _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [incl]:
         with open(p, "rb") as f:
-            h.update(p.encode())
-            h.update(f.read())
+            h.update(os.path.basename(p).encode())      # names, not paths: the digest must not depend on where the repo lies
+            h.update(f.read())                           # (gpurun unpacks it under a scratch path on the GPU box)
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
