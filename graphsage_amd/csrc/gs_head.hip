@@ -630,13 +630,17 @@ __global__ __launch_bounds__(512) void maxpool_sparse_wgrad_kernel(const float* 
 }
 
 // Column-per-lane form (the default): thread t owns hidden column c = 512 z + t and 64 feature accumulators; the s
-// feature-row segments of a group are staged in LDS with an ODD row stride (65 floats), so that lanes reading DIFFERENT
-// arg-max rows at the same feature hit different banks and lanes reading the same row get a broadcast.  The arg-max row
-// and the value of a column are per-lane registers (coalesced loads, no v_readlane), the row base address is computed
-// once per group and every FMA is ONE ds_read_b32 with an immediate offset + ONE v_fmac: 2 instructions per useful FMA
-// instead of ~5 (two v_readlane + address add + ds_read + half a packed FMA).  LDS-bandwidth bound: 512 x 64 x 4 B per
-// (group, feature block).
-#define GS_SPW_LDS_STRIDE 65
+// feature-row segments of a group are staged in LDS with a row stride of 66 floats: rows stay 8-byte aligned, and lanes
+// reading DIFFERENT arg-max rows at the same feature pair hit different banks (ds_read_b64: bank pair (2 r + f) mod 64,
+// distinct for r < 32 rows) while lanes reading the same row get a broadcast.  The arg-max row and the value of a column
+// are per-lane registers (coalesced loads, no v_readlane), the row base address is computed once per group and every PAIR
+// of FMAs is ONE ds_read_b64 with an immediate offset: 1.5 instructions per useful FMA (round 2: ds_read_b32 at an odd
+// stride of 65, 2 per FMA -- the kernel is LDS-bandwidth bound and ds_read_b64 moves twice the bytes per LDS cycle; round
+// 1: ~5).  512 x 64 x 4 B per (group, feature block).
+#define GS_SPW_LDS_STRIDE 66
+#define GS_SPW_DEPTH 4
+typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+template <int PF>
 __global__ __launch_bounds__(512) void maxpool_sparse_wgrad_cols_kernel(const float* __restrict__ X, int64_t ldx,
                                                                          const int32_t* __restrict__ ids, int64_t G, int32_t s,
                                                                          int32_t d, const int32_t* __restrict__ argmax,
@@ -646,51 +650,85 @@ __global__ __launch_bounds__(512) void maxpool_sparse_wgrad_cols_kernel(const fl
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [s][65]
     const int dpad = (d + 3) & ~3;
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int f0 = blockIdx.x * GS_SPW_FB;
+    // (placing the feature blocks of one group slice on one XCD, so that its arg-max rows and values are L2 hits for nine of
+    // ten blocks, was measured: 180 vs 171 us for the step's two launches -- no gain, left out)
+    const int slice = blockIdx.y, fb = blockIdx.x;
+    const int f0 = fb * GS_SPW_FB;
     const int c = blockIdx.z * 512 + tid;
     const bool col_ok = c < hidden;
-    const int64_t g0 = (int64_t)blockIdx.y * groups_per_slice;
+    const int64_t g0 = (int64_t)slice * groups_per_slice;
     const int64_t g1 = min(G, g0 + groups_per_slice);
     const int n4 = s * (GS_SPW_FB / 4);                          // float4 of a group's row segments
     float acc[GS_SPW_FB];
 #pragma unroll
     for (int f = 0; f < GS_SPW_FB; ++f) acc[f] = 0.f;
-    f32x4 pf[GS_SPW_PF];
-    int a_nx = 0;
-    float v_nx = 0.f;
-    auto prefetch = [&](int64_t g) {
+    // A group's work is short (64 FMAs per thread) against the latency of its gathered rows (~2 us from HBM): the rows, arg-max
+    // rows and values of the next GS_SPW_DEPTH groups are in flight (round 2-3: one group ahead -- 156 us for the 5120 x 25 hop,
+    // i.e. ~1.5 us per group of which the arithmetic is 0.3)
+    constexpr int DEPTH = GS_SPW_DEPTH;
+    f32x4 pf[DEPTH][PF];
+    int a_nx[DEPTH];
+    float v_nx[DEPTH];
+    auto prefetch = [&](const int slot, int64_t g) {
 #pragma unroll
-        for (int u = 0; u < GS_SPW_PF; ++u) {
+        for (int u = 0; u < PF; ++u) {
             const int t = tid + u * nthreads;
-            pf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pf[slot][u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < n4) {
                 const int r = t >> 4, q = t & 15;
-                if (f0 + q * 4 < dpad) pf[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)ids[g * s + r] * ldx + f0 + q * 4);
+                if (f0 + q * 4 < dpad) pf[slot][u] = *reinterpret_cast<const f32x4*>(X + (int64_t)ids[g * s + r] * ldx + f0 + q * 4);
             }
         }
-        a_nx = col_ok ? argmax[g * lda + c] : 0;
-        v_nx = col_ok ? dpm[g * ldd + c] : 0.f;
+        a_nx[slot] = col_ok ? argmax[g * lda + c] : 0;
+        v_nx[slot] = col_ok ? dpm[g * ldd + c] : 0.f;
     };
-    if (g0 < g1) prefetch(g0);
-    for (int64_t g = g0; g < g1; ++g) {
-        __syncthreads();  // the previous group's segments are no longer read
 #pragma unroll
-        for (int u = 0; u < GS_SPW_PF; ++u) {
-            const int t = tid + u * nthreads;
-            if (t < n4) {
-                float* dst = xs + (t >> 4) * GS_SPW_LDS_STRIDE + (t & 15) * 4;
-                dst[0] = pf[u].x; dst[1] = pf[u].y; dst[2] = pf[u].z; dst[3] = pf[u].w;
+    for (int j = 0; j < DEPTH; ++j) {
+        a_nx[j] = 0; v_nx[j] = 0.f;
+        if (g0 + j < g1) prefetch(j, g0 + j);
+    }
+    for (int64_t gb = g0; gb < g1; gb += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int64_t g = gb + j;
+            if (g >= g1) break;                            // uniform
+            __syncthreads();  // the previous group's segments are no longer read
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = tid + u * nthreads;
+                if (t < n4) {
+                    float* dst = xs + (t >> 4) * GS_SPW_LDS_STRIDE + (t & 15) * 4;      // 8-byte aligned (264-byte rows)
+                    *reinterpret_cast<gs_f32x2*>(dst) = gs_f32x2{pf[j][u].x, pf[j][u].y};
+                    *reinterpret_cast<gs_f32x2*>(dst + 2) = gs_f32x2{pf[j][u].z, pf[j][u].w};
+                }
             }
-        }
-        const float v = v_nx;
-        const float* row = xs + a_nx * GS_SPW_LDS_STRIDE;
-        __syncthreads();
-        if (g + 1 < g1) prefetch(g + 1);
+            const float v = v_nx[j];
+            // LDS byte address of the lane's arg-max row.  The reads are written as ds_read_b64 by hand: left to the compiler,
+            // pairs of them become ds_read2_b64, which moves HALF the bytes per LDS cycle (MI355X_MICROARCH.md, LDS table).
+            const unsigned row = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)xs +
+                                 (unsigned)a_nx[j] * (GS_SPW_LDS_STRIDE * 4u);
+            __syncthreads();
+            if (g + DEPTH < g1) prefetch(j, g + DEPTH);
+#define GS_RD(i, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[i]) : "v"(row), "i"(off))
+#define GS_RD8(o) GS_RD(0, o); GS_RD(1, o + 8); GS_RD(2, o + 16); GS_RD(3, o + 24); GS_RD(4, o + 32); GS_RD(5, o + 40); \
+                  GS_RD(6, o + 48); GS_RD(7, o + 56)
 #pragma unroll
-        for (int f = 0; f < GS_SPW_FB; ++f) acc[f] += v * row[f];
+            for (int qt = 0; qt < 4; ++qt) {                  // four batches of 8 reads: 16 registers of row data at a time
+                gs_f32x2 x[8];
+                if (qt == 0) { GS_RD8(0); } else if (qt == 1) { GS_RD8(64); } else if (qt == 2) { GS_RD8(128); } else { GS_RD8(192); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[16 * qt + 2 * i] += v * x[i].x;
+                    acc[16 * qt + 2 * i + 1] += v * x[i].y;
+                }
+            }
+#undef GS_RD8
+#undef GS_RD
+        }
     }
     if (col_ok) {
-        float* dst = slabs + ((int64_t)blockIdx.y * d + f0) * ld_slab + c;
+        float* dst = slabs + ((int64_t)slice * d + f0) * ld_slab + c;
 #pragma unroll
         for (int f = 0; f < GS_SPW_FB; ++f)
             if (f0 + f < d) dst[(int64_t)f * ld_slab] = acc[f];
@@ -721,9 +759,15 @@ extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_
                            (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
                            slabs, ld_slab);
     } else {
-        hipLaunchKernelGGL(maxpool_sparse_wgrad_cols_kernel, grid, dim3(threads), (size_t)s * GS_SPW_LDS_STRIDE * sizeof(float),
-                           (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
-                           slabs, ld_slab);
+        // PF: float4 of a group's row segments per thread (16 s of them over the block's threads)
+        if (s * (GS_SPW_FB / 4) <= threads)
+            hipLaunchKernelGGL(maxpool_sparse_wgrad_cols_kernel<1>, grid, dim3(threads), (size_t)s * GS_SPW_LDS_STRIDE * sizeof(float),
+                               (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
+                               slabs, ld_slab);
+        else
+            hipLaunchKernelGGL(maxpool_sparse_wgrad_cols_kernel<GS_SPW_PF>, grid, dim3(threads), (size_t)s * GS_SPW_LDS_STRIDE * sizeof(float),
+                               (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
+                               slabs, ld_slab);
     }
     GS_LAUNCH_CHECK("maxpool_sparse_wgrad_kernel");
     return GS_OK;
