@@ -14,7 +14,8 @@ ACT_IDENTITY = 0
 ACT_RELU = 1
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
 SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
-GS_ABI_VERSION = 5      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+GS_PEER_HANDLE_BYTES = 64
+GS_ABI_VERSION = 6      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -56,6 +57,13 @@ _PROTOS = {
     "gs_comm_init_rank": [POINTER(c_void_p), c_int32, c_int32, _P, c_int32],
     "gs_comm_allreduce_sum_f32": [_P, _P, c_int64, _P],
     "gs_comm_destroy": [_P],
+    "gs_peer_create": [c_int64, c_int32, c_int32, c_int32, c_int64, POINTER(c_void_p)],
+    "gs_peer_export": [_P, _P, c_int32],
+    "gs_peer_attach": [_P, c_int32, _P, c_int32],
+    "gs_peer_attach_local": [_P, _P],
+    "gs_peer_allreduce_sum_f32": [_P, _P, c_int64, _P],
+    "gs_peer_status": [_P, POINTER(c_int64), POINTER(c_int32)],
+    "gs_peer_destroy": [_P],
     "gs_sum_scaled": [_P, c_int64, c_float, _P, c_int, _P],
     "gs_sumsq_scaled": [_P, c_int64, c_float, _P, c_int, _P],
     "gs_stream_create": [POINTER(c_void_p)],

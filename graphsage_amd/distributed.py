@@ -195,6 +195,136 @@ class NativeAllReduce(object):
             self._comm = None
 
 
+class PeerPushAllReduce(object):
+    """grad_hook backed by the C ABI's peer-store exchange (gs_peer_*, csrc/gs_peer.hip; GS_DP_PEER_PUSH=1): every rank
+    stores slice p of its flat gradient straight into rank p's window over xGMI, rank p sums the copies in rank order and
+    stores the sum into every window -- one hop out, one hop back, ONE kernel launch on the engine stream instead of a
+    2(N-1)-hop ring for 0.9 MB.  `capturable = True`: recorded inside the step's hipGraph exactly like NativeAllReduce.
+    The 64-byte IPC handles travel over torch.distributed (plumbing only).  Every device-side wait is bounded; `check()`
+    (called by the models when results are fetched) turns a tripped wait into an exception."""
+    capturable = True
+
+    def __init__(self, engine, chunks=None, spin_limit=None):
+        import ctypes
+        import torch.distributed as dist
+        from . import _lib, ops
+        self.engine = engine
+        self._lib = _lib
+        self._peer = None
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        self.world_size = dist.get_world_size() if multi else 1
+        self.rank = dist.get_rank() if multi else 0
+        self.chunks = int(os.environ.get("GS_PEER_CHUNKS", "0")) if chunks is None else int(chunks)
+        self.spin_limit = int(os.environ.get("GS_PEER_SPIN_LIMIT", "0")) if spin_limit is None else int(spin_limit)
+        self.attempts = 0
+        self._open()
+
+    def _open(self):
+        """Allocate this rank's window, exchange IPC handles, map every peer (collective; every stage's outcome is agreed)."""
+        import ctypes
+        import torch.distributed as dist
+        from . import _lib, ops
+        engine = self.engine
+        multi = self.world_size > 1
+        torch.cuda.set_device(engine.device)
+        h = ctypes.c_void_p()
+        err = None
+        try:
+            ops.call("gs_peer_create", engine.grads.numel(), self.world_size, self.rank, self.chunks, self.spin_limit, ctypes.byref(h))
+            self._peer = h.value
+        except Exception as ex:
+            err = ex
+        if multi and not _agree(err is None, engine):
+            self.close()
+            raise RuntimeError("the exchange window could not be allocated on every rank (this rank: %r)" % (err,))
+        if err is not None:
+            raise err
+        if multi:
+            nb = _lib.GS_PEER_HANDLE_BYTES
+            buf = (ctypes.c_uint8 * nb)()
+            try:
+                ops.call("gs_peer_export", self._peer, ctypes.addressof(buf), nb)
+            except Exception as ex:       # still take part in the gather below
+                err = ex
+            dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            mine = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+            got = [torch.empty_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(got, mine)
+            if err is None:
+                try:
+                    for r, t in enumerate(got):
+                        if r != self.rank:
+                            raw = (ctypes.c_uint8 * nb)(*bytes(t.cpu().tolist()))
+                            ops.call("gs_peer_attach", self._peer, r, ctypes.addressof(raw), nb)
+                except Exception as ex:
+                    err = ex
+            if not _agree(err is None, engine):       # nobody launches the exchange unless everybody mapped everybody
+                self.close()
+                raise RuntimeError("peer windows could not be mapped on every rank (this rank: %r)" % (err,))
+
+    def all_reduce(self, flat, stream=None):
+        from . import ops
+        ops.call("gs_peer_allreduce_sum_f32", self._peer, ops.ptr(flat), flat.numel(), self.engine.stream if stream is None else stream)
+
+    def __call__(self, model):
+        self.all_reduce(self.engine.grads)
+
+    def status(self):
+        """(exchanges completed on this rank, error word) -- call after the engine stream has been synchronised."""
+        import ctypes
+        from . import ops
+        ep, er = ctypes.c_int64(), ctypes.c_int32()
+        ops.call("gs_peer_status", self._peer, ctypes.byref(ep), ctypes.byref(er))
+        return int(ep.value), int(er.value)
+
+    def check(self):
+        ep, er = self.status()
+        if er:
+            raise RuntimeError("peer exchange on rank %d gave up waiting for rank(s) %r (stage bits %d, %d exchanges): the "
+                               "gradients of this step are not the sum over ranks"
+                               % (self.rank, [r for r in range(self.world_size) if (er >> (8 + r)) & 1], er & 3, ep))
+        return ep
+
+    def ranks(self):
+        return self.world_size
+
+    def self_test(self, attempts=3):
+        """One exchange on the gradient buffer itself (zeroed afterwards): sum of (rank + 1), and the error word.  Collective.
+        The first exchange on freshly mapped windows is the one that has been seen to trip its bounded wait (rarely, two
+        processes on one device); a failed attempt is agreed on by all ranks, the windows are re-created and it is tried again."""
+        e = self.engine
+        want = float(sum(range(1, self.world_size + 1)))
+        last = None
+        for attempt in range(attempts):
+            self.attempts = attempt + 1
+            e.grads.fill_(float(self.rank + 1))
+            torch.cuda.synchronize()
+            _agree(True, e)      # a barrier: first-use costs (kernel loading) must not eat into the exchange's bounded wait
+            self.all_reduce(e.grads)
+            e.sync()
+            got = (float(e.grads[0].item()), float(e.grads[-1].item()))
+            e.grads.zero_()
+            torch.cuda.synchronize()
+            ok = True
+            try:
+                self.check()
+                if abs(got[0] - want) > 1e-6 or abs(got[1] - want) > 1e-6:
+                    raise RuntimeError("peer exchange gave %r, expected %r" % (got, want))
+            except RuntimeError as ex:
+                ok, last = False, ex
+            if _agree(ok, e):
+                return True
+            old, self._peer = self._peer, None      # the new windows are allocated while the old ones still exist: new addresses,
+            self._open()                            # new IPC handles
+            self._lib.load().gs_peer_destroy(old)
+        raise RuntimeError("peer exchange failed its self test %d times (this rank's last error: %r)" % (attempts, last))
+
+    def close(self):
+        if self._peer:
+            self._lib.load().gs_peer_destroy(self._peer)
+            self._peer = None
+
+
 class SpinHook(object):
     """Diagnostics: a grad_hook that holds the engine stream for `us` microseconds with ONE sleeping wave (gs_spin_us) --
     the single-GPU stand-in for a latency-bound all-reduce when the data-parallel step schedule is probed without peers
@@ -218,10 +348,33 @@ def make_grad_hook(engine, log=None):
     """The gradient all-reduce hook of a data-parallel run: the in-graph RCCL binding of the C ABI when it initialises
     and passes its self test on EVERY rank (each stage's outcome is agreed collectively, so no rank is left inside a
     collective its peers never enter), else the eager torch.distributed all-reduce between two graphs (GradAllReduce).
-    GS_DP_NATIVE=0 forces the fallback."""
+    GS_DP_NATIVE=0 forces the fallback; GS_DP_PEER_PUSH=1 tries the peer-store exchange (PeerPushAllReduce) first."""
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     hook, ok = None, 0
+    if os.environ.get("GS_DP_PEER_PUSH", "0") == "1":
+        # opt-in: direct peer stores over xGMI (gs_peer.hip).  Construction agrees collectively at every stage; the self
+        # test's waits are bounded on the device, so a failing rank cannot leave its peers blocked.
+        try:
+            hook = PeerPushAllReduce(engine)
+            ok = 1
+        except Exception as ex:
+            if log:
+                log("peer-push hook unavailable on rank %d: %r" % (rank, ex))
+        ok = _agree(ok, engine)
+        if ok:
+            try:
+                hook.self_test()
+            except Exception as ex:
+                ok = 0
+                if log:
+                    log("peer-push hook failed its self test on rank %d: %r" % (rank, ex))
+            ok = _agree(ok, engine)
+        if ok:
+            return hook
+        if hook is not None:
+            hook.close()
+        hook, ok = None, 0
     if os.environ.get("GS_DP_NATIVE", "1") == "1":
         try:
             hook = NativeAllReduce(engine)

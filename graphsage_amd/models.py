@@ -331,6 +331,8 @@ class SampleAndAggregate(object):
 
     def _fetch_unsup(self, B, with_outputs=True):
         self.engine.sync()
+        if hasattr(self.grad_hook, "check"):
+            self.grad_hook.check()
         loss = float(self.loss_dev.item())
         mrr = float(self.mrr_dev.item())
         aff = self.aff_all.numpy()

@@ -278,6 +278,8 @@ class SupervisedGraphsage(SampleAndAggregate):
                     "fused tail launch: hand-over between its workgroups failed (flags %d: 1 = a row-group workgroup "
                     "gave up waiting for its helpers, 2 = unexpected arrival count); results since the last fetch are "
                     "invalid -- set model.fuse_tail = False to use the per-operator schedule" % err)
+        if hasattr(self.grad_hook, "check"):
+            self.grad_hook.check()            # peer-store exchange: a bounded device-side wait that tripped
         loss = float(self.loss_dev.item())
         preds = self.preds.view()[:n].detach().cpu().numpy()
         return loss, preds

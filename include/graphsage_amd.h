@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 5
+#define GS_ABI_VERSION 6
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -651,6 +651,32 @@ int gs_comm_unique_id(void* id_out_host, int32_t len);
 int gs_comm_init_rank(void** comm_out, int32_t nranks, int32_t rank, const void* id_host, int32_t len);
 int gs_comm_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);
 int gs_comm_destroy(void* comm);
+
+/* ---------------------------------------------------------------------------------------------
+ * C2: the same exchange as direct peer stores over xGMI (opt-in; gs_comm_* stays the default).  The flat gradient is
+ * 0.9 MB: instead of a ring (2(N-1) latency-bound hops) every rank stores slice p of its gradient straight into rank
+ * p's window (reduce-scatter, N-1 links in parallel), rank p sums the N copies IN RANK ORDER and stores the sum into
+ * every rank's window (all-gather): one hop out, one hop back, ONE kernel launch on `stream`, capturable into the
+ * step's hipGraph.  Windows are uncached device memory owned by this library and shared with hipIpcMemHandle.
+ *   gs_peer_create        : allocates this rank's window for an n_floats buffer (chunks: workgroups per peer, 0 = sized
+ *                           so that a thread moves ~2 float4 per pass, <= 256 workgroups in all; spin_limit: polls before
+ *                           a wait gives up, 0 = 2^24, of the order of ten seconds)
+ *   gs_peer_export/attach : the 64-byte IPC handle of the own window / maps rank `peer_rank`'s window (the host code
+ *                           ships handles between processes -- torch.distributed / MPI / a file)
+ *   gs_peer_attach_local  : another rank of the SAME process, by object (several streams or devices in one process)
+ *   gs_peer_allreduce_sum_f32 : in-place sum over ranks; every rank ends with identical bits
+ *   gs_peer_status        : epochs completed and the error word (0 ok; bit 0: a peer's copies never arrived, bit 1: a
+ *                           reduced slice never arrived, bits 8..: the ranks waited for in vain) -- every device-side
+ *                           wait is bounded, a missing peer cannot hang the GPU
+ * ------------------------------------------------------------------------------------------- */
+#define GS_PEER_HANDLE_BYTES 64
+int gs_peer_create(int64_t n_floats, int32_t world, int32_t rank, int32_t chunks, int64_t spin_limit, void** peer_out);
+int gs_peer_export(void* peer, void* handle_out_host, int32_t len);
+int gs_peer_attach(void* peer, int32_t peer_rank, const void* handle_host, int32_t len);
+int gs_peer_attach_local(void* peer, void* other_peer);
+int gs_peer_allreduce_sum_f32(void* peer, float* buf, int64_t count, void* stream);
+int gs_peer_status(void* peer, int64_t* epoch_out_host, int32_t* error_out_host);
+int gs_peer_destroy(void* peer);
 
 /* ---------------------------------------------------------------------------------------------
  * hipGraph helpers: the per-step kernel chain is captured once and replayed (no tracing compiler).

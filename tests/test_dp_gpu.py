@@ -32,6 +32,24 @@ def _build(world, rank):
     return gsd, eng, G, it, model, order, ns
 
 
+def _collect(procs, q, n, timeout):
+    """n results from the workers' queue; stops as soon as a worker has died (a crashed rank must not cost the full timeout)."""
+    import queue
+    import time
+    got, t0 = [], time.time()
+    while len(got) < n:
+        try:
+            got.append(q.get(timeout=1.0))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise RuntimeError("worker exit codes %r after %.0f s" % ([p.exitcode for p in procs], time.time() - t0))
+    return got
+
+
 def _worker(rank, world, port, q):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
                        "LOCAL_RANK": "0", "GS_DIST_BACKEND": "gloo"})
@@ -62,7 +80,7 @@ def test_two_rank_dp_matches_single_process_global_batch(dev):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict((r, (w, s)) for r, w, s in [q.get(timeout=240) for _ in range(world)])
+    res = dict((r, (w, s)) for r, w, s in _collect(procs, q, world, 240))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -205,7 +223,7 @@ def test_two_rank_rccl_in_graph_matches_eager_hook():
     procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict((r, (a, b)) for r, a, b in [q.get(timeout=300) for _ in range(world)])
+    res = dict((r, (a, b)) for r, a, b in _collect(procs, q, world, 300))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

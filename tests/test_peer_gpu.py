@@ -1,0 +1,276 @@
+"""-m gpu: the peer-store gradient exchange (gs_peer_*, csrc/gs_peer.hip) -- SURVEY §8e's exchange step as direct stores
+into peer windows.  One device is enough to exercise slices, chunk counters, epochs, double buffering and the bounded
+waits: (a) several ranks of ONE process on their own streams (windows attached by address), bit-exact against the
+rank-ordered fp32 sum; (b) two PROCESSES on cuda:0 with windows mapped through hipIpcMemHandle, training through the
+step hipGraph, bit-identical to the eager torch.distributed hook; (c) an auto-skipping two-GPU run (xGMI) for the
+driver's multi-GPU box.  The oracle for the arithmetic is NumPy fp32 in rank order."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS, B = 4, 32
+
+
+class Rank(object):
+    """One rank of an in-process exchange: a window, a stream, a gradient buffer."""
+
+    def __init__(self, n, world, rank, dev, chunks=0, spin_limit=0):
+        from graphsage_amd import ops
+        self.ops = ops
+        h = ctypes.c_void_p()
+        ops.call("gs_peer_create", n, world, rank, chunks, spin_limit, ctypes.byref(h))
+        self.peer = h.value
+        self.stream = ops.Stream()
+        self.buf = torch.zeros(n, dtype=torch.float32, device=dev)
+
+    def attach(self, other):
+        self.ops.call("gs_peer_attach_local", self.peer, other.peer)
+
+    def launch(self):
+        self.ops.call("gs_peer_allreduce_sum_f32", self.peer, self.ops.ptr(self.buf), self.buf.numel(), self.stream.handle)
+
+    def status(self):
+        ep, er = ctypes.c_int64(), ctypes.c_int32()
+        self.ops.call("gs_peer_status", self.peer, ctypes.byref(ep), ctypes.byref(er))
+        return int(ep.value), int(er.value)
+
+    def close(self):
+        from graphsage_amd import _lib
+        _lib.load().gs_peer_destroy(self.peer)
+
+
+def _ranks(n, world, dev, **kw):
+    rs = [Rank(n, world, r, dev, **kw) for r in range(world)]
+    for a in rs:
+        for b in rs:
+            if a is not b:
+                a.attach(b)
+    return rs
+
+
+def _ordered_sum(parts):
+    s = parts[0].copy()
+    for p in parts[1:]:
+        s = (s + p).astype(np.float32)
+    return s
+
+
+def _run_in_process(dev, world, n, chunks):
+    rs = _ranks(n, world, dev, chunks=chunks)
+    try:
+        rng = np.random.RandomState(world * 1000 + chunks)
+        for epoch in range(5):               # both parities of the double buffer, twice
+            parts = [(rng.standard_normal(n) * 10.0 ** rng.randint(-3, 3)).astype(np.float32) for _ in range(world)]
+            for r, p in zip(rs, parts):
+                r.buf.copy_(torch.from_numpy(p))
+            torch.cuda.synchronize()
+            for r in (rs if epoch % 2 == 0 else rs[::-1]):       # launch order must not matter
+                r.launch()
+            for r in rs:
+                r.stream.sync()
+            want = _ordered_sum(parts)
+            for r in rs:
+                assert r.status() == (epoch + 1, 0)
+                assert np.array_equal(r.buf.cpu().numpy(), want)
+    finally:
+        for r in rs:
+            r.close()
+
+
+@pytest.mark.parametrize("world,n,chunks", [(1, 1000, 0), (2, 230121, 0), (2, 4099, 3), (3, 230121, 4), (3, 7, 1)])
+def test_in_process_ranks_sum_in_rank_order_over_several_epochs(dev, world, n, chunks):
+    _run_in_process(dev, world, n, chunks)
+
+
+@pytest.mark.parametrize("world,n,chunks", [(4, 65536, 8), (8, 230121, 4)])
+def test_many_in_process_ranks_in_a_process_with_enough_hardware_queues(dev, world, n, chunks):
+    """Ranks of one process wait for each other INSIDE their kernels, so each needs a hardware queue of its own; HIP maps a
+    process's streams onto 4 queues by default.  A fresh process with GPU_MAX_HW_QUEUES raised runs the 4- and 8-rank
+    exchanges (separate processes -- the real deployment -- each have their own queues)."""
+    import subprocess
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), str(world), str(n), str(chunks)], env=env, timeout=240,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0 and b"in-process exchange ok" in out.stdout, out.stdout.decode(errors="replace")[-2000:]
+
+
+def test_exchange_replays_from_hipgraphs(dev):
+    """Each rank captures its exchange into its own hipGraph (kernel arguments frozen: the epoch lives in the window) and
+    replays it four times with fresh data."""
+    from graphsage_amd import ops
+    n, world = 50001, 2
+    rs = _ranks(n, world, dev)
+    try:
+        graphs = []
+        for r in rs:
+            g = ops.Graph(r.stream.handle)
+            g.begin()
+            try:
+                r.launch()
+            finally:
+                g.end()
+            graphs.append(g)
+        rng = np.random.RandomState(7)
+        for epoch in range(4):
+            parts = [rng.standard_normal(n).astype(np.float32) for _ in range(world)]
+            for r, p in zip(rs, parts):
+                r.buf.copy_(torch.from_numpy(p))
+            torch.cuda.synchronize()
+            for g in graphs:
+                g.launch()
+            for r in rs:
+                r.stream.sync()
+            for r in rs:
+                assert r.status() == (epoch + 1, 0)
+                assert np.array_equal(r.buf.cpu().numpy(), _ordered_sum(parts))
+    finally:
+        for r in rs:
+            r.close()
+
+
+def test_missing_peer_trips_the_bounded_wait_instead_of_hanging(dev):
+    n, world = 4096, 2
+    rs = _ranks(n, world, dev, spin_limit=1 << 12)          # a few milliseconds
+    try:
+        rs[0].buf.fill_(1.0)
+        torch.cuda.synchronize()
+        rs[0].launch()                                     # rank 1 never shows up
+        rs[0].stream.sync()
+        ep, er = rs[0].status()
+        assert ep == 1 and er == (1 | (256 << 1))          # stage 1, rank 1 never delivered
+    finally:
+        for r in rs:
+            r.close()
+
+
+def test_bad_arguments_are_refused(dev):
+    from graphsage_amd import _lib, ops
+    h = ctypes.c_void_p()
+    with pytest.raises(_lib.GraphsageAmdError):
+        ops.call("gs_peer_create", 100, 2, 2, 0, 0, ctypes.byref(h))           # rank out of range
+    with pytest.raises(_lib.GraphsageAmdError):
+        ops.call("gs_peer_create", 100, 17, 0, 0, 0, ctypes.byref(h))          # world too large
+    r = Rank(100, 2, 0, dev)
+    try:
+        with pytest.raises(_lib.GraphsageAmdError):                            # rank 1 is not attached
+            r.launch()
+        with pytest.raises(_lib.GraphsageAmdError):                            # wrong length
+            ops.call("gs_peer_allreduce_sum_f32", r.peer, ops.ptr(r.buf), 99, r.stream.handle)
+    finally:
+        r.close()
+
+
+# ------------------------------------------------------------------------------------ two processes
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _collect(procs, q, n, timeout):
+    """n results from the workers' queue; stops as soon as a worker has died (a crashed rank must not cost the full timeout)."""
+    import queue
+    import time
+    got, t0 = [], time.time()
+    while len(got) < n:
+        try:
+            got.append(q.get(timeout=1.0))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise RuntimeError("worker exit codes %r after %.0f s" % ([p.exitcode for p in procs], time.time() - t0))
+    return got
+
+
+def _worker(rank, world, port, q, two_gpus):
+    local = rank if two_gpus else 0
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(local), "GS_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(local)
+    from graphsage_amd import distributed as gsd
+    from graphsage_amd import engine as eng
+    from test_model_gpu import build
+    gsd.init_from_env()
+    out = {}
+    for mode in ("peer", "eager"):
+        os.environ["GS_DP_PEER_PUSH"] = "1" if mode == "peer" else "0"
+        os.environ["GS_DP_NATIVE"] = "0"
+        G, it, ph, sampler, model, ns = build(torch.device("cuda:%d" % local), "mean", True, False, csr=True)
+        model.world_size, model.rank = world, rank
+        model.row_offset = rank * B
+        order = it.train_nodes[: 8 * B * 2]
+        e = eng.get_engine()
+        logs = []
+        model.grad_hook = gsd.make_grad_hook(e, log=logs.append)
+        if mode == "peer":
+            assert type(model.grad_hook).__name__ == "PeerPushAllReduce", logs
+            assert model._dp_in_graph()
+        model.attach_device_epoch(gsd.shard_order(order, rank, world, B), it.label_matrix)
+        model.train_steps_device(B, 7, steps_per_launch=2)
+        loss, preds = model._fetch(B)                      # also checks the exchange's error word
+        torch.cuda.synchronize()
+        out[mode] = e.params.cpu().numpy().copy()
+        if mode == "peer":
+            assert any(k[0] == "ptrain_dp" for k in model._graphs), list(model._graphs)
+            out["epochs"] = model.grad_hook.check()
+            info = model.measure_dp_allreduce()             # 12 more exchanges, timed with HIP events on the engine stream
+            assert model.grad_hook.check() == out["epochs"] + 12
+            if rank == 0:
+                sys.stderr.write("peer exchange between two processes: %.1f us stand-alone\n" % info["allreduce_us_standalone"])
+    q.put((rank, out["peer"], out["eager"], out["epochs"]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _two_process_run(two_gpus):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, two_gpus)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict((r, (a, b, n)) for r, a, b, n in _collect(procs, q, world, 300))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])       # replicas identical
+    assert np.array_equal(res[0][0], res[0][1])        # world 2: a + b either way -> the same bits as the eager all-reduce
+    assert res[0][2] == res[1][2] and res[0][2] >= 8   # the self test + 7 steps
+
+
+def test_two_processes_one_device_ipc_windows_train_like_the_eager_hook(dev):
+    """Both ranks on cuda:0 (windows mapped with hipIpcOpenMemHandle), the exchange recorded in 2-step hipGraphs."""
+    _two_process_run(False)
+
+
+def test_two_gpus_peer_push_over_xgmi():
+    """Two GPUs, real xGMI stores.  Auto-skips on a 1-GPU box (the driver's multi-GPU run is the first to execute it)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _two_process_run(True)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    _run_in_process(torch.device("cuda:0"), int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+    print("in-process exchange ok")
