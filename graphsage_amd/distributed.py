@@ -292,6 +292,7 @@ class PeerPushAllReduce(object):
         """One exchange on the gradient buffer itself (zeroed afterwards): sum of (rank + 1), and the error word.  Collective.
         The first exchange on freshly mapped windows is the one that has been seen to trip its bounded wait (rarely, two
         processes on one device); a failed attempt is agreed on by all ranks, the windows are re-created and it is tried again."""
+        from . import ops
         e = self.engine
         want = float(sum(range(1, self.world_size + 1)))
         last = None
@@ -316,13 +317,14 @@ class PeerPushAllReduce(object):
                 return True
             old, self._peer = self._peer, None      # the new windows are allocated while the old ones still exist: new addresses,
             self._open()                            # new IPC handles
-            self._lib.load().gs_peer_destroy(old)
+            ops.call("gs_peer_destroy", old)
         raise RuntimeError("peer exchange failed its self test %d times (this rank's last error: %r)" % (attempts, last))
 
     def close(self):
         if self._peer:
-            self._lib.load().gs_peer_destroy(self._peer)
-            self._peer = None
+            from . import ops
+            peer, self._peer = self._peer, None
+            ops.call("gs_peer_destroy", peer)
 
 
 class SpinHook(object):

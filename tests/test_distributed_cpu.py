@@ -122,3 +122,77 @@ def test_native_allreduce_init_is_failure_safe_across_ranks():
     for rank, outcome, dt, entered_init in res:
         assert outcome.startswith("raised: RCCL cannot be bound on every rank"), (rank, outcome)
         assert not entered_init and dt < 60
+
+
+def _peer_worker(rank, world, port, q):
+    """PeerPushAllReduce's construction when (a) one rank cannot allocate its window, (b) one rank cannot map a peer's window:
+    every stage's outcome is agreed over the bootstrap group, all ranks raise together, windows that were created are
+    destroyed, and nobody launches an exchange."""
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "GS_DIST_BACKEND": "gloo"})
+    import torch.distributed as dist
+    from graphsage_amd import distributed as gsd
+    from graphsage_amd import ops
+    gsd.init_from_env()
+    torch.cuda.set_device = lambda d: None          # no GPU here: the device binding is not what is under test
+    calls = []
+    scenario = {"name": None}
+
+    def fake_call(name, *args):
+        calls.append(name)
+        if name == "gs_peer_create":
+            if scenario["name"] == "create" and rank == 1:
+                raise ops._lib.GraphsageAmdError("out of device memory (test)")
+            args[-1]._obj.value = 0x1000 + len(calls)          # an opaque handle
+            return 0
+        if name == "gs_peer_attach" and scenario["name"] == "attach" and rank == 0:
+            raise ops._lib.GraphsageAmdError("hipIpcOpenMemHandle failed (test)")
+        if name in ("gs_peer_export", "gs_peer_attach", "gs_peer_destroy"):
+            return 0
+        raise AssertionError("unexpected C call %s" % name)
+
+    ops.call = fake_call
+
+    class FakeEngine(object):
+        device = torch.device("cpu")
+        grads = torch.zeros(1000)
+
+    out = {}
+    for name in ("create", "attach", "ok"):
+        scenario["name"] = name
+        del calls[:]
+        try:
+            hook = gsd.PeerPushAllReduce(FakeEngine())
+            out[name] = ("constructed", list(calls))
+            hook.close()
+            assert calls[-1] == "gs_peer_destroy"
+        except RuntimeError as ex:
+            out[name] = ("raised: %s" % ex, list(calls))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_push_hook_construction_is_failure_safe_across_ranks():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        out = res[rank]
+        assert out["create"][0].startswith("raised: the exchange window could not be allocated on every rank"), out["create"]
+        assert "gs_peer_export" not in out["create"][1] and "gs_peer_allreduce_sum_f32" not in out["create"][1]
+        # the rank whose window was created gives it back
+        assert ("gs_peer_destroy" in out["create"][1]) == (rank == 0), out["create"]
+        assert out["attach"][0].startswith("raised: peer windows could not be mapped on every rank"), out["attach"]
+        assert out["attach"][1][-1] == "gs_peer_destroy", out["attach"]
+        assert out["ok"][0] == "constructed" and out["ok"][1].count("gs_peer_attach") == world - 1, out["ok"]
+
