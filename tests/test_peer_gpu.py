@@ -63,8 +63,13 @@ def _ordered_sum(parts):
     return s
 
 
-def _run_in_process(dev, world, n, chunks):
-    rs = _ranks(n, world, dev, chunks=chunks)
+class QueueCollision(RuntimeError):
+    """A wait timed out: two ranks of this process ended up on the same hardware queue (a test-harness artefact -- ranks in
+    different processes, the deployment, cannot collide), so one kernel sat behind the kernel that was waiting for it."""
+
+
+def _run_in_process_once(dev, world, n, chunks):
+    rs = _ranks(n, world, dev, chunks=chunks, spin_limit=1 << 20)
     try:
         rng = np.random.RandomState(world * 1000 + chunks)
         for epoch in range(5):               # both parities of the double buffer, twice
@@ -77,12 +82,23 @@ def _run_in_process(dev, world, n, chunks):
             for r in rs:
                 r.stream.sync()
             want = _ordered_sum(parts)
+            if any(r.status()[1] for r in rs):
+                raise QueueCollision("epoch %d: %r" % (epoch, [r.status() for r in rs]))
             for r in rs:
                 assert r.status() == (epoch + 1, 0)
-                assert np.array_equal(r.buf.cpu().numpy(), want)
+                assert np.array_equal(r.buf.cpu().numpy(), want)       # wrong bits are never retried
     finally:
         for r in rs:
             r.close()
+
+
+def _run_in_process(dev, world, n, chunks, attempts=3):
+    for attempt in range(attempts):
+        try:
+            return _run_in_process_once(dev, world, n, chunks)
+        except QueueCollision:
+            if attempt + 1 == attempts:
+                raise
 
 
 @pytest.mark.parametrize("world,n,chunks", [(1, 1000, 0), (2, 230121, 0), (2, 4099, 3), (3, 230121, 4), (3, 7, 1)])
@@ -97,17 +113,19 @@ def test_many_in_process_ranks_in_a_process_with_enough_hardware_queues(dev, wor
     exchanges (separate processes -- the real deployment -- each have their own queues)."""
     import subprocess
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), str(world), str(n), str(chunks)], env=env, timeout=240,
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    assert out.returncode == 0 and b"in-process exchange ok" in out.stdout, out.stdout.decode(errors="replace")[-2000:]
+    for attempt in range(2):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), str(world), str(n), str(chunks)], env=env, timeout=240,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if out.returncode == 0 and b"in-process exchange ok" in out.stdout:
+            return
+        assert b"QueueCollision" in out.stdout, out.stdout.decode(errors="replace")[-2000:]       # only the harness artefact is retried
+    raise AssertionError(out.stdout.decode(errors="replace")[-2000:])
 
 
-def test_exchange_replays_from_hipgraphs(dev):
-    """Each rank captures its exchange into its own hipGraph (kernel arguments frozen: the epoch lives in the window) and
-    replays it four times with fresh data."""
+def _replay_once(dev):
     from graphsage_amd import ops
     n, world = 50001, 2
-    rs = _ranks(n, world, dev)
+    rs = _ranks(n, world, dev, spin_limit=1 << 20)
     try:
         graphs = []
         for r in rs:
@@ -128,12 +146,25 @@ def test_exchange_replays_from_hipgraphs(dev):
                 g.launch()
             for r in rs:
                 r.stream.sync()
+            if any(r.status()[1] for r in rs):
+                raise QueueCollision("epoch %d: %r" % (epoch, [r.status() for r in rs]))
             for r in rs:
                 assert r.status() == (epoch + 1, 0)
                 assert np.array_equal(r.buf.cpu().numpy(), _ordered_sum(parts))
     finally:
         for r in rs:
             r.close()
+
+
+def test_exchange_replays_from_hipgraphs(dev):
+    """Each rank captures its exchange into its own hipGraph (kernel arguments frozen: the epoch lives in the window) and
+    replays it four times with fresh data."""
+    for attempt in range(3):
+        try:
+            return _replay_once(dev)
+        except QueueCollision:
+            if attempt == 2:
+                raise
 
 
 def test_missing_peer_trips_the_bounded_wait_instead_of_hanging(dev):
