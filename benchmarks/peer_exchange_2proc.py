@@ -38,7 +38,8 @@ def worker(rank, world, port, n, q):
     dev = torch.device("cuda:0")
     e = Shell(n, dev)
     res = {}
-    for chunks in (0, 32, 16, 8, 4, 2, 0, 32, 16, 8, 4, 2, 2, 2, 32, 32):
+    keep = []
+    for chunks in (2, 4, 2, 8, 2, 32, 0, 2, 4, 16, 2, 32, 0, 8, 2, 4, 2, 2, 32, 0, 2, 2, 4, 4, 8, 8, 2, 0, 0, 2):
         hook = gsd.PeerPushAllReduce(e, chunks=chunks, spin_limit=1 << 19)
         try:
             hook.self_test()
@@ -52,10 +53,16 @@ def worker(rank, world, port, n, q):
             e.sync()
             hook.check()
             res.setdefault("chunks%d" % chunks, []).append(round(a.elapsed_ms(b) * 1e3 / reps, 1))
+            res["self_test_attempts"] = res.get("self_test_attempts", []) + [hook.attempts]
+            if hook.failures:
+                res["self_test_failures"] = res.get("self_test_failures", []) + [(chunks, f[:160]) for f in hook.failures]
         except Exception as ex:
             res.setdefault("chunks%d" % chunks, []).append(repr(ex)[45:110])
         dist.barrier()
-        hook.close()
+        if os.environ.get("PEER_KEEP_WINDOWS") == "1":
+            keep.append(hook)          # windows are never freed: no address (and IPC handle) is ever reused
+        else:
+            hook.close()
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -83,7 +90,7 @@ def main():
     res = dict(got)
     for p in procs:
         p.join(timeout=30)
-    print(json.dumps({"n_floats": n, "bytes": 4 * n, "two_processes_one_device_us_per_exchange": res[0], "rank1": res[1]}, indent=1))
+    print("JSON " + json.dumps({"n_floats": n, "bytes": 4 * n, "two_processes_one_device_us_per_exchange": res[0], "rank1": res[1]}))
 
 
 if __name__ == "__main__":

@@ -217,6 +217,7 @@ class PeerPushAllReduce(object):
         self.chunks = int(os.environ.get("GS_PEER_CHUNKS", "0")) if chunks is None else int(chunks)
         self.spin_limit = int(os.environ.get("GS_PEER_SPIN_LIMIT", "0")) if spin_limit is None else int(spin_limit)
         self.attempts = 0
+        self.failures = []          # this rank's failed self-test attempts (diagnostics)
         self._open()
 
     def _open(self):
@@ -290,8 +291,12 @@ class PeerPushAllReduce(object):
 
     def self_test(self, attempts=3):
         """One exchange on the gradient buffer itself (zeroed afterwards): sum of (rank + 1), and the error word.  Collective.
-        The first exchange on freshly mapped windows is the one that has been seen to trip its bounded wait (rarely, two
-        processes on one device); a failed attempt is agreed on by all ranks, the windows are re-created and it is tried again."""
+        Why attempts: when a process frees a window and allocates the next one at the SAME address (a second hook in one
+        process), a peer's hipIpcOpenMemHandle can hand back its mapping of the OLD allocation -- the peer's stores then land
+        in memory nobody polls and the first exchange times out (measured with two processes on one device: 5 of 30
+        re-created hooks, 0 of 30 when no window is ever freed, benchmarks/peer_exchange_2proc.py PEER_KEEP_WINDOWS=1).  A
+        failed attempt is agreed on by all ranks and the windows are re-created WHILE THE OLD ONES STILL EXIST (new
+        addresses, new handles).  One hook per process -- the deployment -- never takes the second attempt."""
         from . import ops
         e = self.engine
         want = float(sum(range(1, self.world_size + 1)))
@@ -313,6 +318,7 @@ class PeerPushAllReduce(object):
                     raise RuntimeError("peer exchange gave %r, expected %r" % (got, want))
             except RuntimeError as ex:
                 ok, last = False, ex
+                self.failures.append(repr(ex))
             if _agree(ok, e):
                 return True
             old, self._peer = self._peer, None      # the new windows are allocated while the old ones still exist: new addresses,
