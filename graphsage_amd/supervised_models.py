@@ -193,10 +193,19 @@ class SupervisedGraphsage(SampleAndAggregate):
             d_outputs1 = self.node_pred.backward(self._dlogits, need_input_grad=True)
             d_out = e.ws_mat("d_agg_out", n, self.agg_out.d)
             ops.l2norm_bwd(d_outputs1, self.outputs1, self._inv_norm, n, d_out, stream=e.stream)
+        # The epilogue (loss mean + device counters) runs BEFORE the backward pass when there is no dropout (its masks are a
+        # function of the device clock and the backward pass regenerates them): a later mini-batch's fan-out sampler can
+        # then ride in this pass's optimizer launch -- it must see the advanced sampler clock and epoch cursor -- as it does
+        # behind the fused tail launch.  (Folding the epilogue into the optimizer launch's last workgroup measured 9 us SLOWER.)
+        early = epilogue is not None and self._dropout_rate() == 0
+        if early:
+            self._epilogue(n, **epilogue)
+        self._early_epilogue = early
+        advanced = early and bool(epilogue.get("step"))
         self.aggregate_backward(d_out)
         e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
-                          side_jobs=wgrad_jobs)
-        if epilogue is not None:      # (doing this in the optimizer launch's last workgroup measured 9 us SLOWER)
+                          side_jobs=wgrad_jobs, step_offset=0 if advanced else 1)
+        if epilogue is not None and not early:
             self._epilogue(n, **epilogue)
 
     def _epilogue(self, n, **counters):
@@ -398,12 +407,13 @@ class SupervisedGraphsage(SampleAndAggregate):
             samples, support = self._sample_phase(batch, n, parity, stage=(self._order, self._cursor, self.label_table, labels))
             return batch, labels, samples, support
 
-        # sampler-in-optimizer-launch: only where the fused tail launch advances the device counters BEFORE the optimizer
+        # sampler-in-optimizer-launch: the device counters are advanced BEFORE the optimizer launch -- by the fused tail
+        # launch, or by the early epilogue of _backward (this pipeline only runs without dropout)
         per_root = 1
         for f in self.num_samples[:0:-1]:
             per_root *= f
-        ride = (self.sampler_rides and mode == "fused" and (local_adam or in_graph) and fused and k > 1 and self._tail_ok()
-                and self._fanout_fusable() and per_root <= 512)
+        ride = (self.sampler_rides and mode == "fused" and (local_adam or in_graph) and fused and k > 1
+                and (self._tail_ok() or self._dropout_rate() == 0) and self._fanout_fusable() and per_root <= 512)
 
         def body():
             p = p0
