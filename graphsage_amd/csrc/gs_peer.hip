@@ -80,6 +80,13 @@ __global__ __launch_bounds__(GS_PEER_THREADS) void peer_allreduce_kernel(const P
     // the epoch is device state (kernel arguments are frozen inside a hipGraph): a private word per workgroup, read here
     // and advanced at the end by the same workgroup, so that all workgroups of all launches agree without any atomics
     const uint32_t epoch = mine.wg_epoch[blockIdx.x] + 1u;
+    if (*mine.error != 0u) {
+        // sticky: an earlier exchange gave up waiting.  Its flags are out of step for good, so every later launch (the rest
+        // of a multi-step hipGraph, say) returns at once instead of spending spin_limit polls each; the host sees the
+        // error word at its next gs_peer_status and has to re-create the windows.
+        if (threadIdx.x == 0) mine.wg_epoch[blockIdx.x] = epoch;
+        return;
+    }
     const int par = (int)(epoch & 1u);
     // chunk w of a slice: [c0, c1) floats, whole float4s
     const int64_t per = ((a.L / 4 + a.W - 1) / a.W) * 4;

@@ -667,7 +667,8 @@ int gs_comm_destroy(void* comm);
  *   gs_peer_allreduce_sum_f32 : in-place sum over ranks; every rank ends with identical bits
  *   gs_peer_status        : epochs completed and the error word (0 ok; bit 0: a peer's copies never arrived, bit 1: a
  *                           reduced slice never arrived, bits 8..: the ranks waited for in vain) -- every device-side
- *                           wait is bounded, a missing peer cannot hang the GPU
+ *                           wait is bounded, a missing peer cannot hang the GPU; the error is sticky (later exchanges
+ *                           return at once, the buffer untouched): re-create the windows
  * ------------------------------------------------------------------------------------------- */
 #define GS_PEER_HANDLE_BYTES 64
 int gs_peer_create(int64_t n_floats, int32_t world, int32_t rank, int32_t chunks, int64_t spin_limit, void** peer_out);

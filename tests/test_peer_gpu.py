@@ -169,7 +169,7 @@ def test_exchange_replays_from_hipgraphs(dev):
 
 def test_missing_peer_trips_the_bounded_wait_instead_of_hanging(dev):
     n, world = 4096, 2
-    rs = _ranks(n, world, dev, spin_limit=1 << 12)          # a few milliseconds
+    rs = _ranks(n, world, dev, spin_limit=1 << 16)          # some tens of milliseconds per timed-out wait
     try:
         rs[0].buf.fill_(1.0)
         torch.cuda.synchronize()
@@ -177,6 +177,22 @@ def test_missing_peer_trips_the_bounded_wait_instead_of_hanging(dev):
         rs[0].stream.sync()
         ep, er = rs[0].status()
         assert ep == 1 and er == (1 | (256 << 1))          # stage 1, rank 1 never delivered
+        # the error is sticky: the next exchanges return at once (no second spin_limit) and leave the buffer alone
+        import time
+        rs[0].buf.fill_(7.0)
+        torch.cuda.synchronize()
+        rs[0].launch()
+        rs[0].stream.sync()
+        t0 = time.time()
+        rs[0].launch()                                     # ... timed on its own: a spinning launch would take >= 1e4 us
+        rs[0].stream.sync()
+        one = time.time() - t0
+        for _ in range(48):
+            rs[0].launch()
+        rs[0].stream.sync()
+        assert one < 0.005, one
+        assert rs[0].status() == (51, 1 | (256 << 1))
+        assert float(rs[0].buf.min().item()) == 7.0 and float(rs[0].buf.max().item()) == 7.0
     finally:
         for r in rs:
             r.close()
