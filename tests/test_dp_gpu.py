@@ -155,6 +155,24 @@ def test_dp_in_graph_schedule_single_rank_matches_and_unsup_in_graph(dev):
         np.testing.assert_allclose(outs[0][0], o[0], rtol=1e-5)
         np.testing.assert_allclose(outs[0][1], o[1], rtol=1e-5, atol=1e-7)
     assert np.array_equal(outs[1][1], outs[2][1])               # the collective's duration does not change the bits
+    # ---- a model WITHOUT the fused tail (gcn): the step epilogue runs ahead of its backward pass, the sampler rides in the
+    #      reduce launch in front of the collective
+    gouts = []
+    for dp in (False, True):
+        G, it, ph, sampler, model, ns = build(dev, "gcn", False, False, csr=True)
+        if dp:
+            hook = NativeAllReduce(eng.get_engine(), world_size=1, rank=0)
+            model.grad_hook = hook
+            assert model._dp_in_graph()
+        model.attach_device_epoch(it.train_nodes[:320], it.label_matrix)
+        model.train_steps_device(32, 9, steps_per_launch=2)
+        loss, preds = model._fetch(32)
+        gouts.append((loss, eng.get_engine().params.cpu().numpy().copy()))
+        if dp:
+            assert any(k[0] == "ptrain_dp" and k[3] == 2 for k in model._graphs), list(model._graphs)
+            hook.close()
+    np.testing.assert_allclose(gouts[0][0], gouts[1][0], rtol=1e-5)
+    np.testing.assert_allclose(gouts[0][1], gouts[1][1], rtol=1e-5, atol=1e-7)
     # ---- unsupervised
     from test_unsup_gpu import build as build_unsup
     res = []
