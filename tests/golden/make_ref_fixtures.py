@@ -497,10 +497,18 @@ UNSUP_CASES = {
                        n_pairs=30, neg_sample_size=6, weight_decay=0.01, learning_rate=0.01, seed=9, np_seed=109),
     "unsup_gcn": dict(aggregator_type="gcn", concat=False, num_samples=[3, 3], dim=32, max_degree=6, batch_size=10,
                       n_pairs=18, neg_sample_size=5, weight_decay=0.0, learning_rate=0.02, seed=10, np_seed=110),
+    # the pooling aggregator under the unsupervised objective (unsupervised_train.py:186-196: hidden_dim 512)
+    "unsup_maxpool": dict(aggregator_type="maxpool", concat=True, num_samples=[3, 2], dim=32, max_degree=6, batch_size=8,
+                          n_pairs=16, neg_sample_size=4, weight_decay=0.005, learning_rate=0.01, seed=14, np_seed=114),
 }
 
 
 def main():
+    only = set(sys.argv[1:])           # optional: names of the fixtures to (re)generate
+    if only:
+        for table in (SUP_CASES, UNSUP_CASES):
+            for k in [k for k in table if k not in only]:
+                del table[k]
     for name, cfg in SUP_CASES.items():
         out = {"cfg": np.asarray(json.dumps(dict(cfg, kind="supervised")))}
         for real in ("float32", "float64"):
@@ -511,6 +519,8 @@ def main():
         for real in ("float32", "float64"):
             run_unsupervised(cfg, real, out)
         save(name, out)
+    if only and "operators" not in only:
+        return
     out = {}
     for real in ("float32", "float64"):
         run_operators(real, out)

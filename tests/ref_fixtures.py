@@ -11,7 +11,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SUP = ["sup_mean", "sup_mean_add_sigmoid", "sup_gcn", "sup_maxpool", "sup_meanpool_sigmoid", "sup_mean_3layer",
        "sup_mean_full_degree", "sup_mean_identity", "sup_mean_tail"]
 SUP_DROPOUT = ["sup_mean_dropout", "sup_maxpool_dropout"]
-UNSUP = ["unsup_mean", "unsup_gcn"]
+UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool"]
 
 
 class Fixture(object):

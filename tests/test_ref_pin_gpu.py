@@ -18,6 +18,11 @@ from ref_fixtures import SUP, UNSUP, Fixture, flat_items
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+# TF's Adam step is lr * g / (|g| + eps_hat) on the first step, eps_hat = 1e-8 / sqrt(1 - beta2) = 3.2e-7: inside that knee
+# d(step)/dg = lr * eps_hat / (|g| + eps_hat)^2 reaches 1e4, so a gradient element of ~1e-7 that agrees with the reference to
+# 2e-9 (far inside the gradient tolerance) moves its parameter by 4e-5.  The parameters-after-Adam comparison therefore takes
+# the elements with |g| > 30 eps_hat; the gradients themselves are compared element by element without this exclusion.
+ADAM_KNEE = 1e-5
 
 
 def close(got, want, msg, atol_rel=1e-4):
@@ -99,7 +104,7 @@ def test_supervised_steps_equal_reference_run(dev, name, fuse):
             got = v.numpy().reshape(want.shape)
             # Adam's first steps move every entry by ~lr * sign(g): entries whose gradient is numerically zero on one
             # side (|g| below fp32 noise) are decided by that noise -- compare the rest
-            solid = np.abs(g) > 1e-6 * max(1e-2, np.abs(g).max())
+            solid = np.abs(g) > max(1e-6 * max(1e-2, np.abs(g).max()), ADAM_KNEE)
             np.testing.assert_allclose(got[solid], want[solid], rtol=RTOL, atol=2e-5, err_msg="after/%s step %d" % (k, s))
             dead = (g == 0) & (v.grad.numpy().reshape(g.shape) == 0)       # e.g. weights behind units that never fire:
             np.testing.assert_allclose(got[dead], want[dead], rtol=0, atol=1e-6,     # only Adam's decaying moments move them
@@ -175,7 +180,7 @@ def test_unsupervised_steps_equal_reference_run(dev, name):
             close(v.grad.numpy(), fx[p + "32/grad/" + k], "grad/%s step %d" % (k, s))
         for k, v in mv.items():
             want, g = fx[p + "32/after/" + k], fx[p + "32/grad/" + k]
-            solid = np.abs(g) > 1e-6 * max(1e-2, np.abs(g).max())
+            solid = np.abs(g) > max(1e-6 * max(1e-2, np.abs(g).max()), ADAM_KNEE)
             np.testing.assert_allclose(v.numpy().reshape(want.shape)[solid], want[solid], rtol=RTOL, atol=2e-5,
                                        err_msg="after/%s step %d" % (k, s))
         for k, v in mv.items():
