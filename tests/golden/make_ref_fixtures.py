@@ -228,7 +228,7 @@ def run_supervised(cfg, real, out):
     layer_infos = [SAGEInfo("node", sampler, s, od) for s in cfg["num_samples"]]
     features = np.vstack([feats, np.zeros((feats.shape[1],))]) if cfg.get("use_features", True) else None
     model = SupervisedGraphsage(C, placeholders, features, adj_info, it.deg, layer_infos=layer_infos,
-                                aggregator_type=cfg["aggregator_type"], model_size="small", sigmoid_loss=sigmoid,
+                                aggregator_type=cfg["aggregator_type"], model_size=cfg.get("model_size", "small"), sigmoid_loss=sigmoid,
                                 concat=cfg["concat"], identity_dim=cfg.get("identity_dim", 0), logging=False)
     tf.nn.dropout = orig_dropout
     nv = named_variables(model, True)
@@ -342,7 +342,7 @@ def run_unsupervised(cfg, real, out):
     layer_infos = [SAGEInfo("node", sampler, s, od) for s in cfg["num_samples"]]
     features = np.vstack([feats, np.zeros((feats.shape[1],))])
     model = SampleAndAggregate(placeholders, features, adj_info, it.deg, layer_infos=layer_infos,
-                               aggregator_type=cfg["aggregator_type"], model_size="small", concat=cfg["concat"],
+                               aggregator_type=cfg["aggregator_type"], model_size=cfg.get("model_size", "small"), concat=cfg["concat"],
                                identity_dim=0, logging=False)
     nv = named_variables(model, False)
     names = sorted(nv)
@@ -490,6 +490,10 @@ SUP_CASES = {
     "sup_maxpool_dropout": dict(aggregator_type="maxpool", concat=True, sigmoid=True, num_samples=[3, 2], dim=16,
                                 max_degree=6, batch_size=16, batches=[list(range(12, 23))], weight_decay=0.0,
                                 learning_rate=0.01, seed=12, np_seed=112, dropout=0.25),
+    # FLAGS.model_size = "big": the pooling MLP is 1024 wide (aggregators.py:139-142)
+    "sup_maxpool_big": dict(aggregator_type="maxpool", concat=True, sigmoid=False, num_samples=[3, 2], dim=16, max_degree=6,
+                            batch_size=16, batches=[list(range(25, 36))], weight_decay=0.01, learning_rate=0.01, seed=15,
+                            np_seed=115, model_size="big"),
 }
 UNSUP_CASES = {
     # embedding widths of 64 (the device's link-prediction launch takes d in {64, 128, 256, 512})
@@ -498,6 +502,8 @@ UNSUP_CASES = {
     "unsup_gcn": dict(aggregator_type="gcn", concat=False, num_samples=[3, 3], dim=32, max_degree=6, batch_size=10,
                       n_pairs=18, neg_sample_size=5, weight_decay=0.0, learning_rate=0.02, seed=10, np_seed=110),
     # the pooling aggregator under the unsupervised objective (unsupervised_train.py:186-196: hidden_dim 512)
+    "unsup_meanpool": dict(aggregator_type="meanpool", concat=True, num_samples=[3, 2], dim=32, max_degree=6, batch_size=7,
+                           n_pairs=17, neg_sample_size=4, weight_decay=0.0, learning_rate=0.01, seed=16, np_seed=116),
     "unsup_maxpool": dict(aggregator_type="maxpool", concat=True, num_samples=[3, 2], dim=32, max_degree=6, batch_size=8,
                           n_pairs=16, neg_sample_size=4, weight_decay=0.005, learning_rate=0.01, seed=14, np_seed=114),
 }

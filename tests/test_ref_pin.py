@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import graphsage_oracle as orc
-from ref_fixtures import SUP, SUP_DROPOUT, UNSUP, Fixture, flat_items
+from ref_fixtures import SUP, SUP_CPU, SUP_DROPOUT, UNSUP, UNSUP_CPU, Fixture, flat_items
 
 TOL = {"32": dict(rtol=1e-4, atol=2e-6), "64": dict(rtol=1e-9, atol=1e-12)}
 DT = {"32": np.float32, "64": np.float64}
@@ -28,7 +28,7 @@ def close(got, want, prec, msg=""):
 # ---------------------------------------------------------------------------------------------------------------
 # S0
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", SUP + SUP_DROPOUT + UNSUP)
+@pytest.mark.parametrize("name", SUP + SUP_CPU + SUP_DROPOUT + UNSUP + UNSUP_CPU)
 def test_padded_adjacency_tables_equal_the_reference_iterators(name):
     """minibatch.py:227-259 (Node iterator) / :76-108 (Edge iterator): same global NumPy stream, same node order."""
     fx = Fixture(name)
@@ -113,7 +113,7 @@ def _dropout_masks(fx, p, dt):
 
 
 @pytest.mark.parametrize("prec", ["32", "64"])
-@pytest.mark.parametrize("name", SUP + SUP_DROPOUT)
+@pytest.mark.parametrize("name", SUP + SUP_CPU + SUP_DROPOUT)
 def test_supervised_steps_equal_reference_run(name, prec):
     fx, dt = Fixture(name), DT[prec]
     c = fx.cfg
@@ -176,7 +176,7 @@ def test_evaluation_on_the_test_adjacency_equals_reference(name, prec):
 # unsupervised model (models.py:332-405, prediction.py:68-110)
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", ["32", "64"])
-@pytest.mark.parametrize("name", UNSUP)
+@pytest.mark.parametrize("name", UNSUP + UNSUP_CPU)
 def test_unsupervised_steps_equal_reference_run(name, prec):
     fx, dt = Fixture(name), DT[prec]
     c = fx.cfg
