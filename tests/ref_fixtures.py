@@ -11,11 +11,13 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SUP = ["sup_mean", "sup_mean_add_sigmoid", "sup_gcn", "sup_maxpool", "sup_meanpool_sigmoid", "sup_mean_3layer",
        "sup_mean_full_degree", "sup_mean_identity", "sup_mean_tail"]
 SUP_DROPOUT = ["sup_mean_dropout", "sup_maxpool_dropout"]
-UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool"]
-# pinned against the oracle on the CPU only so far (tests/test_ref_pin.py); the `-m gpu` suite takes them over once they have
-# been run on an MI355X
+UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool", "unsup_meanpool"]
+# pinned against the oracle on the CPU only so far (tests/test_ref_pin.py): the `-m gpu` builder of test_ref_pin_gpu.py does
+# not pass FLAGS.model_size yet (a trial run through REF_PIN_ALL=1 fails on the 1024-wide weights it is handed)
 SUP_CPU = ["sup_maxpool_big"]
-UNSUP_CPU = ["unsup_meanpool"]
+UNSUP_CPU = []
+if os.environ.get("REF_PIN_ALL") == "1":          # trial run of the CPU-only fixtures through the `-m gpu` tests
+    SUP, UNSUP, SUP_CPU, UNSUP_CPU = SUP + SUP_CPU, UNSUP + UNSUP_CPU, [], []
 
 
 class Fixture(object):
