@@ -12,8 +12,9 @@ SUP = ["sup_mean", "sup_mean_add_sigmoid", "sup_gcn", "sup_maxpool", "sup_meanpo
        "sup_mean_full_degree", "sup_mean_identity", "sup_mean_tail"]
 SUP_DROPOUT = ["sup_mean_dropout", "sup_maxpool_dropout"]
 UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool", "unsup_meanpool"]
-# pinned against the oracle on the CPU only so far (tests/test_ref_pin.py): the `-m gpu` builder of test_ref_pin_gpu.py does
-# not pass FLAGS.model_size yet (a trial run through REF_PIN_ALL=1 fails on the 1024-wide weights it is handed)
+# pinned against the oracle on the CPU only so far (tests/test_ref_pin.py): the `-m gpu` builder of test_ref_pin_gpu.py did
+# not pass FLAGS.model_size when it was last run on an MI355X (REF_PIN_ALL=1: the 1024-wide weights met a 512-wide model);
+# it does now -- move the name into SUP after one green `REF_PIN_ALL=1 pytest tests/test_ref_pin_gpu.py -m gpu`
 SUP_CPU = ["sup_maxpool_big"]
 UNSUP_CPU = []
 if os.environ.get("REF_PIN_ALL") == "1":          # trial run of the CPU-only fixtures through the `-m gpu` tests

@@ -72,7 +72,7 @@ def build_supervised(fx):
     model = SupervisedGraphsage(fx["graph/labels"].shape[1], ph, fx["graph/feats"], adj_info, fx["graph/deg"], layer_infos,
                                 concat=c["concat"], aggregator_type=fx.agg, sigmoid_loss=c["sigmoid"],
                                 learning_rate=c["learning_rate"], weight_decay=c["weight_decay"],
-                                identity_dim=fx.identity_dim)
+                                identity_dim=fx.identity_dim, model_size=c.get("model_size", "small"))
     model.use_graphs = False                      # the padded sampler takes a host permutation per call
     return e, ph, adj_info, sampler, model
 
