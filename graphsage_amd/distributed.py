@@ -205,11 +205,8 @@ class PeerPushAllReduce(object):
     capturable = True
 
     def __init__(self, engine, chunks=None, spin_limit=None):
-        import ctypes
         import torch.distributed as dist
-        from . import _lib, ops
         self.engine = engine
-        self._lib = _lib
         self._peer = None
         multi = dist.is_initialized() and dist.get_world_size() > 1
         self.world_size = dist.get_world_size() if multi else 1
