@@ -217,6 +217,19 @@ def step_traffic_profile(args):
     return {"bytes_per_step": total, "path": os.path.relpath(paths[-1], ROOT), "lib_digest": d.get("lib_digest")}
 
 
+def aux_dominant_profile():
+    """{config: {kernel, avg_us, share}} of the aux configurations from the newest committed kernel traces
+    (profiles/r*_aux_dominant.json, written by benchmarks/aux_dominant.py from the rocprofv3 --kernel-trace summaries)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_aux_dominant.json")))
+    if not paths:
+        return None
+    with open(paths[-1]) as f:
+        d = json.load(f)
+    d["path"] = os.path.relpath(paths[-1], ROOT)
+    return d
+
+
 def timed_events(e, fn, iters, between=None):
     """Average duration (us) of fn() measured with HIP events on the ENGINE stream (torch.cuda.Event would only see
     torch's current stream); `between()` runs before every sample so the caches are in the training state."""
@@ -232,12 +245,34 @@ def timed_events(e, fn, iters, between=None):
     return float(np.mean([a.elapsed_ms(b) for a, b in evs])) * 1e3
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves -- one process per GPU, the
+    contract of `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` -- and hand their output through.  (Before
+    round 5 this command silently ran ONE rank and printed n_gpus: 1.)"""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus and os.environ.get("GS_DIST_BACKEND", "nccl") != "gloo":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (GS_DIST_BACKEND=gloo lets ranks share a device: a "
+                         "functional check of the N > 1 path, not a measurement)" % (args.gpus, n_dev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py --gpus %d without WORLD_SIZE: launching the ranks: %s" % (args.gpus, " ".join(cmd)))
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     args = parse_args()
     t_begin = time.time()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank, local_rank, world = gsd.init_from_env()
-    if world != args.gpus and world > 1:
-        log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    if world != args.gpus:
+        # a line whose n_gpus differs from what was asked for would be recorded under the wrong N
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -323,6 +358,20 @@ def main():
         dt = float(t.item())
         torch.distributed.barrier()
     loss_after = model._fetch_unsup(B)[0] if args.unsupervised else model._fetch(B)[0]
+    # HIP events on the engine stream around the timed call, repeated -- the device-side duration of the same K
+    # steps without the host's launch / synchronisation cost that the wall clock above carries (about 7 us per step at
+    # K = 20); `value` stays the wall-clock figure.  All ranks run it (the steps all-reduce under N > 1); rank 0 reports.
+    ev_reps = 12
+    evs = [(ops.Event(), ops.Event()) for _ in range(ev_reps)]
+    for a, b in evs:
+        a.record(e.stream)
+        run_steps(args.steps)
+        b.record(e.stream)
+    e.sync()
+    ev_ms = np.asarray([a.elapsed_ms(b) for a, b in evs][1:]) / args.steps
+    events = {"ms_per_step_median": float(np.median(ev_ms)), "ms_per_step_p10": float(np.percentile(ev_ms, 10)),
+              "ms_per_step_p90": float(np.percentile(ev_ms, 90)), "launches": int(len(ev_ms)), "steps_per_sample": args.steps,
+              "basis": "hipEventElapsedTime on the engine stream around each call of the timed %d-step region" % args.steps}
 
     roots = (2 * B + 20) if args.unsupervised else B
     edges_per_step = roots * (s2 + s2 * s1)
@@ -333,7 +382,7 @@ def main():
         "metric": metric,
         "value": value, "unit": "sampled-edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "warmup_steps_run": warm_steps,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "ms_per_step_events": events, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "loss_after": loss_after,
@@ -703,7 +752,10 @@ def run_aux(DG, args, B, s1, s2):
     K, spl = args.aux_steps, args.steps_per_launch
     warm = 2 * min(spl, 8) + 6
 
-    def timed(model, e, n_roots, fan1):
+    dominant = aux_dominant_profile()
+
+    def timed(model, e, n_roots, fan1, feat_dim, key, flops_fwd=None):
+        from graphsage_amd import ops
         model.train_steps_device(B, warm, steps_per_launch=spl)
         for _ in range(2):                  # every graph length of the timed call: eager, then captured
             model.train_steps_device(B, K, steps_per_launch=spl)
@@ -712,12 +764,40 @@ def run_aux(DG, args, B, s1, s2):
         model.train_steps_device(B, K, steps_per_launch=spl)
         e.sync()
         dt = time.time() - t0
-        return {"ms_per_step": dt / K * 1e3, "value": n_roots * (s2 + s2 * fan1) * K / dt, "unit": "sampled-edges/s", "steps": K}
+        evs = [(ops.Event(), ops.Event()) for _ in range(6)]
+        for a, b in evs:
+            a.record(e.stream)
+            model.train_steps_device(B, K, steps_per_launch=spl)
+            b.record(e.stream)
+        e.sync()
+        ev = np.asarray([a.elapsed_ms(b) for a, b in evs][1:]) / K
+        r = {"ms_per_step": dt / K * 1e3, "ms_per_step_events_median": float(np.median(ev)),
+             "value": n_roots * (s2 + s2 * fan1) * K / dt, "unit": "sampled-edges/s", "steps": K}
+        # the configuration's own roofline: algorithmic bytes of a step = rows * F * 4 + ids + mean writes
+        rows = n_roots * (1 + s2 + s2 * fan1)
+        alg = rows * feat_dim * 4 + n_roots * (s2 + s2 * fan1) * 4 + n_roots * (1 + s2) * feat_dim * 4
+        r["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_step": alg, "achieved": alg / (dt / K) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac_algorithmic": alg / (dt / K) / 1e9 / HBM_PEAK_GBS}
+        if flops_fwd is not None:
+            # pooling aggregators are bound by the MLP contraction: forward flops of the reference graph over
+            # the WHOLE step's time (the backward pass is not counted: a lower bound of the matrix-pipe utilisation)
+            tf = flops_fwd / (dt / K) / 1e12
+            r["roofline"].update({"bound": "mfma", "algorithmic_flops_fwd_per_step": flops_fwd, "achieved_tflops_fwd_only": tf,
+                                  "peak_tflops": MFMA_F32_PEAK_TF, "frac_mfma_fwd_only": tf / MFMA_F32_PEAK_TF})
+        if dominant and key in dominant.get("configs", {}):
+            r["roofline"]["dominant_kernel"] = dominant["configs"][key]
+            r["roofline"]["dominant_kernel_source"] = "PROFILE-SOURCED: %s" % dominant["path"]
+            r["roofline"]["dominant_kernel_stale"] = dominant.get("lib_digest") != lib_digest()
+        return r
 
     try:
         e, model, ph, _ = build_model(DG, args, 1, 0, "graphsage_maxpool")
         model.attach_device_epoch(np.random.RandomState(123).permutation(DG.train_nodes), DG.label_table)
-        r = timed(model, e, B, s1)
+        F_, H_, D1, D2, C_ = args.feat_dim, 512, args.dim_1, args.dim_2, DG.num_classes
+        n0, n1 = B, B * s2
+        flops = (2.0 * (n0 * s2 + n1 * s1) * F_ * H_ + 2.0 * (n0 + n1) * (F_ + H_) * D1          # layer 0: MLP + both matmuls
+                 + 2.0 * n0 * s2 * (2 * D1) * H_ + 2.0 * n0 * (2 * D1 + H_) * D2 + 2.0 * n0 * 2 * D2 * C_)
+        r = timed(model, e, B, s1, args.feat_dim, "graphsage_maxpool", flops_fwd=flops)
         r["config"] = "configs[2]: Reddit-shaped supervised graphsage_maxpool, fan-out %dx%d, batch %d" % (s1, s2, B)
         r["loss_after"] = model._fetch(B)[0]
         out["graphsage_maxpool"] = r
@@ -726,7 +806,7 @@ def run_aux(DG, args, B, s1, s2):
     try:
         e, model, ph, _ = build_model(DG, args, 1, 0, "gcn")
         model.attach_device_epoch(np.random.RandomState(123).permutation(DG.train_nodes), DG.label_table)
-        r = timed(model, e, B, s1)
+        r = timed(model, e, B, s1, args.feat_dim, "gcn")
         r["config"] = ("configs[1]-shaped: Reddit-shaped supervised gcn (GCNAggregator, dims 2x%d, concat off: "
                        "supervised_train.py:175-185), fan-out %dx%d, batch %d" % (args.dim_1, s1, s2, B))
         r["loss_after"] = model._fetch(B)[0]
@@ -738,7 +818,7 @@ def run_aux(DG, args, B, s1, s2):
         e, model, ph, _ = build_model(DG, args, 1, 0, "graphsage_mean", unsupervised=True)
         pairs = random_walk_pairs_device(DG.train_csr[0], DG.train_csr[1], DG.train_nodes, max_pairs=1000000, seed=123)
         model.attach_device_pairs(pairs.cpu().numpy())
-        r = timed(model, e, 2 * B + 20, s1)
+        r = timed(model, e, 2 * B + 20, s1, args.feat_dim, "unsupervised")
         r["config"] = ("configs[3]: Reddit-shaped unsupervised graphsage_mean (random-walk pairs, 20 negatives), "
                        "fan-out %dx%d, batch %d, ONE GPU's share of the 8-GPU configuration" % (s1, s2, B))
         r["loss_after"] = model._fetch_unsup(B)[0]
@@ -751,7 +831,7 @@ def run_aux(DG, args, B, s1, s2):
         del e, model
         e, model, ph, order, labels, n_edges = build_rmat(a2, 1, 0)
         model.attach_device_epoch(order, labels)
-        r = timed(model, e, B, 15)
+        r = timed(model, e, B, 15, 256, "rmat")
         r["config"] = ("configs[4]: RMAT N=10^7 / E=%d directed, F=256, supervised graphsage_mean, fan-out 15x%d, batch %d, "
                        "ONE GPU's share of the 8-GPU configuration" % (n_edges, s2, B))
         out["rmat"] = r

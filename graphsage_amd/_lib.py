@@ -15,7 +15,7 @@ ACT_RELU = 1
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
 SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
 GS_PEER_HANDLE_BYTES = 64
-GS_ABI_VERSION = 6      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+GS_ABI_VERSION = 7      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -112,7 +112,7 @@ _PROTOS = {
     "gs_finalize_step": [_P, c_int64, c_float, _P, c_int, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_sage_dense_fwd_cogather": [_P, c_int64, _P, c_int32, _P, c_int64, _P, c_int32, c_int64, _P, c_int64, _P, c_int64,
                                    c_int32, c_int, c_int, _P, _P, c_int64, _P, c_int32, _P],
-    "gs_unsup_stage": [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_uint64, _P, _P, _P],
+    "gs_unsup_stage": [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_uint64, _P, c_int64, _P, _P],
     "gs_linkpred_fwd_bwd": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, _P, _P, c_int64, _P, c_int64,
                             _P, POINTER(c_int32), _P],
     "gs_linkpred_norm_fwd_bwd": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, c_int64, _P, _P, _P, c_int64,
@@ -146,7 +146,8 @@ class GatherDesc(ctypes.Structure):
 
 class Dropout(ctypes.Structure):
     """struct gs_dropout (include/graphsage_amd.h)"""
-    _fields_ = [("seed", c_uint64), ("clock_dev", c_void_p), ("site", c_uint32), ("rate", c_float), ("row0", c_int64)]
+    _fields_ = [("seed", c_uint64), ("clock_dev", c_void_p), ("site", c_uint32), ("rate", c_float), ("row0", c_int64),
+                ("keep_bits", c_void_p), ("keep_ld", c_int64)]
 
 
 GS_PULL_MAX = 6

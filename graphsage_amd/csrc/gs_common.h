@@ -69,6 +69,8 @@ struct DropArgs {
     uint32_t thresh16;       // 0 = dropout off
     float scale;             // 1 / keep_prob
     int64_t row0;            // global index of the call's first row
+    const uint8_t* keep;     // parity-test hook: keep bits read from memory instead of the hash (gs_dropout.keep_bits)
+    int64_t keep_ld;
 };
 
 __device__ __forceinline__ uint64_t gs_drop_key(const DropArgs& p) {
@@ -76,7 +78,17 @@ __device__ __forceinline__ uint64_t gs_drop_key(const DropArgs& p) {
     return gs_mix64(p.seed ^ (st * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)p.site << 32) ^ (0xD0ull << 56));
 }
 
-__device__ __forceinline__ f32x4 gs_drop4(f32x4 v, uint64_t key, int64_t grow, int q, uint32_t thresh16, float scale) {
+__device__ __forceinline__ f32x4 gs_drop4(f32x4 v, const DropArgs& p, uint64_t key, int64_t grow, int q) {
+    if (p.keep) {                       // injected masks (uniform branch; tests only)
+        const uint32_t b = *reinterpret_cast<const uint32_t*>(p.keep + grow * p.keep_ld + 4 * q);
+        v.x = (b & 0xffu) ? v.x * p.scale : 0.f;
+        v.y = (b & 0xff00u) ? v.y * p.scale : 0.f;
+        v.z = (b & 0xff0000u) ? v.z * p.scale : 0.f;
+        v.w = (b & 0xff000000u) ? v.w * p.scale : 0.f;
+        return v;
+    }
+    const uint32_t thresh16 = p.thresh16;
+    const float scale = p.scale;
     const uint64_t h = gs_mix64(key + (uint64_t)grow * 0xD1342543DE82EF95ull + (uint64_t)q);
     v.x = (((uint32_t)h) & 0xffffu) >= thresh16 ? v.x * scale : 0.f;
     v.y = (((uint32_t)(h >> 16)) & 0xffffu) >= thresh16 ? v.y * scale : 0.f;
@@ -87,13 +99,17 @@ __device__ __forceinline__ f32x4 gs_drop4(f32x4 v, uint64_t key, int64_t grow, i
 
 // host: C-ABI descriptor -> kernel argument (null / rate 0 = off)
 static inline int gs_drop_args(const gs_dropout* d, DropArgs* out) {
-    DropArgs a = {0ull, nullptr, 0u, 0u, 1.0f, 0};
+    DropArgs a = {0ull, nullptr, 0u, 0u, 1.0f, 0, nullptr, 0};
     if (d && d->rate > 0.f) {
         if (!(d->rate < 1.f)) return -1;
         a.seed = d->seed; a.clock = d->clock_dev; a.site = d->site; a.row0 = d->row0;
         uint32_t t = (uint32_t)(d->rate * 65536.0f + 0.5f);
         a.thresh16 = t < 1u ? 1u : (t > 65535u ? 65535u : t);
         a.scale = 1.0f / (1.0f - d->rate);
+        if (d->keep_bits) {
+            if ((reinterpret_cast<uintptr_t>(d->keep_bits) & 3u) || d->keep_ld <= 0 || (d->keep_ld & 3)) return -1;
+            a.keep = d->keep_bits; a.keep_ld = d->keep_ld;
+        }
     }
     *out = a;
     return 0;

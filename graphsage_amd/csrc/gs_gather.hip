@@ -29,7 +29,7 @@ static int launch_gather_mean(const float* X, int64_t ldx, const int32_t* idx, i
     const int64_t n_items = n * (int64_t)chunks;
     const int64_t blocks = gs_ceil_div(n_items, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gather: grid too large (%lld blocks)", (long long)blocks);
-    GatherArgs a = {X, ldx, idx, n, s, d, S, ld_self, sidx, out, ldo, scale, chunks, {0ull, nullptr, 0u, 0u, 1.0f, 0}};
+    GatherArgs a = {X, ldx, idx, n, s, d, S, ld_self, sidx, out, ldo, scale, chunks, {0ull, nullptr, 0u, 0u, 1.0f, 0, nullptr, 0}};
     if (drop && drop->thresh16) {
         a.drop = *drop;
         if (s >= 8)
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restri
         const int q = (int)(t - r * d4);
         const int64_t src = ids ? (int64_t)ids[r] : r;
         f32x4 v = *reinterpret_cast<const f32x4*>(X + src * ldx + q * 4);
-        if (p.thresh16) v = gs_drop4(v, key, p.row0 + r, q, p.thresh16, p.scale);
+        if (p.thresh16) v = gs_drop4(v, p, key, p.row0 + r, q);
         *reinterpret_cast<f32x4*>(out + r * ldo + q * 4) = gs_mask_tail(v, q * 4, d);
     }
 }

@@ -63,7 +63,7 @@ __device__ __forceinline__ void gather_mean_wave(const GatherArgs& a, const int6
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (DROP) v[u] = gs_drop4(v[u], dkey, drow + jb + j + u, q, a.drop.thresh16, a.drop.scale);
+                    if (DROP) v[u] = gs_drop4(v[u], a.drop, dkey, drow + jb + j + u, q);
                     acc += v[u];
                 }
             }
@@ -80,7 +80,7 @@ __device__ __forceinline__ void gather_mean_wave(const GatherArgs& a, const int6
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float m = (j + u < cnt) ? 1.f : 0.f;
-                    if (DROP) v[u] = gs_drop4(v[u], dkey, drow + jb + min(j + u, cnt - 1), q, a.drop.thresh16, a.drop.scale);
+                    if (DROP) v[u] = gs_drop4(v[u], a.drop, dkey, drow + jb + min(j + u, cnt - 1), q);
                     acc += v[u] * m;
                 }
             }
@@ -142,7 +142,7 @@ static inline int build_cojobs_s(const gs_gather_desc* jobs_host, int32_t n_jobs
         const int chunks = ((q.d + 3) / 4 + 63) / 64;
         J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
                               q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
-                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
+                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0, nullptr, 0}};
         J.wave_start[i] = waves;
         waves += q.n * (int64_t)chunks;
     }

@@ -755,7 +755,7 @@ static int build_cojobs(const gs_gather_desc* jobs_host, int32_t n_jobs, CoGathe
         const int chunks = ((q.d + 3) / 4 + 63) / 64;
         J.job[i] = GatherArgs{q.X, q.ldx, q.idx, q.n, q.s, q.d, q.self_src, q.ld_self, q.self_idx, q.out, q.ldo,
                               q.self_src ? 1.0f / (float)(q.s + 1) : 1.0f / (float)q.s, chunks,
-                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0}};
+                              DropArgs{0ull, nullptr, 0u, 0u, 1.0f, 0, nullptr, 0}};
         J.wave_start[i] = waves;
         waves += q.n * (int64_t)chunks;
     }

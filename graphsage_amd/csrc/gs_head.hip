@@ -716,7 +716,11 @@ __global__ __launch_bounds__(512) void maxpool_sparse_wgrad_cols_kernel(const fl
             for (int qt = 0; qt < 4; ++qt) {                  // four batches of 8 reads: 16 registers of row data at a time
                 gs_f32x2 x[8];
                 if (qt == 0) { GS_RD8(0); } else if (qt == 1) { GS_RD8(64); } else if (qt == 2) { GS_RD8(128); } else { GS_RD8(192); }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the wait is tied to the eight destination registers ("+v"): the FMAs below depend on ITS outputs, so neither
+                // the compiler nor the machine scheduler can hoist them above the wait (the reads land asynchronously)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+                             :: "memory");
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     acc[16 * qt + 2 * i] += v * x[i].x;

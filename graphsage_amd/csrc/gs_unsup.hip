@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void unsup_stage_kernel(const int32_t* __restr
                                                           const uint64_t* __restrict__ cursor, int64_t B,
                                                           const uint32_t* __restrict__ cdf, int64_t n_nodes, int32_t n_neg,
                                                           uint64_t seed, const uint64_t* __restrict__ clock,
-                                                          int32_t* __restrict__ ids_out) {
+                                                          int64_t slot_offset, int32_t* __restrict__ ids_out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pairs && t < B) {
         const uint64_t c = cursor ? *cursor : 0ull;
@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void unsup_stage_kernel(const int32_t* __restr
     if (cdf && t < n_neg) {
         const uint64_t st = clock ? *clock : 0ull;
         const uint64_t key = gs_mix64(seed ^ (st * 0x9E3779B97F4A7C15ull) ^ (0xFFull << 56));
-        const uint32_t r = (uint32_t)(gs_mix64(key + (uint64_t)t) >> 32);
+        // keyed by the GLOBAL slot like the fused fan-out staging (gs_sample_dev.h): data-parallel ranks draw different
+        // negatives and the stand-alone and the fused staging of the same step agree
+        const uint32_t r = (uint32_t)(gs_mix64(key + (uint64_t)t + (uint64_t)slot_offset) >> 32);
         int64_t lo = 0, hi = n_nodes - 1;  // first index with cdf[idx] > r
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
@@ -36,14 +38,14 @@ __global__ __launch_bounds__(256) void unsup_stage_kernel(const int32_t* __restr
 
 extern "C" int gs_unsup_stage(const int32_t* pairs, int64_t n_pairs, const uint64_t* cursor_dev, int64_t B,
                               const uint32_t* cdf, int64_t n_nodes, int32_t n_neg, uint64_t seed,
-                              const uint64_t* clock_dev, int32_t* ids_out, void* stream) {
+                              const uint64_t* clock_dev, int64_t slot_offset, int32_t* ids_out, void* stream) {
     GS_REQUIRE(ids_out && B >= 0 && n_neg >= 0, "gs_unsup_stage: bad args");
     GS_REQUIRE(!pairs || n_pairs > 0, "gs_unsup_stage: empty pair list");
     GS_REQUIRE(!cdf || n_nodes > 0, "gs_unsup_stage: empty cdf");
     const int64_t n = std::max<int64_t>(pairs ? B : 0, cdf ? n_neg : 0);
     if (n == 0) return GS_OK;
     hipLaunchKernelGGL(unsup_stage_kernel, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, pairs,
-                       n_pairs, cursor_dev, B, cdf, n_nodes, n_neg, seed, clock_dev, ids_out);
+                       n_pairs, cursor_dev, B, cdf, n_nodes, n_neg, seed, clock_dev, slot_offset, ids_out);
     GS_LAUNCH_CHECK("unsup_stage_kernel");
     return GS_OK;
 }

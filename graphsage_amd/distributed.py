@@ -319,8 +319,10 @@ class PeerPushAllReduce(object):
             if _agree(ok, e):
                 return True
             old, self._peer = self._peer, None      # the new windows are allocated while the old ones still exist: new addresses,
-            self._open()                            # new IPC handles
-            ops.call("gs_peer_destroy", old)
+            try:
+                self._open()                        # new IPC handles
+            finally:
+                ops.call("gs_peer_destroy", old)    # also when _open() raises (the caller then falls back to RCCL): no leaked window
         raise RuntimeError("peer exchange failed its self test %d times (this rank's last error: %r)" % (attempts, last))
 
     def close(self):

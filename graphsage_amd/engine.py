@@ -42,6 +42,7 @@ class Variable(object):
         # use, re-made after every update of the value
         self.split3 = None
         self.split_dirty = True
+        self.engine = None  # set by Engine.add_variable
 
     @property
     def size(self):
@@ -54,6 +55,11 @@ class Variable(object):
         a = np.asarray(a, dtype=np.float32).reshape(self.rows, self.cols)
         self.value.buf[:, : self.cols].copy_(torch.from_numpy(a))
         self.split_dirty = True
+        if self.split3 is not None and self.engine is not None:
+            # a captured step graph does not re-run split_of's Python: bring the bf16 pieces up to date right here
+            torch.cuda.current_stream().synchronize()
+            ops.split_rows(self.value, out=self.split3, stream=self.engine.stream)
+            self.split_dirty = False
 
     def slab_ptr(self, k):
         return self.slabs.data_ptr() + 4 * k * self.size
@@ -92,6 +98,8 @@ class Engine(object):
         self._wgrad_big_n = int(os.environ.get("GS_WGRAD_BIG_N", 16384))
         self._stream_max_slabs = int(os.environ.get("GS_STREAM_MAX_SLABS", 32))
         self._stream_slice_rows = float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))
+        self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)
+        self._split_vars = []             # variables with a three-piece bf16 copy, re-cut behind every optimizer launch
         self._defer_sampler = False       # neigh_samplers.fanout: hand the launch to the next optimizer launch instead
         self._deferred_sampler = None
 
@@ -99,6 +107,7 @@ class Engine(object):
     def add_variable(self, name, init, decay=False, scatter=False):
         assert not self.finalized, "variables must be created before Engine.finalize()"
         v = Variable(name, init, decay, scatter)
+        v.engine = self
         self.variables.append(v)
         return v
 
@@ -109,7 +118,19 @@ class Engine(object):
 
     def dropout(self, rate, site, row0=0):
         """gs_dropout descriptor keyed by the device step clock (None when rate == 0)."""
-        return ops.dropout_desc(self.dropout_seed, self.sample_clock_dev, site, rate, row0)
+        return ops.dropout_desc(self.dropout_seed, self.sample_clock_dev, site, rate, row0, keep=self._injected_keep.get(site))
+
+    def inject_dropout_masks(self, masks):
+        """Parity tests: {site id: uint8 array [rows, d] of keep bits} used INSTEAD of the counter hash by every dropout call
+        of that site (rows = the site's global row index: all hops of a layer in call order) until cleared with None.  The
+        reference's masks come from TF's RNG, so they are injected like the sampler's permutations."""
+        self._injected_keep = {}
+        for site, m in (masks or {}).items():
+            m = np.ascontiguousarray(m, dtype=np.uint8)
+            buf = torch.zeros((m.shape[0], round_up(m.shape[1], 4)), dtype=torch.uint8, device=self.device)
+            buf[:, : m.shape[1]].copy_(torch.from_numpy(m))
+            self._injected_keep[int(site)] = buf
+        torch.cuda.synchronize()
 
     def finalize(self):
         """Lay all variables out in one flat buffer (16-byte aligned segments)."""
@@ -245,11 +266,13 @@ class Engine(object):
             ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
         return ok, ks
 
-    def _assign_slabs(self, stream):
-        """Pending problems -> gs_wgrad_desc list with slabs assigned behind what each variable already holds."""
+    def _assign_slabs(self, ks_list):
+        """Pending problems -> gs_wgrad_desc list with slabs assigned behind what each variable already holds.  ks_list: the
+        slab count of every pending problem, decided by launch_wgrads (stream policy, or None = tiled policy)."""
         descs = []
-        for var, A, a_idx, dZ, col0, n, tiles in self._pending:
-            k = self._stream_slabs(var, A, a_idx, dZ, n)[1] if stream else self.pick_slabs(n, tiles)
+        for (var, A, a_idx, dZ, col0, n, tiles), k in zip(self._pending, ks_list):
+            if k is None:
+                k = self.pick_slabs(n, tiles)
             if var.n_slabs + k > MAX_SLABS:
                 raise ops._lib.GraphsageAmdError("slab arena of %s exhausted" % var.name)
             d = ops._lib.WgradDesc()
@@ -290,9 +313,17 @@ class Engine(object):
             self.launch_gather_jobs(side_jobs)
             return
         # the whole pass takes the stream kernel, or the tiled one: decided here, over every queued problem, BEFORE any slab
-        # count is assigned (each kernel has its own slab policy)
-        stream = self.stream_gemm and all(self._stream_slabs(v, A, ai, dZ, n)[0] for v, A, ai, dZ, _, n, _ in self._pending)
-        pending = self._assign_slabs(stream)
+        # is assigned (each kernel has its own slab policy).  The stream kernel's (eligible, slab count) is computed ONCE per
+        # problem, in order, against the slabs the earlier problems of the same variable will have taken (`reserved`), and
+        # those counts are the ones assigned -- so a variable whose arena is nearly full cannot shrink a gathered problem's
+        # slab count below what the eligibility check saw.
+        stream, ks_list, reserved = self.stream_gemm, [], {}
+        for v, A, ai, dZ, _, n, _ in self._pending:
+            ok, ks = self._stream_slabs(v, A, ai, dZ, n, reserved=reserved.get(id(v), 0))
+            stream = stream and ok
+            ks_list.append(ks)
+            reserved[id(v)] = reserved.get(id(v), 0) + ks
+        pending = self._assign_slabs(ks_list if stream else [None] * len(self._pending))
         if stream:
             jobs = list(side_jobs or ())
             for a in range(0, len(pending), 12):       # the kernel takes up to 12 problems per launch
@@ -352,19 +383,26 @@ class Engine(object):
         self._params_updated()
 
     def _params_updated(self):
-        """Launches that must follow every optimizer step (e.g. refreshing a materialised copy of a variable)."""
-        for v in self.variables:
-            v.split_dirty = True
+        """Launches that must follow every optimizer step (e.g. refreshing a materialised copy of a variable).
+        Every variable that has a three-piece bf16 copy (split_of) is re-cut HERE, right behind the launch that changed it:
+        inside a captured step the re-cut is then part of the graph whatever the host-side state was at capture time (a
+        host flag read at capture decided it before round 5 -- a train graph captured with the flag clean replayed the
+        pooling MLP on stale pieces)."""
+        for v in self._split_vars:
+            ops.split_rows(v.value, out=v.split3, stream=self.stream)
+            v.split_dirty = False
         for hook in self.post_update_hooks:
             hook()
 
     def split_of(self, var):
-        """The current three-piece copy of var.value^T (gs_split_rows), re-made on the engine stream when the value has
-        changed since the last call -- inside a captured step that launch is part of the step's graph."""
+        """The current three-piece copy of var.value^T (gs_split_rows).  Made on first use; from then on re-made behind every
+        optimizer launch (_params_updated) and -- for values written from the host (Variable.assign sets split_dirty) --
+        here.  A dirty flag met while capturing records one redundant re-cut in the graph, never a missing one."""
         if var.split3 is None:
             K, N = var.rows, var.cols
             var.split3 = torch.empty(ops.split_rows_words(K, N), dtype=torch.int32, device=self.device)
             var.split_dirty = True
+            self._split_vars.append(var)
         if var.split_dirty:
             ops.split_rows(var.value, out=var.split3, stream=self.stream)
             var.split_dirty = False

@@ -220,7 +220,7 @@ class SampleAndAggregate(object):
         e = self.engine
         ops.call("gs_unsup_stage", ops.ptr(pairs), pairs.shape[0] if pairs is not None else 0, ops.ptr(cursor), B,
                  ops.ptr(self._neg_cdf), self._n_cdf, self.neg_sample_size, self.neg_seed, ops.ptr(e.sample_clock_dev),
-                 ops.ptr(roots), e.stream)
+                 int(getattr(self, "row_offset", 0)), ops.ptr(roots), e.stream)
 
     def inject_negatives(self, neg):
         """Parity tests: the negatives of the next host-fed step (the reference draws them from TF's candidate sampler,
@@ -418,6 +418,15 @@ class SampleAndAggregate(object):
             else:
                 self._pipelined_steps_unsup(B, 1)
                 done += 1
+        self._check_exchange()
+
+    def _check_exchange(self):
+        """A gradient exchange with bounded device-side waits (PeerPushAllReduce) reports a tripped wait through an error
+        word: read it once per train_steps_device call, BEFORE further optimizer steps are issued on un-reduced gradients
+        (costs one stream synchronisation per call; hooks without check() skip it)."""
+        if hasattr(self.grad_hook, "check"):
+            self.engine.sync()
+            self.grad_hook.check()
 
     def _dp_in_graph(self):
         """Data-parallel AND the all-reduce hook can be recorded inside the step's hipGraph (NativeAllReduce)."""

@@ -192,11 +192,17 @@ def input_grad_pull(out, rows, d, d_self=None, n_self=0, segments=(), mask_y=Non
     return out
 
 
-def dropout_desc(seed, clock_dev, site, rate, row0=0):
-    """struct gs_dropout; None when rate == 0 (dropout off)."""
+def dropout_desc(seed, clock_dev, site, rate, row0=0, keep=None):
+    """struct gs_dropout; None when rate == 0 (dropout off).  keep: uint8 device tensor [rows, ld] of injected keep bits
+    (parity tests: the masks the reference run drew), addressed by the call's global row index."""
     if not rate:
         return None
-    return _lib.Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(clock_dev), int(site), float(rate), int(row0))
+    d = _lib.Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(clock_dev), int(site), float(rate), int(row0), None, 0)
+    if keep is not None:
+        assert keep.dtype == torch.uint8 and keep.dim() == 2 and keep.stride(1) == 1 and keep.stride(0) % 4 == 0
+        d.keep_bits, d.keep_ld = keep.data_ptr(), keep.stride(0)
+        d._keep = keep
+    return d
 
 
 def dropout_rows(X, ids, n, drop, out, stream=None):

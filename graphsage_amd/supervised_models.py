@@ -477,6 +477,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             else:
                 self.train_step_device(n)
                 done += 1
+        self._check_exchange()
 
     def predict(self):
         """sigmoid / softmax of the logits (supervised_models.py:122-126); filled by the last step."""

@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 6
+#define GS_ABI_VERSION 7
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -364,10 +364,11 @@ int gs_head_fwd_bwd(const float* x, int64_t ldx, int64_t n, int32_t d, const flo
  *   pairs != NULL: batch1[i], batch2[i] = pairs[(*cursor_dev + i) % n_pairs]   (int32 [n_pairs, 2])
  *   cdf   != NULL: negatives drawn from the fixed unigram distribution ~ degree^0.75 with replacement
  *                  (tf.nn.fixed_unigram_candidate_sampler, unique=False): cdf is uint32 [n_nodes],
- *                  cdf[i] = floor(2^32 * P(node <= i)); draw = first i with cdf[i] > hash32(seed, *clock_dev, slot). */
+ *                  cdf[i] = floor(2^32 * P(node <= i)); draw = first i with cdf[i] > hash32(seed, *clock_dev, slot_offset + slot):
+ *                  slot_offset = this rank's first global root (data-parallel ranks draw different negatives). */
 int gs_unsup_stage(const int32_t* pairs, int64_t n_pairs, const uint64_t* cursor_dev, int64_t B,
                    const uint32_t* cdf, int64_t n_nodes, int32_t n_neg, uint64_t seed, const uint64_t* clock_dev,
-                   int32_t* ids_out, void* stream);
+                   int64_t slot_offset, int32_t* ids_out, void* stream);
 
 /* Skip-gram cross-entropy head on the l2-normalised embeddings Y = [outputs1 (B) | outputs2 (B) | neg_outputs (n_neg)]:
  *   loss_rows[i] = xent(1, <o1_i,o2_i>) + neg_weight * sum_j xent(0, <o1_i,neg_j>)         (prediction.py:102-110)
@@ -563,6 +564,12 @@ typedef struct gs_dropout {
     uint32_t site;             /* distinct per dropout call site of a step */
     float rate;                /* in [0, 1) */
     int64_t row0;              /* global index of this call's first row */
+    /* Parity-test hook (NULL in production): when set, the keep mask is READ from this device buffer instead of the
+     * counter hash -- element (row0 + i, c) is kept iff keep_bits[(row0 + i) * keep_ld + c] != 0 -- so that a test can
+     * feed the masks the reference run's tf.nn.dropout drew (aggregators.py:46-47, layers.py:107), like the sampler's
+     * permutations.  4-byte aligned base, keep_ld % 4 == 0 and >= round_up(d, 4). */
+    const uint8_t* keep_bits;
+    int64_t keep_ld;
 } gs_dropout;
 /* out[i, :] = mask(row0 + i, :) * X[ids ? ids[i] : i, :] / keep_prob     (in place allowed when ids == NULL).
  * The same call is the backward of itself (X = upstream gradient). */

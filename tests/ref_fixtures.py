@@ -9,16 +9,12 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SUP = ["sup_mean", "sup_mean_add_sigmoid", "sup_gcn", "sup_maxpool", "sup_meanpool_sigmoid", "sup_mean_3layer",
-       "sup_mean_full_degree", "sup_mean_identity", "sup_mean_tail"]
+       "sup_mean_full_degree", "sup_mean_identity", "sup_mean_tail",
+       "sup_maxpool_big"]             # model_size = "big": hidden 1024 (aggregators.py:139-142)
 SUP_DROPOUT = ["sup_mean_dropout", "sup_maxpool_dropout"]
 UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool", "unsup_meanpool"]
-# pinned against the oracle on the CPU only so far (tests/test_ref_pin.py): the `-m gpu` builder of test_ref_pin_gpu.py did
-# not pass FLAGS.model_size when it was last run on an MI355X (REF_PIN_ALL=1: the 1024-wide weights met a 512-wide model);
-# it does now -- move the name into SUP after one green `REF_PIN_ALL=1 pytest tests/test_ref_pin_gpu.py -m gpu`
-SUP_CPU = ["sup_maxpool_big"]
+SUP_CPU = []
 UNSUP_CPU = []
-if os.environ.get("REF_PIN_ALL") == "1":          # trial run of the CPU-only fixtures through the `-m gpu` tests
-    SUP, UNSUP, SUP_CPU, UNSUP_CPU = SUP + SUP_CPU, UNSUP + UNSUP_CPU, [], []
 
 
 class Fixture(object):

@@ -247,3 +247,28 @@ def test_two_rank_rccl_in_graph_matches_eager_hook():
         assert p.exitcode == 0
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])      # replicas identical
     np.testing.assert_allclose(res[0][0], res[0][1], rtol=1e-5, atol=1e-7)                    # in-graph == eager hook
+
+
+def test_bench_gpus_2_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` WITHOUT a launcher starts its two ranks itself (torch.distributed.run contract) and prints
+    ONE line with n_gpus == 2; ranks share cuda:0 over the gloo bootstrap (a functional check of the N > 1 bench path: sharded
+    epoch order, gradient hook, max-over-ranks timing).  A WORLD_SIZE that disagrees with --gpus is refused, not reported."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"GS_DIST_BACKEND": "gloo", "GS_DP_NATIVE": "0", "GS_FAULT_DUMP_S": "280"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--nodes", "20000",
+           "--avg_degree", "40", "--no-cpu-baseline", "--no-aux"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 1024
+    assert d["config"]["allreduce"] == "GradAllReduce" and d["value"] > 0 and d["ms_per_step_events"]["launches"] >= 10
+    # the mismatch is an error, not a line with the wrong n_gpus
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout) and not [l for l in r2.stdout.splitlines() if l.startswith("{")]

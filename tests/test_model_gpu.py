@@ -402,6 +402,34 @@ def test_pipelined_equals_sequential_other_aggregators(dev, agg_type, concat):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_split_weight_pieces_follow_every_update_under_graph_replay(dev):
+    """The max-pool MLP on the step's distinct ids reads a three-piece bf16 copy of its weights (Engine.split_of).  The copy
+    must be re-cut behind EVERY optimizer step also when the step is a replayed hipGraph: train (eager) / eval (eager) /
+    train (captured) / train (replay) / eval == the same calls without graphs, bit for bit.  (Before round 5 the re-cut was
+    decided by a host flag read at capture time: a train graph captured with the flag clean replayed on stale pieces.)"""
+    outs = []
+    for use_graphs in (False, True):
+        G, it, ph, sampler, model, ns = build(dev, "maxpool", True, False, csr=True, n_nodes=1500)
+        assert eng.get_engine().split_pool
+        model.use_graphs = use_graphs
+        rng = np.random.RandomState(11)
+        B = 128                                         # 128 * (3 + 15) = 2304 gathered rows > 2048: the dedup + split path
+        feeds = []
+        for _ in range(6):
+            b = rng.choice(it.train_nodes, size=B, replace=False).astype(np.int32)
+            feeds.append({ph['batch']: b, ph['labels']: it.label_matrix[b], ph['batch_size']: B})
+        seq = [("t", 0), ("e", 1), ("t", 2), ("t", 3), ("e", 4), ("t", 5), ("e", 1)]
+        res = []
+        for kind, i in seq:
+            loss, preds = (model.train_step if kind == "t" else model.eval_step)(feeds[i])
+            res.append((loss, preds.copy()))
+        assert model.aggregators[0].mlp_layers[0].vars['weights'].split3 is not None, "the split-MFMA path did not run"
+        outs.append((res, eng.get_engine().params.cpu().numpy().copy()))
+    for (l0, p0), (l1, p1) in zip(outs[0][0], outs[1][0]):
+        assert l0 == l1 and np.array_equal(p0, p1)
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_training_learns(dev):
     """A few epochs on a planted-community graph reach a high val micro-F1 (the metric's quality half)."""
     G, it, ph, sampler, model, ns = build(dev, "mean", True, False, csr=True, n_nodes=3000, dim=32)

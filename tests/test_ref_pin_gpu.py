@@ -14,7 +14,7 @@ from graphsage_amd import inits
 from graphsage_amd.models import Placeholder, SAGEInfo, SampleAndAggregate
 from graphsage_amd.neigh_samplers import AdjInfo, PaddedAdjacency, UniformNeighborSampler
 from graphsage_amd.supervised_models import SupervisedGraphsage
-from ref_fixtures import SUP, UNSUP, Fixture, flat_items
+from ref_fixtures import SUP, SUP_DROPOUT, UNSUP, Fixture, flat_items
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -77,8 +77,34 @@ def build_supervised(fx):
     return e, ph, adj_info, sampler, model
 
 
+def reference_dropout_masks(model, fx, p):
+    """{device dropout site: uint8 keep bits [rows, d]} from the masks the reference run drew at step `p`, in the order its
+    graph applies tf.nn.dropout (tests/test_ref_pin.py::_dropout_masks): per layer, per hop: neigh_vecs then self_vecs
+    (aggregators.py:46-47, :104-105) or only the MLP input for the pooling aggregators (layers.py:107), last the
+    prediction Dense (supervised_models.py:88-92).  The device runs all hops of a layer as ONE call, so a site's rows are
+    the hops' rows in hop order (Engine.inject_dropout_masks)."""
+    from graphsage_amd.layers import SITE_DENSE, SITE_MLP, SITE_NEIGH, SITE_SELF
+    pooling = fx.agg in ("maxpool", "meanpool")
+    j, sites = 0, {}
+    for layer in range(fx.K):
+        agg = model.aggregators[layer]
+        neigh, selfs = [], []
+        for hop in range(fx.K - layer):
+            neigh.append(fx[p + "mask%d" % j]); j += 1
+            if not pooling:
+                selfs.append(fx[p + "mask%d" % j]); j += 1
+        d = neigh[0].shape[-1]
+        sites[agg.site + (SITE_MLP if pooling else SITE_NEIGH)] = np.concatenate([m.reshape(-1, d) for m in neigh])
+        if selfs:
+            sites[agg.site + SITE_SELF] = np.concatenate([m.reshape(-1, d) for m in selfs])
+    head = fx[p + "mask%d" % j]
+    assert not fx.has(p + "mask%d" % (j + 1))
+    sites[model.node_pred.site + SITE_DENSE] = head.reshape(-1, head.shape[-1])
+    return sites
+
+
 @pytest.mark.parametrize("fuse", [True, False])
-@pytest.mark.parametrize("name", SUP)
+@pytest.mark.parametrize("name", SUP + SUP_DROPOUT)
 def test_supervised_steps_equal_reference_run(dev, name, fuse):
     fx = Fixture(name)
     c = fx.cfg
@@ -89,7 +115,12 @@ def test_supervised_steps_equal_reference_run(dev, name, fuse):
         p = "s%d/" % s
         batch, labels = fx[p + "batch"], fx[p + "labels"]
         sampler.inject_perms(fx.perms(p, fx.K))
-        loss, preds = model.train_step({ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)})
+        feed = {ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)}
+        if c.get("dropout"):
+            # the reference's tf.nn.dropout draws, injected like the permutations (gs_dropout.keep_bits)
+            e.inject_dropout_masks(reference_dropout_masks(model, fx, p))
+            feed[ph['dropout']] = c["dropout"]                            # supervised_train.py:269
+        loss, preds = model.train_step(feed)
         if name == "sup_mean_tail":
             assert bool(getattr(model, "_tail_used", False)) == fuse     # the headline step's fused-tail launch
         for k in range(fx.K):                                           # S1/S2: bit-exact

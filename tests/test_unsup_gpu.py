@@ -35,7 +35,7 @@ def test_unsup_stage_bit_exact(dev):
     clk = torch.tensor([7], dtype=torch.int64, device=dev)
     cdf_dev = torch.from_numpy(cdf.view(np.int32).copy()).to(dev)
     ops.call("gs_unsup_stage", ops.ptr(torch.from_numpy(pairs).to(dev)), 1000, ops.ptr(cur), B, ops.ptr(cdf_dev), N, nn,
-             123, ops.ptr(clk), ops.ptr(ids), ops.current_stream())
+             123, ops.ptr(clk), 0, ops.ptr(ids), ops.current_stream())
     _sync()
     got = ids.cpu().numpy()
     sel = pairs[(900 + np.arange(B)) % 1000]
@@ -43,7 +43,7 @@ def test_unsup_stage_bit_exact(dev):
     assert np.array_equal(got[2 * B:], sampler_hash.sample_unigram(cdf, nn, 123, 7))
     # distribution ~ degree^0.75: zero-degree nodes are never drawn, heavy nodes are drawn more often
     big = torch.empty(2 * 0 + 50000, dtype=torch.int32, device=dev)
-    ops.call("gs_unsup_stage", None, 0, None, 0, ops.ptr(cdf_dev), N, 50000, 5, ops.ptr(clk), ops.ptr(big), ops.current_stream())
+    ops.call("gs_unsup_stage", None, 0, None, 0, ops.ptr(cdf_dev), N, 50000, 5, ops.ptr(clk), 0, ops.ptr(big), ops.current_stream())
     _sync()
     draws = big.cpu().numpy()
     assert (deg[draws] > 0).all()
@@ -315,8 +315,8 @@ def test_fanout_unsup_staging_bit_exact(dev):
     roots = np.concatenate([sel[:, 0], sel[:, 1], sampler_hash.sample_unigram(cdf, nn, 123, 7)]).astype(np.int32)
     assert np.array_equal(got[:n_roots], roots)
     staged = torch.full((n_roots,), -1, dtype=torch.int32, device=dev)
-    ops.call("gs_unsup_stage", ops.ptr(pairs_dev), 1000, ops.ptr(cur), B, ops.ptr(cdf_dev), N, nn, 123, ops.ptr(clk), ops.ptr(staged),
-             ops.current_stream())
+    ops.call("gs_unsup_stage", ops.ptr(pairs_dev), 1000, ops.ptr(cur), B, ops.ptr(cdf_dev), N, nn, 123, ops.ptr(clk), 0,
+             ops.ptr(staged), ops.current_stream())
     _sync()
     assert np.array_equal(staged.cpu().numpy(), roots)
     hop1 = sampler_hash.sample_uniform_csr(rowptr, col, N, N, roots, fans[0], 123, 7, 0)
@@ -359,3 +359,9 @@ def test_fanout_unsup_staging_bit_exact(dev):
     neg1 = ids_all.cpu().numpy()[2 * B:n_roots]
     assert np.array_equal(neg1, sampler_hash.sample_unigram(cdf, nn, 123, 7, slot_offset=n_roots))
     assert not np.array_equal(neg1, roots[2 * B:])
+    # ... and the stand-alone staging (host-fed / unpipelined steps, eval) keys its negatives the same way
+    staged = torch.full((n_roots,), -1, dtype=torch.int32, device=dev)
+    ops.call("gs_unsup_stage", None, 0, None, B, ops.ptr(cdf_dev), N, nn, 123, ops.ptr(clk), n_roots, ops.ptr(staged),
+             ops.current_stream())
+    _sync()
+    assert np.array_equal(staged.cpu().numpy()[2 * B:], neg1)
