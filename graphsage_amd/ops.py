@@ -317,6 +317,19 @@ def sage_dense_fwd_stream(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, ac
     return out
 
 
+def sage_dense_fwd_panel(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, act, bias, out, jobs, stream=None):
+    """gs_sage_dense_fwd_panel: one workgroup per 48 x 128 output panel for the whole K (a weight panel is pulled from L2
+    once per workgroup) + the gather jobs in ONE launch; arguments as sage_dense_fwd_stream."""
+    import ctypes
+    jobs = list(jobs or ())
+    arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_dense_fwd_panel", self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0,
+         ptr(self_idx), agg.ptr, agg.ld, agg.d, n, W_self.ptr if W_self is not None else None,
+         W_self.ld if W_self is not None else 0, W_neigh.ptr, W_neigh.ld, out_dim, act, ptr(bias), out.ptr, out.ld,
+         ctypes.addressof(arr), len(jobs), _s(stream))
+    return out
+
+
 def split_rows_words(K, N):
     """int32 words of gs_split_rows' output (gs_split_rows_bytes / 4): groups of 8 k up to an even count of 32-k stages."""
     import ctypes

@@ -463,6 +463,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             for _ in range(steps):
                 self.train_step_device(n)
             return
+        lead = self.lead_graph_steps
         done = 0
         data = self._data_fn(n)
         while done < steps:
@@ -471,9 +472,12 @@ class SupervisedGraphsage(SampleAndAggregate):
             # largest even length that fits, so it still is one launch with the sampler riding in the optimizer launches.
             rem = steps - done
             kk = min(k, rem - (rem % 2))
+            if lead and kk > 2 * lead:
+                kk = lead               # a short first graph: the GPU starts after ~20 packets instead of ~100 (see lead_graph_steps)
             if self._primed == n and self._pipe_parity == 0 and kk >= 2:
                 self._pipelined_steps(n, kk, data, fused)
                 done += kk
+                lead = 0
             else:
                 self.train_step_device(n)
                 done += 1
