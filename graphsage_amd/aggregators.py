@@ -238,16 +238,10 @@ class MeanAggregator(_SageBase):
         if side_jobs or stream_fwd:
             # horizontally fused launch: the contraction workgroups + the NEXT step's gather-mean waves share the CUs.
             # Stream form (gs_stream.hip): split-K workgroups without LDS staging, the self rows gathered in the A loads.
-            # Panel form (gs_panel.hip, round 5, default): one workgroup per 48 x 128 output panel for the whole K.
             split_fwd = stream_fwd and e.split_gemm
-            panel_fwd = stream_fwd and e.panel_gemm and not split_fwd and self.output_dim % 4 == 0
 
             def launch(jobs=list(side_jobs or ())):
-                if panel_fwd:
-                    ops.sage_dense_fwd_panel(self_all.src, self_all.ids, means, n_total, self.vars['self_weights'].value,
-                                             self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, jobs,
-                                             stream=e.stream)
-                elif split_fwd:
+                if split_fwd:
                     # the same contraction on the bf16 matrix pipe, operands cut into three bf16 pieces (fp32 accuracy)
                     ops.sage_dense_fwd_split(self_all.src, self_all.ids, means, n_total, e.split_of(self.vars['self_weights']),
                                              e.split_of(self.vars['neigh_weights']), self.output_dim, self.act_code, b, out,
@@ -266,8 +260,7 @@ class MeanAggregator(_SageBase):
             jobs_ = list(side_jobs or ())
             self.last_fused_launch = (launch, {
                 "kernel": "%s: [%d x %d|%d] . [%d x %d] x2 (%s) + %d co-scheduled "
-                          "gather+mean jobs of the next step" % ("sage_panel_fwd_kernel" if panel_fwd else
-                                                                 "sage_split_fwd_kernel" if split_fwd else
+                          "gather+mean jobs of the next step" % ("sage_split_fwd_kernel" if split_fwd else
                                                                  "sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
                                                                  n_total, d_in, means.d, d_in, self.output_dim,
                                                                  "fp32 as 3 bf16 pieces, 6 bf16 MFMAs per product" if split_fwd
@@ -425,10 +418,6 @@ class GCNAggregator(_SageBase):
             # split-MFMA form (gs_split.hip): fp32 operands as three bf16 pieces on the bf16 matrix pipe
             ops.sage_dense_fwd_split(None, None, means, n_total, None, e.split_of(self.vars['weights']), self.output_dim,
                                      self.act_code, b, out, side_jobs, stream=e.stream)
-        elif e.stream_gemm and e.panel_gemm and n_total > 2048 and rate == 0 and self.output_dim % 4 == 0:
-            # panel form (gs_panel.hip): one workgroup per 48 x 128 output panel for the whole K
-            ops.sage_dense_fwd_panel(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
-                                     b, out, side_jobs, stream=e.stream)
         elif e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
             # stream form: LDS-free contraction waves (+ the next step's gather jobs) in one launch
             ops.sage_dense_fwd_stream(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,

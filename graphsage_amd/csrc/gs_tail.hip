@@ -51,6 +51,10 @@ struct TailArgs {
     // split form: z (and the neighbor means) were written by a PREVIOUS launch (sage_tail_z_kernel): this launch has no
     // helper workgroups, waits for nothing and touches no hand-over state
     int32_t z_ready;
+    // GCNAggregator form of layer 1 (aggregators.py:101-116): ONE weight matrix W [D, 2 O] given as Ws = W, Wn = W + O; both
+    // column halves of z contract the SAME operand, the mean over {neighbors} U {self} = (sum_j h_neigh_j + h_self) / (s + 1),
+    // which is also what `means` receives; every row of d_h0 (self and neighbor rows alike) gets relu' * (dz . W^T) / (s + 1).
+    int32_t gcn;
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -126,7 +130,7 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < KW; ++u) bz[t][u] = *reinterpret_cast<const f32x2*>(Wp + (4 * u) * ldw + 32 * t);
-    const float inv_s = 1.0f / (float)s;
+    const float inv_s = 1.0f / (float)s, inv_s1 = 1.0f / (float)(s + 1);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int it = tid + p * TAIL_THREADS;
@@ -134,18 +138,21 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
         const bool valid = r0 + r < n;
         const int i = min(r0 + r, n - 1);
         f32x4 v;
-        if (!term) {
+        if (!term && !a.gcn) {
             v = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
         } else {
             const float* nb = a.h0 + (n + i * s) * ldh0 + c;
             f32x4 hv[TAIL_NB];
+            f32x4 hs = zero4;
+            if (a.gcn) hs = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
 #pragma unroll
             for (int u = 0; u < TAIL_NB; ++u) hv[u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
             v = zero4;
 #pragma unroll
             for (int u = 0; u < TAIL_NB; ++u)
                 if (u < s) v += hv[u];                               // summation order j = 0..s-1, as gather_mean_wave
-            v *= inv_s;
+            if (a.gcn) { v += hs; v *= inv_s1; }                      // ... then the self row, as gather_mean_wave's GCN form
+            else v *= inv_s;
             if (valid && col_base == O) *reinterpret_cast<f32x4*>(a.means + (r0 + r) * (int)a.ldm + c) = v;
         }
         *reinterpret_cast<f32x4*>(As + r * ldh + c) = valid ? v : zero4;
@@ -590,8 +597,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
             const int r = it / D4, c = (it % D4) * 4;
             const int i = r0 + r;
             if (i < n) {
-                const f32x4 g_self = *reinterpret_cast<const f32x4*>(DIN + r * ldi + c);
-                const f32x4 g_mean = *reinterpret_cast<const f32x4*>(DIN + r * ldi + D + c) * inv_s;
+                f32x4 g_self = *reinterpret_cast<const f32x4*>(DIN + r * ldi + c);
+                f32x4 g_mean = *reinterpret_cast<const f32x4*>(DIN + r * ldi + D + c);
+                if (a.gcn) {                                       // one operand, the mean over {neighbors} U {self}: both column
+                    g_self = (g_self + g_mean) * (1.0f / (float)(s + 1));   // halves' input gradients add up, every row gets 1/(s+1)
+                    g_mean = g_self;
+                } else {
+                    g_mean *= inv_s;
+                }
                 f32x4 o;
                 o.x = (mself[p] & 1u) ? g_self.x : 0.f;
                 o.y = (mself[p] & 2u) ? g_self.y : 0.f;
@@ -840,6 +853,9 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     a.c0 = q->c0; a.d0 = q->d0; a.c1 = q->c1; a.d1 = q->d1; a.c2 = q->c2; a.d2 = q->d2;
     a.train = q->train ? 1 : 0;
     a.z_ready = q->z_ready ? 1 : 0;
+    a.gcn = q->gcn ? 1 : 0;
+    GS_REQUIRE(!q->gcn || (q->W_neigh == q->W_self + O && q->ldwn == q->ldws),
+               "gs_sage_tail_fwd_bwd: gcn form takes ONE weight matrix (W_neigh == W_self + out_dim, same ld)");
     GS_REQUIRE(q->sync || q->z_ready, "gs_sage_tail_fwd_bwd: sync (2 * ceil(n / 16) + 2 zero-initialised uint32 words, private "
                                       "to the caller's stream) missing");
     a.sync = q->sync;
@@ -885,6 +901,7 @@ extern "C" int gs_sage_tail_z(const gs_tail_desc* q, const gs_gather_desc* jobs_
     a.Ws = q->W_self; a.ldws = q->ldws; a.Wn = q->W_neigh; a.ldwn = q->ldwn; a.O = O;
     a.means = q->means; a.ldm = q->ldm; a.z = q->z; a.ldz = q->ldz;
     a.z_ready = 1;
+    a.gcn = q->gcn ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     CoGatherS J = {};
     int64_t gw = 0;
@@ -921,6 +938,10 @@ extern "C" int gs_sage_tail_dh0(const gs_tail_desc* q, const gs_gather_desc* job
     GS_CHECK_MAT(q->dz, q->lddz, "gs_sage_tail_dh0 dz");
     GS_CHECK_MAT(q->d_h0, q->lddh, "gs_sage_tail_dh0 d_h0");
     GS_REQUIRE(q->ldh >= D && q->ldws >= O && q->ldwn >= O && q->lddz >= Z && q->lddh >= D, "gs_sage_tail_dh0: leading dimension too small");
+    if (q->gcn) {
+        gs_set_error("gs_sage_tail_dh0: the gcn form is only built into gs_sage_tail_fwd_bwd / gs_sage_tail_z");
+        return GS_ENOTSUP;
+    }
     TailArgs a = {};
     a.h0 = q->h0; a.ldh = q->ldh; a.n = q->n; a.s = q->s; a.D = D;
     a.Ws = q->W_self; a.ldws = q->ldws; a.Wn = q->W_neigh; a.ldwn = q->ldwn; a.O = O;

@@ -90,9 +90,6 @@ class Engine(object):
         # Default: the LDS-tiled pooling MLP (matrix-pipe bound: 564 -> measured below) takes it; the register-streaming layer-0
         # contraction does not (bound by the L2 -> CU operand traffic in either form: 24.7 vs 24.6 us alone, and the per-step
         # re-cut of its weights costs two launches)
-        # "panel" form of the layer-0 forward (gs_panel.hip, round 5): one workgroup per 48 x 128 output panel for the whole K
-        # -- a weight panel is pulled from L2 once per workgroup; default for n > 2048 rows
-        self.panel_gemm = os.environ.get("GS_PANEL_FWD", "1") == "1"
         self.split_gemm = os.environ.get("GS_SPLIT_GEMM", "0") == "1"
         self.split_pool = os.environ.get("GS_SPLIT_POOL", "1") == "1"
         # split-K policy knobs (tuning hooks, benchmarks/slab_sweep.sh), read ONCE

@@ -126,11 +126,6 @@ class SampleAndAggregate(object):
         #  all-reduce, the second-stream pipeline, the weight-stationary form of the layer-0 forward.)
         # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
         self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
-        # train_steps_device: length (even, 0 = off) of the FIRST graph of a call.  hipGraphLaunch hands the GPU a graph's
-        # packets only when all of them are written (~1 us per kernel node): a 20-step graph (81 nodes) starts ~100 us after
-        # the call, which a short timed region pays in full (round 4: 116.7 us/step at the driver's K = 20 against 109 at
-        # K = 200).  A 4-step graph starts after ~20 us and the long graph behind it is submitted while it runs.
-        self.lead_graph_steps = int(os.environ.get("GS_LEAD_GRAPH_STEPS", "4")) & ~1
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
         self.grad_hook = None
@@ -411,19 +406,15 @@ class SampleAndAggregate(object):
             for _ in range(steps):
                 self._pipelined_steps_unsup(B, 1)
             return
-        lead = self.lead_graph_steps
         done = 0
         while done < steps:
             # multi-step graphs always start at buffer parity 0 (one captured graph per length); single steps realign the
             # parity; a shorter tail takes the largest even length that fits
             rem = steps - done
             kk = min(k, rem - (rem % 2))
-            if lead and kk > 2 * lead:
-                kk = lead               # a short first graph: the GPU starts after ~20 packets instead of ~100 (see lead_graph_steps)
             if self._primed == B and self._pipe_parity == 0 and kk >= 2:
                 self._pipelined_steps_unsup(B, kk)
                 done += kk
-                lead = 0
             else:
                 self._pipelined_steps_unsup(B, 1)
                 done += 1
@@ -769,7 +760,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
-                self.cogather_z, e.stream_gemm, e.split_gemm, e.split_pool, e.panel_gemm, str(getattr(self, "pipeline", None)),
+                self.cogather_z, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
                 type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 

@@ -317,19 +317,6 @@ def sage_dense_fwd_stream(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, ac
     return out
 
 
-def sage_dense_fwd_panel(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, act, bias, out, jobs, stream=None):
-    """gs_sage_dense_fwd_panel: one workgroup per 48 x 128 output panel for the whole K (a weight panel is pulled from L2
-    once per workgroup) + the gather jobs in ONE launch; arguments as sage_dense_fwd_stream."""
-    import ctypes
-    jobs = list(jobs or ())
-    arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
-    call("gs_sage_dense_fwd_panel", self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0,
-         ptr(self_idx), agg.ptr, agg.ld, agg.d, n, W_self.ptr if W_self is not None else None,
-         W_self.ld if W_self is not None else 0, W_neigh.ptr, W_neigh.ld, out_dim, act, ptr(bias), out.ptr, out.ld,
-         ctypes.addressof(arr), len(jobs), _s(stream))
-    return out
-
-
 def split_rows_words(K, N):
     """int32 words of gs_split_rows' output (gs_split_rows_bytes / 4): groups of 8 k up to an even count of 32-k stages."""
     import ctypes
@@ -470,7 +457,7 @@ def tail_sync_error(sync, n):
 
 def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels, C, sigmoid_loss, means, z, y, logits,
                       preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), jobs=(), stream=None, sync=None,
-                      split=False, jobs_z=()):
+                      split=False, jobs_z=(), gcn=False):
     """gs_sage_tail_fwd_bwd: layer 1 + head (+ their input gradients when dz / d_h0 are given) in ONE launch.
     counters: up to three (device int64 tensor, delta) pairs advanced at the end of the launch.
     sync: int32 device tensor of tail_sync_words(n) words, zero-initialised once and owned by ONE caller / stream
@@ -501,6 +488,7 @@ def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels
     cs += [(None, 0)] * (3 - len(cs))
     (q.c0, q.d0), (q.c1, q.d1), (q.c2, q.d2) = cs[:3]
     q.s, q.d_in, q.out_dim, q.C, q.sigmoid, q.train = s, h0.d, out_dim, C, 1 if sigmoid_loss else 0, 1 if train else 0
+    q.gcn = 1 if gcn else 0          # GCNAggregator layer 1: W_self / W_neigh are the two column halves of ONE weight matrix
     if split:
         jz = list(jobs_z or ())
         jzarr = (_lib.GatherDesc * max(len(jz), 1))(*jz)

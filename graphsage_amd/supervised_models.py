@@ -65,13 +65,27 @@ class SupervisedGraphsage(SampleAndAggregate):
 
     def _tail_ok(self):
         """The fused layer-1 + head launch (gs_sage_tail_fwd_bwd) applies to the supervised two-layer mean model with
-        concat, no dropout, no trainable identity features and shapes the kernel supports."""
-        if not getattr(self, "fuse_tail", True) or len(self.layer_infos) != 2 or self.aggregator_type != "mean":
+        concat -- and, since round 5, to the two-layer GCN model (one weight matrix, the mean over {neighbors} U {self},
+        aggregators.py:101-116) --, no dropout, no trainable identity features and shapes the kernel supports."""
+        if not getattr(self, "fuse_tail", True) or len(self.layer_infos) != 2 or self.aggregator_type not in ("mean", "gcn"):
             return False
         a1 = self.aggregators[1]
-        return (self.concat and not a1.bias and self._dropout_rate() == 0 and self.embeds is None
-                and self.num_samples[-1] <= 11          # neighbor rows of a batch node are held in registers
-                and ops.sage_tail_supported(2 * self.dims[1], self.dims[2], self.num_classes))
+        if a1.bias or self._dropout_rate() != 0 or self.embeds is not None or self.num_samples[-1] > 11:
+            return False                                 # (s <= 11: the neighbor rows of a batch node are held in registers)
+        if self.aggregator_type == "gcn":
+            # layer-1 input = layer-0 output width (GCN ignores concat, the drivers pass 2 * dim: supervised_train.py:175-185)
+            return self.dims[2] % 2 == 0 and ops.sage_tail_supported(self.dims[1], self.dims[2] // 2, self.num_classes)
+        return self.concat and ops.sage_tail_supported(2 * self.dims[1], self.dims[2], self.num_classes)
+
+    def _tail_weights(self):
+        """(W_self, W_neigh, out_dim O, is_gcn) of the fused tail's layer-1 contraction z = [. W_self | . W_neigh] (z has 2 O
+        columns): the mean aggregator's two matrices, or the two column halves of the GCN aggregator's one."""
+        a1 = self.aggregators[1]
+        if self.aggregator_type == "gcn":
+            O = self.dims[2] // 2
+            W = a1.vars['weights'].value
+            return W.cols_slice(0, O), W.cols_slice(O, 2 * O), O, True
+        return a1.vars['self_weights'].value, a1.vars['neigh_weights'].value, self.dims[2], False
 
     def _forward(self, batch, labels, n, train=False, prefetched=None, side_jobs=None, epilogue=None, tail_jobs=None):
         """sample -> aggregate -> l2_normalize -> node_pred -> loss/preds  (supervised_models.py:79-92,102-126).
@@ -101,8 +115,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         if self._tail_used:
             # layer 1 + l2_normalize + head + loss + every input gradient down to layer 0's pre-activations: ONE launch
             h0 = self._tape[0][4]                       # [n + n*s, 2*dim_1]: layer-0 outputs of both hops
-            a1 = self.aggregators[1]
-            Z = 2 * self.dims[2]
+            W_self1, W_neigh1, O1, gcn1 = self._tail_weights()
+            Z = 2 * O1
             s = self.num_samples[len(self.num_samples) - 1]
             self._tail_means = e.ws_mat("tail_means", n, h0.d)
             self.agg_out = e.ws_mat("tail_z", n, Z)
@@ -130,12 +144,12 @@ class SupervisedGraphsage(SampleAndAggregate):
             jobs_z, jobs_m = [], tail_jobs
             if self.tail_split and tail_jobs:
                 jobs_z, jobs_m = ops.split_gather_jobs(tail_jobs, self.cogather_tail_z)
-            ops.sage_tail_fwd_bwd(h0, n, s, a1.vars['self_weights'].value, a1.vars['neigh_weights'].value, self.dims[2],
+            ops.sage_tail_fwd_bwd(h0, n, s, W_self1, W_neigh1, O1,
                                   self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels, C,
                                   self.sigmoid_loss, self._tail_means, self.agg_out, self.outputs1, self.node_preds,
                                   self.preds, self._dlogits, self._loss_rows, dz=self._tail_dz, d_h0=self._tail_dh0,
                                   counters=counters, jobs=jobs_m, stream=e.stream, sync=self._tail_sync,
-                                  split=self.tail_split, jobs_z=jobs_z)
+                                  split=self.tail_split, jobs_z=jobs_z, gcn=gcn1)
         else:
             self.agg_out = out
             self.outputs1 = e.ws_mat("outputs1", n, out.d)
@@ -176,8 +190,11 @@ class SupervisedGraphsage(SampleAndAggregate):
             h0 = self._tail_h0
             e.wgrad(self.node_pred.vars['weights'], self.outputs1, None, self._dlogits, 0, n)
             e.bgrad(self.node_pred.vars['bias'], self._dlogits, n, self.num_classes)
-            e.wgrad(a1.vars['self_weights'], h0.rows_slice(0, n), None, self._tail_dz, 0, n)
-            e.wgrad(a1.vars['neigh_weights'], self._tail_means, None, self._tail_dz, o, n)
+            if self.aggregator_type == "gcn":
+                e.wgrad(a1.vars['weights'], self._tail_means, None, self._tail_dz, 0, n)   # means = (sum neigh + self) / (s + 1)
+            else:
+                e.wgrad(a1.vars['self_weights'], h0.rows_slice(0, n), None, self._tail_dz, 0, n)
+                e.wgrad(a1.vars['neigh_weights'], self._tail_means, None, self._tail_dz, o, n)
             mode, agg0, rows, offsets, outs = self._tape[0]
             agg0.backward_hops(self._tail_dh0, True, embed_sink=None)
             e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
@@ -463,7 +480,6 @@ class SupervisedGraphsage(SampleAndAggregate):
             for _ in range(steps):
                 self.train_step_device(n)
             return
-        lead = self.lead_graph_steps
         done = 0
         data = self._data_fn(n)
         while done < steps:
@@ -472,12 +488,9 @@ class SupervisedGraphsage(SampleAndAggregate):
             # largest even length that fits, so it still is one launch with the sampler riding in the optimizer launches.
             rem = steps - done
             kk = min(k, rem - (rem % 2))
-            if lead and kk > 2 * lead:
-                kk = lead               # a short first graph: the GPU starts after ~20 packets instead of ~100 (see lead_graph_steps)
             if self._primed == n and self._pipe_parity == 0 and kk >= 2:
                 self._pipelined_steps(n, kk, data, fused)
                 done += kk
-                lead = 0
             else:
                 self.train_step_device(n)
                 done += 1

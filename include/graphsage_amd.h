@@ -230,17 +230,6 @@ int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const int32_t* 
                              const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);
-/* "Panel" form of gs_sage_dense_fwd_stream (same arguments, same maths; aggregators.py:51-58, :110): ONE workgroup per
- * 48-row x 128-column output panel and term for the WHOLE K -- 236 workgroups for the Reddit step's 5632 rows, one per
- * CU -- so that a weight panel is pulled from L2 once per workgroup (100 MB of operand traffic per launch instead of
- * 218); its 8 waves split K, a wave's tile is the full panel (3 x 8 tiles of v_mfma_f32_16x16x4_f32, exact fp32, 16-byte
- * operand loads, a 3-deep register ring of 16-k macro steps), partials summed in wave order through LDS (deterministic).
- * out_dim and ldo multiples of 4, bias (nullable) 16-byte aligned; pad columns [d, round_up(d, 4)) of self / agg must be
- * readable.  Gather jobs ride as extra 8-wave workgroups behind the contraction workgroups. */
-int gs_sage_dense_fwd_panel(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg, int64_t ld_agg,
-                            int32_t d, int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,
-                            int64_t ldw_neigh, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
-                            const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 /* The same contraction on the bf16 matrix pipe WITHOUT giving up fp32: every fp32 operand x is cut into three bf16 pieces
  * x = h + m + l (top / middle / low 8 significant bits: nothing is lost), a product is the sum of piece products -- each formed
  * exactly by v_mfma_f32_32x32x16_bf16 and accumulated in fp32 -- and six of the nine are kept (hh, hm, mh, mm, hl, lh; the
@@ -545,7 +534,10 @@ typedef struct gs_tail_desc {
                               May be NULL when z_ready != 0. */
     int32_t z_ready;       /* != 0: z and means were written by gs_sage_tail_z on this stream (split form): the launch has no
                               helper workgroups, no in-kernel hand-over and needs no sync buffer */
-    int32_t reserved_;
+    int32_t gcn;           /* != 0: GCNAggregator form of layer 1 (aggregators.py:101-116; gs_sage_tail_fwd_bwd and gs_sage_tail_z):
+                              ONE weight matrix W [d_in, 2*out_dim] passed as W_self = W, W_neigh = W + out_dim (same ld); both
+                              column halves of z contract the mean over {neighbors} U {self} = (sum_j h_neigh_j + h_self)/(s+1),
+                              which `means` receives; d_h0 rows (self and neighbors) = relu'(h0) * (dz . W^T) / (s + 1) */
 } gs_tail_desc;
 int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
 /* Split form of the fused tail, first launch: the layer-1 pre-activations z = [h_self . W_self | mean(h_neigh) . W_neigh]

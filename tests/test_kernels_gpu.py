@@ -1015,58 +1015,6 @@ def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias, gathered):
     assert np.array_equal(c_out.numpy(), X[ids1])
 
 
-@pytest.mark.parametrize("n,d,out,two,act,bias,gathered", [
-    (5632, 602, 128, True, ops.ACT_RELU, False, True), (2500, 100, 128, True, ops.ACT_IDENTITY, True, False),
-    (3001, 602, 256, False, ops.ACT_RELU, False, False), (2049, 37, 40, True, ops.ACT_RELU, True, True),
-    (70, 20, 8, True, ops.ACT_RELU, True, True), (33, 8, 64, False, ops.ACT_IDENTITY, False, False),
-    (11484, 256, 128, True, ops.ACT_RELU, False, True), (49, 1, 132, False, ops.ACT_RELU, True, False),
-    (97, 130, 260, True, ops.ACT_IDENTITY, True, False)])
-def test_sage_dense_fwd_panel(dev, n, d, out, two, act, bias, gathered):
-    """gs_sage_dense_fwd_panel (one workgroup per 48 x 128 output panel for the whole K, K split over its 8 waves; gathered
-    or dense self rows; K tails, K shorter than the 8 K slices, ragged row tiles, column panels past N, one and two terms,
-    several panels per term) + the co-scheduled gather jobs vs fp64 NumPy; NaN in every pad column must not leak; two
-    launches give the same bits."""
-    rng = np.random.default_rng(n + d)
-    Nn = 4000
-    X = _asym(rng, (Nn + 1, d)); X[Nn] = 0
-    self_m, mean = _asym(rng, (n, d)), _asym(rng, (n, d))
-    self_ids = rng.integers(0, Nn + 1, size=n).astype(np.int32)
-    if gathered:
-        self_m = X[self_ids]
-    Ws, Wn = _asym(rng, (d, out)) * 0.1, _asym(rng, (d, out)) * 0.1
-    b = (_asym(rng, ((2 if two else 1) * out,)) * 0.1) if bias else None
-    idx = rng.integers(0, Nn + 1, size=(700, 25)).astype(np.int32)
-    ids1 = rng.integers(0, Nn + 1, size=900).astype(np.int32)
-    Xd = Mat.from_numpy(X, dev, 32)
-    sd, md = Mat.from_numpy(self_m, dev), Mat.from_numpy(mean, dev)
-    Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
-    outs = []
-    for rep in range(2):
-        outm = Mat(torch.full((n, (2 if two else 1) * out), float("nan"), device=dev), (2 if two else 1) * out)
-        g_out, c_out = Mat.zeros(700, d, dev), Mat.zeros(900, d, dev)
-        idx_d, ids1_d = _i32(idx.reshape(-1), dev), _i32(ids1, dev)        # descriptors hold raw pointers: keep the tensors
-        bd = torch.from_numpy(b).to(dev) if bias else None
-        jobs = [ops.gather_job(Xd, idx_d, 700, 25, g_out), ops.gather_job(Xd, ids1_d, 900, 1, c_out)]
-        sid_d = _i32(self_ids, dev)
-        if gathered:
-            ops.sage_dense_fwd_panel(Xd, sid_d, md, n, Wsd, Wnd, out, act, bd, outm, jobs)
-        else:
-            ops.sage_dense_fwd_panel(sd if two else None, None, md, n, Wsd if two else None, Wnd, out, act, bd, outm, jobs)
-        _sync()
-        outs.append(outm.numpy().copy())
-    want_n = mean.astype(np.float64) @ Wn
-    want = np.concatenate([self_m.astype(np.float64) @ Ws, want_n], axis=1) if two else want_n
-    if bias:
-        want = want + b
-    if act == ops.ACT_RELU:
-        want = np.maximum(want, 0)
-    assert np.isfinite(outs[0]).all()
-    assert_close_rownorm(outs[0], want)
-    assert np.array_equal(outs[0], outs[1])
-    np.testing.assert_allclose(g_out.numpy(), X[idx].mean(axis=1), **TOL)
-    assert np.array_equal(c_out.numpy(), X[ids1])
-
-
 @pytest.mark.parametrize("slices0", [22, 11, 45])
 def test_dense_wgrad_grouped_stream(dev, slices0):
     """gs_dense_wgrad_grouped_stream: the weight gradients of a mean step (layer 0: 602x128 x2 over 5632 rows, layer 1:

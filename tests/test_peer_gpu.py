@@ -101,9 +101,27 @@ def _run_in_process(dev, world, n, chunks, attempts=3):
                 raise
 
 
+def _fresh_process(*argv):
+    """The in-process exchange in a FRESH process with GPU_MAX_HW_QUEUES raised: ranks of one process wait for each other inside
+    their kernels, so each needs a hardware queue of its own, and a pytest process that has already created dozens of streams
+    (every Engine of every earlier test) maps new streams onto queues that are taken."""
+    import subprocess
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    for attempt in range(2):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(a) for a in argv], env=env, timeout=240,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if out.returncode == 0 and b"in-process exchange ok" in out.stdout:
+            return
+        assert b"QueueCollision" in out.stdout, out.stdout.decode(errors="replace")[-2000:]       # only the harness artefact is retried
+    raise AssertionError(out.stdout.decode(errors="replace")[-2000:])
+
+
 @pytest.mark.parametrize("world,n,chunks", [(1, 1000, 0), (2, 230121, 0), (2, 4099, 3), (3, 230121, 4), (3, 7, 1)])
 def test_in_process_ranks_sum_in_rank_order_over_several_epochs(dev, world, n, chunks):
-    _run_in_process(dev, world, n, chunks)
+    try:
+        _run_in_process(dev, world, n, chunks, attempts=1)
+    except QueueCollision:                 # the harness artefact (see _fresh_process): wrong bits are never retried
+        _fresh_process(world, n, chunks)
 
 
 @pytest.mark.parametrize("world,n,chunks", [(4, 65536, 8), (8, 230121, 4)])
@@ -111,15 +129,7 @@ def test_many_in_process_ranks_in_a_process_with_enough_hardware_queues(dev, wor
     """Ranks of one process wait for each other INSIDE their kernels, so each needs a hardware queue of its own; HIP maps a
     process's streams onto 4 queues by default.  A fresh process with GPU_MAX_HW_QUEUES raised runs the 4- and 8-rank
     exchanges (separate processes -- the real deployment -- each have their own queues)."""
-    import subprocess
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
-    for attempt in range(2):
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), str(world), str(n), str(chunks)], env=env, timeout=240,
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-        if out.returncode == 0 and b"in-process exchange ok" in out.stdout:
-            return
-        assert b"QueueCollision" in out.stdout, out.stdout.decode(errors="replace")[-2000:]       # only the harness artefact is retried
-    raise AssertionError(out.stdout.decode(errors="replace")[-2000:])
+    _fresh_process(world, n, chunks)
 
 
 def _replay_once(dev):
@@ -159,12 +169,10 @@ def _replay_once(dev):
 def test_exchange_replays_from_hipgraphs(dev):
     """Each rank captures its exchange into its own hipGraph (kernel arguments frozen: the epoch lives in the window) and
     replays it four times with fresh data."""
-    for attempt in range(3):
-        try:
-            return _replay_once(dev)
-        except QueueCollision:
-            if attempt == 2:
-                raise
+    try:
+        return _replay_once(dev)
+    except QueueCollision:
+        _fresh_process("replay")
 
 
 def test_missing_peer_trips_the_bounded_wait_instead_of_hanging(dev):
@@ -319,5 +327,14 @@ def test_two_gpus_peer_push_over_xgmi():
 
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
-    _run_in_process(torch.device("cuda:0"), int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+    if sys.argv[1] == "replay":
+        for attempt in range(3):
+            try:
+                _replay_once(torch.device("cuda:0"))
+                break
+            except QueueCollision:
+                if attempt == 2:
+                    raise
+    else:
+        _run_in_process(torch.device("cuda:0"), int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
     print("in-process exchange ok")
