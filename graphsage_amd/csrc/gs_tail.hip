@@ -25,53 +25,8 @@
 #include "gs_common.h"
 #include "gs_gather_dev.h"
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+#include "gs_tail_dev.h"
 
-#define TAIL_ROWS 16
-#define TAIL_THREADS 512
-#define TAIL_WAVES 8
-
-struct TailArgs {
-    const float* h0; int64_t ldh; int64_t n; int32_t s; int32_t D;
-    const float* Ws; int64_t ldws; const float* Wn; int64_t ldwn; int32_t O;
-    const float* Wh; int64_t ldwh; const float* bh; const float* labels; int64_t ldlab; int32_t C; int32_t sigmoid;
-    float* means; int64_t ldm;
-    float* z; int64_t ldz;
-    float* y; int64_t ldy;
-    float* logits; int64_t ldlo; float* preds; int64_t ldp; float* dlogits; int64_t lddl; float* loss_rows;
-    float* dz; int64_t lddz;
-    float* d_h0; int64_t lddh;
-    uint64_t* c0; uint64_t d0; uint64_t* c1; uint64_t d1; uint64_t* c2; uint64_t d2;
-    int32_t train;
-    // hand-over state of the z helpers, G = ceil(n / 16) groups: [0, G) monotonic arrival counters (helpers add 1),
-    // [G, 2G) arrivals already consumed by earlier launches (written only by the group's main workgroup), [2G] error
-    // flags (bit 0: a main workgroup gave up waiting, bit 1: a group saw a number of arrivals other than HP).  Nothing
-    // is ever reset, so a launch does not depend on a reset store of the previous one.
-    uint32_t* sync;
-    // split form: z (and the neighbor means) were written by a PREVIOUS launch (sage_tail_z_kernel): this launch has no
-    // helper workgroups, waits for nothing and touches no hand-over state
-    int32_t z_ready;
-    // GCNAggregator form of layer 1 (aggregators.py:101-116): ONE weight matrix W [D, 2 O] given as Ws = W, Wn = W + O; both
-    // column halves of z contract the SAME operand, the mean over {neighbors} U {self} = (sum_j h_neigh_j + h_self) / (s + 1),
-    // which is also what `means` receives; every row of d_h0 (self and neighbor rows alike) gets relu' * (dz . W^T) / (s + 1).
-    int32_t gcn;
-};
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// WHAT BOUNDS THIS KERNEL: 32 workgroups, one per CU, 8 waves each -- nothing hides latency, and every global load a
-// phase waits for costs a full memory round trip (~1.5-2 us: the operands were last written by another XCD).  A first
-// version that loaded "just in time" spent ~24 dependent round trips (38-59 us for ~3 us of MFMA work).  None of the
-// global operands depends on anything computed here (h0, the weights, the labels are all inputs), so they are
-// PREFETCHED INTO REGISTERS up front, in two waves of requests, and the phases consume them from registers:
-//   S0 (kernel entry): this thread's h0 rows (self + s neighbors, 2 passes) and the wave's whole W slab of the z
-//                      contraction                                                        -> ~216 VGPRs in flight
-//   S1 (after z):      the wave's slices of W_head (both forms), labels / bias, and its two W slabs of the input-gradient
-//                      contraction                                                        -> ~200 VGPRs in flight
-// The relu mask of phase 8 is kept from S0 as bit flags, so h0 is read exactly once.  Barriers between phases are
-// LDS-only (fence on the "local" address space + s_barrier): they do not drain the outstanding global loads.
 #ifdef GS_TIMELINE
 // Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_tail.py): wall-clock stamp (100 MHz) per phase boundary.
 __device__ unsigned long long g_tail_timeline[64 * 16];
@@ -82,133 +37,6 @@ extern "C" int gs_debug_tail_timeline(unsigned long long* out_host, int n) {
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
-
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-__device__ __forceinline__ float tail_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ float tail_wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
-#define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
-
-// z helper (see the role comment in sage_tail_kernel): z[16 rows of group g][64 columns part*64 ..] of
-//   z = [h_self . W_self | mean_j(h_neigh_j) . W_neigh]      (aggregators.py:48-58, concat, identity act)
-// 8 waves = 8 K-slices of the slab's term (a 64-column slab lies in ONE term: 64 divides O), partial 16 x 64 tiles
-// summed in wave order through LDS, then published: stores -> device-scope release fence -> arrival counter.
-// The helper whose slab starts the neighbor term also writes the neighbor means (an input of the weight gradients).
-template <int D, int O>
-__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part, const bool publish = true) {
-    constexpr int ldh = D + 4;
-    constexpr int D4 = D / 4;
-    constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
-    constexpr int KW = D / 4 / TAIL_WAVES;                       // k-steps (4 k each) per wave
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* As = lds;                                             // [16][ldh]  the term's A rows
-    float* Pz = lds + TAIL_ROWS * ldh;                           // [8 waves][16][64] partial tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int r0 = g * TAIL_ROWS, n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
-    const int col_base = part * 64;
-    const int term = col_base >= O ? 1 : 0;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // this wave's weight slice: rows 4 (wave KW + u) + q, columns col_base + 32 t + 2 j (+1)
-    const int ldw = (int)(term ? a.ldwn : a.ldws);
-    const float* Wp = (term ? a.Wn : a.Ws) + (4 * wave * KW + q) * ldw + (col_base - term * O) + 2 * j;
-    f32x2 bz[2][KW];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < KW; ++u) bz[t][u] = *reinterpret_cast<const f32x2*>(Wp + (4 * u) * ldw + 32 * t);
-    const float inv_s = 1.0f / (float)s, inv_s1 = 1.0f / (float)(s + 1);
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int it = tid + p * TAIL_THREADS;
-        const int r = it / D4, c = (it % D4) * 4;
-        const bool valid = r0 + r < n;
-        const int i = min(r0 + r, n - 1);
-        f32x4 v;
-        if (!term && !a.gcn) {
-            v = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
-        } else {
-            const float* nb = a.h0 + (n + i * s) * ldh0 + c;
-            f32x4 hv[TAIL_NB];
-            f32x4 hs = zero4;
-            if (a.gcn) hs = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
-#pragma unroll
-            for (int u = 0; u < TAIL_NB; ++u) hv[u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
-            v = zero4;
-#pragma unroll
-            for (int u = 0; u < TAIL_NB; ++u)
-                if (u < s) v += hv[u];                               // summation order j = 0..s-1, as gather_mean_wave
-            if (a.gcn) { v += hs; v *= inv_s1; }                      // ... then the self row, as gather_mean_wave's GCN form
-            else v *= inv_s;
-            if (valid && col_base == O) *reinterpret_cast<f32x4*>(a.means + (r0 + r) * (int)a.ldm + c) = v;
-        }
-        *reinterpret_cast<f32x4*>(As + r * ldh + c) = valid ? v : zero4;
-    }
-    lds_barrier();
-    {
-        const float* A = As + j * ldh + 4 * wave * KW + q;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 acc0 = zero4, acc1 = zero4;
-#pragma unroll
-            for (int u = 0; u < KW; ++u) {
-                const float av = A[4 * u];
-                acc0 = mfma16(av, bz[t][u].x, acc0);
-                acc1 = mfma16(av, bz[t][u].y, acc1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<f32x2*>(Pz + (wave * TAIL_ROWS + 4 * q + i) * 64 + 32 * t + 2 * j) = f32x2{acc0[i], acc1[i]};
-        }
-    }
-    lds_barrier();
-#pragma unroll
-    for (int p = 0; p < TAIL_ROWS * 32 / TAIL_THREADS; ++p) {     // (row, column pair) items: 16 x 32
-        const int it = tid + p * TAIL_THREADS;
-        const int r = it >> 5, c2 = (it & 31) * 2;
-        f32x2 v = *reinterpret_cast<const f32x2*>(Pz + r * 64 + c2);
-#pragma unroll
-        for (int w = 1; w < TAIL_WAVES; ++w) v += *reinterpret_cast<const f32x2*>(Pz + (w * TAIL_ROWS + r) * 64 + c2);
-        // published with device-scope (write-through) stores: a release FENCE would write back the XCD's whole L2,
-        // dirty gather output of the riders included (measured: z arrived 17 us late)
-        if (r0 + r < n) {
-            union { f32x2 f; unsigned long long u; } cv;
-            cv.f = v;
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.z + (r0 + r) * (int)a.ldz + col_base + c2), cv.u,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (!publish) return;                                        // split form: the kernel boundary is the hand-over
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores are acknowledged ...
-    __syncthreads();                                             // ... and everybody else's
-    if (tid == 0) __hip_atomic_fetch_add(a.sync + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// End of a main workgroup: exactly HP helpers of THIS launch must have arrived since `base` (the helpers never wait, and
-// this runs ~15 us after the hand-over); anything else -- leftovers of a launch that did not finish, a helper that
-// never ran -- is flagged.  The consumed count is then published for the next launch (no reset of the counter).
-template <int HP>
-__device__ __forceinline__ void tail_sync_done(const TailArgs& a, const int G, const int grp, const uint32_t base) {
-    if (threadIdx.x == 0) {
-        const uint32_t cur = __hip_atomic_load(a.sync + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur - base != (uint32_t)HP) __hip_atomic_fetch_or(a.sync + 2 * G, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.sync + G + grp, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 template <int D, int O, int CW>
 __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
     // Co-scheduled gather: the tail occupies n/16 CUs for ~30 us of mostly waiting; the other ~220 CUs (one 8-wave

@@ -261,7 +261,8 @@ class Engine(object):
         ks = int(max(1, min(self._stream_max_slabs, MAX_SLABS - var.n_slabs - reserved, round(n / self._stream_slice_rows))))
         lda, ldz = A.ld, dZ.ld
         if a_idx is not None:
-            ok = (n + ks - 1) // ks <= 510 and (A.rows + 1) * lda * 4 < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
+            # (tables beyond 4 GB -- RMAT's 10.2 GB -- take the kernel's 16-byte-unit row offsets: 64 GB)
+            ok = (n + ks - 1) // ks <= 510 and (A.rows + 1) * (lda // 4) < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
         else:
             ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
         return ok, ks

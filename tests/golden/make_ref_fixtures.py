@@ -484,6 +484,10 @@ SUP_CASES = {
     "sup_mean_tail": dict(aggregator_type="mean", concat=True, sigmoid=False, num_samples=[4, 3], dim=128, max_degree=8,
                           batch_size=32, batches=[list(range(8, 32)) + [40, 41, 42, 43, 44, 45, 46, 47, 48]],
                           weight_decay=0.001, learning_rate=0.01, seed=13, np_seed=113),
+    # ... and the GCN model at widths its fused tail takes (dim 64 -> 2 * 64 = 128 per layer, supervised_train.py:175-185)
+    "sup_gcn_tail": dict(aggregator_type="gcn", concat=False, sigmoid=False, num_samples=[4, 3], dim=64, max_degree=8,
+                         batch_size=32, batches=[list(range(2, 30)) + [50, 51, 52, 53], list(range(30, 47))],
+                         weight_decay=0.001, learning_rate=0.01, seed=17, np_seed=117),
     "sup_mean_dropout": dict(aggregator_type="mean", concat=True, sigmoid=False, num_samples=[4, 3], dim=16, max_degree=8,
                              batch_size=16, batches=[list(range(22, 35)), list(range(44, 52))], weight_decay=0.01,
                              learning_rate=0.01, seed=11, np_seed=111, dropout=0.3),

@@ -10,7 +10,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SUP = ["sup_mean", "sup_mean_add_sigmoid", "sup_gcn", "sup_maxpool", "sup_meanpool_sigmoid", "sup_mean_3layer",
        "sup_mean_full_degree", "sup_mean_identity", "sup_mean_tail",
-       "sup_maxpool_big"]             # model_size = "big": hidden 1024 (aggregators.py:139-142)
+       "sup_maxpool_big",             # model_size = "big": hidden 1024 (aggregators.py:139-142)
+       "sup_gcn_tail"]                # the GCN model at widths the device's fused tail takes (128 per layer)
 SUP_DROPOUT = ["sup_mean_dropout", "sup_maxpool_dropout"]
 UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool", "unsup_meanpool"]
 SUP_CPU = []

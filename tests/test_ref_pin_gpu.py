@@ -121,8 +121,8 @@ def test_supervised_steps_equal_reference_run(dev, name, fuse):
             e.inject_dropout_masks(reference_dropout_masks(model, fx, p))
             feed[ph['dropout']] = c["dropout"]                            # supervised_train.py:269
         loss, preds = model.train_step(feed)
-        if name == "sup_mean_tail":
-            assert bool(getattr(model, "_tail_used", False)) == fuse     # the headline step's fused-tail launch
+        if name in ("sup_mean_tail", "sup_gcn_tail"):
+            assert bool(getattr(model, "_tail_used", False)) == fuse     # the headline step's fused-tail launch (+ its GCN form)
         for k in range(fx.K):                                           # S1/S2: bit-exact
             assert np.array_equal(model.samples1[k + 1].cpu().numpy(), fx[p + "sampled%d" % k].reshape(-1)), (s, k)
         close(loss, fx[p + "32/loss"], "loss step %d" % s)
