@@ -119,6 +119,9 @@ _PROTOS = {
                                  _P, c_int64, _P, _P],
     "gs_linkpred_norm_fwd_bwd_step": [_P, c_int64, c_int64, c_int32, c_int32, c_float, c_float, _P, c_int64, _P, _P, _P, c_int64,
                                       _P, c_int64, _P, _P, c_int, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
+    "gs_linkpred_tail_supported": [c_int32, c_int32, c_int32],
+    "gs_linkpred_tail": [_P, _P, c_int32, _P],
+    "gs_linkpred_tail_neg": [_P, _P, c_int, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_unique_ids": [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
     "gs_dense_fwd_rows_dev": [_P, c_int64, _P, c_int32, c_int64, _P, _P, c_int64, c_int32, c_int, _P, _P, c_int64, _P],
     "gs_segment_max_gather_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P],
@@ -174,6 +177,17 @@ class TailDesc(ctypes.Structure):
                 ("c0", c_void_p), ("d0", c_uint64), ("c1", c_void_p), ("d1", c_uint64), ("c2", c_void_p), ("d2", c_uint64),
                 ("s", c_int32), ("d_in", c_int32), ("out_dim", c_int32), ("C", c_int32), ("sigmoid", c_int32),
                 ("train", c_int32), ("sync", c_void_p), ("z_ready", c_int32), ("gcn", c_int32)]
+
+
+class LpTailDesc(ctypes.Structure):
+    """struct gs_lp_tail_desc (include/graphsage_amd.h)"""
+    _fields_ = [("h0", c_void_p), ("ldh", c_int64), ("B", c_int64), ("n_neg", c_int32), ("s", c_int32), ("d_in", c_int32),
+                ("out_dim", c_int32), ("train", c_int32),
+                ("W_self", c_void_p), ("ldws", c_int64), ("W_neigh", c_void_p), ("ldwn", c_int64),
+                ("means", c_void_p), ("ldm", c_int64), ("z", c_void_p), ("ldz", c_int64), ("y", c_void_p), ("ldy", c_int64),
+                ("dz", c_void_p), ("lddz", c_int64), ("d_h0", c_void_p), ("lddh", c_int64),
+                ("loss_rows", c_void_p), ("rr_rows", c_void_p), ("aff_all", c_void_p), ("ld_aff", c_int64),
+                ("neg_slabs", c_void_p), ("neg_weight", c_float), ("scale", c_float), ("sync", c_void_p)]
 
 
 class FanoutDesc(ctypes.Structure):
@@ -242,7 +256,7 @@ def load(build_if_missing=True):
         fn.restype = c_int
         fn.argtypes = argtypes
     # struct layouts: the library's sizeof() of every descriptor must equal the ctypes mirror's
-    mirrors = [GatherDesc, WgradDesc, VarDesc, FanoutDesc, TailDesc, Dropout, PullDesc]
+    mirrors = [GatherDesc, WgradDesc, VarDesc, FanoutDesc, TailDesc, Dropout, PullDesc, LpTailDesc]
     sizes = (c_int32 * 16)()
     n = lib.gs_abi_struct_sizes(sizes, 16)
     if n != len(mirrors):

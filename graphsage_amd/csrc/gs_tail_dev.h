@@ -34,7 +34,30 @@ struct TailArgs {
     // column halves of z contract the SAME operand, the mean over {neighbors} U {self} = (sum_j h_neigh_j + h_self) / (s + 1),
     // which is also what `means` receives; every row of d_h0 (self and neighbor rows alike) gets relu' * (dz . W^T) / (s + 1).
     int32_t gcn;
+    // Row map of the unsupervised tail (gs_unsup_tail.hip), 0 = off: the rows are [batch1 (pairB) | batch2 (pairB) | negatives];
+    // groups [0, pair_groups) hold 8 PAIRS each -- local rows 0..7 = batch1 rows 8 g .. 8 g + 7, local rows 8..15 = their
+    // batch2 partners pairB + 8 g .. -- so that a pair meets in ONE workgroup; groups behind them hold 16 negatives each.
+    int32_t pairB, pair_groups;
 };
+
+// Source row of local row r of group g (and whether it exists); rows that do not exist map to a valid row, never stored.
+__device__ __forceinline__ int tail_row(const TailArgs& a, const int g, const int r, bool& valid) {
+    const int n = (int)a.n;
+    if (a.pairB == 0) {
+        const int i = g * TAIL_ROWS + r;
+        valid = i < n;
+        return min(i, n - 1);
+    }
+    if (g < a.pair_groups) {
+        const int p = 8 * g + (r & 7);
+        valid = p < a.pairB;
+        const int pc = min(p, a.pairB - 1);
+        return r < 8 ? pc : a.pairB + pc;
+    }
+    const int i = 2 * a.pairB + TAIL_ROWS * (g - a.pair_groups) + r;
+    valid = i < n;
+    return min(i, n - 1);
+}
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -87,7 +110,7 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     float* Pz = lds + TAIL_ROWS * ldh;                           // [8 waves][16][64] partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int r0 = g * TAIL_ROWS, n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
+    const int n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
     const int col_base = part * 64;
     const int term = col_base >= O ? 1 : 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -104,8 +127,8 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     for (int p = 0; p < PASSES; ++p) {
         const int it = tid + p * TAIL_THREADS;
         const int r = it / D4, c = (it % D4) * 4;
-        const bool valid = r0 + r < n;
-        const int i = min(r0 + r, n - 1);
+        bool valid;
+        const int i = tail_row(a, g, r, valid);
         f32x4 v;
         if (!term && !a.gcn) {
             v = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
@@ -122,7 +145,7 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
                 if (u < s) v += hv[u];                               // summation order j = 0..s-1, as gather_mean_wave
             if (a.gcn) { v += hs; v *= inv_s1; }                      // ... then the self row, as gather_mean_wave's GCN form
             else v *= inv_s;
-            if (valid && col_base == O) *reinterpret_cast<f32x4*>(a.means + (r0 + r) * (int)a.ldm + c) = v;
+            if (valid && col_base == O) *reinterpret_cast<f32x4*>(a.means + i * (int)a.ldm + c) = v;
         }
         *reinterpret_cast<f32x4*>(As + r * ldh + c) = valid ? v : zero4;
     }
@@ -153,10 +176,12 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
         for (int w = 1; w < TAIL_WAVES; ++w) v += *reinterpret_cast<const f32x2*>(Pz + (w * TAIL_ROWS + r) * 64 + c2);
         // published with device-scope (write-through) stores: a release FENCE would write back the XCD's whole L2,
         // dirty gather output of the riders included (measured: z arrived 17 us late)
-        if (r0 + r < n) {
+        bool zvalid;
+        const int zi = tail_row(a, g, r, zvalid);
+        if (zvalid) {
             union { f32x2 f; unsigned long long u; } cv;
             cv.f = v;
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.z + (r0 + r) * (int)a.ldz + col_base + c2), cv.u,
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.z + zi * (int)a.ldz + col_base + c2), cv.u,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

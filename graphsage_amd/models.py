@@ -116,6 +116,9 @@ class SampleAndAggregate(object):
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         # unsupervised pipeline: share of the gather riding in the last layer's lean launch
+        # unsupervised three-launch form (forward | fused link-prediction tail | weight gradients)
+        self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.35))
+        self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.25))
         self.cogather_z = float(os.environ.get("GS_COGATHER_Z", 0.04))        # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
         # DIAGNOSTIC (one test pins it bit-identical): the fused tail as two launches (z helpers | row-group workgroups) --
         # no dependency between workgroups of a launch, the safe form under tools that serialise workgroups; +11 us per step
@@ -209,7 +212,8 @@ class SampleAndAggregate(object):
         torch.cuda.synchronize()
 
     _OUT_ATTRS = ("samples1", "outputs_all", "outputs1", "agg_out", "_loss_rows", "_rr_rows", "aff_all", "_d_agg_out",
-                  "_loss_accumulate", "_tape")
+                  "_loss_accumulate", "_tape", "_lp_tail_used", "_tail_h0", "_tail_means", "_tail_dh0", "_lp_sync",
+                  "_lp_sync_shape", "_epilogue_folded")
 
     def _roots(self, B, parity=None):
         """[batch1 (B) | batch2 (B) | negatives] = the head of the contiguous id buffer."""
@@ -238,7 +242,7 @@ class SampleAndAggregate(object):
         roots[2 * B: 2 * B + self.neg_sample_size].copy_(torch.from_numpy(neg))
         torch.cuda.current_stream().synchronize()
 
-    def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None, epilogue=None, z_jobs=None):
+    def _forward_unsup(self, roots, B, n_roots, train, prefetched=None, side_jobs=None, epilogue=None, z_jobs=None, tail_jobs=None):
         """_build (:347-370) + _loss (:385-391) + _accuracy (:393-405) and, when training, the gradient of the
         link-prediction head w.r.t. the normalised embeddings."""
         e = self.engine
@@ -246,17 +250,25 @@ class SampleAndAggregate(object):
         if prefetched is None:
             prefetched = self._data_phase(roots, n_roots, getattr(self, "_parity", 0))
         samples1, support_sizes1, means0 = prefetched
+        contiguous = all(b.data_ptr() == a.data_ptr() + 4 * a.numel() for a, b in zip(samples1[:-1], samples1[1:]))
+        self._lp_tail_used = bool(contiguous and self._lp_tail_ok() and n_roots == 2 * B + self.neg_sample_size)
         out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n_roots,
                                 aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
-                                layer0_means=means0, layer0_side_jobs=side_jobs, last_layer_side_jobs=z_jobs)
+                                layer0_means=means0, layer0_side_jobs=side_jobs, last_layer_side_jobs=z_jobs,
+                                _stop_after_layer=0 if self._lp_tail_used else None)
         self.samples1 = samples1
+        self._loss_rows = e.ws_f32("loss_rows", B)
+        self._rr_rows = e.ws_f32("rr_rows", B)
+        self.aff_all = e.ws_mat("aff_all", B, self.neg_sample_size + 1)
+        if self._lp_tail_used:
+            if self._tape[0][0] != "batched":
+                raise ops._lib.GraphsageAmdError("fused tail needs the contiguous id buffer (model.sample on ids_buffer)")
+            self._forward_lp_tail(B, n_roots, train, epilogue, tail_jobs)
+            return
         self.agg_out = out
         d = out.d
         self.outputs_all = e.ws_mat("outputs_all", n_roots, d)
         self.outputs1 = self.outputs_all.rows_slice(0, B)
-        self._loss_rows = e.ws_f32("loss_rows", B)
-        self._rr_rows = e.ws_f32("rr_rows", B)
-        self.aff_all = e.ws_mat("aff_all", B, self.neg_sample_size + 1)
         # l2_normalize (:368-370) + link-prediction loss / MRR ranks (:385-405) + their gradient carried back through the
         # normalisation: ONE launch (+ a 20-workgroup one for the negatives' rows); d_agg_out = dLoss/d(aggregator output)
         self._d_agg_out = e.ws_mat("d_agg_out", n_roots, d)
@@ -283,6 +295,62 @@ class SampleAndAggregate(object):
                     first = False
             self._loss_accumulate = not fold
 
+    def _lp_tail_ok(self):
+        """The fused layer-1 + link-prediction launches (gs_linkpred_tail / gs_linkpred_tail_neg) apply to the two-layer mean
+        model with concat, no aggregator bias, no dropout, no trainable identity features, at shapes the kernel supports."""
+        if not getattr(self, "fuse_tail", True) or len(self.layer_infos) != 2 or self.aggregator_type != "mean":
+            return False
+        a1 = self.aggregators[1]
+        return (self.concat and not a1.bias and self._dropout_rate() == 0 and self.embeds is None
+                and self.num_samples[-1] <= 11
+                and ops.linkpred_tail_supported(2 * self.dims[1], self.dims[2], self.neg_sample_size))
+
+    def _forward_lp_tail(self, B, n_roots, train, epilogue, tail_jobs):
+        """Layer 1 + l2_normalize + link-prediction loss / MRR (+ every input gradient down to layer 0's pre-activations when
+        training) as the two launches of gs_unsup_tail.hip; gather jobs of the next step ride in the first one."""
+        e = self.engine
+        h0 = self._tape[0][4]                       # [n + n*s, 2*dim_1]: layer-0 outputs of both hops
+        a1 = self.aggregators[1]
+        O = self.dims[2]
+        Z = 2 * O
+        s = self.num_samples[len(self.num_samples) - 1]
+        nn = self.neg_sample_size
+        self._tail_h0 = h0
+        self._tail_means = e.ws_mat("tail_means", n_roots, h0.d)
+        self.agg_out = e.ws_mat("tail_z", n_roots, Z)
+        self.outputs_all = e.ws_mat("outputs_all", n_roots, Z)
+        self.outputs1 = self.outputs_all.rows_slice(0, B)
+        self._d_agg_out = e.ws_mat("d_agg_out", n_roots, Z)
+        self._tail_dh0 = e.ws_mat((self.name, "d_hidden", 0), h0.rows, h0.d)
+        slabs = e.ws_f32(("lp_neg_slabs", B, nn, Z), ((B + 7) // 8) * nn * Z)
+        self._lp_sync = e.ws_i32(("lp_tail_sync", self.name, B, nn), ops.lp_tail_sync_words(B, nn))
+        self._lp_sync_shape = (B, nn)
+        desc = ops.linkpred_tail_desc(h0, B, nn, s, a1.vars['self_weights'].value, a1.vars['neigh_weights'].value, O,
+                                      self._tail_means, self.agg_out, self.outputs_all, self._loss_rows, self._rr_rows,
+                                      self.aff_all, self.link_pred_layer.neg_sample_weights, 1.0 / B, self._lp_sync,
+                                      dz=self._d_agg_out if train else None, d_h0=self._tail_dh0 if train else None,
+                                      neg_slabs=slabs if train else None)
+        ops.linkpred_tail(desc, jobs=tail_jobs, stream=e.stream)
+        # launch 2 always follows (it commits the hand-over state); the step epilogue rides in it unless dropout needs the
+        # clock untouched until the backward pass has run (this path runs without dropout: always folded when given)
+        fold = epilogue is not None
+        self._epilogue_folded = fold
+        counters = []
+        if fold:
+            counters = [(e.step_dev, epilogue.get("step", 0)), (e.sample_clock_dev, epilogue.get("clock", 0)),
+                        (epilogue.get("cursor"), epilogue.get("cursor_delta", 0))]
+        ops.linkpred_tail_neg(desc, loss_out=self.loss_dev if fold else None, accumulate=False,
+                              mrr_out=self.mrr_dev if fold else None, counters=counters, stream=e.stream)
+        self._loss_accumulate = False
+        if self.weight_decay != 0.0:
+            first = not fold
+            for a in self.aggregators:
+                for v in a.vars.values():
+                    ops.call("gs_sumsq_scaled", v.value.ptr, v.size, 0.5 * self.weight_decay / B, self.loss_dev.data_ptr(),
+                             0 if first else 1, e.stream)
+                    first = False
+            self._loss_accumulate = not fold
+
     def _backward_unsup(self, B, n_roots, fuse_adam, wgrad_jobs=None, epilogue=None):
         """Reverse schedule.  The epilogue (loss / mrr means + device counters) runs FIRST: the fan-out sampler of a later
         step may ride in this pass's optimizer launch and must see the advanced sampler clock and pair cursor; the
@@ -296,7 +364,17 @@ class SampleAndAggregate(object):
             self._epilogue_unsup(B, **epilogue)
         advanced = (early or folded) and bool(epilogue.get("step"))
         e.begin_backward()
-        self.aggregate_backward(self._d_agg_out)
+        if getattr(self, "_lp_tail_used", False):
+            # the fused tail produced every input gradient; queue the weight gradients it feeds (as SupervisedGraphsage._backward)
+            a1 = self.aggregators[1]
+            o = self.dims[2]
+            h0 = self._tail_h0
+            e.wgrad(a1.vars['self_weights'], h0.rows_slice(0, n_roots), None, self._d_agg_out, 0, n_roots)
+            e.wgrad(a1.vars['neigh_weights'], self._tail_means, None, self._d_agg_out, o, n_roots)
+            mode, agg0, rows, offsets, outs = self._tape[0]
+            agg0.backward_hops(self._tail_dh0, True, embed_sink=None)
+        else:
+            self.aggregate_backward(self._d_agg_out)
         # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
         e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
                           side_jobs=wgrad_jobs, step_offset=0 if advanced else 1)
@@ -331,6 +409,13 @@ class SampleAndAggregate(object):
 
     def _fetch_unsup(self, B, with_outputs=True):
         self.engine.sync()
+        if getattr(self, "_lp_sync", None) is not None:
+            err = ops.lp_tail_sync_error(self._lp_sync, *self._lp_sync_shape)
+            if err:
+                raise ops._lib.GraphsageAmdError(
+                    "fused link-prediction tail: hand-over between its workgroups failed (flags %d: 1 = a main workgroup gave up "
+                    "waiting for its helpers, 2 = unexpected arrival count); results since the last fetch are invalid -- set "
+                    "model.fuse_tail = False to use the per-operator schedule" % err)
         if hasattr(self.grad_hook, "check"):
             self.grad_hook.check()
         loss = float(self.loss_dev.item())
@@ -514,14 +599,23 @@ class SampleAndAggregate(object):
                 self._prefetched[(B, q)] = (roots_q, n_roots_q, (samples, support, means_q))
                 roots, n_roots, pre = self._prefetched[(B, p)]
                 self._parity = p
-                fwd_jobs, wgrad_jobs = ops.split_gather_jobs(jobs, self.cogather_split)
+                tail_jobs = []
+                if self._lp_tail_ok() and self.cogather_lp_tail > 0:
+                    # three-launch form (layer-0 forward | fused link-prediction tail | weight gradients): the tail is long and
+                    # thin (66 main workgroups), the rest of the chip streams its share of the gather at the full rate
+                    f_fwd, f_tail = self.cogather_lp_fwd, self.cogather_lp_tail
+                    fwd_jobs, rest = ops.split_gather_jobs(jobs, f_fwd)
+                    tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, f_tail / max(1e-6, 1.0 - f_fwd)))
+                else:
+                    fwd_jobs, wgrad_jobs = ops.split_gather_jobs(jobs, self.cogather_split)
                 z_jobs = []
-                if self.cogather_z > 0 and len(self.num_samples) > 1:
+                if not tail_jobs and self.cogather_z > 0 and len(self.num_samples) > 1 and not self._lp_tail_ok():
                     # the last layer's lean launch (gs_sage_tail_z) leaves most of the chip idle: a share rides there at
                     # the full HBM rate
                     wgrad_jobs, z_jobs = ops.split_gather_jobs(wgrad_jobs, max(0.0, 1.0 - self.cogather_z / max(1e-6, 1.0 - self.cogather_split)))
                 epilogue = dict(step=1 if local_adam else 0, clock=1, cursor=self._cursor, cursor_delta=B)
-                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue, z_jobs=z_jobs)
+                self._forward_unsup(roots, B, n_roots, True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue, z_jobs=z_jobs,
+                                    tail_jobs=tail_jobs)
                 self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
                 if e._deferred_sampler is not None:
                     raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
@@ -760,7 +854,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
-                self.cogather_z, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
+                self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
                 type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 

@@ -528,6 +528,54 @@ def sage_tail_dh0(h0, n, s, W_self, W_neigh, out_dim, dz, d_h0, jobs=(), stream=
     return d_h0
 
 
+def linkpred_tail_supported(d_in, out_dim, n_neg):
+    return bool(_lib.load().gs_linkpred_tail_supported(int(d_in), int(out_dim), int(n_neg)))
+
+
+def lp_tail_sync_words(B, n_neg):
+    """Size (uint32 words) of the hand-over buffer of linkpred_tail for B pairs and n_neg negatives."""
+    return 2 * ((B + 7) // 8 + (n_neg + 15) // 16) + 2
+
+
+def lp_tail_sync_error(sync, B, n_neg):
+    return int(sync[2 * ((B + 7) // 8 + (n_neg + 15) // 16)].item())
+
+
+def linkpred_tail_desc(h0, B, n_neg, s, W_self, W_neigh, out_dim, means, z, y, loss_rows, rr_rows, aff_all, neg_weight, scale,
+                       sync, dz=None, d_h0=None, neg_slabs=None):
+    """struct gs_lp_tail_desc of the unsupervised fused tail (see include/graphsage_amd.h); dz / d_h0 / neg_slabs given =
+    training (forward + backward), else forward only."""
+    assert sync.numel() >= lp_tail_sync_words(B, n_neg)
+    q = _lib.LpTailDesc()
+    q._keep = (sync, neg_slabs)
+    q.h0, q.ldh, q.B, q.n_neg, q.s, q.d_in, q.out_dim = h0.ptr, h0.ld, B, n_neg, s, h0.d, out_dim
+    q.W_self, q.ldws, q.W_neigh, q.ldwn = W_self.ptr, W_self.ld, W_neigh.ptr, W_neigh.ld
+    q.means, q.ldm, q.z, q.ldz, q.y, q.ldy = means.ptr, means.ld, z.ptr, z.ld, y.ptr, y.ld
+    train = dz is not None and d_h0 is not None and neg_slabs is not None
+    q.train = 1 if train else 0
+    if train:
+        q.dz, q.lddz, q.d_h0, q.lddh, q.neg_slabs = dz.ptr, dz.ld, d_h0.ptr, d_h0.ld, ptr(neg_slabs)
+    q.loss_rows, q.rr_rows = ptr(loss_rows), ptr(rr_rows)
+    q.aff_all, q.ld_aff = (aff_all.ptr, aff_all.ld) if aff_all is not None else (None, 0)
+    q.neg_weight, q.scale, q.sync = float(neg_weight), float(scale), ptr(sync)
+    return q
+
+
+def linkpred_tail(desc, jobs=(), stream=None):
+    """gs_linkpred_tail: launch 1 of the unsupervised fused tail (+ gather jobs riding)."""
+    jobs = list(jobs or ())
+    jarr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_linkpred_tail", ctypes.addressof(desc), ctypes.addressof(jarr), len(jobs), _s(stream))
+
+
+def linkpred_tail_neg(desc, loss_out=None, accumulate=False, mrr_out=None, counters=(), stream=None):
+    """gs_linkpred_tail_neg: launch 2 (the negatives' rows, the step epilogue, the commit of the hand-over state)."""
+    cs = [(ptr(c), int(d)) for c, d in counters if c is not None and d]
+    cs += [(None, 0)] * (3 - len(cs))
+    call("gs_linkpred_tail_neg", ctypes.addressof(desc), ptr(loss_out), 1 if accumulate else 0, ptr(mrr_out),
+         cs[0][0], cs[0][1], cs[1][0], cs[1][1], cs[2][0], cs[2][1], _s(stream))
+
+
 # ------------------------------------------------------------------------------------------ K6
 def reduce_slabs(slabs, n_slabs, slab_stride, rows, cols, ld_slab, weight_decay, w_ptr, ldw, grad_ptr, ldg,
                  accumulate=False, stream=None):

@@ -43,7 +43,7 @@ extern "C" {
 const char* gs_last_error(void);
 int gs_abi_version(void);
 /* sizeof() of the descriptor structs below, in declaration order (gs_gather_desc, gs_wgrad_desc, gs_var_desc,
- * gs_fanout_desc, gs_tail_desc, gs_dropout, gs_pull_desc): writes min(count, capacity) values, returns the count.  A
+ * gs_fanout_desc, gs_tail_desc, gs_dropout, gs_pull_desc, gs_lp_tail_desc): writes min(count, capacity) values, returns the count.  A
  * binding compares them with its own struct definitions at load time. */
 int gs_abi_struct_sizes(int32_t* sizes_out_host, int32_t capacity);
 /* Fills CU count, XCD count (8 on MI355X), gcnArchName (>= 64 bytes) of the current device. */
@@ -540,6 +540,43 @@ typedef struct gs_tail_desc {
                               which `means` receives; d_h0 rows (self and neighbors) = relu'(h0) * (dz . W^T) / (s + 1) */
 } gs_tail_desc;
 int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
+
+/* Fused tail of the UNSUPERVISED two-layer mean model (models.py:362-405, prediction.py:68-110), two launches:
+ *   gs_linkpred_tail      layer 1 (z helpers, as gs_sage_tail_fwd_bwd) -> main workgroups of 8 PAIRS each: l2_normalize
+ *                         (models.py:368-370), affinities / xent loss / MRR rank (prediction.py:102-110, models.py:393-405), dY,
+ *                         dz = l2norm'(dY) of the 2 B pair rows, [d_self | d_means] = dz . W^T, d_h0 = relu'(h0) * (...) of
+ *                         their rows, and one slab [n_neg, 2*out_dim] per main of the negatives' gradient w.r.t. their
+ *                         normalised rows; + gather jobs riding as extra workgroups (a long, thin launch: the rest of the
+ *                         chip streams the next step's gather at the full HBM rate);
+ *   gs_linkpred_tail_neg  the negatives' rows: slabs summed in main order -> dz -> d_h0 of their rows; + the step epilogue
+ *                         (loss_out = mean(loss_rows) (+= if accumulate), mrr_out = mean(rr_rows), counters c0..c2 advanced
+ *                         by d0..d2; loss_out == NULL: no epilogue) + the commit of the hand-over state.  MUST follow every
+ *                         gs_linkpred_tail on the same stream (train == 0: only the epilogue / commit run).
+ * Rows: h0 [n + n*s, d_in] with n = 2 B + n_neg roots [batch1 | batch2 | negatives] (row n + i*s + j = j-th sample of root
+ * i); z / y / dz [n, 2*out_dim]; means [n, d_in]; loss_rows / rr_rows [B]; aff_all [B, n_neg + 1] = [neg_aff | aff]
+ * (nullable); neg_slabs [ceil(B / 8)][n_neg][2*out_dim]; sync: 2 * (ceil(B / 8) + ceil(n_neg / 16)) + 2 device words,
+ * zero-initialised once, private to one stream (word 2 G = error flags as gs_tail_desc.sync).
+ * Supported (gs_linkpred_tail_supported): d_in in {128, 256}, out_dim in {64, 128}, n_neg <= 32, s <= 11; concat, no bias. */
+typedef struct gs_lp_tail_desc {
+    const float* h0; int64_t ldh;
+    int64_t B; int32_t n_neg, s, d_in, out_dim, train;
+    const float* W_self; int64_t ldws;
+    const float* W_neigh; int64_t ldwn;
+    float* means; int64_t ldm;
+    float* z; int64_t ldz;
+    float* y; int64_t ldy;
+    float* dz; int64_t lddz;
+    float* d_h0; int64_t lddh;
+    float* loss_rows; float* rr_rows;
+    float* aff_all; int64_t ld_aff;
+    float* neg_slabs;
+    float neg_weight, scale;
+    uint32_t* sync;
+} gs_lp_tail_desc;
+int gs_linkpred_tail_supported(int32_t d_in, int32_t out_dim, int32_t n_neg);
+int gs_linkpred_tail(const gs_lp_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
+int gs_linkpred_tail_neg(const gs_lp_tail_desc* desc_host, float* loss_out, int accumulate, float* mrr_out, uint64_t* c0,
+                         uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);
 /* Split form of the fused tail, first launch: the layer-1 pre-activations z = [h_self . W_self | mean(h_neigh) . W_neigh]
  * and the neighbor means of the descriptor (its head / label / gradient fields are ignored) as a LEAN kernel -- 4 x 64-column
  * helper workgroups per 16 rows, <= 128 VGPRs, 49 KB of LDS -- so that the gather jobs riding in the launch stream at the

@@ -503,6 +503,10 @@ UNSUP_CASES = {
     # embedding widths of 64 (the device's link-prediction launch takes d in {64, 128, 256, 512})
     "unsup_mean": dict(aggregator_type="mean", concat=True, num_samples=[4, 3], dim=32, max_degree=8, batch_size=12,
                        n_pairs=30, neg_sample_size=6, weight_decay=0.01, learning_rate=0.01, seed=9, np_seed=109),
+    # ... at widths the device's fused layer-1 + link-prediction launches take (2 * 64 = 128 per layer; 12 pairs = one full and
+    # one ragged group of 8 pairs)
+    "unsup_mean_tail": dict(aggregator_type="mean", concat=True, num_samples=[4, 3], dim=64, max_degree=8, batch_size=12,
+                            n_pairs=30, neg_sample_size=6, weight_decay=0.01, learning_rate=0.01, seed=18, np_seed=118),
     "unsup_gcn": dict(aggregator_type="gcn", concat=False, num_samples=[3, 3], dim=32, max_degree=6, batch_size=10,
                       n_pairs=18, neg_sample_size=5, weight_decay=0.0, learning_rate=0.02, seed=10, np_seed=110),
     # the pooling aggregator under the unsupervised objective (unsupervised_train.py:186-196: hidden_dim 512)

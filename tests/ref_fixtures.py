@@ -13,7 +13,8 @@ SUP = ["sup_mean", "sup_mean_add_sigmoid", "sup_gcn", "sup_maxpool", "sup_meanpo
        "sup_maxpool_big",             # model_size = "big": hidden 1024 (aggregators.py:139-142)
        "sup_gcn_tail"]                # the GCN model at widths the device's fused tail takes (128 per layer)
 SUP_DROPOUT = ["sup_mean_dropout", "sup_maxpool_dropout"]
-UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool", "unsup_meanpool"]
+UNSUP = ["unsup_mean", "unsup_gcn", "unsup_maxpool", "unsup_meanpool",
+         "unsup_mean_tail"]            # widths the device's fused layer-1 + link-prediction launches take (128 per layer)
 SUP_CPU = []
 UNSUP_CPU = []
 

@@ -191,6 +191,7 @@ def test_unsupervised_steps_equal_reference_run(dev, name):
         sampler.inject_perms(fx.perms(p, 3 * K))
         model.inject_negatives(neg)
         loss, ranks, aff_all, mrr, outputs1 = model.train_step({ph['batch1']: b1, ph['batch2']: b2, ph['batch_size']: B})
+        assert bool(getattr(model, "_lp_tail_used", False)) == (name == "unsup_mean_tail")     # the fused two-launch tail
         roots = np.concatenate([b1, b2, neg])
         assert np.array_equal(model.samples1[0].cpu().numpy(), roots)
         for k in range(K):

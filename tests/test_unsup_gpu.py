@@ -365,3 +365,81 @@ def test_fanout_unsup_staging_bit_exact(dev):
              ops.current_stream())
     _sync()
     assert np.array_equal(staged.cpu().numpy()[2 * B:], neg1)
+
+
+@pytest.mark.parametrize("dim,nn,B", [(64, 6, 29), (128, 20, 64), (64, 32, 8), (128, 5, 3)])
+def test_unsup_fused_tail_matches_oracle_and_the_unfused_schedule(dev, dim, nn, B):
+    """The fused layer-1 + link-prediction launches (gs_linkpred_tail / gs_linkpred_tail_neg; two-layer mean model at widths
+    128 / 256) vs the NumPy oracle -- loss, embeddings, affinities, MRR, every gradient, ragged pair groups (B not a multiple
+    of 8), 5 .. 32 negatives -- and vs the per-operator schedule (fuse_tail = False) of the same step; evaluation too."""
+    wd = 0.01
+    res_dev = []
+    for fuse in (True, False):
+        G, it, ph, sampler, model, ns = build("mean", True, wd=wd, nn=nn, dim=dim)
+        model.use_graphs = False
+        model.fuse_tail = fuse
+        rng = np.random.RandomState(3)
+        edges = it.train_edges[:B]
+        perms = [rng.permutation(it.max_degree) for _ in range(3 * len(ns))]
+        params = oracle_agg_params(model, "mean")
+        sampler.inject_perms(perms)
+        feed = {ph['batch1']: edges[:, 0], ph['batch2']: edges[:, 1], ph['batch_size']: B}
+        loss, ranks, aff_all, mrr, outputs1 = model.train_step(feed)
+        assert bool(getattr(model, "_lp_tail_used", False)) == fuse
+        grads = [{k: v.grad.numpy().copy() for k, v in a.vars.items()} for a in model.aggregators]
+        full = model.outputs_all.numpy().copy()
+        sampler.inject_perms(perms)
+        eloss, eranks, emrr, eouts = model.eval_step(feed)
+        res_dev.append((loss, aff_all, mrr, outputs1, grads, full, eloss, emrr, eouts))
+        if fuse:
+            neg = sampler_hash.sample_unigram(sampler_hash.unigram_cdf_u32(it.deg), nn, 123, 0)
+            samples, support = sample_three_calls(it.adj, edges[:, 0], edges[:, 1], neg, ns, perms)
+            for got, want in zip(model.samples1, samples):
+                assert np.array_equal(got.cpu().numpy(), want)
+            res = orc.unsupervised_fwd_bwd(params, G.padded_features(), samples, support, model.dims, ns, B, nn, "mean", True,
+                                           weight_decay=wd)
+            np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(outputs1, res["outputs1"], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(aff_all, res["aff_all"], rtol=1e-4, atol=1e-4)
+            assert abs(mrr - res["mrr"]) < 0.05
+            for li, g in enumerate(grads):
+                for k, got in g.items():
+                    w = res["grads"][li][k]
+                    np.testing.assert_allclose(got.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                               err_msg="%d/%s" % (li, k))
+    a, b = res_dev
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a[5], b[5], rtol=1e-5, atol=1e-6)            # every normalised embedding, negatives included
+    for ga, gb in zip(a[4], b[4]):
+        for k in ga:
+            np.testing.assert_allclose(ga[k], gb[k], rtol=1e-4, atol=1e-5 * max(1e-2, np.abs(gb[k]).max()), err_msg=k)
+    np.testing.assert_allclose(a[6], b[6], rtol=1e-5)                        # evaluation: loss, mrr, embeddings
+    assert abs(a[7] - b[7]) < 0.05
+    np.testing.assert_allclose(a[8], b[8], rtol=1e-5, atol=1e-6)
+
+
+def test_unsup_fused_tail_pipeline_equals_feed_path(dev):
+    """At widths the fused tail takes: device-resident pairs + rider pipeline + multi-step hipGraph replay == host-fed eager
+    steps, bit for bit (the hand-over counters survive replays; 12 steps on one buffer)."""
+    outs = []
+    for mode in ("feed", "device", "device_multi"):
+        G, it, ph, sampler, model, ns = build("mean", True, csr=True, dim=64, nn=20, n_nodes=1500)
+        pairs = it.train_edges[:12 * 32]
+        if mode == "feed":
+            model.use_graphs = False
+            for i in range(12):
+                e = pairs[i * 32:(i + 1) * 32]
+                model.train_step({ph['batch1']: e[:, 0], ph['batch2']: e[:, 1], ph['batch_size']: 32})
+        else:
+            model.attach_device_pairs(pairs)
+            if mode == "device":
+                for i in range(12):
+                    model.train_step_device(32)
+            else:
+                model.train_steps_device(32, 12, steps_per_launch=4)
+        assert model._lp_tail_used
+        loss = model._fetch_unsup(32)[0]                                # reads the hand-over error word
+        outs.append((loss, eng.get_engine().params.cpu().numpy().copy()))
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], outs[2][1])
