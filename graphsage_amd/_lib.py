@@ -121,7 +121,7 @@ _PROTOS = {
                                       _P, c_int64, _P, _P, c_int, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
     "gs_linkpred_tail_supported": [c_int32, c_int32, c_int32],
     "gs_linkpred_tail": [_P, _P, c_int32, _P],
-    "gs_linkpred_tail_neg": [_P, _P, c_int, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P],
+    "gs_linkpred_tail_neg": [_P, _P, c_int, _P, _P, c_uint64, _P, c_uint64, _P, c_uint64, _P, c_int32, _P],
     "gs_unique_ids": [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
     "gs_dense_fwd_rows_dev": [_P, c_int64, _P, c_int32, c_int64, _P, _P, c_int64, c_int32, c_int, _P, _P, c_int64, _P],
     "gs_segment_max_gather_fwd": [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P],

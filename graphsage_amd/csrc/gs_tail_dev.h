@@ -191,6 +191,100 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     if (tid == 0) __hip_atomic_fetch_add(a.sync + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// z helper of a whole TERM (gs_unsup_tail.hip): all O columns of z's self half (term 0) or neighbor-mean half (term 1) of
+// group g -- the term's A rows are fetched ONCE (the 64-column helper above fetches them once per slab: the neighbor term's
+// 11 rows per output row twice for O = 128) and a group needs 2 helper workgroups instead of 2 O / 64, so that the helpers of
+// 66 groups AND the main workgroups are resident together on 256 CUs.  Every output element is formed exactly as by
+// tail_z_helper (same K slices, same order): bit-identical z.
+template <int D, int O>
+__device__ __forceinline__ void tail_z_term_helper(const TailArgs& a, const int g, const int term) {
+    constexpr int NS = O / 64;                                   // 64-column slabs of the term
+    constexpr int ldh = D + 4;
+    constexpr int D4 = D / 4;
+    constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
+    constexpr int KW = D / 4 / TAIL_WAVES;                       // k-steps (4 k each) per wave
+    constexpr int PW = 64 * NS;                                  // row length of the partial tiles
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                                             // [16][ldh]  the term's A rows
+    float* Pz = lds + TAIL_ROWS * ldh;                           // [8 waves][16][PW] partial tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int ldw = (int)(term ? a.ldwn : a.ldws);
+    const float* Wp = (term ? a.Wn : a.Ws) + (4 * wave * KW + q) * ldw + 2 * j;
+    f32x2 bz[NS][2][KW];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < KW; ++u) bz[ns][t][u] = *reinterpret_cast<const f32x2*>(Wp + (4 * u) * ldw + 64 * ns + 32 * t);
+    const float inv_s = 1.0f / (float)s;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it / D4, c = (it % D4) * 4;
+        bool valid;
+        const int i = tail_row(a, g, r, valid);
+        f32x4 v;
+        if (!term) {
+            v = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
+        } else {
+            const float* nb = a.h0 + (n + i * s) * ldh0 + c;
+            f32x4 hv[TAIL_NB];
+#pragma unroll
+            for (int u = 0; u < TAIL_NB; ++u) hv[u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
+            v = zero4;
+#pragma unroll
+            for (int u = 0; u < TAIL_NB; ++u)
+                if (u < s) v += hv[u];                               // summation order j = 0..s-1, as gather_mean_wave
+            v *= inv_s;
+            if (valid) *reinterpret_cast<f32x4*>(a.means + i * (int)a.ldm + c) = v;
+        }
+        *reinterpret_cast<f32x4*>(As + r * ldh + c) = valid ? v : zero4;
+    }
+    lds_barrier();
+    {
+        const float* A = As + j * ldh + 4 * wave * KW + q;
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+                for (int u = 0; u < KW; ++u) {
+                    const float av = A[4 * u];
+                    acc0 = mfma16(av, bz[ns][t][u].x, acc0);
+                    acc1 = mfma16(av, bz[ns][t][u].y, acc1);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x2*>(Pz + (wave * TAIL_ROWS + 4 * q + i) * PW + 64 * ns + 32 * t + 2 * j) = f32x2{acc0[i], acc1[i]};
+            }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int p = 0; p < TAIL_ROWS * (PW / 2) / TAIL_THREADS; ++p) {   // (row, column pair) items: 16 x PW / 2
+        const int it = tid + p * TAIL_THREADS;
+        const int r = it / (PW / 2), c2 = (it % (PW / 2)) * 2;
+        f32x2 v = *reinterpret_cast<const f32x2*>(Pz + r * PW + c2);
+#pragma unroll
+        for (int w = 1; w < TAIL_WAVES; ++w) v += *reinterpret_cast<const f32x2*>(Pz + (w * TAIL_ROWS + r) * PW + c2);
+        bool zvalid;
+        const int zi = tail_row(a, g, r, zvalid);
+        if (zvalid) {                                                // device-scope (write-through) stores, see tail_z_helper
+            union { f32x2 f; unsigned long long u; } cv;
+            cv.f = v;
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.z + zi * (int)a.ldz + term * O + c2), cv.u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.sync + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // End of a main workgroup: exactly HP helpers of THIS launch must have arrived since `base` (the helpers never wait, and
 // this runs ~15 us after the hand-over); anything else -- leftovers of a launch that did not finish, a helper that
 // never ran -- is flagged.  The consumed count is then published for the next launch (no reset of the counter).

@@ -16,7 +16,7 @@
 //             + the commit of the negative groups' hand-over counters.
 //
 // Hand-over: as in sage_tail_kernel -- helpers have the lower block indices and never wait; a main waits (bounded, error
-// word) for the HP helpers of ITS group and of the negative groups; counters are monotonic, a group's consumed count is
+// word) for the 2 helpers (one per term) of ITS group and of the negative groups; counters are monotonic, a group's consumed count is
 // written by its main (pair groups) or by launch 2 (negative groups: every main reads them).
 #include "gs_tail_dev.h"
 
@@ -33,24 +33,25 @@ struct LpArgs {
 template <int D, int O>
 __global__ __launch_bounds__(TAIL_THREADS) void sage_lp_tail_kernel(const LpArgs L, const CoGatherS J) {
     const TailArgs& a = L.t;
-    constexpr int HP = 2 * O / 64;
+    constexpr int HP = 2;                              // helper workgroups per group: one per TERM (tail_z_term_helper)
     constexpr int Z = 2 * O, DJ = Z / 64;
     const int GP = a.pair_groups;
     const int NGH = (L.n_neg + TAIL_ROWS - 1) / TAIL_ROWS;
     const int G = GP + NGH;
     // roles by block index: helpers of the NEGATIVE groups first (every main waits for them), then the pair groups'
-    // helpers, then the mains, then gather riders
+    // helpers, then the mains, then gather riders.  2 (64 + 2) helpers + 64 mains = 196 workgroups for B = 512: all resident
+    // at once (one per CU), so the mains prefetch their operands while the helpers compute z.
     if ((int)blockIdx.x >= HP * G + GP) {
         run_gather_item<13>(J, ((int64_t)blockIdx.x - (HP * G + GP)) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
     if ((int)blockIdx.x < HP * NGH) {
-        tail_z_helper<D, O>(a, GP + (int)blockIdx.x / HP, (int)blockIdx.x % HP);
+        tail_z_term_helper<D, O>(a, GP + (int)blockIdx.x / HP, (int)blockIdx.x % HP);
         return;
     }
     if ((int)blockIdx.x < HP * G) {
         const int b = (int)blockIdx.x - HP * NGH;
-        tail_z_helper<D, O>(a, b / HP, b % HP);
+        tail_z_term_helper<D, O>(a, b / HP, b % HP);
         return;
     }
     const int grp = (int)blockIdx.x - HP * G;
@@ -386,9 +387,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_lp_tail_kernel(const LpArgs
 // [d_self | d_means]); block NWG NGH: the step epilogue + the commit of the negative groups' consumed counters.
 // train == 0 (evaluation): only that last block.
 template <int D, int O>
-__global__ __launch_bounds__(TAIL_THREADS, 2) void lp_neg_tail_kernel(const LpArgs L, const StepEpilogue epi) {
+__global__ __launch_bounds__(TAIL_THREADS, 2) void lp_neg_tail_kernel(const LpArgs L, const StepEpilogue epi, const CoGatherS J) {
     const TailArgs& a = L.t;
-    constexpr int HP = 2 * O / 64;
+    constexpr int HP = 2;                              // as in sage_lp_tail_kernel
     constexpr int NWG = 2 * D / 128, Z = 2 * O, Z4 = Z / 4, M7 = O / 16;
     constexpr int ldzs = Z + 4, ldi = 128 + 4;
     const int GP = a.pair_groups;
@@ -397,7 +398,13 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void lp_neg_tail_kernel(const LpAr
     const int work_blocks = a.train ? NWG * NGH : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x >= work_blocks) {
+    if ((int)blockIdx.x > work_blocks) {
+        // gather riders: this launch is nine workgroups of dependent round trips -- the rest of the chip streams a share of the
+        // next step's gather meanwhile (two 8-wave workgroups per CU)
+        run_gather_item<13>(J, ((int64_t)blockIdx.x - work_blocks - 1) * TAIL_WAVES + wave, lane);
+        return;
+    }
+    if ((int)blockIdx.x == work_blocks) {
         float* red = lds;
         if (tid == 0) {
             // every main of launch 1 has finished (kernel boundary): the arrivals of the negative groups are consumed; exactly
@@ -464,25 +471,43 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void lp_neg_tail_kernel(const LpAr
     }
     // ---- the rows' gradient w.r.t. their normalised embeddings: slabs of all mains, summed in main order (16 loads in flight);
     //      wave w owns rows w and w + 8, lane = float4 column
+    // (both rows' slab loads are issued together: 2 x 16 float4 in flight per lane, 4 round trips for 64 slabs instead of 8)
+    f32x4 g2[2] = {zero4, zero4}, zv2[2] = {zero4, zero4};
+    {
+        const int qn0 = TAIL_ROWS * ng + wave, qn1 = qn0 + 8;
+        const bool v0 = qn0 < n_neg && lane < Z4, v1 = qn1 < n_neg && lane < Z4;
+        const size_t stride4 = (size_t)n_neg * Z4;
+        const f32x4* sp0 = reinterpret_cast<const f32x4*>(L.neg_slabs + (size_t)min(qn0, n_neg - 1) * Z) + min(lane, Z4 - 1);
+        const f32x4* sp1 = reinterpret_cast<const f32x4*>(L.neg_slabs + (size_t)min(qn1, n_neg - 1) * Z) + min(lane, Z4 - 1);
+        if (v0) zv2[0] = *reinterpret_cast<const f32x4*>(a.z + (int64_t)(2 * B + qn0) * a.ldz + 4 * lane);
+        if (v1) zv2[1] = *reinterpret_cast<const f32x4*>(a.z + (int64_t)(2 * B + qn1) * a.ldz + 4 * lane);
+        int sI = 0;
+        for (; sI + 16 <= GP; sI += 16) {
+            f32x4 va[16], vb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                va[u] = sp0[(size_t)(sI + u) * stride4];
+                vb[u] = sp1[(size_t)(sI + u) * stride4];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                g2[0] += va[u];
+                g2[1] += vb[u];
+            }
+        }
+        for (; sI < GP; ++sI) {
+            g2[0] += sp0[(size_t)sI * stride4];
+            g2[1] += sp1[(size_t)sI * stride4];
+        }
+        if (!v0) g2[0] = zero4;
+        if (!v1) g2[1] = zero4;
+    }
+#pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = wave + 8 * rr;                 // local row
         const int qn = TAIL_ROWS * ng + row;           // negative index
         const bool rvalid = qn < n_neg;                // wave-uniform
-        f32x4 g = zero4, zv = zero4;
-        if (rvalid && lane < Z4) {
-            const f32x4* sp = reinterpret_cast<const f32x4*>(L.neg_slabs + (size_t)qn * Z) + lane;
-            const size_t stride4 = (size_t)n_neg * Z4;
-            int sI = 0;
-            for (; sI + 16 <= GP; sI += 16) {
-                f32x4 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = sp[(size_t)(sI + u) * stride4];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) g += v[u];
-            }
-            for (; sI < GP; ++sI) g += sp[(size_t)sI * stride4];
-            zv = *reinterpret_cast<const f32x4*>(a.z + (int64_t)(2 * B + qn) * a.ldz + 4 * lane);
-        }
+        const f32x4 g = g2[rr], zv = zv2[rr];
         float ss = (zv.x * zv.x + zv.y * zv.y) + (zv.z * zv.z + zv.w * zv.w);
         ss = tail_wave_sum(ss);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-12f));
@@ -542,7 +567,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void lp_neg_tail_kernel(const LpAr
 static size_t lp_tail_lds_bytes(int D, int O) {
     const int Z = 2 * O;
     const size_t main_f = (size_t)TAIL_ROWS * (2 * D + 8) + (size_t)2 * TAIL_ROWS * (Z + 4) + (size_t)LP_MAX_NEG * (Z + 4) + 8 * 64 + TAIL_ROWS;
-    const size_t helper_f = (size_t)TAIL_ROWS * (D + 4) + (size_t)TAIL_WAVES * TAIL_ROWS * 64;
+    const size_t helper_f = (size_t)TAIL_ROWS * (D + 4) + (size_t)TAIL_WAVES * TAIL_ROWS * O;      // tail_z_term_helper: O columns
     return std::max(main_f, helper_f) * sizeof(float);
 }
 
@@ -561,7 +586,7 @@ static int launch_lp_tail(const LpArgs& L, const CoGatherS& J, int64_t gather_wa
     }
     const int NGH = (L.n_neg + TAIL_ROWS - 1) / TAIL_ROWS;
     const int G = L.t.pair_groups + NGH;
-    const int64_t blocks = (int64_t)(2 * O / 64) * G + L.t.pair_groups + gs_ceil_div(gather_waves, TAIL_WAVES);
+    const int64_t blocks = (int64_t)2 * G + L.t.pair_groups + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_linkpred_tail: grid too large");
     hipLaunchKernelGGL((sage_lp_tail_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lp_tail_lds_bytes(D, O), st, L, J);
     GS_LAUNCH_CHECK("sage_lp_tail_kernel");
@@ -569,11 +594,12 @@ static int launch_lp_tail(const LpArgs& L, const CoGatherS& J, int64_t gather_wa
 }
 
 template <int D, int O>
-static int launch_lp_neg(const LpArgs& L, const StepEpilogue& epi, hipStream_t st) {
+static int launch_lp_neg(const LpArgs& L, const StepEpilogue& epi, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
     const int NGH = (L.n_neg + TAIL_ROWS - 1) / TAIL_ROWS;
     const size_t lds = ((size_t)TAIL_ROWS * (2 * O + 4) + (size_t)TAIL_ROWS * (128 + 4)) * sizeof(float);
-    const int blocks = (L.t.train ? (2 * D / 128) * NGH : 0) + 1;
-    hipLaunchKernelGGL((lp_neg_tail_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, L, epi);
+    const int64_t blocks = (L.t.train ? (2 * D / 128) * NGH : 0) + 1 + gs_ceil_div(gather_waves, TAIL_WAVES);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_linkpred_tail_neg: grid too large");
+    hipLaunchKernelGGL((lp_neg_tail_kernel<D, O>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, L, epi, J);
     GS_LAUNCH_CHECK("lp_neg_tail_kernel");
     return GS_OK;
 }
@@ -637,9 +663,14 @@ extern "C" int gs_linkpred_tail(const gs_lp_tail_desc* q, const gs_gather_desc* 
 }
 
 extern "C" int gs_linkpred_tail_neg(const gs_lp_tail_desc* q, float* loss_out, int accumulate, float* mrr_out, uint64_t* c0,
-                                    uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream) {
+                                    uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2,
+                                    const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
     LpArgs L;
     int rc = lp_args(q, &L, "gs_linkpred_tail_neg");
+    if (rc != GS_OK) return rc;
+    CoGatherS J = {};
+    int64_t gw = 0;
+    rc = build_cojobs_s(jobs_host, n_jobs, &J, &gw);
     if (rc != GS_OK) return rc;
     StepEpilogue epi = {};
     if (loss_out) {
@@ -649,8 +680,8 @@ extern "C" int gs_linkpred_tail_neg(const gs_lp_tail_desc* q, float* loss_out, i
     }
     hipStream_t st = (hipStream_t)stream;
     const int D = q->d_in, O = q->out_dim;
-    if (D == 256 && O == 128) return launch_lp_neg<256, 128>(L, epi, st);
-    if (D == 256 && O == 64) return launch_lp_neg<256, 64>(L, epi, st);
-    if (D == 128 && O == 128) return launch_lp_neg<128, 128>(L, epi, st);
-    return launch_lp_neg<128, 64>(L, epi, st);
+    if (D == 256 && O == 128) return launch_lp_neg<256, 128>(L, epi, J, gw, st);
+    if (D == 256 && O == 64) return launch_lp_neg<256, 64>(L, epi, J, gw, st);
+    if (D == 128 && O == 128) return launch_lp_neg<128, 128>(L, epi, J, gw, st);
+    return launch_lp_neg<128, 64>(L, epi, J, gw, st);
 }

@@ -117,8 +117,9 @@ class SampleAndAggregate(object):
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         # unsupervised pipeline: share of the gather riding in the last layer's lean launch
         # unsupervised three-launch form (forward | fused link-prediction tail | weight gradients)
-        self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.35))
-        self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.25))
+        self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.28))
+        self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.30))
+        self.cogather_lp_neg = float(os.environ.get("GS_COGATHER_LP_NEG", 0.12))
         self.cogather_z = float(os.environ.get("GS_COGATHER_Z", 0.04))        # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
         # DIAGNOSTIC (one test pins it bit-identical): the fused tail as two launches (z helpers | row-group workgroups) --
         # no dependency between workgroups of a launch, the safe form under tools that serialise workgroups; +11 us per step
@@ -129,6 +130,8 @@ class SampleAndAggregate(object):
         #  all-reduce, the second-stream pipeline, the weight-stationary form of the layer-0 forward.)
         # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
         self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
+        # the fused tail launches (supervised: gs_sage_tail_fwd_bwd; unsupervised: gs_linkpred_tail); 0 = per-operator schedule
+        self.fuse_tail = os.environ.get("GS_FUSE_TAIL", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
         self.grad_hook = None
@@ -263,7 +266,11 @@ class SampleAndAggregate(object):
         if self._lp_tail_used:
             if self._tape[0][0] != "batched":
                 raise ops._lib.GraphsageAmdError("fused tail needs the contiguous id buffer (model.sample on ids_buffer)")
-            self._forward_lp_tail(B, n_roots, train, epilogue, tail_jobs)
+            tj, nj = tail_jobs, None
+            if tail_jobs and self.cogather_lp_neg > 0 and self.cogather_lp_tail > 0:
+                # the second launch (nine workgroups) carries its own share of the gather
+                tj, nj = ops.split_gather_jobs(tail_jobs, self.cogather_lp_tail / (self.cogather_lp_tail + self.cogather_lp_neg))
+            self._forward_lp_tail(B, n_roots, train, epilogue, tj, nj)
             return
         self.agg_out = out
         d = out.d
@@ -305,7 +312,7 @@ class SampleAndAggregate(object):
                 and self.num_samples[-1] <= 11
                 and ops.linkpred_tail_supported(2 * self.dims[1], self.dims[2], self.neg_sample_size))
 
-    def _forward_lp_tail(self, B, n_roots, train, epilogue, tail_jobs):
+    def _forward_lp_tail(self, B, n_roots, train, epilogue, tail_jobs, neg_jobs=None):
         """Layer 1 + l2_normalize + link-prediction loss / MRR (+ every input gradient down to layer 0's pre-activations when
         training) as the two launches of gs_unsup_tail.hip; gather jobs of the next step ride in the first one."""
         e = self.engine
@@ -340,7 +347,7 @@ class SampleAndAggregate(object):
             counters = [(e.step_dev, epilogue.get("step", 0)), (e.sample_clock_dev, epilogue.get("clock", 0)),
                         (epilogue.get("cursor"), epilogue.get("cursor_delta", 0))]
         ops.linkpred_tail_neg(desc, loss_out=self.loss_dev if fold else None, accumulate=False,
-                              mrr_out=self.mrr_dev if fold else None, counters=counters, stream=e.stream)
+                              mrr_out=self.mrr_dev if fold else None, counters=counters, jobs=neg_jobs, stream=e.stream)
         self._loss_accumulate = False
         if self.weight_decay != 0.0:
             first = not fold
@@ -603,7 +610,7 @@ class SampleAndAggregate(object):
                 if self._lp_tail_ok() and self.cogather_lp_tail > 0:
                     # three-launch form (layer-0 forward | fused link-prediction tail | weight gradients): the tail is long and
                     # thin (66 main workgroups), the rest of the chip streams its share of the gather at the full rate
-                    f_fwd, f_tail = self.cogather_lp_fwd, self.cogather_lp_tail
+                    f_fwd, f_tail = self.cogather_lp_fwd, self.cogather_lp_tail + self.cogather_lp_neg
                     fwd_jobs, rest = ops.split_gather_jobs(jobs, f_fwd)
                     tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, f_tail / max(1e-6, 1.0 - f_fwd)))
                 else:
@@ -854,7 +861,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
-                self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
+                self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
                 type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 

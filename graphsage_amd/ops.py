@@ -568,12 +568,14 @@ def linkpred_tail(desc, jobs=(), stream=None):
     call("gs_linkpred_tail", ctypes.addressof(desc), ctypes.addressof(jarr), len(jobs), _s(stream))
 
 
-def linkpred_tail_neg(desc, loss_out=None, accumulate=False, mrr_out=None, counters=(), stream=None):
-    """gs_linkpred_tail_neg: launch 2 (the negatives' rows, the step epilogue, the commit of the hand-over state)."""
+def linkpred_tail_neg(desc, loss_out=None, accumulate=False, mrr_out=None, counters=(), jobs=(), stream=None):
+    """gs_linkpred_tail_neg: launch 2 (the negatives' rows, the step epilogue, the commit of the hand-over state) + gather jobs."""
     cs = [(ptr(c), int(d)) for c, d in counters if c is not None and d]
     cs += [(None, 0)] * (3 - len(cs))
+    jobs = list(jobs or ())
+    jarr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
     call("gs_linkpred_tail_neg", ctypes.addressof(desc), ptr(loss_out), 1 if accumulate else 0, ptr(mrr_out),
-         cs[0][0], cs[0][1], cs[1][0], cs[1][1], cs[2][0], cs[2][1], _s(stream))
+         cs[0][0], cs[0][1], cs[1][0], cs[1][1], cs[2][0], cs[2][1], ctypes.addressof(jarr), len(jobs), _s(stream))
 
 
 # ------------------------------------------------------------------------------------------ K6

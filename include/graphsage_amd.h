@@ -550,7 +550,8 @@ int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
  *                         chip streams the next step's gather at the full HBM rate);
  *   gs_linkpred_tail_neg  the negatives' rows: slabs summed in main order -> dz -> d_h0 of their rows; + the step epilogue
  *                         (loss_out = mean(loss_rows) (+= if accumulate), mrr_out = mean(rr_rows), counters c0..c2 advanced
- *                         by d0..d2; loss_out == NULL: no epilogue) + the commit of the hand-over state.  MUST follow every
+ *                         by d0..d2; loss_out == NULL: no epilogue) + the commit of the hand-over state + gather jobs riding (nine
+ *                         workgroups of dependent round trips leave the chip free).  MUST follow every
  *                         gs_linkpred_tail on the same stream (train == 0: only the epilogue / commit run).
  * Rows: h0 [n + n*s, d_in] with n = 2 B + n_neg roots [batch1 | batch2 | negatives] (row n + i*s + j = j-th sample of root
  * i); z / y / dz [n, 2*out_dim]; means [n, d_in]; loss_rows / rr_rows [B]; aff_all [B, n_neg + 1] = [neg_aff | aff]
@@ -576,7 +577,8 @@ typedef struct gs_lp_tail_desc {
 int gs_linkpred_tail_supported(int32_t d_in, int32_t out_dim, int32_t n_neg);
 int gs_linkpred_tail(const gs_lp_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_linkpred_tail_neg(const gs_lp_tail_desc* desc_host, float* loss_out, int accumulate, float* mrr_out, uint64_t* c0,
-                         uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, void* stream);
+                         uint64_t d0, uint64_t* c1, uint64_t d1, uint64_t* c2, uint64_t d2, const gs_gather_desc* jobs_host,
+                         int32_t n_jobs, void* stream);
 /* Split form of the fused tail, first launch: the layer-1 pre-activations z = [h_self . W_self | mean(h_neigh) . W_neigh]
  * and the neighbor means of the descriptor (its head / label / gradient fields are ignored) as a LEAN kernel -- 4 x 64-column
  * helper workgroups per 16 rows, <= 128 VGPRs, 49 KB of LDS -- so that the gather jobs riding in the launch stream at the

@@ -388,14 +388,15 @@ def test_unsup_fused_tail_matches_oracle_and_the_unfused_schedule(dev, dim, nn, 
         assert bool(getattr(model, "_lp_tail_used", False)) == fuse
         grads = [{k: v.grad.numpy().copy() for k, v in a.vars.items()} for a in model.aggregators]
         full = model.outputs_all.numpy().copy()
+        got_samples = [t.cpu().numpy().copy() for t in model.samples1]
         sampler.inject_perms(perms)
         eloss, eranks, emrr, eouts = model.eval_step(feed)
         res_dev.append((loss, aff_all, mrr, outputs1, grads, full, eloss, emrr, eouts))
         if fuse:
             neg = sampler_hash.sample_unigram(sampler_hash.unigram_cdf_u32(it.deg), nn, 123, 0)
             samples, support = sample_three_calls(it.adj, edges[:, 0], edges[:, 1], neg, ns, perms)
-            for got, want in zip(model.samples1, samples):
-                assert np.array_equal(got.cpu().numpy(), want)
+            for got, want in zip(got_samples, samples):
+                assert np.array_equal(got, want)
             res = orc.unsupervised_fwd_bwd(params, G.padded_features(), samples, support, model.dims, ns, B, nn, "mean", True,
                                            weight_decay=wd)
             np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
