@@ -62,6 +62,9 @@ _PROTOS = {
     "gs_peer_attach": [_P, c_int32, _P, c_int32],
     "gs_peer_attach_local": [_P, _P],
     "gs_peer_allreduce_sum_f32": [_P, _P, c_int64, _P],
+    "gs_peer_set_probe_wait": [_P, c_int32],
+    "gs_peer_step": [_P, _P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
+                     _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P, c_int32, _P],
     "gs_peer_status": [_P, POINTER(c_int64), POINTER(c_int32)],
     "gs_peer_destroy": [_P],
     "gs_sum_scaled": [_P, c_int64, c_float, _P, c_int, _P],

@@ -116,6 +116,30 @@ static inline int gs_drop_args(const gs_dropout* d, DropArgs* out) {
 }
 
 
+// TF-1.x Adam on one element, with the elementwise clip of supervised_models.py:96-99 in front (clip <= 0: off).  ONE body for
+// gs_adam_step, the fused slab-sum + Adam launch and the data-parallel step launch, compiled without FMA contraction, so that
+// the three schedules give the same bits whatever code surrounds the call.
+__device__ __forceinline__ void gs_adam_elem(float& p, float& m, float& v, float g, const float gscale, const float clip,
+                                             const float b1, const float b2, const float eps, const float lr_t) {
+#pragma clang fp contract(off)
+    g = g * gscale;
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    m = b1 * m + (1.0f - b1) * g;
+    v = b2 * v + (1.0f - b2) * g * g;
+    p = p - lr_t * m / (sqrtf(v) + eps);
+}
+// g + wd * p (the gradient of the weight-decay term, supervised_models.py:104-108), without FMA contraction (see gs_adam_elem)
+__device__ __forceinline__ f32x4 gs_wd_add(const f32x4 g, const f32x4 p, const float wd) {
+#pragma clang fp contract(off)
+    f32x4 r;
+    r.x = g.x + p.x * wd; r.y = g.y + p.y * wd; r.z = g.z + p.z * wd; r.w = g.w + p.w * wd;
+    return r;
+}
+__device__ __forceinline__ float gs_adam_lr_t(const float lr, const float b1, const float b2, const uint64_t* step_dev, const int step_offset) {
+    const float t = (float)((step_dev ? *step_dev : 0ull) + (uint64_t)step_offset);
+    return lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+}
+
 // Step epilogue body (one 256-thread workgroup): loss_out = scale * sum(loss_rows[0:n]) (+= if accumulate), optionally
 // aux_out = aux_scale * sum(aux_rows[0:n]), both in a fixed order, then the device counters advance.  Shared by
 // finalize_step_kernel (gs_runtime.hip) and the launches that carry the epilogue as an extra workgroup.

@@ -104,16 +104,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t count, float lr,
                                                    float b1, float b2, float eps, float clip, float gscale,
                                                    const uint64_t* __restrict__ step_dev, int step_offset) {
-    const float t = (float)((step_dev ? *step_dev : 0ull) + (uint64_t)step_offset);
-    const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    const float lr_t = gs_adam_lr_t(lr, b1, b2, step_dev, step_offset);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-        float g = grad[i] * gscale;
-        if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
-        const float mi = b1 * m[i] + (1.0f - b1) * g;
-        const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+        float pi = p[i], mi = m[i], vi = v[i];
+        gs_adam_elem(pi, mi, vi, grad[i], gscale, clip, b1, b2, eps, lr_t);
         m[i] = mi;
         v[i] = vi;
-        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        p[i] = pi;
     }
 }
 
@@ -197,10 +194,7 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
         return;
     }
     float lr_t = 0.f;
-    if (fuse_adam) {
-        const float t = (float)((step_dev ? *step_dev : 0ull) + (uint64_t)step_offset);
-        lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
-    }
+    if (fuse_adam) lr_t = gs_adam_lr_t(lr, b1, b2, step_dev, step_offset);
     if (loss_rows && blockIdx.x == 0 && threadIdx.x < 64) {
         // the step's scalar loss (supervised_models.py:111-118 reduce_mean): one wave, fixed order
         float sacc = 0.f;
@@ -238,17 +232,14 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
             }
             if (V.clear[k]) *reinterpret_cast<f32x4*>(sp) = f32x4{0.f, 0.f, 0.f, 0.f};   // atomic accumulator: consume
         }
-        if (V.decay[k] && wd != 0.f) g += p * wd;
+        if (V.decay[k] && wd != 0.f) g = gs_wd_add(g, p, wd);
         *reinterpret_cast<f32x4*>(grads + i) = g;
         if (fuse_adam) {
-            g *= gscale;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float ge = g[e];
-                if (clip > 0.f) ge = fminf(fmaxf(ge, -clip), clip);
-                mi[e] = b1 * mi[e] + (1.0f - b1) * ge;
-                vi[e] = b2 * vi[e] + (1.0f - b2) * ge * ge;
-                p[e] -= lr_t * mi[e] / (sqrtf(vi[e]) + eps);
+                float pe = p[e], me = mi[e], ve = vi[e];
+                gs_adam_elem(pe, me, ve, g[e], gscale, clip, b1, b2, eps, lr_t);
+                p[e] = pe; mi[e] = me; vi[e] = ve;
             }
             *reinterpret_cast<f32x4*>(m + i) = mi;
             *reinterpret_cast<f32x4*>(v + i) = vi;

@@ -215,7 +215,21 @@ class PeerPushAllReduce(object):
         self.spin_limit = int(os.environ.get("GS_PEER_SPIN_LIMIT", "0")) if spin_limit is None else int(spin_limit)
         self.attempts = 0
         self.failures = []          # this rank's failed self-test attempts (diagnostics)
+        # the step's last launch as ONE kernel: slab sum | exchange | clip + Adam (gs_peer_step) instead of three launches
+        # around the exchange (the models ask through fused_handle()); 0 = the three-launch schedule
+        self.fused_step = os.environ.get("GS_PEER_FUSED_STEP", "1") == "1"
         self._open()
+
+    # One window per (shape, rank) for the PROCESS'S LIFETIME: a window is never freed while a peer may still map it, and a
+    # re-created hook (a second model in the same process, bench.py's legs) re-uses the window AND the peers' mappings of it.
+    # Round 4 freed and re-allocated windows per hook: a peer's hipIpcOpenMemHandle could then return its stale mapping of the
+    # old allocation at the same address (5 of 30 re-created hooks timed out on their first exchange) and the self test retried
+    # on fresh windows -- a workaround; with the cache no mapping is ever re-made.  The epoch / flag state in the window simply
+    # continues (all ranks continue in lockstep); a window whose sticky error word is set is dropped from the cache.
+    _windows = {}
+
+    def _cache_key(self):
+        return (int(self.engine.grads.numel()), self.world_size, self.rank, self.chunks, self.spin_limit, str(self.engine.device))
 
     def _open(self):
         """Allocate this rank's window, exchange IPC handles, map every peer (collective; every stage's outcome is agreed)."""
@@ -225,6 +239,12 @@ class PeerPushAllReduce(object):
         engine = self.engine
         multi = self.world_size > 1
         torch.cuda.set_device(engine.device)
+        cached = PeerPushAllReduce._windows.get(self._cache_key()) if not getattr(self, "_fresh", False) else None
+        if (not multi and cached) or (multi and _agree(cached is not None, engine)):
+            self._peer = cached                    # every rank still holds its window and its mappings of the peers' windows
+            self.reused = True
+            return
+        self.reused = False
         h = ctypes.c_void_p()
         err = None
         try:
@@ -259,6 +279,7 @@ class PeerPushAllReduce(object):
             if not _agree(err is None, engine):       # nobody launches the exchange unless everybody mapped everybody
                 self.close()
                 raise RuntimeError("peer windows could not be mapped on every rank (this rank: %r)" % (err,))
+        PeerPushAllReduce._windows[self._cache_key()] = self._peer
 
     def all_reduce(self, flat, stream=None):
         from . import ops
@@ -266,6 +287,15 @@ class PeerPushAllReduce(object):
 
     def __call__(self, model):
         self.all_reduce(self.engine.grads)
+
+    def set_probe_wait(self, us):
+        """Diagnostics: every exchange workgroup of the fused step launch holds its hand-over for `us` microseconds."""
+        from . import ops
+        ops.call("gs_peer_set_probe_wait", self._peer, int(us))
+
+    def fused_handle(self):
+        """The window handle for Engine.finish_backward(peer=...) (gs_peer_step), or None for the three-launch schedule."""
+        return self._peer if self.fused_step else None
 
     def status(self):
         """(exchanges completed on this rank, error word) -- call after the engine stream has been synchronised."""
@@ -319,17 +349,23 @@ class PeerPushAllReduce(object):
             if _agree(ok, e):
                 return True
             old, self._peer = self._peer, None      # the new windows are allocated while the old ones still exist: new addresses,
+            PeerPushAllReduce._windows.pop(self._cache_key(), None)
+            self._fresh = True
             try:
                 self._open()                        # new IPC handles
             finally:
+                self._fresh = False
                 ops.call("gs_peer_destroy", old)    # also when _open() raises (the caller then falls back to RCCL): no leaked window
         raise RuntimeError("peer exchange failed its self test %d times (this rank's last error: %r)" % (attempts, last))
 
     def close(self):
+        """Detach from the window.  A cached window (the normal case) stays allocated and mapped for the process's lifetime
+        (see _windows); only a window that is not in the cache -- a failed open -- is freed here."""
         if self._peer:
             from . import ops
             peer, self._peer = self._peer, None
-            ops.call("gs_peer_destroy", peer)
+            if PeerPushAllReduce._windows.get(self._cache_key()) != peer:
+                ops.call("gs_peer_destroy", peer)
 
 
 class SpinHook(object):

@@ -353,7 +353,7 @@ class Engine(object):
         return arr
 
     def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0, side_jobs=None,
-                        loss=None, step_offset=1):
+                        loss=None, step_offset=1, peer=None, peer_jobs=None):
         """One grouped launch for every queued weight gradient, then ONE launch that sums the slabs into the
         flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass.
         loss = (loss_rows, n, scale, loss_out, accumulate): the step's scalar loss is formed by that launch too;
@@ -368,6 +368,19 @@ class Engine(object):
                 ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
                 1 if lacc else 0)
         rider = getattr(self, "_deferred_sampler", None)
+        if peer is not None:
+            # data-parallel step with the peer-store exchange: slab sum | exchange | clip + Adam are ONE launch (gs_peer_step);
+            # grad_scale = 1 / world; the deferred sampler rides behind the exchange workgroups
+            self._deferred_sampler = None
+            pj = list(peer_jobs or ())        # gather+mean jobs of the next step behind the (mostly waiting) exchange workgroups
+            pjarr = (ops._lib.GatherDesc * max(len(pj), 1))(*pj)
+            ops.call("gs_peer_step", peer, ctypes.addressof(arr), len(self.variables), ops.ptr(self.params), ops.ptr(self.grads),
+                     ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats, float(weight_decay), lr, 0.9, 0.999, 1e-8,
+                     clip, grad_scale, ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
+                     1 if lacc else 0, ctypes.addressof(rider) if rider is not None else None, ctypes.addressof(pjarr), len(pj),
+                     self.stream)
+            self._params_updated()
+            return
         if rider is not None:
             # a later mini-batch's fan-out sampler rides in this launch (neigh_samplers.fanout under _defer_sampler)
             self._deferred_sampler = None

@@ -116,6 +116,10 @@ class SampleAndAggregate(object):
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         # unsupervised pipeline: share of the gather riding in the last layer's lean launch
+        # data-parallel step ending in gs_peer_step (slab sum | peer exchange | Adam as one launch): share of the next step's
+        # gather riding behind its exchange workgroups, which mostly wait for the peers (0 = off; one GPU cannot measure it:
+        # bench.py GS_PROBE_DP_PEER=<us> probes the schedule with a stand-in wait)
+        self.cogather_dp_opt = float(os.environ.get("GS_COGATHER_DP_OPT", 0.0))
         # unsupervised three-launch form (forward | fused link-prediction tail | weight gradients)
         self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.28))
         self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.30))
@@ -383,8 +387,12 @@ class SampleAndAggregate(object):
         else:
             self.aggregate_backward(self._d_agg_out)
         # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
-        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, grad_scale=1.0,
-                          side_jobs=wgrad_jobs, step_offset=0 if advanced else 1)
+        peer = None if fuse_adam else self._peer_fused()
+        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0,
+                          grad_scale=1.0 / self.world_size if peer else 1.0, side_jobs=wgrad_jobs, step_offset=0 if advanced else 1,
+                          peer=peer)
+        if peer and not advanced:
+            e.advance(step=1)          # as _optimize(): the unsupervised DP epilogue leaves the optimizer step counter alone
         if epilogue is not None and not early and not folded:
             self._epilogue_unsup(B, **epilogue)
 
@@ -520,6 +528,14 @@ class SampleAndAggregate(object):
             self.engine.sync()
             self.grad_hook.check()
 
+    def _peer_fused(self):
+        """Window handle when the data-parallel step ends in ONE launch (slab sum | peer exchange | clip + Adam, gs_peer_step):
+        the in-graph schedule with a PeerPushAllReduce hook whose fused_step is on; None otherwise."""
+        if not self._dp_in_graph():
+            return None
+        fh = getattr(self.grad_hook, "fused_handle", None)
+        return fh() if fh is not None else None
+
     def _dp_in_graph(self):
         """Data-parallel AND the all-reduce hook can be recorded inside the step's hipGraph (NativeAllReduce)."""
         return self.grad_hook is not None and getattr(self.grad_hook, "capturable", False)
@@ -626,7 +642,7 @@ class SampleAndAggregate(object):
                 self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
                 if e._deferred_sampler is not None:
                     raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
-                if in_graph:
+                if in_graph and not self._peer_fused():
                     # backward | ncclAllReduce (recorded in the graph) | clip + Adam
                     self.grad_hook(self)
                     self._optimize()
@@ -861,8 +877,8 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
-                self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
-                type(self.grad_hook).__name__,
+                self.cogather_z, self.cogather_dp_opt, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.split_gemm, e.split_pool, str(getattr(self, "pipeline", None)),
+                type(self.grad_hook).__name__, getattr(self.grad_hook, "fused_step", None),
                 id(self.grad_hook), law)
 
     def _run(self, key, fn):

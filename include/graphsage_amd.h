@@ -725,6 +725,21 @@ int gs_peer_export(void* peer, void* handle_out_host, int32_t len);
 int gs_peer_attach(void* peer, int32_t peer_rank, const void* handle_host, int32_t len);
 int gs_peer_attach_local(void* peer, void* other_peer);
 int gs_peer_allreduce_sum_f32(void* peer, float* buf, int64_t count, void* stream);
+/* The data-parallel step's last launch: gs_flat_reduce_adam (slab sum + weight decay) | the exchange | gs_adam_step as ONE
+ * kernel on the caller's stream (arguments as gs_flat_reduce_adam_sample; the window must have been created for `total`
+ * floats and the variables must cover the whole flat buffer): workgroup (p, w) forms chunk w of slice p of the local
+ * gradient from the split-K slabs and stores it straight into rank p's window, sums the copies of its own slice in rank
+ * order, and applies clip + Adam to the chunk of rank p's reduced slice as it lands (also written to `grads`).  The fan-out
+ * sampler of a later mini-batch and gather+mean jobs of the next one ride behind the exchange workgroups, which mostly wait.
+ * Same sums in the same order as the three-launch schedule: bit-identical parameters; grad_scale is 1 / world. */
+/* Diagnostics: every exchange workgroup of gs_peer_step holds its hand-over for `us` microseconds (0 = off) -- a one-GPU
+ * stand-in for the peers' latency when the data-parallel schedule is probed without peers. */
+int gs_peer_set_probe_wait(void* peer, int32_t us);
+int gs_peer_step(void* peer, const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
+                 int64_t total, float weight_decay, float lr, float beta1, float beta2, float eps, float clip, float grad_scale,
+                 const uint64_t* step_dev, int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
+                 float* loss_out, int loss_accumulate, const gs_fanout_desc* sampler_host, const gs_gather_desc* jobs_host,
+                 int32_t n_jobs, void* stream);
 int gs_peer_status(void* peer, int64_t* epoch_out_host, int32_t* error_out_host);
 int gs_peer_destroy(void* peer);
 

@@ -272,3 +272,35 @@ def test_bench_gpus_2_launches_its_own_ranks(dev):
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout) and not [l for l in r2.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("agg", ["mean", "maxpool"])
+def test_peer_fused_step_single_rank_equals_local_adam(dev, agg):
+    """The data-parallel step's last launch as ONE kernel (gs_peer_step: slab sum | peer exchange | clip + Adam) with a world of
+    one rank == the three-launch schedule (slab sum | exchange | Adam) == the single-GPU fused optimizer launch, bit for bit,
+    through multi-step hipGraphs with the sampler riding behind the exchange workgroups."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from graphsage_amd import distributed as gsd
+    from graphsage_amd import engine as eng
+    from test_model_gpu import build
+    outs = []
+    for mode in ("local", "peer_fused", "peer_three_launches"):
+        G, it, ph, sampler, model, ns = build(torch.device("cuda:0"), agg, True, False, csr=True, wd=0.01)
+        e = eng.get_engine()
+        if mode != "local":
+            hook = gsd.PeerPushAllReduce(e)
+            hook.fused_step = mode == "peer_fused"
+            assert hook.self_test()
+            model.grad_hook = hook
+            assert model._dp_in_graph() and (model._peer_fused() is not None) == (mode == "peer_fused")
+        model.attach_device_epoch(it.train_nodes[: 8 * B], it.label_matrix)
+        model.train_steps_device(B, 7, steps_per_launch=2)
+        loss, preds = model._fetch(B)
+        outs.append((loss, e.params.cpu().numpy().copy(), e.adam_v.cpu().numpy().copy()))
+        if mode != "local":
+            assert hook.check() >= 7
+            hook.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0]
+        assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
