@@ -260,6 +260,16 @@ __global__ __launch_bounds__(GS_PEER_THREADS) void peer_step_kernel(const PeerAr
         if (threadIdx.x == 0)
             __hip_atomic_store(a.win[p].rs_flag + ((int64_t)me * a.W + w) * GS_PEER_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // (the parameters and Adam moments of this thread's first quad of phase C' are requested NOW: they depend on nothing the
+    //  exchange produces, and phase C' is otherwise one more dependent round trip behind the last flag)
+    const int64_t i_first = c0 + (int64_t)threadIdx.x * 4;
+    f32x4 pv0 = zero4, mi0 = zero4, vi0 = zero4;
+    if (i_first < c1 && i_first < lim) {
+        const int64_t f = (int64_t)p * a.L + i_first;
+        pv0 = *reinterpret_cast<const f32x4*>(S.params + f);
+        mi0 = *reinterpret_cast<const f32x4*>(S.m + f);
+        vi0 = *reinterpret_cast<const f32x4*>(S.v + f);
+    }
     // ---- B. chunk w of MY slice has landed from every rank: sum the copies in rank order, store the sum into rank p's full[]
     {
         int ok = 1;
@@ -307,9 +317,12 @@ __global__ __launch_bounds__(GS_PEER_THREADS) void peer_step_kernel(const PeerAr
             if (i >= lim) continue;
             const int64_t f = (int64_t)p * a.L + i;
             const f32x4 gr = *(const f32x4*)(src + i);
-            f32x4 pv = *reinterpret_cast<const f32x4*>(S.params + f);
-            f32x4 mi = *reinterpret_cast<const f32x4*>(S.m + f);
-            f32x4 vi = *reinterpret_cast<const f32x4*>(S.v + f);
+            f32x4 pv = pv0, mi = mi0, vi = vi0;
+            if (i != i_first) {
+                pv = *reinterpret_cast<const f32x4*>(S.params + f);
+                mi = *reinterpret_cast<const f32x4*>(S.m + f);
+                vi = *reinterpret_cast<const f32x4*>(S.v + f);
+            }
             *reinterpret_cast<f32x4*>(a.grads + f) = gr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -355,7 +368,7 @@ static PeerWindow peer_layout(char* base, int64_t L, int32_t world, int32_t W) {
 extern "C" int gs_peer_create(int64_t n_floats, int32_t world, int32_t rank, int32_t chunks, int64_t spin_limit, void** peer_out) {
     GS_REQUIRE(peer_out && n_floats > 0 && world >= 1 && world <= GS_PEER_MAX_WORLD && rank >= 0 && rank < world,
                "gs_peer_create: need n > 0, 1 <= world <= %d, 0 <= rank < world", GS_PEER_MAX_WORLD);
-    GS_REQUIRE(chunks >= 0 && chunks <= 64 && spin_limit >= 0 && spin_limit <= 0xffffffffll, "gs_peer_create: chunks 0..64, spin_limit 0..2^32-1");
+    GS_REQUIRE(chunks >= 0 && chunks <= 256 && spin_limit >= 0 && spin_limit <= 0xffffffffll, "gs_peer_create: chunks 0..256, spin_limit 0..2^32-1");
     GsPeer* g = new (std::nothrow) GsPeer();
     GS_REQUIRE(g != nullptr, "gs_peer_create: out of host memory");
     memset(g, 0, sizeof(*g));
@@ -363,7 +376,10 @@ extern "C" int gs_peer_create(int64_t n_floats, int32_t world, int32_t rank, int
     g->L = peer_slice_len(n_floats, world);
     // chunks = 0: about two float4 per thread and pass, at most 256 workgroups in all (they must be co-resident: they wait
     // for peers inside the kernel)
-    g->W = chunks > 0 ? chunks : (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, 256 / world), (g->L + 2047) / 2048));
+    // (round 5: one float4 per thread and pass where the 256-workgroup budget allows -- every pass of a chunk is a dependent
+    //  memory round trip through uncached memory, so fewer, fatter workgroups only add round trips: world = 1, L = 230 k:
+    //  225 chunks instead of 64)
+    g->W = chunks > 0 ? chunks : (int32_t)std::max<int64_t>(1, std::min<int64_t>(256 / world, (g->L + 1023) / 1024));
     g->spin_limit = spin_limit > 0 ? (uint32_t)spin_limit : (1u << 24);
     g->bytes = peer_window_bytes(g->L, world, g->W);
     void* p = nullptr;

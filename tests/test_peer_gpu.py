@@ -338,3 +338,69 @@ if __name__ == "__main__":
     else:
         _run_in_process(torch.device("cuda:0"), int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
     print("in-process exchange ok")
+
+
+def test_peer_step_kernel_single_rank_equals_the_optimizer_launches(dev):
+    """gs_peer_step (slab sum | exchange | clip + Adam in ONE launch) with a world of one rank on random slabs == gs_flat_reduce_adam
+    with fuse_adam (the single-GPU optimizer launch) == gs_flat_reduce_adam | gs_adam_step (the three-launch data-parallel
+    schedule without its exchange): parameters, Adam moments and gradients bit for bit, over three steps; weight decay on the
+    decayed variables, ragged slab counts, a variable without slabs."""
+    from graphsage_amd import _lib, ops
+    rng = np.random.RandomState(5)
+    sizes = [602 * 128, 602 * 128, 256 * 128, 44, 256 * 44, 4]
+    n_slabs = [22, 3, 1, 2, 0, 5]
+    decay = [1, 1, 0, 1, 1, 0]
+    total = sum(sizes)
+    p0 = (rng.standard_normal(total) * 0.1).astype(np.float32)
+    slabs_np = [(rng.standard_normal(max(k, 1) * sz) * 10.0 ** rng.randint(-4, 1)).astype(np.float32) for sz, k in zip(sizes, n_slabs)]
+    step0 = 3
+
+    def run(mode):
+        st = ops.Stream()
+        P = torch.from_numpy(p0.copy()).to(dev)
+        G = torch.zeros(total, device=dev)
+        M = torch.zeros(total, device=dev)
+        V = torch.zeros(total, device=dev)
+        step = torch.tensor([step0], dtype=torch.int64, device=dev)
+        sl = [torch.from_numpy(a.copy()).to(dev) for a in slabs_np]
+        arr = (_lib.VarDesc * len(sizes))()
+        off = 0
+        for i, (sz, k, d) in enumerate(zip(sizes, n_slabs, decay)):
+            arr[i].offset, arr[i].size, arr[i].slabs, arr[i].n_slabs, arr[i].decay, arr[i].clear = off, sz, sl[i].data_ptr(), k, d, 0
+            off += sz
+        h = ctypes.c_void_p()
+        if mode == "peer":
+            ops.call("gs_peer_create", total, 1, 0, 0, 0, ctypes.byref(h))
+        torch.cuda.synchronize()
+        out = []
+        for it in range(3):
+            common = (ctypes.addressof(arr), len(sizes), ops.ptr(P), ops.ptr(G), ops.ptr(M), ops.ptr(V), total, 0.01)
+            if mode == "peer":
+                ops.call("gs_peer_step", h.value, *common, 0.01, 0.9, 0.999, 1e-8, 5.0, 1.0, ops.ptr(step), 1, None, 0, 0.0, None, 0,
+                         None, None, 0, st.handle)
+            elif mode == "fused":
+                ops.call("gs_flat_reduce_adam", *common, 1, 0.01, 0.9, 0.999, 1e-8, 5.0, 1.0, ops.ptr(step), 1, None, 0, 0.0, None, 0,
+                         st.handle)
+            else:
+                ops.call("gs_flat_reduce_adam", *common, 0, 0.01, 0.9, 0.999, 1e-8, 5.0, 1.0, ops.ptr(step), 1, None, 0, 0.0, None, 0,
+                         st.handle)
+                ops.adam_step(P, G, M, V, total, 0.01, step, clip=5.0, grad_scale=1.0, step_offset=1, stream=st.handle)
+            ops.advance_counter(step, 1, stream=st.handle)
+            st.sync()
+            out.append([t.cpu().numpy().copy() for t in (P, G, M, V)])
+        if mode == "peer":
+            ep, er = ctypes.c_int64(), ctypes.c_int32()
+            ops.call("gs_peer_status", h.value, ctypes.byref(ep), ctypes.byref(er))
+            assert (ep.value, er.value) == (3, 0)
+            _lib.load().gs_peer_destroy(h.value)
+        return out
+
+    res = {m: run(m) for m in ("fused", "three", "peer")}
+    names = ("params", "grads", "adam_m", "adam_v")
+    for it in range(3):
+        for k, nm in enumerate(names):
+            for other in ("three", "peer"):
+                a, b = res["fused"][it][k], res[other][it][k]
+                bad = np.flatnonzero(a != b)
+                assert bad.size == 0, "step %d %s: %s differs from the fused optimizer launch in %d of %d elements (first at %d: %r vs %r)" % (
+                    it, nm, other, bad.size, a.size, bad[0], a[bad[0]], b[bad[0]])
