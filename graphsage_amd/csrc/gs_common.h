@@ -116,23 +116,33 @@ static inline int gs_drop_args(const gs_dropout* d, DropArgs* out) {
 }
 
 
+// A product that the compiler cannot contract into an FMA with a following add: the value passes through an empty asm
+// statement.  (hipcc runs with -ffp-contract=fast, which IGNORES `#pragma clang fp contract(off)`; measured in round 5: the
+// scalar Adam kernel and the fused float4 one differed in 7 % of the parameters by one ulp from the second step on.)
+__device__ __forceinline__ float gs_mul_nofma(const float a, const float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 // TF-1.x Adam on one element, with the elementwise clip of supervised_models.py:96-99 in front (clip <= 0: off).  ONE body for
-// gs_adam_step, the fused slab-sum + Adam launch and the data-parallel step launch, compiled without FMA contraction, so that
-// the three schedules give the same bits whatever code surrounds the call.
+// gs_adam_step, the fused slab-sum + Adam launch and the data-parallel step launch (gs_peer_step), every product kept apart
+// from the add behind it, so that the three schedules give the same bits whatever code surrounds the call.
 __device__ __forceinline__ void gs_adam_elem(float& p, float& m, float& v, float g, const float gscale, const float clip,
                                              const float b1, const float b2, const float eps, const float lr_t) {
-#pragma clang fp contract(off)
-    g = g * gscale;
+    g = gs_mul_nofma(g, gscale);
     if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
-    m = b1 * m + (1.0f - b1) * g;
-    v = b2 * v + (1.0f - b2) * g * g;
-    p = p - lr_t * m / (sqrtf(v) + eps);
+    m = gs_mul_nofma(b1, m) + gs_mul_nofma(1.0f - b1, g);
+    v = gs_mul_nofma(b2, v) + gs_mul_nofma(gs_mul_nofma(1.0f - b2, g), g);
+    float q = gs_mul_nofma(lr_t, m) / (sqrtf(v) + eps);
+    asm volatile("" : "+v"(q));
+    p = p - q;
 }
-// g + wd * p (the gradient of the weight-decay term, supervised_models.py:104-108), without FMA contraction (see gs_adam_elem)
+// g + wd * p (the gradient of the weight-decay term, supervised_models.py:104-108), the product kept apart from the add
 __device__ __forceinline__ f32x4 gs_wd_add(const f32x4 g, const f32x4 p, const float wd) {
-#pragma clang fp contract(off)
     f32x4 r;
-    r.x = g.x + p.x * wd; r.y = g.y + p.y * wd; r.z = g.z + p.z * wd; r.w = g.w + p.w * wd;
+    r.x = g.x + gs_mul_nofma(p.x, wd); r.y = g.y + gs_mul_nofma(p.y, wd);
+    r.z = g.z + gs_mul_nofma(p.z, wd); r.w = g.w + gs_mul_nofma(p.w, wd);
     return r;
 }
 __device__ __forceinline__ float gs_adam_lr_t(const float lr, const float b1, const float b2, const uint64_t* step_dev, const int step_offset) {
