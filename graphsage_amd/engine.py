@@ -98,6 +98,7 @@ class Engine(object):
         self._wgrad_big_n = int(os.environ.get("GS_WGRAD_BIG_N", 16384))
         self._stream_max_slabs = int(os.environ.get("GS_STREAM_MAX_SLABS", 32))
         self._stream_slice_rows = float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))
+        self._stream_wide_rows = os.environ.get("GS_STREAM_WIDE_ROWS", "0") == "1"
         self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)
         self._split_vars = []             # variables with a three-piece bf16 copy, re-cut behind every optimizer launch
         self._defer_sampler = False       # neigh_samplers.fanout: hand the launch to the next optimizer launch instead
@@ -261,8 +262,11 @@ class Engine(object):
         ks = int(max(1, min(self._stream_max_slabs, MAX_SLABS - var.n_slabs - reserved, round(n / self._stream_slice_rows))))
         lda, ldz = A.ld, dZ.ld
         if a_idx is not None:
-            # (tables beyond 4 GB -- RMAT's 10.2 GB -- take the kernel's 16-byte-unit row offsets: 64 GB)
-            ok = (n + ks - 1) // ks <= 510 and (A.rows + 1) * (lda // 4) < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
+            # (the kernel also takes tables beyond 4 GB -- 16-byte-unit row offsets, gs_stream.hip GATHERED == 2 -- but the
+            #  one configuration that has one, RMAT with F = 256, is slower on it: 95.2 vs 77.3 us/step, round 5 -- its 8 tiles
+            #  per problem give the stream policy ~400 waves for 1024 SIMDs; GS_STREAM_WIDE_ROWS=1 selects it)
+            limit = (A.rows + 1) * (lda // 4) if self._stream_wide_rows else (A.rows + 1) * lda * 4
+            ok = (n + ks - 1) // ks <= 510 and limit < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
         else:
             ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
         return ok, ks

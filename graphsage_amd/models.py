@@ -121,9 +121,9 @@ class SampleAndAggregate(object):
         # bench.py GS_PROBE_DP_PEER=<us> probes the schedule with a stand-in wait)
         self.cogather_dp_opt = float(os.environ.get("GS_COGATHER_DP_OPT", 0.0))
         # unsupervised three-launch form (forward | fused link-prediction tail | weight gradients)
-        self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.28))
-        self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.30))
-        self.cogather_lp_neg = float(os.environ.get("GS_COGATHER_LP_NEG", 0.12))
+        self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.30))
+        self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.25))
+        self.cogather_lp_neg = float(os.environ.get("GS_COGATHER_LP_NEG", 0.10))
         self.cogather_z = float(os.environ.get("GS_COGATHER_Z", 0.04))        # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
         # DIAGNOSTIC (one test pins it bit-identical): the fused tail as two launches (z helpers | row-group workgroups) --
         # no dependency between workgroups of a launch, the safe form under tools that serialise workgroups; +11 us per step
