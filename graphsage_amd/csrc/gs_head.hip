@@ -739,6 +739,154 @@ __global__ __launch_bounds__(512) void maxpool_sparse_wgrad_cols_kernel(const fl
     }
 }
 
+// LDS-DMA form of the column-per-lane kernel (round 5; the default for hidden >= 512 and s <= 32).
+// What was wrong with the form above (profiles/r05_maxpool_kernel_stats.md: 149 us for the 5120 x 25 hop, 1.4 us per group for
+// 0.2 us of LDS time): its "prefetch" loads a row through `X + ids[g s + r] * ldx` -- the row load depends on the id load,
+// so the compiler puts s_waitcnt vmcnt(0) between the two, and vmcnt is an in-order counter: that wait also drains the row
+// loads of every group ahead.  Each group paid a full memory round trip; a register ring deep enough to fix it does not
+// fit beside 64 accumulators in the 128 VGPRs that keep two workgroups on a CU (tried: 740 bytes of scratch per lane).
+// Here nothing that is in flight lives in a VGPR:
+//   * the slice's sampled ids are staged in LDS once per GS_SPD_IDS_CAP ids (one round trip per chunk, not per group);
+//   * the row segments, arg-max rows and values of group g + 3 go global -> LDS with global_load_lds_dword (one wave
+//     instruction = one 256-byte row segment at a wave-uniform LDS address, i.e. the padded 66-float row stride of the
+//     bank-conflict-free ds_read_b64 pattern survives -- the 16-byte form would force a lane-linear layout) into a ring of
+//     GS_SPD_NBUF stages; every wave issues exactly RPW + 2 of them per group, so `s_waitcnt vmcnt(2 (RPW + 2))` says
+//     "my part of group g has landed", and ONE s_barrier per group makes everybody's part visible and frees the stage
+//     that group g - 1 was read from (its reads were retired by the lgkmcnt(0) of the last batch);
+//   * every load is unconditional (clamped group / row / column; a clamped group is multiplied by v = 0, a clamped column
+//     lands in an accumulator that is never stored): straight-line code, exact counts.
+// Arithmetic and summation order per (feature, column) are those of the form above: bit-identical slabs.
+#define GS_SPD_NBUF 4
+#define GS_SPD_IDS_CAP 3072     // sampled ids of a slice staged in LDS at a time (12 KB: 122 groups of 25)
+template <int RPW>              // row segments per wave and group: ceil(s / 8)
+__global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                        const int32_t* __restrict__ ids, int64_t G, int32_t s,
+                                                                        int32_t d, const int32_t* __restrict__ argmax,
+                                                                        int64_t lda, const float* __restrict__ dpm, int64_t ldd,
+                                                                        int32_t hidden, int64_t groups_per_slice,
+                                                                        float* __restrict__ slabs, int64_t ld_slab) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    constexpr int NBUF = GS_SPD_NBUF;
+    constexpr int ROWS = 8 * RPW;                                // row slots of a stage (>= s)
+    constexpr int STAGE = ROWS * GS_SPW_LDS_STRIDE + 1024;       // floats: rows | int32 arg-max[512] | float value[512]
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [NBUF][STAGE] | int32 ids[GS_SPD_IDS_CAP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.y, fb = blockIdx.x;
+    const int f0 = fb * GS_SPW_FB;
+    const int c = blockIdx.z * 512 + tid;
+    const bool col_ok = c < hidden;
+    const int cc = min(c, hidden - 1);                           // loads of a column past the end: clamped, never stored
+    const int fcol = min(f0 + lane, d - 1);                      // this lane's feature of a row segment (clamped into the row)
+    const int64_t g0 = (int64_t)slice * groups_per_slice;
+    const int64_t g1 = min(G, g0 + groups_per_slice);
+    int32_t* ids_l = reinterpret_cast<int32_t*>(xs + NBUF * STAGE);
+    const int chunk_groups = max(1, GS_SPD_IDS_CAP / s);
+    float acc[GS_SPW_FB];
+#pragma unroll
+    for (int f = 0; f < GS_SPW_FB; ++f) acc[f] = 0.f;
+    const unsigned xs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)xs;
+
+    for (int64_t gc = g0; gc < g1; gc += chunk_groups) {
+        const int64_t ge = min(g1, gc + chunk_groups);
+        const int ng = (int)(ge - gc);
+        __syncthreads();                                         // the previous chunk's ids / stages are no longer read
+        for (int i = tid; i < ng * s; i += 512) ids_l[i] = ids[gc * s + i];
+        __syncthreads();
+        int id_nx[RPW];                                          // source rows of the NEXT issue (read from LDS one issue ahead)
+        auto read_ids = [&](const int gl) {
+            const int gq = min(gl, ng - 1);
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) id_nx[u] = __builtin_amdgcn_readfirstlane(ids_l[gq * s + min(wave + 8 * u, s - 1)]);   // wave-uniform: scalar row address
+        };
+        auto issue = [&](const int st, const int gl) {           // group gc + min(gl, ng - 1) -> stage st: RPW + 2 DMA per wave
+            const int64_t g = gc + min(gl, ng - 1);
+            float* sb = xs + st * STAGE;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u)
+                __builtin_amdgcn_global_load_lds(X + (int64_t)id_nx[u] * ldx + fcol,
+                                                 (lds_ptr_t)(sb + (wave + 8 * u) * GS_SPW_LDS_STRIDE), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(argmax + g * lda + cc, (lds_ptr_t)(sb + ROWS * GS_SPW_LDS_STRIDE + wave * 64), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(dpm + g * ldd + cc, (lds_ptr_t)(sb + ROWS * GS_SPW_LDS_STRIDE + 512 + wave * 64), 4, 0, 0);
+            read_ids(gl + 1);
+        };
+        read_ids(0);
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j) issue(j, j);
+        const int rounds = (ng + NBUF - 1) / NBUF;
+        for (int rd = 0; rd < rounds; ++rd) {
+#pragma unroll
+            for (int j = 0; j < NBUF; ++j) {
+                const int gl = rd * NBUF + j;                    // group gc + gl is consumed from stage j
+                // my part of group gl has landed: the two groups issued after it may still be in flight
+                if (RPW == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (RPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (RPW == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                    // ... and so has everybody's; stage (j + 3) % 4 (group gl - 1) is free
+                asm volatile("" ::: "memory");
+                issue((j + NBUF - 1) % NBUF, gl + NBUF - 1);
+                const float* sb = xs + j * STAGE;
+                const int a_cur = reinterpret_cast<const int32_t*>(sb + ROWS * GS_SPW_LDS_STRIDE)[tid];
+                const float v_ld = (sb + ROWS * GS_SPW_LDS_STRIDE + 512)[tid];
+                const float v = gl < ng ? v_ld : 0.f;            // a clamped (repeated) group adds nothing
+                // LDS byte address of the lane's arg-max row.  The reads are written as ds_read_b64 by hand: left to the compiler,
+                // pairs of them become ds_read2_b64, which moves HALF the bytes per LDS cycle (MI355X_MICROARCH.md, LDS table).
+                const unsigned row = xs_base + (unsigned)(j * STAGE + a_cur * GS_SPW_LDS_STRIDE) * 4u;
+#define GS_RD(xv, i, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xv[i]) : "v"(row), "i"(off) : "memory")
+#define GS_RD8(xv, o) GS_RD(xv, 0, o); GS_RD(xv, 1, o + 8); GS_RD(xv, 2, o + 16); GS_RD(xv, 3, o + 24); GS_RD(xv, 4, o + 32); \
+                      GS_RD(xv, 5, o + 40); GS_RD(xv, 6, o + 48); GS_RD(xv, 7, o + 56)
+                // the wait is tied to the eight destination registers ("+v"): the FMAs depend on ITS outputs, so neither the
+                // compiler nor the machine scheduler can hoist them above the wait (the reads land asynchronously).
+#define GS_WAIT(n, xv) asm volatile("s_waitcnt lgkmcnt(" #n ")" \
+                             : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]) \
+                             :: "memory")
+#define GS_FMA8(xv, base) _Pragma("unroll") for (int i = 0; i < 8; ++i) { acc[base + 2 * i] += v * xv[i].x; acc[base + 2 * i + 1] += v * xv[i].y; }
+                // (two batches in flight need 16 more registers and spill at the 128 VGPRs that keep two workgroups on a CU -- and a
+                //  spill reload is a VMEM operation the compiler waits for with vmcnt(0), which drains the DMA ring)
+                gs_f32x2 xa[8];
+                GS_RD8(xa, 0);
+                GS_WAIT(0, xa);
+                GS_FMA8(xa, 0)
+                GS_RD8(xa, 64);
+                GS_WAIT(0, xa);
+                GS_FMA8(xa, 16)
+                GS_RD8(xa, 128);
+                GS_WAIT(0, xa);
+                GS_FMA8(xa, 32)
+                GS_RD8(xa, 192);
+                GS_WAIT(0, xa);
+                GS_FMA8(xa, 48)
+#undef GS_FMA8
+#undef GS_WAIT
+#undef GS_RD8
+#undef GS_RD
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped look-ahead issues of the chunk's last groups
+    }
+    if (col_ok) {
+        float* dst = slabs + ((int64_t)slice * d + f0) * ld_slab + c;
+#pragma unroll
+        for (int f = 0; f < GS_SPW_FB; ++f)
+            if (f0 + f < d) dst[(int64_t)f * ld_slab] = acc[f];
+    }
+}
+
+template <int RPW>
+static void launch_spw_dma(dim3 grid, hipStream_t st, const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
+                           int32_t d, const int32_t* argmax, int64_t lda, const float* dpm, int64_t ldd, int32_t hidden, int64_t gps,
+                           float* slabs, int64_t ld_slab) {
+    const size_t lds = ((size_t)GS_SPD_NBUF * (8 * RPW * GS_SPW_LDS_STRIDE + 1024) + GS_SPD_IDS_CAP) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)maxpool_sparse_wgrad_dma_kernel<RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(maxpool_sparse_wgrad_dma_kernel<RPW>, grid, dim3(512), lds, st, X, ldx, ids, n_groups, s, d, argmax, lda, dpm,
+                       ldd, hidden, gps, slabs, ld_slab);
+}
+
 extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
                                        int32_t d, const int32_t* argmax, int64_t lda, const float* d_pooled_masked,
                                        int64_t ldd, int32_t hidden, int32_t n_slabs, float* slabs, int64_t ld_slab,
@@ -762,6 +910,14 @@ extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_
         hipLaunchKernelGGL(maxpool_sparse_wgrad_kernel<1>, grid, dim3(threads), (size_t)s * GS_SPW_FB * sizeof(float),
                            (hipStream_t)stream, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps,
                            slabs, ld_slab);
+    } else if (threads == 512 && s <= 32 && !getenv("GS_SPW_NO_DMA")) {
+        // the LDS-DMA pipeline (<= 62 KB of LDS: two workgroups per CU)
+        hipStream_t st = (hipStream_t)stream;
+        const int rpw = (s + 7) / 8;
+        if (rpw == 1) launch_spw_dma<1>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
+        else if (rpw == 2) launch_spw_dma<2>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
+        else if (rpw == 3) launch_spw_dma<3>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
+        else launch_spw_dma<4>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
     } else {
         // PF: float4 of a group's row segments per thread (16 s of them over the block's threads)
         if (s * (GS_SPW_FB / 4) <= threads)
