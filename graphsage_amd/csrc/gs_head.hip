@@ -758,13 +758,13 @@ __global__ __launch_bounds__(512) void maxpool_sparse_wgrad_cols_kernel(const fl
 // Arithmetic and summation order per (feature, column) are those of the form above: bit-identical slabs.
 #define GS_SPD_NBUF 4
 #define GS_SPD_IDS_CAP 3072     // sampled ids of a slice staged in LDS at a time (12 KB: 122 groups of 25)
-template <int RPW>              // row segments per wave and group: ceil(s / 8)
-__global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const float* __restrict__ X, int64_t ldx,
-                                                                        const int32_t* __restrict__ ids, int64_t G, int32_t s,
-                                                                        int32_t d, const int32_t* __restrict__ argmax,
-                                                                        int64_t lda, const float* __restrict__ dpm, int64_t ldd,
-                                                                        int32_t hidden, int64_t groups_per_slice,
-                                                                        float* __restrict__ slabs, int64_t ld_slab) {
+// DIAG (benchmarks/micro_spw.py only, wrong values): bit 0 = no LDS reads / FMAs, bit 1 = no DMA inside the loop, bit 2 = no
+// barrier inside the loop, bit 3 = row reads without FMAs, bit 4 = FMAs without row reads.
+template <int RPW, int DIAG>              // RPW: row segments per wave and group = ceil(s / 8)
+__device__ __forceinline__ void spw_dma_body(const float* __restrict__ X, int64_t ldx, const int32_t* __restrict__ ids, int64_t G,
+                                             int32_t s, int32_t d, const int32_t* __restrict__ argmax, int64_t lda,
+                                             const float* __restrict__ dpm, int64_t ldd, int32_t hidden, int64_t groups_per_slice,
+                                             float* __restrict__ slabs, int64_t ld_slab, const int slice, const int fb) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int NBUF = GS_SPD_NBUF;
     constexpr int ROWS = 8 * RPW;                                // row slots of a stage (>= s)
@@ -772,7 +772,6 @@ __global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const 
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [NBUF][STAGE] | int32 ids[GS_SPD_IDS_CAP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slice = blockIdx.y, fb = blockIdx.x;
     const int f0 = fb * GS_SPW_FB;
     const int c = blockIdx.z * 512 + tid;
     const bool col_ok = c < hidden;
@@ -819,13 +818,15 @@ __global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const 
             for (int j = 0; j < NBUF; ++j) {
                 const int gl = rd * NBUF + j;                    // group gc + gl is consumed from stage j
                 // my part of group gl has landed: the two groups issued after it may still be in flight
-                if (RPW == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                if (DIAG & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (RPW == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else if (RPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (RPW == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                    // ... and so has everybody's; stage (j + 3) % 4 (group gl - 1) is free
+                if (!(DIAG & 4)) __builtin_amdgcn_s_barrier();   // ... and so has everybody's; stage (j + 3) % 4 (group gl - 1) is free
                 asm volatile("" ::: "memory");
-                issue((j + NBUF - 1) % NBUF, gl + NBUF - 1);
+                if (!(DIAG & 2)) issue((j + NBUF - 1) % NBUF, gl + NBUF - 1);
+                if (DIAG & 1) continue;
                 const float* sb = xs + j * STAGE;
                 const int a_cur = reinterpret_cast<const int32_t*>(sb + ROWS * GS_SPW_LDS_STRIDE)[tid];
                 const float v_ld = (sb + ROWS * GS_SPW_LDS_STRIDE + 512)[tid];
@@ -845,6 +846,21 @@ __global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const 
                 // (two batches in flight need 16 more registers and spill at the 128 VGPRs that keep two workgroups on a CU -- and a
                 //  spill reload is a VMEM operation the compiler waits for with vmcnt(0), which drains the DMA ring)
                 gs_f32x2 xa[8];
+                if (DIAG & 16) {                                 // diagnostics: the FMAs without the row reads
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xa[i] = gs_f32x2{v, __int_as_float(a_cur)};
+                    GS_FMA8(xa, 0) GS_FMA8(xa, 16) GS_FMA8(xa, 32) GS_FMA8(xa, 48)
+                    continue;
+                }
+                if (DIAG & 8) {                                  // diagnostics: the row reads without the FMAs
+#define GS_USE8(xv) _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(xv[i]));
+                    GS_RD8(xa, 0); GS_WAIT(0, xa); GS_USE8(xa)
+                    GS_RD8(xa, 64); GS_WAIT(0, xa); GS_USE8(xa)
+                    GS_RD8(xa, 128); GS_WAIT(0, xa); GS_USE8(xa)
+                    GS_RD8(xa, 192); GS_WAIT(0, xa); GS_USE8(xa)
+#undef GS_USE8
+                    continue;
+                }
                 GS_RD8(xa, 0);
                 GS_WAIT(0, xa);
                 GS_FMA8(xa, 0)
@@ -873,17 +889,34 @@ __global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const 
     }
 }
 
-template <int RPW>
+// Measured on an MI355X at the Reddit shape (benchmarks/micro_spw.py, gpurun_out/r5q-r5s; 5120 groups x 25, cold rows):
+//   this kernel 142 us (117 us inside the step, where the rows are warm) vs 152 (149) for the register-staged form;
+//   DMA only 85 us = 577 MB at 6.8 TB/s (rows 308 MB + arg-max / values 21 MB x 10 feature blocks + slabs 59 MB);
+//   row reads only 68 us, FMAs only 45 us, both 88 us, both without the barrier 88 us: LDS reads and FMAs of the
+//   same CU add up instead of overlapping, the barrier costs nothing.
+// Tried on top and not kept (bit-identical slabs, no gain): the feature blocks of a slice on ONE XCD (arg-max / values from L2:
+// DMA only 74 us, whole kernel 143 vs 142 us); two batches of eight reads in flight at one workgroup per CU (173 us).
+template <int RPW, int DIAG>
+__global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                        const int32_t* __restrict__ ids, int64_t G, int32_t s,
+                                                                        int32_t d, const int32_t* __restrict__ argmax,
+                                                                        int64_t lda, const float* __restrict__ dpm, int64_t ldd,
+                                                                        int32_t hidden, int64_t groups_per_slice,
+                                                                        float* __restrict__ slabs, int64_t ld_slab) {
+    spw_dma_body<RPW, DIAG>(X, ldx, ids, G, s, d, argmax, lda, dpm, ldd, hidden, groups_per_slice, slabs, ld_slab, blockIdx.y, blockIdx.x);
+}
+
+template <int RPW, int DIAG = 0>
 static void launch_spw_dma(dim3 grid, hipStream_t st, const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
                            int32_t d, const int32_t* argmax, int64_t lda, const float* dpm, int64_t ldd, int32_t hidden, int64_t gps,
                            float* slabs, int64_t ld_slab) {
     const size_t lds = ((size_t)GS_SPD_NBUF * (8 * RPW * GS_SPW_LDS_STRIDE + 1024) + GS_SPD_IDS_CAP) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)maxpool_sparse_wgrad_dma_kernel<RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)maxpool_sparse_wgrad_dma_kernel<RPW, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(maxpool_sparse_wgrad_dma_kernel<RPW>, grid, dim3(512), lds, st, X, ldx, ids, n_groups, s, d, argmax, lda, dpm,
+    hipLaunchKernelGGL((maxpool_sparse_wgrad_dma_kernel<RPW, DIAG>), grid, dim3(512), lds, st, X, ldx, ids, n_groups, s, d, argmax, lda, dpm,
                        ldd, hidden, gps, slabs, ld_slab);
 }
 
@@ -917,7 +950,17 @@ extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_
         if (rpw == 1) launch_spw_dma<1>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
         else if (rpw == 2) launch_spw_dma<2>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
         else if (rpw == 3) launch_spw_dma<3>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
-        else launch_spw_dma<4>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
+        else {
+            static const int diag = getenv("GS_SPW_DIAG") ? atoi(getenv("GS_SPW_DIAG")) : 0;     // benchmarks/micro_spw.py
+#define GS_SPW_V(...) launch_spw_dma<__VA_ARGS__>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab)
+            if (diag == 1) GS_SPW_V(4, 1);                       // DMA + barriers only
+            else if (diag == 2) GS_SPW_V(4, 2);                  // compute only
+            else if (diag == 6) GS_SPW_V(4, 6);                  // ... without the barrier
+            else if (diag == 14) GS_SPW_V(4, 14);                // ... row reads only
+            else if (diag == 22) GS_SPW_V(4, 22);                // ... FMAs only
+#undef GS_SPW_V
+            else launch_spw_dma<4>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
+        }
     } else {
         // PF: float4 of a group's row segments per thread (16 s of them over the block's threads)
         if (s * (GS_SPW_FB / 4) <= threads)

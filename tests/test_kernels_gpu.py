@@ -414,7 +414,12 @@ def test_pool_max_on_unique_ids_equals_fused_launch(dev, groups, d, hid):
 
 
 @pytest.mark.parametrize("n,s,d,hid,k", [(203, 25, 602, 512, 7), (37, 10, 50, 128, 5), (9, 3, 70, 100, 2),
-                                          (64, 16, 33, 64, 3), (21, 25, 40, 1100, 2)])
+                                          (64, 16, 33, 64, 3), (21, 25, 40, 1100, 2),
+                                          # the LDS-DMA pipeline (hidden >= 512, s <= 32): 1, 2, 3, 4 row segments per wave, a slice
+                                          # longer than the ids staged in LDS at a time (300 groups x 25 > 3072 ids: three chunks),
+                                          # fewer groups than pipeline stages, a ragged last slice, s = 32
+                                          (50, 3, 602, 512, 3), (512, 10, 602, 512, 16), (77, 20, 130, 640, 4), (600, 25, 100, 512, 2),
+                                          (2, 25, 64, 512, 1), (3, 8, 65, 512, 2), (45, 32, 70, 512, 4)])
 def test_maxpool_sparse_wgrad(dev, n, s, d, hid, k):
     """dW = X[ids]^T . dH with dH one-hot per (group, column) == the dense product, without ever forming dH."""
     rng = np.random.default_rng(29)
