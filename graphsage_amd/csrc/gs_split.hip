@@ -527,6 +527,181 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledAr
     }
 }
 
+// Wide form (round 5): workgroup = 128 rows x 256 columns, 8 waves = 2 (rows of 64) x 4 (columns of 64), wave tile 64 x 64 = four
+// MFMA tiles with an h-h and a small-terms accumulator each (128 accumulator registers).  Why: in the 128 x 128 form above a
+// wave reads 18 fragments (ds_read_b128) and the workgroup writes 48 (ds_write_b128) per 24 MFMAs and wave -- the LDS pipe is
+// ~78 % busy (576 read + 624 write cycles per 1536 matrix-pipe cycles of a stage) and the matrix pipe reaches 0.36 of its roof.
+// Here a wave reads 24 fragments per 48 MFMAs, the A rows are cut once per 256 instead of 128 output columns (44 VALU per
+// 48 MFMAs) and the workgroup's LDS traffic is 768 read + 936 write cycles per 3072 matrix-pipe cycles: ~55 %.
+// Stage = 32 k as above; the B registers are single-buffered (W3 is L2-resident; a stage now lasts twice as long), the A
+// registers keep their two sets.  Same piece products in the same order per accumulator: bit-identical to the 128 x 128 form.
+__global__ __launch_bounds__(512) void split_tiled_fwd_wide_kernel(const SplitTiledArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_PLANE = 128 * ST_LDA * 2;                 // bytes
+    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 12 * 256 * 16, BUF = A_BYTES + B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
+    const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
+    const int nwg = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nwg) return;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 256;
+    const int K = g.K, N = g.N;
+    const int stages = (K + 31) >> 5;
+    const int arow = tid >> 2, aq = tid & 3;                   // A: row of the tile, 8-float quarter of the stage
+    const int grow = min(m0 + arow, count - 1);
+    const int64_t srow = g.idx ? (int64_t)g.idx[grow] : (int64_t)grow;
+    const int bcol = tid & 255, bch = wave >> 2;               // B: column of the tile, chunks bch, bch + 2, ... (12 per stage, 6 per thread)
+    const int bc = min(n0 + bcol, N - 1);
+    const char* __restrict__ W3b = (const char*)g.W3;
+    const uint32_t bcol_off = (uint32_t)bc * 16u, plane_b = (uint32_t)N * 16u;
+    f32x4 ra[2][2];
+    u32x4 rb[6];
+    const int stages2 = (stages + 1) & ~1;
+    const int K4 = ((K + 3) >> 2) << 2;
+    auto gload_a = [&](const int set, const int s) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int k = min(32 * s + 8 * aq + 4 * v, K4 - 4);
+            ra[set][v] = *reinterpret_cast<const f32x4*>(g.X + srow * g.ldx + k);
+        }
+    };
+    auto gload_b = [&](const int s) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int c = bch + 2 * j;
+            const uint32_t off = (uint32_t)(12 * min(s, stages2 - 1) + c) * plane_b + bcol_off;
+            rb[j] = *reinterpret_cast<const u32x4*>(W3b + off);
+        }
+    };
+    auto lds_store_a = [&](const int set, const int s, unsigned char* buf) {
+        f32x4 x[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int k = 32 * s + 8 * aq + 4 * v;
+            x[v].x = k < K ? ra[set][v].x : 0.f;
+            x[v].y = k + 1 < K ? ra[set][v].y : 0.f;
+            x[v].z = k + 2 < K ? ra[set][v].z : 0.f;
+            x[v].w = k + 3 < K ? ra[set][v].w : 0.f;
+        }
+        u32x4 h0, m0_, l0;
+        gs_split8(x[0], x[1], h0, m0_, l0);
+        unsigned char* pa = buf + (arow * ST_LDA + 8 * aq) * 2;
+        *reinterpret_cast<u32x4*>(pa) = h0;
+        *reinterpret_cast<u32x4*>(pa + A_PLANE) = m0_;
+        *reinterpret_cast<u32x4*>(pa + 2 * A_PLANE) = l0;
+    };
+    auto lds_store_b = [&](unsigned char* buf) {
+        unsigned char* pb = buf + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(pb + ((bch + 2 * j) * 256 + bcol) * 16) = rb[j];
+    };
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x16 acc[2][2], sml[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; sml[i][j][e] = 0.f; }
+    auto compute = [&](const unsigned char* buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fa[i][p] = *reinterpret_cast<const u32x4*>(buf + p * A_PLANE + ((64 * wm + 32 * i + l31) * ST_LDA + 16 * q + 8 * lh) * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fb[j][p] = *reinterpret_cast<const u32x4*>(buf + A_BYTES + (((2 * q + lh) * 3 + p) * 256 + 64 * wn + 32 * j + l31) * 16);
+            // piece product outermost, the four tiles innermost: no MFMA accumulates into the result of the one issued before it
+#define GS_PP(dst, pa, pb) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+                               dst[i][j] = gs_mfma_bf16(fa[i][pa], fb[j][pb], dst[i][j]);
+            GS_PP(sml, 0, 2)     // h l
+            GS_PP(sml, 2, 0)     // l h
+            GS_PP(sml, 1, 1)     // m m
+            GS_PP(sml, 0, 1)     // h m
+            GS_PP(sml, 1, 0)     // m h
+            GS_PP(acc, 0, 0)     // h h
+#undef GS_PP
+        }
+    };
+    // pipeline: stage s computes from LDS buffer s & 1; the B chunks of stage s + 1 are requested at the top of stage s (BEFORE the
+    // A rows of stage s + 2: vmcnt retires in order, so the wait for B must not stand behind the younger A request), stage s + 1
+    // is cut / copied into the other buffer behind the MFMAs.
+    gload_a(0, 0);
+    gload_b(0);
+    gload_a(1, 1);
+    lds_store_a(0, 0, smem);
+    lds_store_b(smem);
+    __syncthreads();
+    for (int s = 0; s < stages2; s += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int ss = s + par;
+            unsigned char* cur = smem + par * BUF;
+            unsigned char* nxt = smem + (par ^ 1) * BUF;
+            gload_b(ss + 1);
+            gload_a(par, ss + 2);
+            compute(cur);
+            lds_store_a(par ^ 1, ss + 1, nxt);
+            lds_store_b(nxt);
+#pragma unroll
+            for (int q = 0; q < 48; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
+                if (q < 12) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // two LDS reads
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                // three VALU
+                    __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                // an LDS read or write
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // bias + activation, then through a wave-private LDS region (free after the last barrier) so that a lane stores 16 contiguous
+    // bytes of a row; the wave's two row halves go through the same region one after the other
+    float* otile = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + l31;
+            const float bv = (g.bias && col < N) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = (acc[i][j][e] + sml[i][j][e]) + bv;
+                if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                otile[((e & 3) + 8 * (e >> 2) + 4 * lh) * 68 + 32 * j + l31] = v;
+            }
+        }
+        const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+        const int colg = n0 + 64 * wn + c4;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = 4 * it + r0;
+            const int row = m0 + 64 * wm + 32 * i + r;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(otile + r * 68 + c4);
+            if (row < count) {
+                float* dst = g.out + (int64_t)row * g.ldo + colg;
+                if (colg + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+                else {
+                    if (colg < N) dst[0] = v.x;
+                    if (colg + 1 < N) dst[1] = v.y;
+                    if (colg + 2 < N) dst[2] = v.z;
+                }
+            }
+        }
+    }
+}
+
 extern "C" int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
                                        const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
                                        void* stream) {
@@ -537,6 +712,19 @@ extern "C" int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_
     GS_REQUIRE(ldo % 4 == 0 && gs_aligned16(out), "gs_dense_fwd_rows_split: out must be 16-byte aligned with ldo % 4 == 0");
     GS_REQUIRE(split_rows_bytes(d, out_dim) < (1ll << 32), "gs_dense_fwd_rows_split: W3 must stay below 4 GB");
     SplitTiledArgs g = {X, idx, (const u32x4*)W3, bias, out, n_dev, ldx, ldo, (int32_t)n_max, d, out_dim, act};
+    static const int wide_min = getenv("GS_SPLIT_WIDE_MIN_N") ? atoi(getenv("GS_SPLIT_WIDE_MIN_N")) : 256;       // 0 = never
+    if (wide_min > 0 && out_dim >= wide_min) {
+        const int64_t wblocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 256);
+        const size_t wlds = 2 * (3 * 128 * ST_LDA * 2 + 12 * 256 * 16);
+        static bool wattr_set = false;
+        if (!wattr_set) {
+            GS_HIP(hipFuncSetAttribute((const void*)split_tiled_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+            wattr_set = true;
+        }
+        hipLaunchKernelGGL(split_tiled_fwd_wide_kernel, dim3((unsigned)wblocks), dim3(512), wlds, (hipStream_t)stream, g);
+        GS_LAUNCH_CHECK("split_tiled_fwd_wide_kernel");
+        return GS_OK;
+    }
     const int64_t blocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 128);
     const size_t lds = 2 * (3 * 128 * ST_LDA * 2 + 12 * 128 * 16);
     static bool attr_set = false;
