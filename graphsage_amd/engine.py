@@ -97,6 +97,9 @@ class Engine(object):
         self._wgrad_max_slabs = int(os.environ.get("GS_WGRAD_MAX_SLABS", 32))
         self._wgrad_big_n = int(os.environ.get("GS_WGRAD_BIG_N", 16384))
         self._stream_max_slabs = int(os.environ.get("GS_STREAM_MAX_SLABS", 32))
+        # contraction waves of ONE round: one per SIMD (4 per CU); the stream weight-gradient launch is cut to fit it (launch_wgrads)
+        self._stream_wave_slots = int(os.environ.get("GS_STREAM_WAVE_SLOTS", 0)) or (
+            4 * torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 1024)
         self._stream_slice_rows = float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))
         self._stream_wide_rows = os.environ.get("GS_STREAM_WIDE_ROWS", "0") == "1"
         self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)
@@ -271,6 +274,28 @@ class Engine(object):
             ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
         return ok, ks
 
+    def _fit_one_round(self, ks_list):
+        """The stream weight-gradient launch runs one contraction WAVE per (64 x 64 tile, slice) and a wave holds its SIMD for its
+        whole slice: with between one and two waves per SIMD the launch takes TWO wave times although the second round is mostly
+        empty (unsupervised Reddit step: 40 tiles x 32 slices = 1280 waves of 359 rows on 1024 SIMDs = 2 x 359 row times;
+        25 slices = 1000 waves of 460 rows = 1 x 460 -- and 7 fewer slabs for the optimizer launch to sum: 186.9 vs 190.0
+        us/step, gpurun_out/r5z).  Slab counts of the problems that are cut at all are scaled down to fit one round when that
+        keeps a row-gathered problem's slices within the 510 rows its offsets have registers for; launches beyond ~2 rounds
+        are left alone (the quantisation matters less and less)."""
+        slots = self._stream_wave_slots
+        waves = sum(p[6] * k for p, k in zip(self._pending, ks_list))
+        if not (slots < waves < 1.8 * slots):
+            return ks_list
+        fixed = sum(p[6] * k for p, k in zip(self._pending, ks_list) if k <= 1)
+        f = (slots - fixed) / float(max(1, waves - fixed))
+        out = []
+        for (var, A, a_idx, dZ, col0, n, tiles), k in zip(self._pending, ks_list):
+            k2 = max(1, int(k * f)) if k > 1 else k
+            if a_idx is not None and (n + k2 - 1) // k2 > 510:
+                return ks_list                    # a gathered problem would outgrow its slice: keep the launch as it was
+            out.append(k2)
+        return out
+
     def _assign_slabs(self, ks_list):
         """Pending problems -> gs_wgrad_desc list with slabs assigned behind what each variable already holds.  ks_list: the
         slab count of every pending problem, decided by launch_wgrads (stream policy, or None = tiled policy)."""
@@ -328,6 +353,8 @@ class Engine(object):
             stream = stream and ok
             ks_list.append(ks)
             reserved[id(v)] = reserved.get(id(v), 0) + ks
+        if stream:
+            ks_list = self._fit_one_round(ks_list)
         pending = self._assign_slabs(ks_list if stream else [None] * len(self._pending))
         if stream:
             jobs = list(side_jobs or ())
