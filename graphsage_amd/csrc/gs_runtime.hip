@@ -57,6 +57,14 @@ extern "C" int gs_stream_destroy(void* stream) {
     return GS_OK;
 }
 extern "C" int gs_stream_sync(void* stream) {
+    // GS_SYNC_SPIN=1 (diagnostics, benchmarks/r5_launch_probe.sh): poll the stream instead of sleeping on its completion signal
+    static const bool spin = getenv("GS_SYNC_SPIN") && atoi(getenv("GS_SYNC_SPIN")) != 0;
+    if (spin) {
+        hipError_t q;
+        while ((q = hipStreamQuery((hipStream_t)stream)) == hipErrorNotReady) { }
+        GS_HIP(q);
+        return GS_OK;
+    }
     GS_HIP(hipStreamSynchronize((hipStream_t)stream));
     return GS_OK;
 }
@@ -70,7 +78,10 @@ extern "C" int gs_capture_end(void* stream, void** graph_exec_out) {
     hipGraph_t graph = nullptr;
     GS_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
     hipGraphExec_t exec = nullptr;
-    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    // GS_GRAPH_INSTANTIATE_FLAGS (diagnostics): hipGraphInstantiateFlags, e.g. 2 = upload the executable graph at instantiation
+    static const int inst_flags = getenv("GS_GRAPH_INSTANTIATE_FLAGS") ? atoi(getenv("GS_GRAPH_INSTANTIATE_FLAGS")) : 0;
+    hipError_t e = inst_flags ? hipGraphInstantiateWithFlags(&exec, graph, (unsigned long long)inst_flags)
+                              : hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);  // the executable graph keeps what it needs
     if (e != hipSuccess) {
         gs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
