@@ -77,7 +77,7 @@ def pool():
     X = Mat(torch.randn((N + 1, 608), generator=g).to(dev), F)
     X.buf[:, F:] = 0
     rows = 133120
-    ids = torch.sort(torch.randperm(N, generator=g)[:83000]).values.to(torch.int32).to(dev)
+    ids = torch.sort(torch.randperm(N, generator=g)[:100000]).values.to(torch.int32).to(dev)
     cnt = torch.tensor([83000], dtype=torch.int32, device=dev)
     W = Mat(torch.randn((F, H), generator=g).to(dev) * 0.05, H)
     b = torch.zeros(H, device=dev)
@@ -88,9 +88,57 @@ def pool():
                                                        H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, s), s, iters=10, warmup=3)
     r["pool_split_tiled_us"] = timeit(lambda: ops.call("gs_dense_fwd_rows_split", X.ptr, X.ld, ops.ptr(ids), F, rows, ops.ptr(cnt), ops.ptr(W3),
                                                         H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, s), s, iters=10, warmup=3)
+    ws = torch.empty(ops.split_tiled_ws_words(), dtype=torch.float32, device=dev)
+    # row counts around the Reddit step's distinct ids: 1300 tiles (83 k), an exact multiple of 256 (81,920), and in between
+    for c in (83000, 81920, 84500, 90000, 98000):
+        cnt.fill_(c)
+        r["pool_split_tiled_%d_us" % c] = timeit(lambda: ops.call("gs_dense_fwd_rows_split", X.ptr, X.ld, ops.ptr(ids), F, rows, ops.ptr(cnt), ops.ptr(W3),
+                                                                   H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, s), s, iters=10, warmup=3)
+        r["pool_split_tiled_ws_%d_us" % c] = timeit(lambda: ops.call("gs_dense_fwd_rows_split_ws", X.ptr, X.ld, ops.ptr(ids), F, rows, ops.ptr(cnt),
+                                                                      ops.ptr(W3), H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, ops.ptr(ws),
+                                                                      4 * ws.numel(), s), s, iters=10, warmup=3)
+    X2, rexp = ops.split_table_f16(X, stream=s)
+    W2 = ops.split_rows_f16(W, stream=s)
+    for c in (83000, 81920, 90000):
+        cnt.fill_(c)
+        r["pool_split16_%d_us" % c] = timeit(lambda: ops.call("gs_dense_fwd_rows_split16", ops.ptr(X2), ops.ptr(rexp), ops.ptr(ids), F, rows, ops.ptr(cnt),
+                                                               ops.ptr(W2), H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, None, 0, s), s, iters=10, warmup=3)
+        r["pool_split16_ws_%d_us" % c] = timeit(lambda: ops.call("gs_dense_fwd_rows_split16", ops.ptr(X2), ops.ptr(rexp), ops.ptr(ids), F, rows, ops.ptr(cnt),
+                                                                  ops.ptr(W2), H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, ops.ptr(ws),
+                                                                  4 * ws.numel(), s), s, iters=10, warmup=3)
     r["GF"] = 2.0 * 83000 * F * H / 1e9
     print(json.dumps(r, indent=1))
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pool":
     pool()
+
+
+def poolloop(seconds=24.0):
+    """The pooling MLP in a loop for `seconds` (benchmarks/r5_clock_probe.sh polls rocm-smi meanwhile)."""
+    import time
+    dev = torch.device("cuda:0")
+    st = ops.Stream()
+    s = st.handle
+    N, F, H = 232965, 602, 512
+    g = torch.Generator(device="cpu").manual_seed(0)
+    X = Mat(torch.randn((N + 1, 608), generator=g).to(dev), F)
+    X.buf[:, F:] = 0
+    rows = 133120
+    ids = torch.sort(torch.randperm(N, generator=g)[:100000]).values.to(torch.int32).to(dev)
+    cnt = torch.tensor([81920], dtype=torch.int32, device=dev)
+    W = Mat(torch.randn((F, H), generator=g).to(dev) * 0.05, H)
+    b = torch.zeros(H, device=dev)
+    W3 = ops.split_rows(W, stream=s)
+    out = Mat.zeros(rows, H, dev)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < seconds:
+        us = timeit(lambda: ops.call("gs_dense_fwd_rows_split", X.ptr, X.ld, ops.ptr(ids), F, rows, ops.ptr(cnt), ops.ptr(W3),
+                                      H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, s), s, iters=200, warmup=0)
+        n += 1
+        print("t=%.2fs: %.1f us per launch (81,920 rows = five full rounds)" % (time.time() - t0, us), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "poolloop":
+    poolloop()

@@ -15,7 +15,7 @@ ACT_RELU = 1
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
 SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
 GS_PEER_HANDLE_BYTES = 64
-GS_ABI_VERSION = 7      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+GS_ABI_VERSION = 8      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -94,6 +94,13 @@ _PROTOS = {
     "gs_split_rows_bytes": [c_int32, c_int32, _P],
     "gs_split_rows": [_P, c_int64, c_int32, c_int32, _P, _P],
     "gs_dense_fwd_rows_split": [_P, c_int64, _P, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P],
+    "gs_split_rows_f16_bytes": [c_int32, c_int32, _P],
+    "gs_split_rows_f16": [_P, c_int64, c_int32, c_int32, _P, _P],
+    "gs_split_table_f16_bytes": [c_int64, c_int32, _P, _P],
+    "gs_split_table_f16": [_P, c_int64, c_int64, c_int32, _P, _P, _P],
+    "gs_dense_fwd_rows_split16": [_P, _P, _P, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P, c_int64, _P],
+    "gs_dense_fwd_rows_split_ws_bytes": [_P],
+    "gs_dense_fwd_rows_split_ws": [_P, c_int64, _P, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P, c_int64, _P],
     "gs_sage_dense_fwd_split": [_P, c_int64, _P, _P, c_int64, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P,
                                 c_int32, _P],
     "gs_flat_reduce_adam_sample": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,

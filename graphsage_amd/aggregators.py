@@ -571,11 +571,21 @@ class _PoolingAggregator(_SageBase):
                      ops.ptr(inv), ops.ptr(cnt), e.stream)
             Hu = e.ws_mat((self.name, "H_unique", k), rows_total, self.hidden_dim)
             W, bmlp = mlp.vars['weights'].value, mlp.vars['bias'].value.buf
-            if e.split_pool:
+            if e.split_pool and e.pool_f16 and not x_all.requires_grad:
+                # ... on the fp16 matrix pipe, operands as two fp16 pieces each (fp32 accuracy class, half the matrix-pipe work of
+                # the three-piece form below, which is bound by the chip's POWER cap): the constant feature table is cut once
+                X2, rexp = e.table16_of(X)
+                ws = e.ws_f32((self.name, "split_ws"), ops.split_tiled_ws_words())
+                ops.call("gs_dense_fwd_rows_split16", ops.ptr(X2), ops.ptr(rexp), ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt),
+                         ops.ptr(e.split_of(mlp.vars['weights'], form="f16x2")), self.hidden_dim, ACT_RELU, ops.ptr(bmlp),
+                         Hu.ptr, Hu.ld, ops.ptr(ws), 4 * ws.numel(), e.stream)
+            elif e.split_pool:
                 # the 51 GF of the pooling MLP on the bf16 matrix pipe, operands as three bf16 pieces (fp32 accuracy)
-                ops.call("gs_dense_fwd_rows_split", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt),
+                # (+ a workspace: the last, nearly empty round of its one-per-CU workgroups is cut along K, gs_split.hip)
+                ws = e.ws_f32((self.name, "split_ws"), ops.split_tiled_ws_words())
+                ops.call("gs_dense_fwd_rows_split_ws", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt),
                          ops.ptr(e.split_of(mlp.vars['weights'])), self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld,
-                         e.stream)
+                         ops.ptr(ws), 4 * ws.numel(), e.stream)
             else:
                 ops.call("gs_dense_fwd_rows_dev", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt), W.ptr, W.ld,
                          self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld, e.stream)

@@ -344,7 +344,28 @@ struct SplitTiledArgs {
     const float* X; const int32_t* idx; const u32x4* W3; const float* bias; float* out; const int32_t* n_dev;
     int64_t ldx, ldo;
     int32_t n_max, K, N, act;
+    float* ws;            // wide form: partial tiles of the split-K tail round (nullable: no split), [<= n_cu][128][256]
+    int32_t n_cu;         // ... and the number of workgroup slots of the chip (one workgroup per CU: 156 KB of LDS)
 };
+
+// Tail round of the wide form.  Its workgroups run one per CU in lock step (equal work, 156 KB of LDS each), so nwg = 1300 tiles
+// on 256 CUs are SIX rounds of which the last one keeps 20 CUs busy: 346 us for 5.08 rounds of work.  With a workspace the
+// rem = nwg % n_cu tiles of the last round are cut along K into S = min(stage pairs, n_cu / rem) parts -- rem * S workgroups
+// that write fp32 partial tiles (no bias / activation) -- and split_tiled_fixup_kernel sums the S parts of a tile in part order
+// (deterministic) behind it.  Tiles [0, full) are computed as before.
+struct WideSchedule { int full, rem, S; };
+__device__ __host__ __forceinline__ WideSchedule wide_schedule(const int nwg, const int stages2, const int n_cu, const bool have_ws) {
+    WideSchedule w = {nwg, 0, 1};
+    if (have_ws && n_cu > 0) {
+        const int r = nwg % n_cu;
+        if (r > 0 && 2 * r <= n_cu) {
+            const int pairs = stages2 >> 1;
+            const int sp = pairs < n_cu / r ? pairs : n_cu / r;
+            if (sp >= 2) { w.full = nwg - r; w.rem = r; w.S = sp; }
+        }
+    }
+    return w;
+}
 
 __global__ __launch_bounds__(512) void split_tiled_fwd_kernel(const SplitTiledArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -544,13 +565,21 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_wide_kernel(const SplitTi
     const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
     const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
     const int nwg = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nwg) return;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
-    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 256;
     const int K = g.K, N = g.N;
     const int stages = (K + 31) >> 5;
+    const WideSchedule sch = wide_schedule(nwg, (stages + 1) & ~1, g.n_cu, g.ws != nullptr);
+    if ((int)blockIdx.x >= sch.full + sch.rem * sch.S) return;
+    int tile, part = -1;                                       // part >= 0: a K part of a tail-round tile (partial tile -> g.ws)
+    if ((int)blockIdx.x < sch.full) {
+        const int q8 = sch.full >> 3, r8 = sch.full & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    } else {
+        const int r = (int)blockIdx.x - sch.full;              // the S parts of a tile sit on S consecutive block ids
+        tile = sch.full + r / sch.S;
+        part = r - (r / sch.S) * sch.S;
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 256;
     const int arow = tid >> 2, aq = tid & 3;                   // A: row of the tile, 8-float quarter of the stage
     const int grow = min(m0 + arow, count - 1);
     const int64_t srow = g.idx ? (int64_t)g.idx[grow] : (int64_t)grow;
@@ -636,13 +665,21 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_wide_kernel(const SplitTi
     // pipeline: stage s computes from LDS buffer s & 1; the B chunks of stage s + 1 are requested at the top of stage s (BEFORE the
     // A rows of stage s + 2: vmcnt retires in order, so the wait for B must not stand behind the younger A request), stage s + 1
     // is cut / copied into the other buffer behind the MFMAs.
-    gload_a(0, 0);
-    gload_b(0);
-    gload_a(1, 1);
-    lds_store_a(0, 0, smem);
+    // (a K part of a tail-round tile covers the stage pairs [pairs part / S, pairs (part + 1) / S): the look-ahead loads past its
+    //  end are valid addresses whose values are written to LDS and never read)
+    int s_begin = 0, s_end = stages2;
+    if (part >= 0) {
+        const int pairs = stages2 >> 1;
+        s_begin = 2 * ((pairs * part) / sch.S);
+        s_end = 2 * ((pairs * (part + 1)) / sch.S);
+    }
+    gload_a(0, s_begin);
+    gload_b(s_begin);
+    gload_a(1, s_begin + 1);
+    lds_store_a(0, s_begin, smem);
     lds_store_b(smem);
     __syncthreads();
-    for (int s = 0; s < stages2; s += 2) {
+    for (int s = s_begin; s < s_end; s += 2) {
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             const int ss = s + par;
@@ -669,16 +706,18 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_wide_kernel(const SplitTi
     // bias + activation, then through a wave-private LDS region (free after the last barrier) so that a lane stores 16 contiguous
     // bytes of a row; the wave's two row halves go through the same region one after the other
     float* otile = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+    const bool partial = part >= 0;
+    float* wtile = partial ? g.ws + (int64_t)((int)blockIdx.x - sch.full) * (128 * 256) : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + 64 * wn + 32 * j + l31;
-            const float bv = (g.bias && col < N) ? g.bias[col] : 0.f;
+            const float bv = (!partial && g.bias && col < N) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = (acc[i][j][e] + sml[i][j][e]) + bv;
-                if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                if (!partial && g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
                 otile[((e & 3) + 8 * (e >> 2) + 4 * lh) * 68 + 32 * j + l31] = v;
             }
         }
@@ -689,7 +728,9 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_wide_kernel(const SplitTi
             const int r = 4 * it + r0;
             const int row = m0 + 64 * wm + 32 * i + r;
             const f32x4 v = *reinterpret_cast<const f32x4*>(otile + r * 68 + c4);
-            if (row < count) {
+            if (partial) {                                     // the whole 128 x 256 partial tile, dense (rows / columns past the end are finite and unused)
+                *reinterpret_cast<f32x4*>(wtile + (64 * wm + 32 * i + r) * 256 + 64 * wn + c4) = v;
+            } else if (row < count) {
                 float* dst = g.out + (int64_t)row * g.ldo + colg;
                 if (colg + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
                 else {
@@ -702,9 +743,73 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_wide_kernel(const SplitTi
     }
 }
 
+// out tile = act(sum of the S partial tiles of a tail-round tile, in part order, + bias): one workgroup per (tile, 32-row band)
+__global__ __launch_bounds__(256) void split_tiled_fixup_kernel(const SplitTiledArgs g) {
+    const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
+    const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
+    const int nwg = tiles_m * tiles_n;
+    const WideSchedule sch = wide_schedule(nwg, (((g.K + 31) >> 5) + 1) & ~1, g.n_cu, g.ws != nullptr);
+    const int t = (int)blockIdx.x >> 2, band = (int)blockIdx.x & 3;
+    if (t >= sch.rem) return;
+    const int tile = sch.full + t;
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 256;
+    const int c4 = ((int)threadIdx.x & 63) * 4;                 // 64 threads x 16 bytes = one 256-column row
+    const int colg = n0 + c4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+        if (colg < g.N) bv.x = g.bias[colg];
+        if (colg + 1 < g.N) bv.y = g.bias[colg + 1];
+        if (colg + 2 < g.N) bv.z = g.bias[colg + 2];
+        if (colg + 3 < g.N) bv.w = g.bias[colg + 3];
+    }
+    const float* base = g.ws + (int64_t)t * sch.S * (128 * 256);
+    for (int r = 32 * band + ((int)threadIdx.x >> 6); r < 32 * band + 32; r += 4) {
+        const int row = m0 + r;
+        if (row >= count) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + r * 256 + c4);
+        for (int p = 1; p < sch.S; ++p) v += *reinterpret_cast<const f32x4*>(base + (int64_t)p * (128 * 256) + r * 256 + c4);
+        v += bv;
+        if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        float* dst = g.out + (int64_t)row * g.ldo + colg;
+        if (colg + 3 < g.N) *reinterpret_cast<f32x4*>(dst) = v;
+        else {
+            if (colg < g.N) dst[0] = v.x;
+            if (colg + 1 < g.N) dst[1] = v.y;
+            if (colg + 2 < g.N) dst[2] = v.z;
+        }
+    }
+}
+
+static int dense_fwd_rows_split_impl(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
+                                     const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+                                     float* ws, int64_t ws_bytes, void* stream);
+
+extern "C" int gs_dense_fwd_rows_split_ws_bytes(int64_t* bytes_out_host) {
+    GS_REQUIRE(bytes_out_host, "gs_dense_fwd_rows_split_ws_bytes: null out");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    GS_HIP(hipGetDevice(&dev));
+    GS_HIP(hipGetDeviceProperties(&prop, dev));
+    *bytes_out_host = (int64_t)prop.multiProcessorCount * 128 * 256 * sizeof(float);
+    return GS_OK;
+}
+
+extern "C" int gs_dense_fwd_rows_split_ws(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max,
+                                          const int32_t* n_dev, const void* W3, int32_t out_dim, int act, const float* bias,
+                                          float* out, int64_t ldo, float* ws, int64_t ws_bytes, void* stream) {
+    return dense_fwd_rows_split_impl(X, ldx, idx, d, n_max, n_dev, W3, out_dim, act, bias, out, ldo, ws, ws_bytes, stream);
+}
+
 extern "C" int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
                                        const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
                                        void* stream) {
+    return dense_fwd_rows_split_impl(X, ldx, idx, d, n_max, n_dev, W3, out_dim, act, bias, out, ldo, nullptr, 0, stream);
+}
+
+static int dense_fwd_rows_split_impl(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
+                                     const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+                                     float* ws, int64_t ws_bytes, void* stream) {
     if (n_max == 0) return GS_OK;
     GS_REQUIRE(X && W3 && out && d > 0 && out_dim > 0 && n_max > 0 && n_max < (1ll << 30), "gs_dense_fwd_rows_split: bad args");
     GS_CHECK_MAT(X, ldx, "gs_dense_fwd_rows_split X");
@@ -714,15 +819,31 @@ extern "C" int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_
     SplitTiledArgs g = {X, idx, (const u32x4*)W3, bias, out, n_dev, ldx, ldo, (int32_t)n_max, d, out_dim, act};
     static const int wide_min = getenv("GS_SPLIT_WIDE_MIN_N") ? atoi(getenv("GS_SPLIT_WIDE_MIN_N")) : 256;       // 0 = never
     if (wide_min > 0 && out_dim >= wide_min) {
-        const int64_t wblocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 256);
+        int64_t wblocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 256);
         const size_t wlds = 2 * (3 * 128 * ST_LDA * 2 + 12 * 256 * 16);
         static bool wattr_set = false;
+        static int n_cu = 0;
         if (!wattr_set) {
             GS_HIP(hipFuncSetAttribute((const void*)split_tiled_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+            int dev = 0;
+            hipDeviceProp_t prop;
+            GS_HIP(hipGetDevice(&dev));
+            GS_HIP(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount;
             wattr_set = true;
         }
+        // split-K tail round (see wide_schedule): needs a workspace of one partial tile per CU
+        static const bool no_tail = getenv("GS_SPLIT_WIDE_TAIL") && atoi(getenv("GS_SPLIT_WIDE_TAIL")) == 0;     // A/B hook
+        const bool tail = ws && !no_tail && n_cu > 0 && ws_bytes >= (int64_t)n_cu * 128 * 256 * (int64_t)sizeof(float);
+        GS_REQUIRE(!ws || gs_aligned16(ws), "gs_dense_fwd_rows_split_ws: the workspace must be 16-byte aligned");
+        if (tail) { g.ws = ws; g.n_cu = n_cu; wblocks += n_cu; }
         hipLaunchKernelGGL(split_tiled_fwd_wide_kernel, dim3((unsigned)wblocks), dim3(512), wlds, (hipStream_t)stream, g);
         GS_LAUNCH_CHECK("split_tiled_fwd_wide_kernel");
+        if (tail) {
+            // at most n_cu / 2 tail tiles, four 32-row bands each (workgroups of tiles that do not exist return at once)
+            hipLaunchKernelGGL(split_tiled_fixup_kernel, dim3((unsigned)(2 * n_cu)), dim3(256), 0, (hipStream_t)stream, g);
+            GS_LAUNCH_CHECK("split_tiled_fixup_kernel");
+        }
         return GS_OK;
     }
     const int64_t blocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 128);

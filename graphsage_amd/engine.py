@@ -42,6 +42,7 @@ class Variable(object):
         # use, re-made after every update of the value
         self.split3 = None
         self.split_dirty = True
+        self.split_form = "bf16x3"   # or "f16x2": two fp16 pieces under a column scale (gs_split_rows_f16, the pooling MLP)
         self.engine = None  # set by Engine.add_variable
 
     @property
@@ -58,8 +59,15 @@ class Variable(object):
         if self.split3 is not None and self.engine is not None:
             # a captured step graph does not re-run split_of's Python: bring the bf16 pieces up to date right here
             torch.cuda.current_stream().synchronize()
-            ops.split_rows(self.value, out=self.split3, stream=self.engine.stream)
-            self.split_dirty = False
+            self.recut(self.engine.stream)
+
+    def recut(self, stream):
+        """Bring the cut copy of the value (split3) up to date, in the form its consumer reads."""
+        if self.split_form == "f16x2":
+            ops.split_rows_f16(self.value, out=self.split3, stream=stream)
+        else:
+            ops.split_rows(self.value, out=self.split3, stream=stream)
+        self.split_dirty = False
 
     def slab_ptr(self, k):
         return self.slabs.data_ptr() + 4 * k * self.size
@@ -103,6 +111,10 @@ class Engine(object):
         self._stream_slice_rows = float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))
         self._stream_wide_rows = os.environ.get("GS_STREAM_WIDE_ROWS", "0") == "1"
         self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)
+        self._table16 = {}                # constant feature tables cut into two fp16 pieces (table16_of)
+        # the pooling MLP on the fp16 matrix pipe with two-piece operands (gs_split16.hip): half the matrix-pipe work of the
+        # three-piece bf16 form, same accuracy class; needs a constant feature table (no trainable identity features)
+        self.pool_f16 = os.environ.get("GS_POOL_F16", "1") == "1"
         self._split_vars = []             # variables with a three-piece bf16 copy, re-cut behind every optimizer launch
         self._defer_sampler = False       # neigh_samplers.fanout: hand the launch to the next optimizer launch instead
         self._deferred_sampler = None
@@ -434,24 +446,35 @@ class Engine(object):
         host flag read at capture decided it before round 5 -- a train graph captured with the flag clean replayed the
         pooling MLP on stale pieces)."""
         for v in self._split_vars:
-            ops.split_rows(v.value, out=v.split3, stream=self.stream)
-            v.split_dirty = False
+            v.recut(self.stream)
         for hook in self.post_update_hooks:
             hook()
 
-    def split_of(self, var):
+    def split_of(self, var, form="bf16x3"):
         """The current three-piece copy of var.value^T (gs_split_rows).  Made on first use; from then on re-made behind every
         optimizer launch (_params_updated) and -- for values written from the host (Variable.assign sets split_dirty) --
         here.  A dirty flag met while capturing records one redundant re-cut in the graph, never a missing one."""
-        if var.split3 is None:
+        if var.split3 is None or var.split_form != form:
             K, N = var.rows, var.cols
-            var.split3 = torch.empty(ops.split_rows_words(K, N), dtype=torch.int32, device=self.device)
+            words = ops.split_rows_f16_words(K, N) if form == "f16x2" else ops.split_rows_words(K, N)
+            var.split3 = torch.empty(words, dtype=torch.int32, device=self.device)
+            var.split_form = form
             var.split_dirty = True
-            self._split_vars.append(var)
+            if var not in self._split_vars:
+                self._split_vars.append(var)
         if var.split_dirty:
-            ops.split_rows(var.value, out=var.split3, stream=self.stream)
-            var.split_dirty = False
+            var.recut(self.stream)
         return var.split3
+
+    def table16_of(self, X):
+        """The two-piece fp16 copy of a CONSTANT feature table (gs_split_table_f16): made once per table (keyed by its buffer), on
+        the first -- eager -- execution of a step; (X2, row exponents)."""
+        key = (X.ptr, X.rows, X.d, X.ld)
+        hit = self._table16.get(key)
+        if hit is None:
+            hit = ops.split_table_f16(X, stream=self.stream) + (X.buf,)      # (the table itself is kept alive with its copy)
+            self._table16[key] = hit
+        return hit[0], hit[1]
 
     def advance(self, step=0, clock=0, cursor=None, cursor_delta=0, loss_rows=None, n=0, loss_out=None, accumulate=False,
                 aux_rows=None, aux_out=None):

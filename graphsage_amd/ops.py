@@ -325,6 +325,20 @@ def split_rows_words(K, N):
     return int(n.value) // 4
 
 
+_SPLIT_WS_WORDS = None
+
+
+def split_tiled_ws_words():
+    """fp32 words of the workspace gs_dense_fwd_rows_split_ws wants (one 128 x 256 partial tile per CU)."""
+    global _SPLIT_WS_WORDS
+    if _SPLIT_WS_WORDS is None:
+        import ctypes
+        n = ctypes.c_int64()
+        call("gs_dense_fwd_rows_split_ws_bytes", ctypes.byref(n))
+        _SPLIT_WS_WORDS = int(n.value) // 4
+    return _SPLIT_WS_WORDS
+
+
 def split_rows(W, out=None, stream=None):
     """gs_split_rows: the three bf16 pieces of W^T ([groups of 8 k][3][N][8] bf16, as an int32 tensor) for the split-MFMA
     contractions; W is a Mat [K, N]."""
@@ -333,6 +347,36 @@ def split_rows(W, out=None, stream=None):
         out = torch.empty(split_rows_words(K, N), dtype=torch.int32, device=W.buf.device)
     call("gs_split_rows", W.ptr, W.ld, K, N, ptr(out), _s(stream))
     return out
+
+
+def split_rows_f16_words(K, N):
+    """int32 words of gs_split_rows_f16's output: the two fp16 pieces of the scaled weights + the column exponents."""
+    import ctypes
+    n = ctypes.c_int64()
+    call("gs_split_rows_f16_bytes", int(K), int(N), ctypes.byref(n))
+    return int(n.value) // 4
+
+
+def split_rows_f16(W, out=None, stream=None):
+    """gs_split_rows_f16: W [K, N] as two fp16 pieces per element under a power-of-two scale per COLUMN ([groups of 8 k][2][N][8]
+    fp16 + N int32 exponents, as an int32 tensor) for gs_dense_fwd_rows_split16."""
+    K, N = W.rows, W.d
+    if out is None:
+        out = torch.empty(split_rows_f16_words(K, N), dtype=torch.int32, device=W.buf.device)
+    call("gs_split_rows_f16", W.ptr, W.ld, K, N, ptr(out), _s(stream))
+    return out
+
+
+def split_table_f16(X, stream=None):
+    """gs_split_table_f16: a (constant) feature table as two fp16 pieces per element under a power-of-two scale per ROW.
+    Returns (X2 int32 tensor: [rows][2][KP] fp16, row exponents int32 [rows])."""
+    import ctypes
+    tb, eb = ctypes.c_int64(), ctypes.c_int64()
+    call("gs_split_table_f16_bytes", X.rows, X.d, ctypes.byref(tb), ctypes.byref(eb))
+    X2 = torch.empty(int(tb.value) // 4, dtype=torch.int32, device=X.buf.device)
+    rexp = torch.empty(int(eb.value) // 4, dtype=torch.int32, device=X.buf.device)
+    call("gs_split_table_f16", X.ptr, X.ld, X.rows, X.d, ptr(X2), ptr(rexp), _s(stream))
+    return X2, rexp
 
 
 def sage_dense_fwd_split(self_m, self_idx, agg, n, W3_self, W3_neigh, out_dim, act, bias, out, jobs, stream=None):

@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 7
+#define GS_ABI_VERSION 8
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -247,6 +247,43 @@ int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_des
 int gs_split_rows_bytes(int32_t K, int32_t N, int64_t* bytes_out_host);
 int gs_dense_fwd_rows_split(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
                             const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo, void* stream);
+/* gs_dense_fwd_rows_split with a workspace (ABI 8): the wide form's workgroups run one per CU in lock step, so a tile count
+ * that is not a multiple of the CU count ends in a round that keeps a few CUs busy (Reddit max-pool step: 1300 tiles on 256 CUs
+ * = six rounds for 5.08 rounds of work).  With ws (>= gs_dense_fwd_rows_split_ws_bytes, 16-byte aligned, contents undefined
+ * on entry and on return) the tiles of that last round are cut along K into up to ten parts whose fp32 partial tiles are summed
+ * in part order by a second, small launch: deterministic, same accuracy class, NOT bit-identical to the call without ws for
+ * the rows of those tiles (one more association of the same products).  ws = NULL: gs_dense_fwd_rows_split. */
+int gs_dense_fwd_rows_split_ws_bytes(int64_t* bytes_out_host);
+int gs_dense_fwd_rows_split_ws(const float* X, int64_t ldx, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
+                               const void* W3, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+                               float* ws, int64_t ws_bytes, void* stream);
+/* ---- The same contraction on the fp16 matrix pipe with TWO pieces per operand (ABI 8, csrc/gs_split16.hip).
+ * Why: the three-piece kernel runs the chip into its power cap (1400 W, engine clock down to 2.02 GHz:
+ * profiles/r05_pool_clock_probe.txt), and its ~310 G MACs are most of that energy.  Here x 2^e = h + m + r with h = fp16(x 2^e),
+ * m = fp16(x 2^e - h), round to nearest: |r| <= 2^-23 |x 2^e| -- at most ONE fp32 ulp: h keeps 11 bits, the residual has <= 12 of which
+ * m keeps 11 (2^-25 on average) -- under a power-of-two scale per feature-table
+ * row / weight column that puts its largest element at 2^13..2^14 (no overflow; m stays a normal fp16 for every element within
+ * 2^-15 of the largest; below that the absolute error is <= 2^-25 in scaled units, 2^-38 of the largest element).  A product is
+ * h h' + h m' + m h' (exact 11 x 11 bit products, fp32 accumulation; the dropped m m' is <= 2^-22 |x y| worst case, 2^-24 rms),
+ * the scales are taken out exactly in the epilogue.  Over a K-term dot product what is given up is a random walk of sqrt(K)
+ * 2^-23 against the K-term sum, one to two orders of magnitude below the rounding of the fp32 accumulation itself: measured
+ * against fp64 the outputs are as accurate as the three-piece kernel's and more accurate than an fp32 FMA chain
+ * (tests/test_split_gemm_gpu.py prints all three), at HALF the matrix-pipe work.  Inputs, outputs, accumulation: fp32; the
+ * three-piece form stays available (GS_POOL_F16=0) and bench.py reports the step with both.
+ *   gs_split_rows_f16: W [K, ldw >= N] fp32 -> W2 [KP / 8][2][N][8] fp16 + N int32 column exponents (KP = K rounded up to an even
+ *     count of 32-k stages, zero beyond K); call it after every update of W (Engine.split_of(form="f16x2") does).
+ *   gs_split_table_f16: a CONSTANT table X [rows, ldx >= d] -> X2 [rows][2][KP] fp16 + rows int32 row exponents, once (the
+ *     reference's features are a non-trainable tf.Variable: models.py:299); 2 x 2 bytes per element = the fp32 table's bytes.
+ *   gs_dense_fwd_rows_split16: out[i] = act(X[idx[i]] . W + bias), i < min(n_max, *n_dev), from X2 / W2 (aggregators.py:176-179 via
+ *     layers.py:104-116 on the step's distinct ids): 128 x 256 workgroup tiles, both operand tiles are plain copies global -> LDS,
+ *     24 MFMAs (v_mfma_f32_32x32x16_f16) per 16 fragment reads; ws as for gs_dense_fwd_rows_split_ws (nullable). */
+int gs_split_rows_f16_bytes(int32_t K, int32_t N, int64_t* bytes_out_host);
+int gs_split_rows_f16(const float* W, int64_t ldw, int32_t K, int32_t N, void* W2, void* stream);
+int gs_split_table_f16_bytes(int64_t rows, int32_t d, int64_t* table_bytes_out_host, int64_t* exp_bytes_out_host);
+int gs_split_table_f16(const float* X, int64_t ldx, int64_t rows, int32_t d, void* X2, int32_t* rexp, void* stream);
+int gs_dense_fwd_rows_split16(const void* X2, const int32_t* rexp, const int32_t* idx, int32_t d, int64_t n_max, const int32_t* n_dev,
+                              const void* W2, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo, float* ws,
+                              int64_t ws_bytes, void* stream);
 int gs_split_rows(const float* W, int64_t ldw, int32_t K, int32_t N, void* W3, void* stream);
 int gs_sage_dense_fwd_split(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg, int64_t ld_agg,
                             int32_t d, int64_t n, const void* W3_self, const void* W3_neigh, int32_t out_dim, int act,

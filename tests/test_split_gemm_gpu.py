@@ -199,3 +199,169 @@ def test_dense_fwd_rows_split(dev, n_max, count, d, out, act, bias):
     err32 = np.abs(ref[:count].astype(np.float64) - want[:count]).max() / rms
     print("d=%d: max error / rms vs fp64: fp32 MFMA kernel %.3g, split kernel %.3g" % (d, err32, err))
     assert err <= max(2.5 * err32, 5e-7) and err < 4e-6
+    # the same call with a workspace (ABI 8): the last round of the wide form's workgroups is cut along K (these shapes have fewer
+    # tiles than CUs: EVERY tile takes that path) -- deterministic, same accuracy class, rows beyond the count untouched
+    ws = torch.full((ops.split_tiled_ws_words(),), float("nan"), dtype=torch.float32, device=dev)
+    outs_ws = []
+    for rep in range(2):
+        o = Mat.zeros(n_max, out, dev)
+        o.buf.fill_(-7.0)
+        ops.call("gs_dense_fwd_rows_split_ws", Xd.ptr, Xd.ld, ops.ptr(ids_d), d, n_max, ops.ptr(cnt), ops.ptr(w3), out, act,
+                 ops.ptr(bd), o.ptr, o.ld, ops.ptr(ws), 4 * ws.numel(), ops.current_stream())
+        torch.cuda.synchronize()
+        outs_ws.append(o.numpy())
+    assert np.array_equal(outs_ws[0], outs_ws[1])
+    assert np.all(outs_ws[0][count:] == -7.0)
+    err_ws = np.abs(outs_ws[0][:count].astype(np.float64) - want[:count]).max() / rms
+    print("      with the split-K tail round: %.3g" % err_ws)
+    assert err_ws <= max(2.5 * err32, 5e-7) and err_ws < 4e-6
+
+
+def test_dense_fwd_rows_split_tail_round_mixes_whole_and_split_tiles(dev):
+    """More tiles than CUs: whole tiles in the full rounds, K parts + fix-up launch for the rest (the pooling MLP's situation: 1300
+    tiles on 256 CUs).  Against fp64 and against the call without a workspace: equal bits on the rows of whole tiles."""
+    n_cu = ops.split_tiled_ws_words() // (128 * 256)
+    d, out = 96, 512
+    count = 128 * (n_cu // 2 + 9) - 37                      # tiles = 2 (n_cu / 2 + 9) = n_cu + 18: one full round + 18 tail tiles
+    n_max = count + 300
+    rng = np.random.default_rng(5)
+    Nn = 3000
+    X = rng.normal(size=(Nn + 1, d)).astype(np.float32)
+    ids = rng.integers(0, Nn + 1, size=n_max).astype(np.int32)
+    W = (rng.normal(size=(d, out)) * 0.1).astype(np.float32)
+    b = (rng.normal(size=(out,)) * 0.1).astype(np.float32)
+    Xd, Wd = Mat.from_numpy(X, dev, 32), Mat.from_numpy(W, dev)
+    w3 = ops.split_rows(Wd)
+    ids_d, cnt, bd = _i32(ids, dev), _i32(np.asarray([count]), dev), torch.from_numpy(b).to(dev)
+    ws = torch.full((ops.split_tiled_ws_words(),), float("nan"), dtype=torch.float32, device=dev)
+    res = {}
+    for name in ("plain", "ws", "ws2"):
+        o = Mat.zeros(n_max, out, dev)
+        o.buf.fill_(-7.0)
+        if name == "plain":
+            ops.call("gs_dense_fwd_rows_split", Xd.ptr, Xd.ld, ops.ptr(ids_d), d, n_max, ops.ptr(cnt), ops.ptr(w3), out, ops.ACT_RELU,
+                     ops.ptr(bd), o.ptr, o.ld, ops.current_stream())
+        else:
+            ops.call("gs_dense_fwd_rows_split_ws", Xd.ptr, Xd.ld, ops.ptr(ids_d), d, n_max, ops.ptr(cnt), ops.ptr(w3), out, ops.ACT_RELU,
+                     ops.ptr(bd), o.ptr, o.ld, ops.ptr(ws), 4 * ws.numel(), ops.current_stream())
+        torch.cuda.synchronize()
+        res[name] = o.numpy()
+    assert np.array_equal(res["ws"], res["ws2"])
+    assert np.all(res["ws"][count:] == -7.0)
+    full_rows = 128 * (n_cu // 2)                              # the first n_cu tiles = n_cu / 2 row tiles x 2 column tiles
+    assert np.array_equal(res["ws"][:full_rows], res["plain"][:full_rows])
+    want = np.maximum(X[ids[:count]].astype(np.float64) @ W.astype(np.float64) + b, 0)
+    rms = np.sqrt((want ** 2).mean())
+    assert np.abs(res["ws"][:count] - want).max() / rms < 4e-6
+    assert np.abs(res["plain"][:count] - want).max() / rms < 4e-6
+
+
+@pytest.mark.parametrize("n_max,count,d,out,act,bias,wild", [
+    (6000, 5000, 602, 512, ops.ACT_RELU, True, False),      # the pooling MLP's shape (fewer rows), device-side row count
+    (300, 300, 602, 512, ops.ACT_RELU, True, True),         # rows / columns / elements over a wide exponent range
+    (1000, 777, 50, 512, ops.ACT_RELU, True, False),        # PPI's F = 50: one stage pair
+    (700, 700, 40, 100, ops.ACT_IDENTITY, False, True),     # N = 100: a ragged column tile
+    (260, 130, 256, 1024, ops.ACT_RELU, True, False)])      # model_size "big": hidden 1024
+def test_dense_fwd_rows_split16(dev, n_max, count, d, out, act, bias, wild):
+    """gs_dense_fwd_rows_split16 (two fp16 pieces per operand under row / column scales, three products) vs fp64, beside the fp32
+    yardstick and the three-piece bf16 kernel: same accuracy class; rows beyond the count untouched; deterministic; with and
+    without the split-K tail workspace."""
+    rng = np.random.default_rng(n_max + d + out + 16)
+    Nn = 5000
+    X = rng.normal(size=(Nn + 1, d)).astype(np.float32); X[Nn] = 0
+    W = (rng.normal(size=(d, out)) * 0.1).astype(np.float32)
+    if wild:
+        X *= np.ldexp(1.0, rng.integers(-40, 40, size=(Nn + 1, 1))).astype(np.float32)             # row magnitudes 2^-40 .. 2^40
+        X[:, : d // 3] *= np.ldexp(1.0, rng.integers(-12, 0, size=(Nn + 1, d // 3))).astype(np.float32)   # small elements within a row
+        W *= np.ldexp(1.0, rng.integers(-30, 30, size=(1, out))).astype(np.float32)                # column magnitudes
+        X[7] = 0                                                                                   # an all-zero row
+        W[:, 3] = 0                                                                                # an all-zero column
+    ids = rng.integers(0, Nn + 1, size=n_max).astype(np.int32)
+    ids[:4] = [7, Nn, 7, 0]
+    b = (rng.normal(size=(out,)) * 0.1).astype(np.float32) if bias else None
+    Xd, Wd = Mat.from_numpy(X, dev, 32), Mat.from_numpy(W, dev)
+    X2, rexp = ops.split_table_f16(Xd)
+    w2 = ops.split_rows_f16(Wd)
+    w3 = ops.split_rows(Wd)
+    ids_d = _i32(ids, dev)
+    cnt = _i32(np.asarray([count]), dev)
+    bd = torch.from_numpy(b).to(dev) if bias else None
+    ws = torch.full((ops.split_tiled_ws_words(),), float("nan"), dtype=torch.float32, device=dev)
+    res = {}
+    for name in ("plain", "plain2", "ws", "ws2", "bf16x3"):
+        o = Mat.zeros(n_max, out, dev)
+        o.buf.fill_(-7.0)
+        if name == "bf16x3":
+            ops.call("gs_dense_fwd_rows_split", Xd.ptr, Xd.ld, ops.ptr(ids_d), d, n_max, ops.ptr(cnt), ops.ptr(w3), out, act,
+                     ops.ptr(bd), o.ptr, o.ld, ops.current_stream())
+        else:
+            w = ws if name.startswith("ws") else None
+            ops.call("gs_dense_fwd_rows_split16", ops.ptr(X2), ops.ptr(rexp), ops.ptr(ids_d), d, n_max, ops.ptr(cnt), ops.ptr(w2), out, act,
+                     ops.ptr(bd), o.ptr, o.ld, ops.ptr(w), 4 * ws.numel() if w is not None else 0, ops.current_stream())
+        torch.cuda.synchronize()
+        res[name] = o.numpy()
+    assert np.array_equal(res["plain"], res["plain2"]) and np.array_equal(res["ws"], res["ws2"])
+    want = X[ids].astype(np.float64) @ W.astype(np.float64)
+    if bias:
+        want = want + b
+    pre = want.copy()
+    if act == ops.ACT_RELU:
+        want = np.maximum(want, 0)
+    ref32 = X[ids] @ W
+    if bias:
+        ref32 = ref32 + b
+    if act == ops.ACT_RELU:
+        ref32 = np.maximum(ref32, 0)
+    # errors relative to the scale of each output's own dot product (|x| . |w|): row and column magnitudes differ by 2^+-70 here
+    mag = np.abs(X[ids]).astype(np.float64) @ np.abs(W).astype(np.float64) + (np.abs(b) if bias else 0) + 1e-300
+    errs = {}
+    for name in ("plain", "ws", "bf16x3"):
+        got = res[name].astype(np.float64)
+        assert np.all(res[name][count:] == -7.0), name
+        assert np.all(np.isfinite(res[name][:count])), name
+        errs[name] = (np.abs(got[:count] - want[:count]) / mag[:count]).max()
+    e32 = (np.abs(ref32[:count].astype(np.float64) - want[:count]) / mag[:count]).max()
+    print("d=%d wild=%s: max |error| / (|x|.|w|) vs fp64: fp32 %.3g, three bf16 pieces %.3g, two fp16 pieces %.3g (with the tail split %.3g)"
+          % (d, wild, e32, errs["bf16x3"], errs["plain"], errs["ws"]))
+    for name in ("plain", "ws"):
+        assert errs[name] <= max(2.5 * e32, 2.5 * errs["bf16x3"], 2e-7), (name, errs, e32)
+        assert errs[name] < 1e-6
+
+
+def test_split_pieces_f16_reconstruct_to_one_rounding(dev):
+    """h + m of gs_split_table_f16 / gs_split_rows_f16 under their scales == the fp32 value to within ONE fp32 ulp (2^-23 relative:
+    h keeps 11 bits, the residual has at most 12 and m keeps 11 of them) for elements within 2^-15 of the row's / column's
+    largest, and to half a scaled fp16 subnormal ulp below that; exponents put the largest element at 2^13 .. 2^14; all-zero rows /
+    columns get exponent 0."""
+    rng = np.random.default_rng(3)
+    rows, d = 200, 77
+    X = rng.normal(size=(rows, d)).astype(np.float32) * np.ldexp(1.0, rng.integers(-30, 30, size=(rows, 1))).astype(np.float32)
+    X[:, :20] *= np.ldexp(1.0, rng.integers(-30, 0, size=(rows, 20))).astype(np.float32)
+    X[5] = 0
+    Xd = Mat.from_numpy(X, dev, 32)
+    X2, rexp = ops.split_table_f16(Xd)
+    torch.cuda.synchronize()
+    KP = X2.numel() * 2 // (rows * 2)
+    pieces = X2.view(torch.float16).cpu().numpy().reshape(rows, 2, KP).astype(np.float64)
+    e = rexp.cpu().numpy().astype(np.int64)
+    assert KP % 64 == 0 and KP >= d
+    assert np.all(pieces[:, :, d:] == 0)
+    assert e[5] == 0
+    mx = np.abs(X).max(axis=1).astype(np.float64)
+    nz = mx > 0
+    scaled = mx[nz] * np.exp2(e[nz].astype(np.float64))
+    assert np.all((scaled >= 2.0 ** 13) & (scaled < 2.0 ** 14))
+    rec = (pieces[:, 0, :d] + pieces[:, 1, :d]) * np.exp2(-e.astype(np.float64))[:, None]
+    err = np.abs(rec - X.astype(np.float64))
+    tol = np.maximum(np.abs(X).astype(np.float64) * 2.0 ** -23, (mx * 2.0 ** -13 * 2.0 ** -25)[:, None])   # half the scaled fp16 subnormal ulp (2^-24 at a row maximum of 2^13..2^14)
+    assert np.all(err <= tol * 1.0001)
+    W = X.T.copy()                                              # columns of W = rows of X
+    Wd = Mat.from_numpy(W, dev)
+    w2 = ops.split_rows_f16(Wd)
+    torch.cuda.synchronize()
+    K, N = d, rows
+    body = w2[: w2.numel() - N].view(torch.float16).cpu().numpy().reshape(KP // 8, 2, N, 8).astype(np.float64)
+    ce = w2[w2.numel() - N:].cpu().numpy().astype(np.int64)
+    assert np.array_equal(ce, e)
+    recw = (body[:, 0] + body[:, 1]).transpose(0, 2, 1).reshape(KP, N)[:K] * np.exp2(-ce.astype(np.float64))[None, :]
+    assert np.all(np.abs(recw - W.astype(np.float64)) <= tol.T * 1.0001)
