@@ -142,3 +142,35 @@ def poolloop(seconds=24.0):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "poolloop":
     poolloop()
+
+
+def pool16():
+    """gs_dense_fwd_rows_split16 alone at 81,920 rows (five full rounds of one-per-CU workgroups) and 83,000 (diagnostics variants)."""
+    dev = torch.device("cuda:0")
+    st = ops.Stream()
+    s = st.handle
+    N, F, H = 232965, 602, 512
+    g = torch.Generator(device="cpu").manual_seed(0)
+    X = Mat(torch.randn((N + 1, 608), generator=g).to(dev), F)
+    X.buf[:, F:] = 0
+    rows = 133120
+    ids = torch.sort(torch.randperm(N, generator=g)[:100000]).values.to(torch.int32).to(dev)
+    cnt = torch.tensor([81920], dtype=torch.int32, device=dev)
+    W = Mat(torch.randn((F, H), generator=g).to(dev) * 0.05, H)
+    b = torch.zeros(H, device=dev)
+    out = Mat.zeros(rows, H, dev)
+    X2, rexp = ops.split_table_f16(X, stream=s)
+    W2 = ops.split_rows_f16(W, stream=s)
+    ws = torch.empty(ops.split_tiled_ws_words(), dtype=torch.float32, device=dev)
+    r = {}
+    for c in (81920, 83000):
+        cnt.fill_(c)
+        r["pool_split16_ws_%d_us" % c] = timeit(lambda: ops.call("gs_dense_fwd_rows_split16", ops.ptr(X2), ops.ptr(rexp), ops.ptr(ids), F, rows, ops.ptr(cnt),
+                                                                  ops.ptr(W2), H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, ops.ptr(ws),
+                                                                  4 * ws.numel(), s), s, iters=20, warmup=5)
+    r["split_rows_f16_us"] = timeit(lambda: ops.split_rows_f16(W, out=W2, stream=s), s, iters=20, warmup=3)
+    print(json.dumps(r))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pool16":
+    pool16()

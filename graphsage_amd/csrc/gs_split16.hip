@@ -209,12 +209,22 @@ __global__ __launch_bounds__(512) void split16_tiled_fwd_kernel(const Split16Arg
     const uint32_t bcol_off = (uint32_t)bc * 16u, plane_b = (uint32_t)N * 16u;
     u32x4 ra[2][2];                                            // two register sets for A (stage s + 2 is requested while s computes)
     u32x4 rb[4];
+    // (S16_DIAG_*: diagnostics builds only, benchmarks/probes/build_variant.sh -- wrong values, the kernel's time without one component)
     auto gload_a = [&](const int set, const int s) {           // (past the end: the last stage again -- valid addresses, unused values)
+#ifdef S16_DIAG_NOGLOAD
+        ra[set][0] = ra[set][1] = u32x4{(unsigned)s, 1u, 2u, (unsigned)tid};
+        return;
+#endif
         const int so = 32 * min(s, stages2 - 1);
         ra[set][0] = *reinterpret_cast<const u32x4*>(xrow + so);
         ra[set][1] = *reinterpret_cast<const u32x4*>(xrow + KP + so);
     };
     auto gload_b = [&](const int s) {
+#ifdef S16_DIAG_NOGLOAD
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[j] = u32x4{(unsigned)s, 1u, 2u, (unsigned)tid};
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = bch + 2 * j;                         // chunk = (k-group of the stage) * 2 + piece: W2's own order
@@ -223,11 +233,19 @@ __global__ __launch_bounds__(512) void split16_tiled_fwd_kernel(const Split16Arg
         }
     };
     auto lds_store_a = [&](const int set, unsigned char* buf) {
+#ifdef S16_DIAG_NOLDSW
+        asm volatile("" :: "v"(ra[set][0]), "v"(ra[set][1]));
+        return;
+#endif
         unsigned char* pa = buf + (arow * S16_LDA + 8 * aq) * 2;
         *reinterpret_cast<u32x4*>(pa) = ra[set][0];
         *reinterpret_cast<u32x4*>(pa + A_PLANE) = ra[set][1];
     };
     auto lds_store_b = [&](unsigned char* buf) {
+#ifdef S16_DIAG_NOLDSW
+        asm volatile("" :: "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3]));
+        return;
+#endif
         unsigned char* pb = buf + A_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(pb + ((bch + 2 * j) * 256 + bcol) * 16) = rb[j];
@@ -244,6 +262,15 @@ __global__ __launch_bounds__(512) void split16_tiled_fwd_kernel(const Split16Arg
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             u32x4 fa[2][2], fb[2][2];
+#ifdef S16_DIAG_NOLDSR
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    fa[i][p] = u32x4{(unsigned)q, (unsigned)(uintptr_t)buf, 2u, (unsigned)tid};
+                    fb[i][p] = u32x4{(unsigned)p, (unsigned)(uintptr_t)buf, 3u, (unsigned)tid};
+                }
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -254,6 +281,11 @@ __global__ __launch_bounds__(512) void split16_tiled_fwd_kernel(const Split16Arg
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
                     fb[j][p] = *reinterpret_cast<const u32x4*>(buf + A_BYTES + (((2 * q + lh) * 2 + p) * 256 + 64 * wn + 32 * j + l31) * 16);
+#endif
+#ifdef S16_DIAG_NOMFMA
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int p = 0; p < 2; ++p) asm volatile("" :: "v"(fa[i][p]), "v"(fb[i][p]));
+            continue;
+#endif
             // piece product outermost, the four tiles innermost: no MFMA accumulates into the result of the one issued before it
 #define GS_PP(dst, pa, pb) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
                                dst[i][j] = gs_mfma_f16(fa[i][pa], fb[j][pb], dst[i][j]);
@@ -297,6 +329,194 @@ __global__ __launch_bounds__(512) void split16_tiled_fwd_kernel(const Split16Arg
     }
     // scale back, bias + activation, through a wave-private LDS region (free after the last barrier) so that a lane stores 16
     // contiguous bytes of a row; a K part of a tail-round tile stores its raw partial sums instead
+    float* otile = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+    const bool partial = part >= 0;
+    float* wtile = partial ? g.ws + (int64_t)((int)blockIdx.x - sch.full) * (128 * 256) : nullptr;
+    const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+    const int colg = n0 + 64 * wn + c4;
+    int ce[4] = {0, 0, 0, 0};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (!partial) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ce[u] = g.cexp[min(colg + u, N - 1)];
+        if (g.bias) {
+            if (colg < N) bv.x = g.bias[colg];
+            if (colg + 1 < N) bv.y = g.bias[colg + 1];
+            if (colg + 2 < N) bv.z = g.bias[colg + 2];
+            if (colg + 3 < N) bv.w = g.bias[colg + 3];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                otile[((e & 3) + 8 * (e >> 2) + 4 * lh) * 68 + 32 * j + l31] = acc[i][j][e] + sml[i][j][e];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = 4 * it + r0;
+            const int row = m0 + 64 * wm + 32 * i + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(otile + r * 68 + c4);
+            if (partial) {
+                *reinterpret_cast<f32x4*>(wtile + (64 * wm + 32 * i + r) * 256 + 64 * wn + c4) = v;
+            } else if (row < count) {
+                const int re = g.rexp[g.idx ? g.idx[row] : row];
+                v.x = ldexpf(v.x, -(re + ce[0])) + bv.x;
+                v.y = ldexpf(v.y, -(re + ce[1])) + bv.y;
+                v.z = ldexpf(v.z, -(re + ce[2])) + bv.z;
+                v.w = ldexpf(v.w, -(re + ce[3])) + bv.w;
+                if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                float* dst = g.out + (int64_t)row * g.ldo + colg;
+                if (colg + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+                else {
+                    if (colg < N) dst[0] = v.x;
+                    if (colg + 1 < N) dst[1] = v.y;
+                    if (colg + 2 < N) dst[2] = v.z;
+                }
+            }
+        }
+    }
+}
+
+// LDS-DMA form (the default): the same tiles, arithmetic and summation order as split16_tiled_fwd_kernel -- bit-identical outputs --
+// but NOTHING on the way global -> LDS lives in a VGPR.  Measured on the register-staged form (-D variants, gpurun_out/
+// s16_variants.txt, 83,000 rows): MFMAs + barriers alone 155 us, + fragment reads 169, + LDS writes 184, + global loads 268 --
+// a W2 chunk requested at the top of a stage is written to LDS at its end, one stage (~0.6 us) of latency cover, and six
+// ds_write_b128 per thread and stage go through a write path two SIMDs share.  Here both operand tiles are global_load_lds_dwordx4
+// (one wave instruction = 1 KB at a wave-uniform LDS address + 16 lane) into a ring of THREE stage buffers: stage s + 2 is
+// requested at the top of stage s, `s_waitcnt vmcnt(6)` at its end says "stage s + 1 has landed" (six DMA per thread and stage,
+// retired in order) and leaves stage s + 2 in flight across the raw s_barrier (__syncthreads would drain it with vmcnt(0)).
+//   A plane in LDS: [128 rows][4 chunks of 8 k] without padding (the DMA writes lane-linear); row r holds chunk c at position
+//   c ^ ((r >> 2) & 3) -- the permutation is applied to the SOURCE address of the DMA and again to the fragment reads (the same
+//   involution): the 16 lanes of a ds_read_b128 pass touch all 64 banks once.
+#define S16_NBUF 3
+__global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args g) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_PLANE = 128 * 64;                          // bytes
+    constexpr int A_BYTES = 2 * A_PLANE, B_BYTES = 8 * 256 * 16, BUF = A_BYTES + B_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
+    const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
+    const int nwg = tiles_m * tiles_n;
+    const int N = g.N, KP = g.KP;
+    const int stages2 = KP >> 5;
+    const Sched16 sch = split16_schedule(nwg, stages2, g.n_cu, g.ws != nullptr);
+    if ((int)blockIdx.x >= sch.full + sch.rem * sch.S) return;
+    int tile, part = -1;
+    if ((int)blockIdx.x < sch.full) {
+        const int q8 = sch.full >> 3, r8 = sch.full & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    } else {
+        const int r = (int)blockIdx.x - sch.full;
+        tile = sch.full + r / sch.S;
+        part = r - (r / sch.S) * sch.S;
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 256;
+    // ---- DMA roles: thread (row tid >> 2, position tid & 3) of the A planes; column tid & 255, chunks (wave >> 2) + 2 j of B
+    const int arow = tid >> 2;
+    const int akc = (tid & 3) ^ ((arow >> 2) & 3);             // the 8-k chunk that lands at this thread's position
+    const int grow = min(m0 + arow, count - 1);
+    const int64_t srow = g.idx ? (int64_t)g.idx[grow] : (int64_t)grow;
+    const _Float16* __restrict__ xrow = g.X2 + srow * 2 * (int64_t)KP + 8 * akc;
+    const int bch = wave >> 2;
+    const int bc = min(n0 + (tid & 255), N - 1);
+    const char* __restrict__ W2b = (const char*)g.W2 + (uint32_t)bc * 16u;
+    const uint32_t plane_b = (uint32_t)N * 16u;
+    const int a_dst = wave * 1024, b_dst = A_BYTES + (wave & 3) * 1024;     // wave-uniform LDS offsets (+ 16 lane by the hardware)
+    auto issue = [&](const int s, unsigned char* buf) {        // six DMA per thread (past the end: the last stage again, unused)
+        const int sc = min(s, stages2 - 1);
+        __builtin_amdgcn_global_load_lds(xrow + 32 * sc, (lds_ptr_t)(buf + a_dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(xrow + KP + 32 * sc, (lds_ptr_t)(buf + A_PLANE + a_dst), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = bch + 2 * j;
+            __builtin_amdgcn_global_load_lds(W2b + (uint32_t)(8 * sc + c) * plane_b, (lds_ptr_t)(buf + b_dst + c * 4096), 16, 0, 0);
+        }
+    };
+    const int wm = wave >> 2, wn = wave & 3;
+    const int sw = (l31 >> 2) & 3;
+    const int a_rd = (64 * wm + l31) * 64;                     // + 32 i rows, + plane, + ((2 q + lh) ^ sw) * 16
+    const int a_q0 = ((0 + lh) ^ sw) * 16, a_q1 = ((2 + lh) ^ sw) * 16;
+    const int b_rd = A_BYTES + (64 * wn + l31) * 16 + lh * 2 * 4096;        // + (2 q) groups, + piece, + 32 j columns
+    f32x16 acc[2][2], sml[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; sml[i][j][e] = 0.f; }
+    // One stage of a wave = 24 MFMAs in a PINNED order (a sched_barrier behind every one): left to the scheduler, the MFMAs of one
+    // accumulator end up back to back (runs of four and five in the first build of this kernel) and each waits for the result of
+    // the one before it.  Order per 16-k half: (h m) x 4 tiles, (h h) x 4 tiles, (m h) x 4 tiles -- the same accumulator comes up
+    // again four MFMAs later at the earliest.
+    // The stage's barrier sits in its MIDDLE: the fragment reads of the second half ride between the MFMAs of the first, then
+    // "stage s + 1 has landed" (vmcnt) + "my reads of this stage's buffer are done" (lgkmcnt) + s_barrier, then the second half's
+    // MFMAs carry the reads of stage s + 1's FIRST half -- no wave starts a stage by waiting for its fragments (with the barrier at
+    // the end of the stage both waves of a SIMD did, at the same time: the matrix pipe idled through an LDS round trip per stage).
+    u32x4 fa[2][2][2], fb[2][2][2];                            // [half q][i | j][piece]
+    auto rd_a = [&](const unsigned char* buf, const int q, const int i, const int p) {
+        fa[q][i][p] = *reinterpret_cast<const u32x4*>(buf + p * A_PLANE + a_rd + i * (32 * 64) + (q ? a_q1 : a_q0));
+    };
+    auto rd_b = [&](const unsigned char* buf, const int q, const int j, const int p) {
+        fb[q][j][p] = *reinterpret_cast<const u32x4*>(buf + b_rd + (4 * q + p) * 4096 + j * (32 * 16));
+    };
+#define S16_SB __builtin_amdgcn_sched_barrier(0);
+#define S16_MM(dst, q, i, j, pa, pb) dst[i][j] = gs_mfma_f16(fa[q][i][pa], fb[q][j][pb], dst[i][j]); S16_SB
+    int s_begin = 0, s_end = stages2;
+    if (part >= 0) {
+        const int pairs = stages2 >> 1;
+        s_begin = 2 * ((pairs * part) / sch.S);
+        s_end = 2 * ((pairs * (part + 1)) / sch.S);
+    }
+    issue(s_begin, smem);
+    issue(s_begin + 1, smem + BUF);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rd_a(smem, 0, 0, 0); rd_b(smem, 0, 0, 1); rd_b(smem, 0, 1, 1); rd_a(smem, 0, 1, 0);
+    rd_b(smem, 0, 0, 0); rd_b(smem, 0, 1, 0); rd_a(smem, 0, 0, 1); rd_a(smem, 0, 1, 1);
+    int slot = 0;                                              // ring slot of stage s
+#pragma unroll 1
+    for (int s = s_begin; s < s_end; ++s) {
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        const int slot2 = slot == 0 ? 2 : slot - 1;            // (slot + 2) % 3: last read before the barrier of stage s - 1
+        const unsigned char* cur = smem + slot * BUF;
+        const unsigned char* nxt = smem + slot1 * BUF;
+        issue(s + 2, smem + slot2 * BUF);
+        S16_SB
+        S16_MM(sml, 0, 0, 0, 0, 1) rd_a(cur, 1, 0, 0); S16_SB
+        S16_MM(sml, 0, 0, 1, 0, 1) rd_a(cur, 1, 1, 0); S16_SB
+        S16_MM(sml, 0, 1, 0, 0, 1) rd_b(cur, 1, 0, 1); S16_SB
+        S16_MM(sml, 0, 1, 1, 0, 1) rd_b(cur, 1, 1, 1); S16_SB
+        S16_MM(acc, 0, 0, 0, 0, 0) rd_b(cur, 1, 0, 0); S16_SB
+        S16_MM(acc, 0, 0, 1, 0, 0) rd_b(cur, 1, 1, 0); S16_SB
+        S16_MM(acc, 0, 1, 0, 0, 0) rd_a(cur, 1, 0, 1); S16_SB
+        S16_MM(acc, 0, 1, 1, 0, 0) rd_a(cur, 1, 1, 1); S16_SB
+        S16_MM(sml, 0, 0, 0, 1, 0) S16_MM(sml, 0, 0, 1, 1, 0) S16_MM(sml, 0, 1, 0, 1, 0) S16_MM(sml, 0, 1, 1, 1, 0)
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // stage s + 1 has landed (mine); my reads of `cur` are done
+        __builtin_amdgcn_s_barrier();                          // ... everybody's: `nxt` is readable, `cur` may be overwritten (stage s + 3)
+        asm volatile("" ::: "memory");
+        S16_SB
+        S16_MM(sml, 1, 0, 0, 0, 1) rd_a(nxt, 0, 0, 0); S16_SB
+        S16_MM(sml, 1, 0, 1, 0, 1) rd_b(nxt, 0, 0, 1); S16_SB
+        S16_MM(sml, 1, 1, 0, 0, 1) rd_b(nxt, 0, 1, 1); S16_SB
+        S16_MM(sml, 1, 1, 1, 0, 1) rd_a(nxt, 0, 1, 0); S16_SB
+        S16_MM(acc, 1, 0, 0, 0, 0) rd_b(nxt, 0, 0, 0); S16_SB
+        S16_MM(acc, 1, 0, 1, 0, 0) rd_b(nxt, 0, 1, 0); S16_SB
+        S16_MM(acc, 1, 1, 0, 0, 0) rd_a(nxt, 0, 0, 1); S16_SB
+        S16_MM(acc, 1, 1, 1, 0, 0) rd_a(nxt, 0, 1, 1); S16_SB
+        S16_MM(sml, 1, 0, 0, 1, 0) S16_MM(sml, 1, 0, 1, 1, 0) S16_MM(sml, 1, 1, 0, 1, 0) S16_MM(sml, 1, 1, 1, 1, 0)
+        slot = slot1;
+    }
+#undef S16_MM
+#undef S16_SB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests of the last two stages
+    __syncthreads();
+    // ---- epilogue: as split16_tiled_fwd_kernel
     float* otile = reinterpret_cast<float*>(smem) + wave * (32 * 68);
     const bool partial = part >= 0;
     float* wtile = partial ? g.ws + (int64_t)((int)blockIdx.x - sch.full) * (128 * 256) : nullptr;
@@ -408,11 +628,15 @@ extern "C" int gs_dense_fwd_rows_split16(const void* X2, const int32_t* rexp, co
     g.bias = bias; g.out = out; g.n_dev = n_dev; g.ldo = ldo;
     g.n_max = (int32_t)n_max; g.K = d; g.KP = KP; g.N = out_dim; g.act = act;
     int64_t blocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 256);
-    const size_t lds = 2 * (2 * 128 * S16_LDA * 2 + 8 * 256 * 16);
+    static const bool dma = !(getenv("GS_SPLIT16_DMA") && atoi(getenv("GS_SPLIT16_DMA")) == 0);       // 0: the register-staged form (A/B)
+    const size_t lds = dma ? (size_t)S16_NBUF * (2 * 128 * 64 + 8 * 256 * 16) : (size_t)2 * (2 * 128 * S16_LDA * 2 + 8 * 256 * 16);
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
-        GS_HIP(hipFuncSetAttribute((const void*)split16_tiled_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GS_HIP(hipFuncSetAttribute((const void*)split16_dma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   S16_NBUF * (2 * 128 * 64 + 8 * 256 * 16)));
+        GS_HIP(hipFuncSetAttribute((const void*)split16_tiled_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   2 * (2 * 128 * S16_LDA * 2 + 8 * 256 * 16)));
         int dev = 0;
         hipDeviceProp_t prop;
         GS_HIP(hipGetDevice(&dev));
@@ -424,8 +648,9 @@ extern "C" int gs_dense_fwd_rows_split16(const void* X2, const int32_t* rexp, co
     const bool tail = ws && !no_tail && n_cu > 0 && ws_bytes >= (int64_t)n_cu * 128 * 256 * (int64_t)sizeof(float);
     GS_REQUIRE(!ws || gs_aligned16(ws), "gs_dense_fwd_rows_split16: the workspace must be 16-byte aligned");
     if (tail) { g.ws = ws; g.n_cu = n_cu; blocks += n_cu; }
-    hipLaunchKernelGGL(split16_tiled_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
-    GS_LAUNCH_CHECK("split16_tiled_fwd_kernel");
+    if (dma) hipLaunchKernelGGL(split16_dma_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(split16_tiled_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
+    GS_LAUNCH_CHECK("split16 forward kernel");
     if (tail) {
         hipLaunchKernelGGL(split16_fixup_kernel, dim3((unsigned)(2 * n_cu)), dim3(256), 0, (hipStream_t)stream, g);
         GS_LAUNCH_CHECK("split16_fixup_kernel");
