@@ -846,7 +846,23 @@ def run_aux(DG, args, B, s1, s2):
         r = timed(model, e, B, s1, args.feat_dim, "graphsage_maxpool", flops_fwd=flops)
         r["config"] = "configs[2]: Reddit-shaped supervised graphsage_maxpool, fan-out %dx%d, batch %d" % (s1, s2, B)
         r["loss_after"] = model._fetch(B)[0]
+        r["pooling_mlp_arithmetic"] = ("fp32 operands as two fp16 pieces each under row / column scales, three exact products per "
+                                       "element pair on the fp16 matrix pipe, fp32 accumulation (csrc/gs_split16.hip)"
+                                       if e.pool_f16 else "fp32 operands as three bf16 pieces each, six products (csrc/gs_split.hip)")
         out["graphsage_maxpool"] = r
+        if e.pool_f16:
+            # the same step with the pooling MLP in the three-piece bf16 arithmetic of round 4 (no operand bit dropped, six products;
+            # power-bound): reported beside the default so that the arithmetic change is visible in the driver's own record
+            del model
+            os.environ["GS_POOL_F16"] = "0"
+            try:
+                e, model, ph, _ = build_model(DG, args, 1, 0, "graphsage_maxpool")
+                model.attach_device_epoch(np.random.RandomState(123).permutation(DG.train_nodes), DG.label_table)
+                r3 = timed(model, e, B, s1, args.feat_dim, "graphsage_maxpool_bf16x3", flops_fwd=flops)
+                r["three_bf16_pieces"] = {"ms_per_step": r3["ms_per_step"], "ms_per_step_events_median": r3["ms_per_step_events_median"],
+                                          "loss_after": model._fetch(B)[0]}
+            finally:
+                os.environ["GS_POOL_F16"] = "1"
     except Exception as ex:            # an aux failure must not lose the headline line
         out["graphsage_maxpool"] = {"error": repr(ex)}
     try:

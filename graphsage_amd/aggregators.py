@@ -639,9 +639,16 @@ class _PoolingAggregator(_SageBase):
         n_out = self.output_dim * (2 if self.concat else 1)
         out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
-        ops.sage_dense_fwd(self_all.src, self_all.ids, pooled, None, n_total, self.vars['self_weights'].value,
-                           self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
-                           stream=e.stream)
+        if (e.stream_gemm and self.concat and n_total > 2048 and self.output_dim % 2 == 0
+                and os.environ.get("GS_STREAM_FWD_POOL", "1") == "1"):
+            # the stream form of the two contractions (split-K workgroups, no LDS staging, the self rows gathered in the A loads),
+            # with each term's own reduction length: 23 instead of 33 us for the Reddit step's layer 0
+            ops.sage_dense_fwd_stream2(self_all.src, self_all.ids, pooled, n_total, self.vars['self_weights'].value,
+                                       self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, stream=e.stream)
+        else:
+            ops.sage_dense_fwd(self_all.src, self_all.ids, pooled, None, n_total, self.vars['self_weights'].value,
+                               self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,
+                               stream=e.stream)
         self._push((self_all, neighs, pieces, (H, rows_total), pooled, argmax, out, rate))
         return out
 

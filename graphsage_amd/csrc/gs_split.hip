@@ -360,7 +360,8 @@ __device__ __host__ __forceinline__ WideSchedule wide_schedule(const int nwg, co
         const int r = nwg % n_cu;
         if (r > 0 && 2 * r <= n_cu) {
             const int pairs = stages2 >> 1;
-            const int sp = pairs < n_cu / r ? pairs : n_cu / r;
+            int sp = pairs < n_cu / r ? pairs : n_cu / r;
+            if (sp > 10) sp = 10;                               // (the fix-up launch keeps a tile's parts in registers: <= 10)
             if (sp >= 2) { w.full = nwg - r; w.rem = r; w.S = sp; }
         }
     }
@@ -745,15 +746,19 @@ __global__ __launch_bounds__(512) void split_tiled_fwd_wide_kernel(const SplitTi
 
 // out tile = act(sum of the S partial tiles of a tail-round tile, in part order, + bias): one workgroup per (tile, 32-row band)
 __global__ __launch_bounds__(256) void split_tiled_fixup_kernel(const SplitTiledArgs g) {
+    // one workgroup per (tail tile, four rows); a thread owns 16 bytes of ONE row: its S partial values are independent loads
+    // (a first version walked eight rows and the S parts in a serial loop per thread: 24 us of load latency for 26 MB)
     const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
     const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
     const int nwg = tiles_m * tiles_n;
     const WideSchedule sch = wide_schedule(nwg, (((g.K + 31) >> 5) + 1) & ~1, g.n_cu, g.ws != nullptr);
-    const int t = (int)blockIdx.x >> 2, band = (int)blockIdx.x & 3;
+    const int t = (int)blockIdx.x >> 5, r = 4 * ((int)blockIdx.x & 31) + ((int)threadIdx.x >> 6);
     if (t >= sch.rem) return;
     const int tile = sch.full + t;
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * 256;
+    const int row = m0 + r;
+    if (row >= count) return;
     const int c4 = ((int)threadIdx.x & 63) * 4;                 // 64 threads x 16 bytes = one 256-column row
     const int colg = n0 + c4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -763,21 +768,21 @@ __global__ __launch_bounds__(256) void split_tiled_fixup_kernel(const SplitTiled
         if (colg + 2 < g.N) bv.z = g.bias[colg + 2];
         if (colg + 3 < g.N) bv.w = g.bias[colg + 3];
     }
-    const float* base = g.ws + (int64_t)t * sch.S * (128 * 256);
-    for (int r = 32 * band + ((int)threadIdx.x >> 6); r < 32 * band + 32; r += 4) {
-        const int row = m0 + r;
-        if (row >= count) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(base + r * 256 + c4);
-        for (int p = 1; p < sch.S; ++p) v += *reinterpret_cast<const f32x4*>(base + (int64_t)p * (128 * 256) + r * 256 + c4);
-        v += bv;
-        if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        float* dst = g.out + (int64_t)row * g.ldo + colg;
-        if (colg + 3 < g.N) *reinterpret_cast<f32x4*>(dst) = v;
-        else {
-            if (colg < g.N) dst[0] = v.x;
-            if (colg + 1 < g.N) dst[1] = v.y;
-            if (colg + 2 < g.N) dst[2] = v.z;
-        }
+    const float* base = g.ws + (int64_t)t * sch.S * (128 * 256) + r * 256 + c4;
+    f32x4 pv[10];                                               // S <= 10 parts (stage pairs of K <= 640); summed in part order
+#pragma unroll
+    for (int p = 0; p < 10; ++p) pv[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)min(p, sch.S - 1) * (128 * 256));
+    f32x4 v = pv[0];
+#pragma unroll
+    for (int p = 1; p < 10; ++p) if (p < sch.S) v += pv[p];
+    v += bv;
+    if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float* dst = g.out + (int64_t)row * g.ldo + colg;
+    if (colg + 3 < g.N) *reinterpret_cast<f32x4*>(dst) = v;
+    else {
+        if (colg < g.N) dst[0] = v.x;
+        if (colg + 1 < g.N) dst[1] = v.y;
+        if (colg + 2 < g.N) dst[2] = v.z;
     }
 }
 
@@ -841,7 +846,7 @@ static int dense_fwd_rows_split_impl(const float* X, int64_t ldx, const int32_t*
         GS_LAUNCH_CHECK("split_tiled_fwd_wide_kernel");
         if (tail) {
             // at most n_cu / 2 tail tiles, four 32-row bands each (workgroups of tiles that do not exist return at once)
-            hipLaunchKernelGGL(split_tiled_fixup_kernel, dim3((unsigned)(2 * n_cu)), dim3(256), 0, (hipStream_t)stream, g);
+            hipLaunchKernelGGL(split_tiled_fixup_kernel, dim3((unsigned)(16 * n_cu)), dim3(256), 0, (hipStream_t)stream, g);
             GS_LAUNCH_CHECK("split_tiled_fixup_kernel");
         }
         return GS_OK;

@@ -47,15 +47,18 @@ static inline int split16_kp(int32_t K) { return 32 * split16_stages2(K); }     
 // ------------------------------------------------------------------------------------------------ W -> W2
 // W [K, N] fp32 -> W2 [KP/8 groups of 8 k][2 pieces][N][8] fp16 (per group and piece the N columns side by side, 16 bytes each: the 32
 // lanes of a B-fragment load read 512 contiguous bytes) followed by the N column exponents (int32).
-// One workgroup of 16 waves per 64 columns (lane = column: coalesced rows of W): the waves split K for the column maxima (LDS), then
-// the groups of 8 k for the cut -- ~40 independent loads per thread and phase.  (A first version ran ONE thread per column over the
-// whole K twice: 130 us per call for the 602 x 512 weights, behind every optimizer launch.)
+// Workgroups of 16 waves per (64 columns, quarter of the k-groups) (lane = column: coalesced rows of W): the waves split K for the
+// column maxima (LDS; every quarter repeats them -- W is L2-resident), then the quarter's groups of 8 k for the cut: ~40 + 10
+// independent loads per thread.  (A first version ran ONE thread per column over the whole K twice: 130 us per call for the
+// 602 x 512 weights, behind every optimizer launch; one workgroup per 64 columns: 16 us.)
 #define S16_ROWS_WAVES 16
+#define S16_ROWS_KSPLIT 4
 __global__ __launch_bounds__(64 * S16_ROWS_WAVES) void split16_rows_kernel(const float* __restrict__ W, int64_t ldw, int32_t K, int32_t N,
                                                                            int32_t KP, _Float16* __restrict__ W2, int32_t* __restrict__ cexp) {
     __shared__ float smax[S16_ROWS_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
+    const int n = (blockIdx.x / S16_ROWS_KSPLIT) * 64 + lane;
+    const int kq = blockIdx.x % S16_ROWS_KSPLIT;
     const int nc = min(n, N - 1);                              // (a column past the end: loads clamped, nothing stored)
     float mx = 0.f;
 #pragma unroll 8
@@ -65,8 +68,8 @@ __global__ __launch_bounds__(64 * S16_ROWS_WAVES) void split16_rows_kernel(const
 #pragma unroll
     for (int w = 0; w < S16_ROWS_WAVES; ++w) mx = fmaxf(mx, smax[w][lane]);
     const int e = gs_scale_exp(mx);
-    if (wave == 0 && n < N) cexp[n] = e;
-    for (int kg = wave; kg < KP / 8; kg += S16_ROWS_WAVES) {
+    if (wave == 0 && kq == 0 && n < N) cexp[n] = e;
+    for (int kg = kq * S16_ROWS_WAVES + wave; kg < KP / 8; kg += S16_ROWS_WAVES * S16_ROWS_KSPLIT) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)min(8 * kg + j, K - 1) * ldw + nc];
@@ -96,7 +99,7 @@ extern "C" int gs_split_rows_f16(const float* W, int64_t ldw, int32_t K, int32_t
     GS_REQUIRE(gs_aligned16(W2), "gs_split_rows_f16: W2 must be 16-byte aligned");
     const int KP = split16_kp(K);
     int32_t* cexp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(W2) + (int64_t)(KP / 8) * 2 * N * 16);
-    hipLaunchKernelGGL(split16_rows_kernel, dim3((unsigned)gs_ceil_div(N, 64)), dim3(64 * S16_ROWS_WAVES), 0, (hipStream_t)stream, W, ldw, K, N, KP,
+    hipLaunchKernelGGL(split16_rows_kernel, dim3((unsigned)(gs_ceil_div(N, 64) * S16_ROWS_KSPLIT)), dim3(64 * S16_ROWS_WAVES), 0, (hipStream_t)stream, W, ldw, K, N, KP,
                        (_Float16*)W2, cexp);
     GS_LAUNCH_CHECK("split16_rows_kernel");
     return GS_OK;
@@ -166,7 +169,8 @@ __device__ __host__ __forceinline__ Sched16 split16_schedule(const int nwg, cons
         const int r = nwg % n_cu;
         if (r > 0 && 2 * r <= n_cu) {
             const int pairs = stages2 >> 1;
-            const int sp = pairs < n_cu / r ? pairs : n_cu / r;
+            int sp = pairs < n_cu / r ? pairs : n_cu / r;
+            if (sp > 10) sp = 10;                               // (the fix-up launch keeps a tile's parts in registers: <= 10)
             if (sp >= 2) { w.full = nwg - r; w.rem = r; w.S = sp; }
         }
     }
@@ -428,6 +432,9 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
     const uint32_t plane_b = (uint32_t)N * 16u;
     const int a_dst = wave * 1024, b_dst = A_BYTES + (wave & 3) * 1024;     // wave-uniform LDS offsets (+ 16 lane by the hardware)
     auto issue = [&](const int s, unsigned char* buf) {        // six DMA per thread (past the end: the last stage again, unused)
+#ifdef S16_DIAG_NODMA
+        if (s > 1) return;
+#endif
         const int sc = min(s, stages2 - 1);
         __builtin_amdgcn_global_load_lds(xrow + 32 * sc, (lds_ptr_t)(buf + a_dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(xrow + KP + 32 * sc, (lds_ptr_t)(buf + A_PLANE + a_dst), 16, 0, 0);
@@ -459,13 +466,23 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
     // the end of the stage both waves of a SIMD did, at the same time: the matrix pipe idled through an LDS round trip per stage).
     u32x4 fa[2][2][2], fb[2][2][2];                            // [half q][i | j][piece]
     auto rd_a = [&](const unsigned char* buf, const int q, const int i, const int p) {
+#ifdef S16_DIAG_NOLDSR2
+        fa[q][i][p] = u32x4{(unsigned)q, (unsigned)(uintptr_t)buf, 2u, (unsigned)tid}; return;
+#endif
         fa[q][i][p] = *reinterpret_cast<const u32x4*>(buf + p * A_PLANE + a_rd + i * (32 * 64) + (q ? a_q1 : a_q0));
     };
     auto rd_b = [&](const unsigned char* buf, const int q, const int j, const int p) {
+#ifdef S16_DIAG_NOLDSR2
+        fb[q][j][p] = u32x4{(unsigned)p, (unsigned)(uintptr_t)buf, 3u, (unsigned)tid}; return;
+#endif
         fb[q][j][p] = *reinterpret_cast<const u32x4*>(buf + b_rd + (4 * q + p) * 4096 + j * (32 * 16));
     };
 #define S16_SB __builtin_amdgcn_sched_barrier(0);
+#ifdef S16_DIAG_NOMFMA2
+#define S16_MM(dst, q, i, j, pa, pb) asm volatile("" :: "v"(fa[q][i][pa]), "v"(fb[q][j][pb])); S16_SB
+#else
 #define S16_MM(dst, q, i, j, pa, pb) dst[i][j] = gs_mfma_f16(fa[q][i][pa], fb[q][j][pb], dst[i][j]); S16_SB
+#endif
     int s_begin = 0, s_end = stages2;
     if (part >= 0) {
         const int pairs = stages2 >> 1;
@@ -516,6 +533,9 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
 #undef S16_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests of the last two stages
     __syncthreads();
+#ifdef S16_DIAG_NOEPI
+    if (acc[0][0][0] + sml[1][1][3] + acc[1][0][5] + sml[0][1][7] != 12345.678f) return;
+#endif
     // ---- epilogue: as split16_tiled_fwd_kernel
     float* otile = reinterpret_cast<float*>(smem) + wave * (32 * 68);
     const bool partial = part >= 0;
@@ -570,20 +590,21 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
 // out tile = act(2^-(e_row + e_col) * (sum of the S partial tiles of a tail-round tile, in part order) + bias): one workgroup per
 // (tile, 32-row band)
 __global__ __launch_bounds__(256) void split16_fixup_kernel(const Split16Args g) {
+    // one workgroup per (tail tile, four rows); a thread owns 16 bytes of ONE row: its S partial values are independent loads
+    // (a first version walked eight rows and the S parts in a serial loop per thread: 24 us of load latency for 26 MB)
     const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
     const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
     const int nwg = tiles_m * tiles_n;
     const Sched16 sch = split16_schedule(nwg, g.KP >> 5, g.n_cu, g.ws != nullptr);
-    const int t = (int)blockIdx.x >> 2, band = (int)blockIdx.x & 3;
+    const int t = (int)blockIdx.x >> 5, r = 4 * ((int)blockIdx.x & 31) + ((int)threadIdx.x >> 6);
     if (t >= sch.rem) return;
     const int tile = sch.full + t;
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * 256;
+    const int row = m0 + r;
+    if (row >= count) return;
     const int c4 = ((int)threadIdx.x & 63) * 4;                 // 64 threads x 16 bytes = one 256-column row
     const int colg = n0 + c4;
-    int ce[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ce[u] = g.cexp[min(colg + u, g.N - 1)];
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (g.bias) {
         if (colg < g.N) bv.x = g.bias[colg];
@@ -591,25 +612,28 @@ __global__ __launch_bounds__(256) void split16_fixup_kernel(const Split16Args g)
         if (colg + 2 < g.N) bv.z = g.bias[colg + 2];
         if (colg + 3 < g.N) bv.w = g.bias[colg + 3];
     }
-    const float* base = g.ws + (int64_t)t * sch.S * (128 * 256);
-    for (int r = 32 * band + ((int)threadIdx.x >> 6); r < 32 * band + 32; r += 4) {
-        const int row = m0 + r;
-        if (row >= count) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(base + r * 256 + c4);
-        for (int p = 1; p < sch.S; ++p) v += *reinterpret_cast<const f32x4*>(base + (int64_t)p * (128 * 256) + r * 256 + c4);
-        const int re = g.rexp[g.idx ? g.idx[row] : row];
-        v.x = ldexpf(v.x, -(re + ce[0])) + bv.x;
-        v.y = ldexpf(v.y, -(re + ce[1])) + bv.y;
-        v.z = ldexpf(v.z, -(re + ce[2])) + bv.z;
-        v.w = ldexpf(v.w, -(re + ce[3])) + bv.w;
-        if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        float* dst = g.out + (int64_t)row * g.ldo + colg;
-        if (colg + 3 < g.N) *reinterpret_cast<f32x4*>(dst) = v;
-        else {
-            if (colg < g.N) dst[0] = v.x;
-            if (colg + 1 < g.N) dst[1] = v.y;
-            if (colg + 2 < g.N) dst[2] = v.z;
-        }
+    int ce[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ce[u] = g.cexp[min(colg + u, g.N - 1)];
+    const int re = g.rexp[g.idx ? g.idx[row] : row];
+    const float* base = g.ws + (int64_t)t * sch.S * (128 * 256) + r * 256 + c4;
+    f32x4 pv[10];                                               // S <= 10 parts (stage pairs of K <= 640); summed in part order
+#pragma unroll
+    for (int p = 0; p < 10; ++p) pv[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)min(p, sch.S - 1) * (128 * 256));
+    f32x4 v = pv[0];
+#pragma unroll
+    for (int p = 1; p < 10; ++p) if (p < sch.S) v += pv[p];
+    v.x = ldexpf(v.x, -(re + ce[0])) + bv.x;
+    v.y = ldexpf(v.y, -(re + ce[1])) + bv.y;
+    v.z = ldexpf(v.z, -(re + ce[2])) + bv.z;
+    v.w = ldexpf(v.w, -(re + ce[3])) + bv.w;
+    if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float* dst = g.out + (int64_t)row * g.ldo + colg;
+    if (colg + 3 < g.N) *reinterpret_cast<f32x4*>(dst) = v;
+    else {
+        if (colg < g.N) dst[0] = v.x;
+        if (colg + 1 < g.N) dst[1] = v.y;
+        if (colg + 2 < g.N) dst[2] = v.z;
     }
 }
 
@@ -652,7 +676,7 @@ extern "C" int gs_dense_fwd_rows_split16(const void* X2, const int32_t* rexp, co
     else hipLaunchKernelGGL(split16_tiled_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
     GS_LAUNCH_CHECK("split16 forward kernel");
     if (tail) {
-        hipLaunchKernelGGL(split16_fixup_kernel, dim3((unsigned)(2 * n_cu)), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(split16_fixup_kernel, dim3((unsigned)(16 * n_cu)), dim3(256), 0, (hipStream_t)stream, g);
         GS_LAUNCH_CHECK("split16_fixup_kernel");
     }
     return GS_OK;

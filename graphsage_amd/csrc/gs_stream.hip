@@ -55,6 +55,7 @@ struct FwdTerm {
     const int32_t* a_idx;  // nullable row gather (layer 0: the self rows of the feature table)
     const float* W;        // [K, ldw]
     int32_t lda, ldw;
+    int32_t K;             // the term's reduction length (the pooling aggregators' self / pooled terms differ: 602 | 512)
 };
 struct FwdArgs {
     FwdTerm t[2];
@@ -95,7 +96,7 @@ __device__ __forceinline__ void stream_fwd_tile(const FwdArgs& g, const int tile
     const int tile_m = it / g.tiles_n, tile_n = it - tile_m * g.tiles_n;
     const int m0 = tile_m * 32, n0 = tile_n * 64;
     const FwdTerm& T = g.t[term];
-    const int K = g.K, N = g.N;
+    const int K = T.K, N = g.N;
     const int nfull = K >> 3;                              // macro steps whose 8 k are all < K
     const int mb = (nfull * wave) >> 2, me = (nfull * (wave + 1)) >> 2;   // this wave's macro steps
     const int arow = min(m0 + l31, g.M - 1);
@@ -460,10 +461,34 @@ __global__ __launch_bounds__(256) void stream_wgrad_kernel(const WgradArgs G, co
 // ------------------------------------------------------------------------------------------ host side
 static inline int rup4s(int x) { return (x + 3) & ~3; }
 
+static int sage_dense_fwd_stream_impl(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self, const float* agg,
+                                      int64_t ld_agg, int32_t d, int64_t n, const float* W_self, int64_t ldw_self,
+                                      const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias,
+                                      float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
+
 extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg,
                                         int64_t ld_agg, int32_t d, int64_t n, const float* W_self, int64_t ldw_self,
                                         const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias,
                                         float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    return sage_dense_fwd_stream_impl(self, ld_self, self_idx, d, agg, ld_agg, d, n, W_self, ldw_self, W_neigh, ldw_neigh, out_dim, act,
+                                      bias, out, ldo, jobs_host, n_jobs, stream);
+}
+
+// the same launch with different reduction lengths of the two terms (pooling aggregators: self rows of d_self features, pooled rows of
+// d_agg = hidden_dim; aggregators.py:183-187 / :261-265)
+extern "C" int gs_sage_dense_fwd_stream2(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self, const float* agg,
+                                         int64_t ld_agg, int32_t d_agg, int64_t n, const float* W_self, int64_t ldw_self,
+                                         const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias,
+                                         float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    GS_REQUIRE(self && d_self > 0, "gs_sage_dense_fwd_stream2: needs a self term");
+    return sage_dense_fwd_stream_impl(self, ld_self, self_idx, d_self, agg, ld_agg, d_agg, n, W_self, ldw_self, W_neigh, ldw_neigh,
+                                      out_dim, act, bias, out, ldo, jobs_host, n_jobs, stream);
+}
+
+static int sage_dense_fwd_stream_impl(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self, const float* agg,
+                                      int64_t ld_agg, int32_t d, int64_t n, const float* W_self, int64_t ldw_self,
+                                      const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias,
+                                      float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
     GS_REQUIRE(n > 0 && agg && W_neigh && out && d > 0 && out_dim > 0, "gs_sage_dense_fwd_stream: bad args");
     GS_REQUIRE(out_dim % 2 == 0 && ldo % 2 == 0, "gs_sage_dense_fwd_stream: out_dim and ldo must be even (8-byte column pairs)");
     GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_stream agg");
@@ -474,16 +499,16 @@ extern "C" int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, cons
     if (self) {
         GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_stream self");
         GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd_stream W_self");
-        GS_REQUIRE(ld_self >= rup4s(d) && ldw_self >= out_dim, "gs_sage_dense_fwd_stream: self ld too small");
-        g.t[0] = FwdTerm{self, self_idx, W_self, (int32_t)ld_self, (int32_t)ldw_self};
-        g.t[1] = FwdTerm{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
+        GS_REQUIRE(ld_self >= rup4s(d_self) && ldw_self >= out_dim, "gs_sage_dense_fwd_stream: self ld too small");
+        g.t[0] = FwdTerm{self, self_idx, W_self, (int32_t)ld_self, (int32_t)ldw_self, d_self};
+        g.t[1] = FwdTerm{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh, d};
         g.nterms = 2;
     } else {
-        g.t[0] = FwdTerm{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh};
+        g.t[0] = FwdTerm{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh, d};
         g.nterms = 1;
     }
     GS_REQUIRE(ldo >= out_dim * g.nterms, "gs_sage_dense_fwd_stream: ldo too small");
-    GS_REQUIRE(std::max(ld_self, ld_agg) < (1ll << 31) && ((int64_t)d + 8) * std::max(ldw_self, ldw_neigh) * 4 < (1ll << 32),
+    GS_REQUIRE(std::max(ld_self, ld_agg) < (1ll << 31) && ((int64_t)std::max(d, self ? d_self : 0) + 8) * std::max(ldw_self, ldw_neigh) * 4 < (1ll << 32),
                "gs_sage_dense_fwd_stream: 32-bit offsets exceeded");
     g.M = (int32_t)n; g.N = out_dim; g.K = d; g.C = out; g.ldc = (int32_t)ldo; g.bias = bias; g.act = act;
     GS_REQUIRE(n < (1ll << 31) - 64, "gs_sage_dense_fwd_stream: too many rows");

@@ -317,6 +317,17 @@ def sage_dense_fwd_stream(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, ac
     return out
 
 
+def sage_dense_fwd_stream2(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, act, bias, out, jobs=(), stream=None):
+    """gs_sage_dense_fwd_stream2: the stream contraction with different reduction lengths of the two terms (pooling aggregators:
+    self rows of self_m.d features gathered through self_idx | pooled rows of agg.d = hidden_dim), concat output."""
+    import ctypes
+    jobs = list(jobs or ())
+    arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_dense_fwd_stream2", self_m.ptr, self_m.ld, ptr(self_idx), self_m.d, agg.ptr, agg.ld, agg.d, n, W_self.ptr, W_self.ld,
+         W_neigh.ptr, W_neigh.ld, out_dim, act, ptr(bias), out.ptr, out.ld, ctypes.addressof(arr), len(jobs), _s(stream))
+    return out
+
+
 def split_rows_words(K, N):
     """int32 words of gs_split_rows' output (gs_split_rows_bytes / 4): groups of 8 k up to an even count of 32-k stages."""
     import ctypes

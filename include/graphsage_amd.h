@@ -228,6 +228,13 @@ int gs_sage_dense_fwd_stream(const float* self, int64_t ld_self, const int32_t* 
                              int32_t d, int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,
                              int64_t ldw_neigh, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
                              const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
+/* gs_sage_dense_fwd_stream2 (ABI 8): the same launch with different reduction lengths of the two terms -- the pooling
+ * aggregators' from_self = self[self_idx] . W_self over d_self features and from_neighs = pooled . W_neigh over d_agg = hidden_dim
+ * (aggregators.py:183-187, :261-265), concat form; pad columns of both operands readable as above. */
+int gs_sage_dense_fwd_stream2(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self, const float* agg,
+                              int64_t ld_agg, int32_t d_agg, int64_t n, const float* W_self, int64_t ldw_self,
+                              const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias, float* out,
+                              int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);
 /* The same contraction on the bf16 matrix pipe WITHOUT giving up fp32: every fp32 operand x is cut into three bf16 pieces

@@ -1020,6 +1020,32 @@ def test_sage_dense_fwd_stream(dev, n, d, out, two, act, bias, gathered):
     assert np.array_equal(c_out.numpy(), X[ids1])
 
 
+@pytest.mark.parametrize("n,d_self,d_agg,out,gathered", [(5632, 602, 512, 128, True), (2100, 50, 1024, 64, False), (70, 602, 37, 6, True)])
+def test_sage_dense_fwd_stream2_terms_of_different_length(dev, n, d_self, d_agg, out, gathered):
+    """gs_sage_dense_fwd_stream2: the pooling aggregators' layer -- self rows of d_self features (gathered or dense) . W_self |
+    pooled rows of d_agg = hidden_dim . W_neigh, concat + bias + relu -- vs NumPy."""
+    rng = np.random.default_rng(n + d_self + d_agg)
+    Nn = 3000
+    X = _asym(rng, (Nn + 1, d_self)); X[Nn] = 0
+    self_ids = rng.integers(0, Nn + 1, size=n).astype(np.int32)
+    self_m = X[self_ids] if gathered else _asym(rng, (n, d_self))
+    pooled = _asym(rng, (n, d_agg))
+    Ws, Wn = _asym(rng, (d_self, out)) * 0.1, _asym(rng, (d_agg, out)) * 0.1
+    b = _asym(rng, (2 * out,)) * 0.1
+    Xd = Mat.from_numpy(X, dev, 32)
+    sd, pd = Mat.from_numpy(self_m, dev), Mat.from_numpy(pooled, dev)
+    outm = Mat.zeros(n, 2 * out, dev)
+    sid_d = _i32(self_ids, dev)
+    Wsd, Wnd, bd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev), torch.from_numpy(b).to(dev)
+    if gathered:
+        ops.sage_dense_fwd_stream2(Xd, sid_d, pd, n, Wsd, Wnd, out, ops.ACT_RELU, bd, outm)
+    else:
+        ops.sage_dense_fwd_stream2(sd, None, pd, n, Wsd, Wnd, out, ops.ACT_RELU, bd, outm)
+    _sync()
+    want = np.maximum(np.concatenate([self_m.astype(np.float64) @ Ws, pooled.astype(np.float64) @ Wn], axis=1) + b, 0)
+    assert_close_rownorm(outm.numpy(), want)
+
+
 @pytest.mark.parametrize("slices0", [22, 11, 45])
 def test_dense_wgrad_grouped_stream(dev, slices0):
     """gs_dense_wgrad_grouped_stream: the weight gradients of a mean step (layer 0: 602x128 x2 over 5632 rows, layer 1:
