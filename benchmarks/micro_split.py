@@ -174,3 +174,32 @@ def pool16():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pool16":
     pool16()
+
+
+def poolloop16(seconds=14.0):
+    """gs_dense_fwd_rows_split16 in a loop for `seconds` (rocm-smi polled meanwhile: clock / power of the two-piece form)."""
+    import time
+    dev = torch.device("cuda:0")
+    st = ops.Stream()
+    s = st.handle
+    N, F, H = 232965, 602, 512
+    g = torch.Generator(device="cpu").manual_seed(0)
+    X = Mat(torch.randn((N + 1, 608), generator=g).to(dev), F)
+    X.buf[:, F:] = 0
+    rows = 133120
+    ids = torch.sort(torch.randperm(N, generator=g)[:100000]).values.to(torch.int32).to(dev)
+    cnt = torch.tensor([81920], dtype=torch.int32, device=dev)
+    W = Mat(torch.randn((F, H), generator=g).to(dev) * 0.05, H)
+    b = torch.zeros(H, device=dev)
+    out = Mat.zeros(rows, H, dev)
+    X2, rexp = ops.split_table_f16(X, stream=s)
+    W2 = ops.split_rows_f16(W, stream=s)
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        us = timeit(lambda: ops.call("gs_dense_fwd_rows_split16", ops.ptr(X2), ops.ptr(rexp), ops.ptr(ids), F, rows, ops.ptr(cnt),
+                                      ops.ptr(W2), H, ops.ACT_RELU, ops.ptr(b), out.ptr, out.ld, None, 0, s), s, iters=200, warmup=0)
+        print("t=%.2fs: %.1f us per launch (81,920 rows = five full rounds)" % (time.time() - t0, us), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "poolloop16":
+    poolloop16()

@@ -576,7 +576,11 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
                 v.w = ldexpf(v.w, -(re + ce[3])) + bv.w;
                 if (g.act == GS_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 float* dst = g.out + (int64_t)row * g.ldo + colg;
+#ifdef S16_NT_STORE
+                if (colg + 3 < N) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#else
                 if (colg + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+#endif
                 else {
                     if (colg < N) dst[0] = v.x;
                     if (colg + 1 < N) dst[1] = v.y;
