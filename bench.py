@@ -837,6 +837,8 @@ def run_aux(DG, args, B, s1, s2):
         return r
 
     try:
+        from graphsage_amd import inits
+        inits.set_seed(123)                # both max-pool legs below start from the SAME initial weights
         e, model, ph, _ = build_model(DG, args, 1, 0, "graphsage_maxpool")
         model.attach_device_epoch(np.random.RandomState(123).permutation(DG.train_nodes), DG.label_table)
         F_, H_, D1, D2, C_ = args.feat_dim, 512, args.dim_1, args.dim_2, DG.num_classes
@@ -856,6 +858,7 @@ def run_aux(DG, args, B, s1, s2):
             del model
             os.environ["GS_POOL_F16"] = "0"
             try:
+                inits.set_seed(123)
                 e, model, ph, _ = build_model(DG, args, 1, 0, "graphsage_maxpool")
                 model.attach_device_epoch(np.random.RandomState(123).permutation(DG.train_nodes), DG.label_table)
                 r3 = timed(model, e, B, s1, args.feat_dim, "graphsage_maxpool_bf16x3", flops_fwd=flops)
