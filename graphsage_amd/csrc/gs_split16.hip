@@ -161,14 +161,15 @@ struct Split16Args {
     int32_t n_max, K, KP, N, act;
     float* ws;            // partial tiles of the split-K tail round (nullable: no split), [<= n_cu][128][256]
     int32_t n_cu;
+    int32_t units;        // what a tail-round tile is cut into: 32-k stages (DMA form) or stage PAIRS (register-staged form)
 };
 struct Sched16 { int full, rem, S; };
-__device__ __host__ __forceinline__ Sched16 split16_schedule(const int nwg, const int stages2, const int n_cu, const bool have_ws) {
+__device__ __host__ __forceinline__ Sched16 split16_schedule(const int nwg, const int units, const int n_cu, const bool have_ws) {
     Sched16 w = {nwg, 0, 1};
     if (have_ws && n_cu > 0) {
         const int r = nwg % n_cu;
         if (r > 0 && 2 * r <= n_cu) {
-            const int pairs = stages2 >> 1;
+            const int pairs = units;
             int sp = pairs < n_cu / r ? pairs : n_cu / r;
             if (sp > 10) sp = 10;                               // (the fix-up launch keeps a tile's parts in registers: <= 10)
             if (sp >= 2) { w.full = nwg - r; w.rem = r; w.S = sp; }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512) void split16_tiled_fwd_kernel(const Split16Arg
     const int nwg = tiles_m * tiles_n;
     const int N = g.N, KP = g.KP;
     const int stages2 = KP >> 5;
-    const Sched16 sch = split16_schedule(nwg, stages2, g.n_cu, g.ws != nullptr);
+    const Sched16 sch = split16_schedule(nwg, g.units, g.n_cu, g.ws != nullptr);
     if ((int)blockIdx.x >= sch.full + sch.rem * sch.S) return;
     int tile, part = -1;                                       // part >= 0: a K part of a tail-round tile (partial tile -> g.ws)
     if ((int)blockIdx.x < sch.full) {
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
     const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
     const int nwg = tiles_m * tiles_n;
     const int N = g.N, KP = g.KP;
-    const int stages2 = KP >> 5;
-    const Sched16 sch = split16_schedule(nwg, stages2, g.n_cu, g.ws != nullptr);
+    const int stages = (g.K + 31) >> 5;                        // (the table's rows are padded to an EVEN stage count for the register-
+    const Sched16 sch = split16_schedule(nwg, g.units, g.n_cu, g.ws != nullptr);   //  staged form; this one stops at the last stage that holds a k < K)
     if ((int)blockIdx.x >= sch.full + sch.rem * sch.S) return;
     int tile, part = -1;
     if ((int)blockIdx.x < sch.full) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
 #ifdef S16_DIAG_NODMA
         if (s > 1) return;
 #endif
-        const int sc = min(s, stages2 - 1);
+        const int sc = min(s, stages - 1);
         __builtin_amdgcn_global_load_lds(xrow + 32 * sc, (lds_ptr_t)(buf + a_dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(xrow + KP + 32 * sc, (lds_ptr_t)(buf + A_PLANE + a_dst), 16, 0, 0);
 #pragma unroll
@@ -483,14 +484,13 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
 #else
 #define S16_MM(dst, q, i, j, pa, pb) dst[i][j] = gs_mfma_f16(fa[q][i][pa], fb[q][j][pb], dst[i][j]); S16_SB
 #endif
-    int s_begin = 0, s_end = stages2;
+    int s_begin = 0, s_end = stages;
     if (part >= 0) {
-        const int pairs = stages2 >> 1;
-        s_begin = 2 * ((pairs * part) / sch.S);
-        s_end = 2 * ((pairs * (part + 1)) / sch.S);
+        s_begin = (stages * part) / sch.S;
+        s_end = (stages * (part + 1)) / sch.S;
     }
     issue(s_begin, smem);
-    issue(s_begin + 1, smem + BUF);
+    issue(s_begin + 1, smem + BUF);                            // (a one-stage part: the stage behind it, landed and never read)
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -503,7 +503,8 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
         const int slot2 = slot == 0 ? 2 : slot - 1;            // (slot + 2) % 3: last read before the barrier of stage s - 1
         const unsigned char* cur = smem + slot * BUF;
         const unsigned char* nxt = smem + slot1 * BUF;
-        issue(s + 2, smem + slot2 * BUF);
+        const bool ahead = s + 2 < s_end;                      // nothing is requested past the end of the tile / part
+        if (ahead) issue(s + 2, smem + slot2 * BUF);
         S16_SB
         S16_MM(sml, 0, 0, 0, 0, 1) rd_a(cur, 1, 0, 0); S16_SB
         S16_MM(sml, 0, 0, 1, 0, 1) rd_a(cur, 1, 1, 0); S16_SB
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
         S16_MM(acc, 0, 1, 0, 0, 0) rd_a(cur, 1, 0, 1); S16_SB
         S16_MM(acc, 0, 1, 1, 0, 0) rd_a(cur, 1, 1, 1); S16_SB
         S16_MM(sml, 0, 0, 0, 1, 0) S16_MM(sml, 0, 0, 1, 1, 0) S16_MM(sml, 0, 1, 0, 1, 0) S16_MM(sml, 0, 1, 1, 1, 0)
-        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // stage s + 1 has landed (mine); my reads of `cur` are done
+        if (ahead) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // stage s + 1 has landed (mine); my reads of `cur` are done
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (nothing younger in flight in the last two stages)
         __builtin_amdgcn_s_barrier();                          // ... everybody's: `nxt` is readable, `cur` may be overwritten (stage s + 3)
         asm volatile("" ::: "memory");
         S16_SB
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256) void split16_fixup_kernel(const Split16Args g)
     const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
     const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
     const int nwg = tiles_m * tiles_n;
-    const Sched16 sch = split16_schedule(nwg, g.KP >> 5, g.n_cu, g.ws != nullptr);
+    const Sched16 sch = split16_schedule(nwg, g.units, g.n_cu, g.ws != nullptr);
     const int t = (int)blockIdx.x >> 5, r = 4 * ((int)blockIdx.x & 31) + ((int)threadIdx.x >> 6);
     if (t >= sch.rem) return;
     const int tile = sch.full + t;
@@ -675,6 +677,7 @@ extern "C" int gs_dense_fwd_rows_split16(const void* X2, const int32_t* rexp, co
     static const bool no_tail = getenv("GS_SPLIT_WIDE_TAIL") && atoi(getenv("GS_SPLIT_WIDE_TAIL")) == 0;     // A/B hook
     const bool tail = ws && !no_tail && n_cu > 0 && ws_bytes >= (int64_t)n_cu * 128 * 256 * (int64_t)sizeof(float);
     GS_REQUIRE(!ws || gs_aligned16(ws), "gs_dense_fwd_rows_split16: the workspace must be 16-byte aligned");
+    g.units = dma ? (d + 31) / 32 : split16_stages2(d) / 2;
     if (tail) { g.ws = ws; g.n_cu = n_cu; blocks += n_cu; }
     if (dma) hipLaunchKernelGGL(split16_dma_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(split16_tiled_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
