@@ -562,7 +562,7 @@ class _PoolingAggregator(_SageBase):
         H = None
         if dedup:
             X, ids, nv_rows = x_all.src, x_all.ids, x_all.src.rows
-            rank_ws = e.ws_i32((self.name, "dd_rank", k), nv_rows)
+            rank_ws = e.ws_i32((self.name, "dd_rank", k), 2 * nv_rows)       # [flags | ranks]: zero-initialised, self-cleaning
             sums_ws = e.ws_i32((self.name, "dd_sums", k), 256)
             uniq = e.ws_i32((self.name, "dd_uniq", k), rows_total)
             inv = e.ws_i32((self.name, "dd_inv", k), rows_total)

@@ -5,15 +5,14 @@
 // sampled ids are duplicates, so the 82 GF pooling GEMM can run on the unique rows (52 GF) and the reduce_max can pick
 // its rows through an index.  ids are node ids in [0, n_values): a flag array + prefix sum gives, in ascending id order,
 //   uniq[0 .. U)   the distinct ids,   inv[j] = position of ids[j] in uniq,   count = U (device word)
-// deterministically (no atomics, no sort), in five small launches.
+// deterministically (no atomics, no sort), in four small launches.
 #include "gs_common.h"
 
 #define DD_BLOCKS 256
 
-__global__ __launch_bounds__(256) void dd_clear_kernel(int32_t* __restrict__ flags, int64_t nv) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += (int64_t)gridDim.x * blockDim.x) flags[t] = 0;
-}
-
+// Workspace: rank_ws = [flags (n_values) | ranks (n_values)].  The flag half must be ZERO on first use; every call leaves it zero
+// again (the rank kernel clears what it has read), so there is no clear launch, and the block offsets are summed by the rank
+// blocks themselves (no scan launch): four launches instead of six (round 5: ~5 us of launch latency each).
 __global__ __launch_bounds__(256) void dd_mark_kernel(const int32_t* __restrict__ ids, int64_t m, int32_t* __restrict__ flags,
                                                       int64_t nv) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += (int64_t)gridDim.x * blockDim.x) {
@@ -37,37 +36,30 @@ __global__ __launch_bounds__(256) void dd_count_kernel(const int32_t* __restrict
     __shared__ int red[4];
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, nv);
     int c = 0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) c += flags[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) c += flags[i] != 0;
     const int tot = dd_block_sum(c, red);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-// exclusive scan of the DD_BLOCKS block counts in place; total -> count_out
-__global__ __launch_bounds__(DD_BLOCKS) void dd_scan_sums_kernel(int32_t* __restrict__ sums, int32_t* __restrict__ count_out) {
-    __shared__ int buf[2][DD_BLOCKS];
-    const int t = threadIdx.x;
-    const int own = sums[t];
-    buf[0][t] = own;
-    __syncthreads();
-    int cur = 0;
-    for (int off = 1; off < DD_BLOCKS; off <<= 1) {
-        buf[1 - cur][t] = buf[cur][t] + (t >= off ? buf[cur][t - off] : 0);
-        cur = 1 - cur;
-        __syncthreads();
-    }
-    sums[t] = buf[cur][t] - own;                                // exclusive
-    if (t == DD_BLOCKS - 1) count_out[0] = buf[cur][t];
-}
-
-// flags -> ranks in place (rank of an unflagged entry = number of flagged entries before it), uniq[rank] = id
-__global__ __launch_bounds__(256) void dd_rank_kernel(int32_t* __restrict__ flags, int64_t nv, int64_t chunk,
-                                                      const int32_t* __restrict__ offs, int32_t* __restrict__ uniq) {
+// flags -> ranks (rank of an unflagged entry = number of flagged entries before it), uniq[rank] = id; the flags are cleared behind
+// the read; block b's offset = sum of the block counts before it (DD_BLOCKS = blockDim: one count per thread); the last block
+// writes the total
+__global__ __launch_bounds__(DD_BLOCKS) void dd_rank_kernel(int32_t* __restrict__ flags, int32_t* __restrict__ ranks, int64_t nv,
+                                                            int64_t chunk, const int32_t* __restrict__ sums,
+                                                            int32_t* __restrict__ uniq, int32_t* __restrict__ count_out) {
     __shared__ int part[256];
+    __shared__ int red[4];
+    const int own = sums[threadIdx.x];
+    const int before = dd_block_sum((int)threadIdx.x < (int)blockIdx.x ? own : 0, red);
+    if (blockIdx.x == DD_BLOCKS - 1) {
+        const int total = dd_block_sum(own, red);
+        if (threadIdx.x == 0) count_out[0] = total;
+    }
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, nv);
     const int64_t per = (chunk + 255) / 256;
     const int64_t a = min(lo + (int64_t)threadIdx.x * per, hi), b = min(a + per, hi);
     int c = 0;
-    for (int64_t i = a; i < b; ++i) c += flags[i];
+    for (int64_t i = a; i < b; ++i) c += flags[i] != 0;
     part[threadIdx.x] = c;
     __syncthreads();
     // exclusive scan of the 256 per-thread counts (Hillis-Steele, in place with a double read per step)
@@ -77,11 +69,12 @@ __global__ __launch_bounds__(256) void dd_rank_kernel(int32_t* __restrict__ flag
         part[threadIdx.x] += v;
         __syncthreads();
     }
-    int r = offs[blockIdx.x] + part[threadIdx.x] - c;
+    int r = before + part[threadIdx.x] - c;
     for (int64_t i = a; i < b; ++i) {
         const int f = flags[i];
-        flags[i] = r;
+        ranks[i] = r;
         if (f) {
+            flags[i] = 0;
             uniq[r] = (int32_t)i;
             ++r;
         }
@@ -103,13 +96,12 @@ extern "C" int gs_unique_ids(const int32_t* ids, int64_t m, int64_t n_values, in
     hipStream_t st = (hipStream_t)stream;
     const int64_t chunk = gs_ceil_div(n_values, DD_BLOCKS);
     const int mblocks = (int)std::min<int64_t>(gs_ceil_div(m, 256), 2048);
-    // (a kernel, not hipMemsetAsync: a memset node inside a captured step graph faulted at replay for some batch sizes)
-    hipLaunchKernelGGL(dd_clear_kernel, dim3((unsigned)std::min<int64_t>(gs_ceil_div(n_values, 256), 2048)), dim3(256), 0, st, rank_ws, n_values);
-    hipLaunchKernelGGL(dd_mark_kernel, dim3(mblocks), dim3(256), 0, st, ids, m, rank_ws, n_values);
-    hipLaunchKernelGGL(dd_count_kernel, dim3(DD_BLOCKS), dim3(256), 0, st, rank_ws, n_values, chunk, sums_ws);
-    hipLaunchKernelGGL(dd_scan_sums_kernel, dim3(1), dim3(DD_BLOCKS), 0, st, sums_ws, count_out);
-    hipLaunchKernelGGL(dd_rank_kernel, dim3(DD_BLOCKS), dim3(256), 0, st, rank_ws, n_values, chunk, sums_ws, uniq_out);
-    hipLaunchKernelGGL(dd_inv_kernel, dim3(mblocks), dim3(256), 0, st, ids, m, rank_ws, n_values, inv_out);
+    int32_t* flags = rank_ws;
+    int32_t* ranks = rank_ws + n_values;
+    hipLaunchKernelGGL(dd_mark_kernel, dim3(mblocks), dim3(256), 0, st, ids, m, flags, n_values);
+    hipLaunchKernelGGL(dd_count_kernel, dim3(DD_BLOCKS), dim3(256), 0, st, flags, n_values, chunk, sums_ws);
+    hipLaunchKernelGGL(dd_rank_kernel, dim3(DD_BLOCKS), dim3(DD_BLOCKS), 0, st, flags, ranks, n_values, chunk, sums_ws, uniq_out, count_out);
+    hipLaunchKernelGGL(dd_inv_kernel, dim3(mblocks), dim3(256), 0, st, ids, m, ranks, n_values, inv_out);
     GS_LAUNCH_CHECK("gs_unique_ids");
     return GS_OK;
 }

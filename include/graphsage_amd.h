@@ -334,7 +334,8 @@ int gs_dense_pool_max_fwd(const float* X, int64_t ldx, const int32_t* idx, int32
  * step's 133 k sampled ids are duplicates):
  *   gs_unique_ids            ids [m] in [0, n_values) -> uniq [count] (ascending), inv [m] (position of ids[j] in uniq) and the
  *                            device word count, by flag array + prefix sum (deterministic, static launch shapes);
- *                            rank_ws: n_values int32 words, sums_ws: 256
+ *                            rank_ws: 2 * n_values int32 words whose FIRST n_values are zero on first use (every call leaves them
+ *                            zero again: no clear launch; ABI 8), sums_ws: 256
  *   gs_dense_fwd_rows_dev    out[i] = act(X[idx[i]] . W + bias) for i < min(n_max, *n_dev): the row count is a device word
  *   gs_segment_max_gather_fwd  pooled[i, c] = max_j H[inv[i*s + j], c], argmax = first j attaining it: the bits of
  *                            gs_dense_pool_max_fwd on the expanded rows */

@@ -356,7 +356,8 @@ def test_unique_ids(dev, m, nv):
     ids = rng.integers(0, nv, size=m).astype(np.int32)
     ids[:7] = [nv - 1, 0, nv - 1, 5 % nv, 5 % nv, 0, nv - 1]
     ids_d = _i32(ids, dev)
-    rank = torch.full((nv,), -5, dtype=torch.int32, device=dev)
+    rank = torch.zeros(2 * nv, dtype=torch.int32, device=dev)          # [flags | ranks]: the flag half zero on first use, self-cleaning
+    rank[nv:] = -5
     sums = torch.zeros(256, dtype=torch.int32, device=dev)
     uniq = torch.full((m,), -1, dtype=torch.int32, device=dev)
     inv = torch.full((m,), -1, dtype=torch.int32, device=dev)
@@ -369,6 +370,7 @@ def test_unique_ids(dev, m, nv):
         assert U == len(want_u)
         assert np.array_equal(uniq.cpu().numpy()[:U], want_u)
         assert np.array_equal(inv.cpu().numpy(), want_inv.astype(np.int32))
+        assert int(rank[:nv].abs().sum().item()) == 0                  # the flag half is left zero
 
 
 @pytest.mark.parametrize("groups,d,hid", [([(5120, 25), (512, 10)], 602, 512), ([(700, 10)], 50, 130), ([(90, 64), (30, 3)], 33, 64)])
@@ -392,7 +394,7 @@ def test_pool_max_on_unique_ids_equals_fused_launch(dev, groups, d, hid):
         ops.dense_pool_max_fwd(Xd, idx_d[hr:hr + n * s], n, s, Wd, bd, p1.rows_slice(r, r + n), a1[r:r + n])
         r, hr = r + n, hr + n * s
     nv = Nn + 1
-    rank, sums = torch.zeros(nv, dtype=torch.int32, device=dev), torch.zeros(256, dtype=torch.int32, device=dev)
+    rank, sums = torch.zeros(2 * nv, dtype=torch.int32, device=dev), torch.zeros(256, dtype=torch.int32, device=dev)
     uniq, inv = torch.zeros(m, dtype=torch.int32, device=dev), torch.zeros(m, dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     ops.call("gs_unique_ids", ops.ptr(idx_d), m, nv, ops.ptr(rank), ops.ptr(sums), ops.ptr(uniq), ops.ptr(inv), ops.ptr(cnt), None)

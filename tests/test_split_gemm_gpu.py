@@ -351,6 +351,12 @@ def test_split_pieces_f16_reconstruct_to_one_rounding(dev):
     nz = mx > 0
     scaled = mx[nz] * np.exp2(e[nz].astype(np.float64))
     assert np.all((scaled >= 2.0 ** 13) & (scaled < 2.0 ** 14))
+    # bit for bit the CPU restatement (oracle/split_pieces.py): same exponents, same round-to-nearest-even cuts, fp16 subnormals kept
+    from oracle import split_pieces as sp
+    h_o, m_o, e_o = sp.cut_rows_f16(X)
+    assert np.array_equal(e, e_o)
+    assert np.array_equal(X2.view(torch.float16).cpu().numpy().reshape(rows, 2, KP)[:, 0, :d].view(np.uint16), h_o.view(np.uint16))
+    assert np.array_equal(X2.view(torch.float16).cpu().numpy().reshape(rows, 2, KP)[:, 1, :d].view(np.uint16), m_o.view(np.uint16))
     rec = (pieces[:, 0, :d] + pieces[:, 1, :d]) * np.exp2(-e.astype(np.float64))[:, None]
     err = np.abs(rec - X.astype(np.float64))
     tol = np.maximum(np.abs(X).astype(np.float64) * 2.0 ** -23, (mx * 2.0 ** -13 * 2.0 ** -25)[:, None])   # half the scaled fp16 subnormal ulp (2^-24 at a row maximum of 2^13..2^14)
