@@ -863,7 +863,11 @@ def run_aux(DG, args, B, s1, s2):
                 model.attach_device_epoch(np.random.RandomState(123).permutation(DG.train_nodes), DG.label_table)
                 r3 = timed(model, e, B, s1, args.feat_dim, "graphsage_maxpool_bf16x3", flops_fwd=flops)
                 r["three_bf16_pieces"] = {"ms_per_step": r3["ms_per_step"], "ms_per_step_events_median": r3["ms_per_step_events_median"],
-                                          "loss_after": model._fetch(B)[0]}
+                                          "loss_after": model._fetch(B)[0],
+                                          "note": "same seed, data and step count as the default leg: the two arithmetics give the same "
+                                                  "last-batch loss to 4 digits over the first 222 steps (benchmarks/debug_pool_legs.py: "
+                                                  "3.7202 ... 3.7155 | 3.7156); once the model leaves the chance plateau (ln 41) the "
+                                                  "single-batch losses of any two runs that differ in the last bit drift apart"}
             finally:
                 os.environ["GS_POOL_F16"] = "1"
     except Exception as ex:            # an aux failure must not lose the headline line
