@@ -396,6 +396,18 @@ __global__ __launch_bounds__(512) void split16_tiled_fwd_kernel(const Split16Arg
 //   c ^ ((r >> 2) & 3) -- the permutation is applied to the SOURCE address of the DMA and again to the fragment reads (the same
 //   involution): the 16 lanes of a ds_read_b128 pass touch all 64 banks once.
 #define S16_NBUF 3
+#ifdef S16_TIMELINE
+// Diagnostics build only (-DS16_TIMELINE, benchmarks/timeline_split16.py): shader-clock stamps of wave 0 of the first 256 workgroups.
+//   [0] entry  [1] first stages requested  [2] first barrier passed  [3] K loop left  [4] epilogue done
+//   [8 + 4 s + 0..3] stage s: first half issued | vmcnt / lgkmcnt wait over | barrier passed | second half issued
+__device__ unsigned long long g_s16_tl[256 * 128];
+extern "C" int gs_debug_s16_timeline(unsigned long long* out_host, int n) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_s16_tl), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define S16_STAMP(k) do { if (tid == 0 && blockIdx.x < 256 && (k) < 128) g_s16_tl[blockIdx.x * 128 + (k)] = clock64(); } while (0)
+#else
+#define S16_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args g) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -403,6 +415,7 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
     constexpr int A_BYTES = 2 * A_PLANE, B_BYTES = 8 * 256 * 16, BUF = A_BYTES + B_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
+    S16_STAMP(0);
     const int count = min(g.n_max, g.n_dev ? *g.n_dev : g.n_max);
     const int tiles_n = (g.N + 255) >> 8, tiles_m = (count + 127) >> 7;
     const int nwg = tiles_m * tiles_n;
@@ -425,7 +438,25 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
     const int arow = tid >> 2;
     const int akc = (tid & 3) ^ ((arow >> 2) & 3);             // the 8-k chunk that lands at this thread's position
     const int grow = min(m0 + arow, count - 1);
+    const int wm = wave >> 2, wn = wave & 3;
+    // The scale exponents of the 16 output rows this thread will store (epilogue: rows 64 wm + 32 i + 4 it + (lane >> 4)), requested
+    // HERE: their ids in one round trip with the A row's id, their exponents in the next, both long landed when the epilogue needs
+    // them.  (Loaded inside the epilogue -- behind its `row < count` branches -- every one of the 16 was two dependent round trips
+    // of its own: 19.8 k of a workgroup's 68.5 k cycles, benchmarks/timeline_split16.py.)
+    int erow[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = min(m0 + 64 * wm + 32 * i + 4 * it + (lane >> 4), count - 1);
+            erow[i][it] = g.idx ? g.idx[rr] : rr;
+        }
     const int64_t srow = g.idx ? (int64_t)g.idx[grow] : (int64_t)grow;
+    int rexp_r[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) rexp_r[i][it] = g.rexp[erow[i][it]];
     const _Float16* __restrict__ xrow = g.X2 + srow * 2 * (int64_t)KP + 8 * akc;
     const int bch = wave >> 2;
     const int bc = min(n0 + (tid & 255), N - 1);
@@ -445,7 +476,6 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
             __builtin_amdgcn_global_load_lds(W2b + (uint32_t)(8 * sc + c) * plane_b, (lds_ptr_t)(buf + b_dst + c * 4096), 16, 0, 0);
         }
     };
-    const int wm = wave >> 2, wn = wave & 3;
     const int sw = (l31 >> 2) & 3;
     const int a_rd = (64 * wm + l31) * 64;                     // + 32 i rows, + plane, + ((2 q + lh) ^ sw) * 16
     const int a_q0 = ((0 + lh) ^ sw) * 16, a_q1 = ((2 + lh) ^ sw) * 16;
@@ -491,9 +521,11 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
     }
     issue(s_begin, smem);
     issue(s_begin + 1, smem + BUF);                            // (a one-stage part: the stage behind it, landed and never read)
+    S16_STAMP(1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    S16_STAMP(2);
     rd_a(smem, 0, 0, 0); rd_b(smem, 0, 0, 1); rd_b(smem, 0, 1, 1); rd_a(smem, 0, 1, 0);
     rd_b(smem, 0, 0, 0); rd_b(smem, 0, 1, 0); rd_a(smem, 0, 0, 1); rd_a(smem, 0, 1, 1);
     int slot = 0;                                              // ring slot of stage s
@@ -515,10 +547,13 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
         S16_MM(acc, 0, 1, 0, 0, 0) rd_a(cur, 1, 0, 1); S16_SB
         S16_MM(acc, 0, 1, 1, 0, 0) rd_a(cur, 1, 1, 1); S16_SB
         S16_MM(sml, 0, 0, 0, 1, 0) S16_MM(sml, 0, 0, 1, 1, 0) S16_MM(sml, 0, 1, 0, 1, 0) S16_MM(sml, 0, 1, 1, 1, 0)
+        S16_STAMP(8 + 4 * (s - s_begin));
         if (ahead) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // stage s + 1 has landed (mine); my reads of `cur` are done
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // (nothing younger in flight in the last two stages)
+        S16_STAMP(9 + 4 * (s - s_begin));
         __builtin_amdgcn_s_barrier();                          // ... everybody's: `nxt` is readable, `cur` may be overwritten (stage s + 3)
         asm volatile("" ::: "memory");
+        S16_STAMP(10 + 4 * (s - s_begin));
         S16_SB
         S16_MM(sml, 1, 0, 0, 0, 1) rd_a(nxt, 0, 0, 0); S16_SB
         S16_MM(sml, 1, 0, 1, 0, 1) rd_b(nxt, 0, 0, 1); S16_SB
@@ -529,8 +564,10 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
         S16_MM(acc, 1, 1, 0, 0, 0) rd_a(nxt, 0, 0, 1); S16_SB
         S16_MM(acc, 1, 1, 1, 0, 0) rd_a(nxt, 0, 1, 1); S16_SB
         S16_MM(sml, 1, 0, 0, 1, 0) S16_MM(sml, 1, 0, 1, 1, 0) S16_MM(sml, 1, 1, 0, 1, 0) S16_MM(sml, 1, 1, 1, 1, 0)
+        S16_STAMP(11 + 4 * (s - s_begin));
         slot = slot1;
     }
+    S16_STAMP(3);
 #undef S16_MM
 #undef S16_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests of the last two stages
@@ -571,7 +608,7 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
             if (partial) {
                 *reinterpret_cast<f32x4*>(wtile + (64 * wm + 32 * i + r) * 256 + 64 * wn + c4) = v;
             } else if (row < count) {
-                const int re = g.rexp[g.idx ? g.idx[row] : row];
+                const int re = rexp_r[i][it];
                 v.x = ldexpf(v.x, -(re + ce[0])) + bv.x;
                 v.y = ldexpf(v.y, -(re + ce[1])) + bv.y;
                 v.z = ldexpf(v.z, -(re + ce[2])) + bv.z;
@@ -591,6 +628,7 @@ __global__ __launch_bounds__(512) void split16_dma_fwd_kernel(const Split16Args 
             }
         }
     }
+    S16_STAMP(4);
 }
 
 // out tile = act(2^-(e_row + e_col) * (sum of the S partial tiles of a tail-round tile, in part order) + bias): one workgroup per
