@@ -829,7 +829,13 @@ def run_aux(DG, args, B, s1, s2):
             # the WHOLE step's time (the backward pass is not counted: a lower bound of the matrix-pipe utilisation)
             tf = flops_fwd / (dt / K) / 1e12
             r["roofline"].update({"bound": "mfma", "algorithmic_flops_fwd_per_step": flops_fwd, "achieved_tflops_fwd_only": tf,
-                                  "peak_tflops": MFMA_F32_PEAK_TF, "frac_mfma_fwd_only": tf / MFMA_F32_PEAK_TF})
+                                  "peak_tflops": MFMA_F32_PEAK_TF, "frac_mfma_fwd_only": tf / MFMA_F32_PEAK_TF,
+                                  "peak_basis": "fp32 MFMA peak (the pipe a plain fp32 contraction of the reference graph would use). These "
+                                                "flops are the REFERENCE graph's (every gathered row through the MLP); the device runs the MLP "
+                                                "once per DISTINCT id (51 of 82 GF) as two-piece fp16 / three-piece bf16 products on the "
+                                                "fp16 / bf16 pipe -- the dominant kernel's own roofline (0.38 of its three-product roof at the "
+                                                "clock power management leaves it, MFMA busy 33 %) is in DESIGN.md section 4 and "
+                                                "profiles/r05_mfma_util_maxpool.md, r05_pool_clock_probe.txt"})
         if dominant and key in dominant.get("configs", {}):
             r["roofline"]["dominant_kernel"] = dominant["configs"][key]
             r["roofline"]["dominant_kernel_source"] = "PROFILE-SOURCED: %s" % dominant["path"]
