@@ -555,7 +555,10 @@ class _PoolingAggregator(_SageBase):
         # through an index (37 % fewer GEMM rows at Reddit's degree)
         # gs_unique_ids makes three passes over a flag word per TABLE row (independent of the batch): worth it while the table
         # is within a small multiple of the step's sampled rows (Reddit: 233 k rows for 133 k ids), not for 10^7-node graphs
-        dedup = (fused_pool and x_all is not None and x_all.ids is not None and rows_total > 2048
+        dedup_min = getattr(self, "dedup_min_rows", None)
+        if dedup_min is None:
+            dedup_min = int(os.environ.get("GS_POOL_DEDUP_MIN_ROWS", "2048"))
+        dedup = (fused_pool and x_all is not None and x_all.ids is not None and rows_total > dedup_min
                  and x_all.src.rows < (1 << 31)
                  and x_all.src.rows <= int(os.environ.get("GS_POOL_DEDUP_MAX_RATIO", "16")) * rows_total
                  and getattr(self, "dedup_pool", os.environ.get("GS_POOL_DEDUP", "1") != "0"))
@@ -571,9 +574,14 @@ class _PoolingAggregator(_SageBase):
                      ops.ptr(inv), ops.ptr(cnt), e.stream)
             Hu = e.ws_mat((self.name, "H_unique", k), rows_total, self.hidden_dim)
             W, bmlp = mlp.vars['weights'].value, mlp.vars['bias'].value.buf
-            if e.split_pool and e.pool_f16 and not x_all.requires_grad:
+            self.last_pool_kernel = None
+            if (e.split_pool and e.pool_f16 and not x_all.requires_grad and e.is_constant_table(X) and e.table16_fits(X)):
                 # ... on the fp16 matrix pipe, operands as two fp16 pieces each (fp32 accuracy class, half the matrix-pipe work of
-                # the three-piece form below, which is bound by the chip's POWER cap): the constant feature table is cut once
+                # the three-piece form below, which is bound by the chip's POWER cap): the constant feature table is cut once.
+                # A table with trainable leading columns (identity features, rewritten behind every optimizer launch) is NOT
+                # constant -- its cut-once copy would be stale from the second step on -- and takes the three-piece kernel below,
+                # which cuts the rows it reads in registers.
+                self.last_pool_kernel = "split16"
                 X2, rexp = e.table16_of(X)
                 ws = e.ws_f32((self.name, "split_ws"), ops.split_tiled_ws_words())
                 ops.call("gs_dense_fwd_rows_split16", ops.ptr(X2), ops.ptr(rexp), ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt),
@@ -582,11 +590,13 @@ class _PoolingAggregator(_SageBase):
             elif e.split_pool:
                 # the 51 GF of the pooling MLP on the bf16 matrix pipe, operands as three bf16 pieces (fp32 accuracy)
                 # (+ a workspace: the last, nearly empty round of its one-per-CU workgroups is cut along K, gs_split.hip)
+                self.last_pool_kernel = "split_bf16x3"
                 ws = e.ws_f32((self.name, "split_ws"), ops.split_tiled_ws_words())
                 ops.call("gs_dense_fwd_rows_split_ws", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt),
                          ops.ptr(e.split_of(mlp.vars['weights'])), self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld,
                          ops.ptr(ws), 4 * ws.numel(), e.stream)
             else:
+                self.last_pool_kernel = "fp32_mfma"
                 ops.call("gs_dense_fwd_rows_dev", X.ptr, X.ld, ops.ptr(uniq), X.d, rows_total, ops.ptr(cnt), W.ptr, W.ld,
                          self.hidden_dim, ACT_RELU, ops.ptr(bmlp), Hu.ptr, Hu.ld, e.stream)
             r = hr = 0

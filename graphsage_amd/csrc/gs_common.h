@@ -38,6 +38,20 @@ void gs_set_error(const char* fmt, ...);
         }                                                                                   \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives more than one GPU must
+// set it on each of them (a once-per-process flag left the second device's launches of > 64 KB LDS failing).  One bit per
+// device ordinal and call site; the result is checked.  Usage: GS_LDS_ATTR(bytes, kernel<template, args>);
+#define GS_LDS_ATTR(bytes, ...)                                                                                             \
+    do {                                                                                                                    \
+        static unsigned long long done__ = 0ull;                                                                            \
+        int dev__ = 0;                                                                                                      \
+        GS_HIP(hipGetDevice(&dev__));                                                                                       \
+        if (dev__ >= 64 || !((done__ >> dev__) & 1ull)) {                                                                   \
+            GS_HIP(hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            if (dev__ < 64) done__ |= 1ull << dev__;                                                                        \
+        }                                                                                                                   \
+    } while (0)
+
 static inline bool gs_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __host__ __device__ static inline int64_t gs_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -488,11 +488,7 @@ static int launch_head(const float* x, int64_t ldx, int64_t n, const float* W, i
                        const float* labels, int64_t ldlab, int32_t C, int sigmoid_loss, float* y, int64_t ldy,
                        float* logits, int64_t ldlo, float* preds, int64_t ldp, float* dlogits, int64_t lddl,
                        float* loss_rows, float* dx, int64_t lddx, size_t lds_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        GS_HIP(hipFuncSetAttribute((const void*)head_fwd_bwd_kernel<DJ, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    GS_LDS_ATTR(160 * 1024, head_fwd_bwd_kernel<DJ, CQ>);
     const int rows_per_wave = n >= 4096 ? 4 : 1;
     const int64_t blocks = gs_ceil_div(n, 4 * rows_per_wave);
     hipLaunchKernelGGL((head_fwd_bwd_kernel<DJ, CQ>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, x, ldx, n, W, ldw,
@@ -907,17 +903,14 @@ __global__ __launch_bounds__(512, 4) void maxpool_sparse_wgrad_dma_kernel(const 
 }
 
 template <int RPW, int DIAG = 0>
-static void launch_spw_dma(dim3 grid, hipStream_t st, const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
+static int launch_spw_dma(dim3 grid, hipStream_t st, const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
                            int32_t d, const int32_t* argmax, int64_t lda, const float* dpm, int64_t ldd, int32_t hidden, int64_t gps,
                            float* slabs, int64_t ld_slab) {
     const size_t lds = ((size_t)GS_SPD_NBUF * (8 * RPW * GS_SPW_LDS_STRIDE + 1024) + GS_SPD_IDS_CAP) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)maxpool_sparse_wgrad_dma_kernel<RPW, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
+    GS_LDS_ATTR(80 * 1024, maxpool_sparse_wgrad_dma_kernel<RPW, DIAG>);
     hipLaunchKernelGGL((maxpool_sparse_wgrad_dma_kernel<RPW, DIAG>), grid, dim3(512), lds, st, X, ldx, ids, n_groups, s, d, argmax, lda, dpm,
                        ldd, hidden, gps, slabs, ld_slab);
+    return GS_OK;
 }
 
 extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_t* ids, int64_t n_groups, int32_t s,
@@ -947,20 +940,22 @@ extern "C" int gs_maxpool_sparse_wgrad(const float* X, int64_t ldx, const int32_
         // the LDS-DMA pipeline (<= 62 KB of LDS: two workgroups per CU)
         hipStream_t st = (hipStream_t)stream;
         const int rpw = (s + 7) / 8;
-        if (rpw == 1) launch_spw_dma<1>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
-        else if (rpw == 2) launch_spw_dma<2>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
-        else if (rpw == 3) launch_spw_dma<3>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
+        int rc = GS_OK;
+#define GS_SPW_V(...) launch_spw_dma<__VA_ARGS__>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab)
+        if (rpw == 1) rc = GS_SPW_V(1);
+        else if (rpw == 2) rc = GS_SPW_V(2);
+        else if (rpw == 3) rc = GS_SPW_V(3);
         else {
             static const int diag = getenv("GS_SPW_DIAG") ? atoi(getenv("GS_SPW_DIAG")) : 0;     // benchmarks/micro_spw.py
-#define GS_SPW_V(...) launch_spw_dma<__VA_ARGS__>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab)
-            if (diag == 1) GS_SPW_V(4, 1);                       // DMA + barriers only
-            else if (diag == 2) GS_SPW_V(4, 2);                  // compute only
-            else if (diag == 6) GS_SPW_V(4, 6);                  // ... without the barrier
-            else if (diag == 14) GS_SPW_V(4, 14);                // ... row reads only
-            else if (diag == 22) GS_SPW_V(4, 22);                // ... FMAs only
-#undef GS_SPW_V
-            else launch_spw_dma<4>(grid, st, X, ldx, ids, n_groups, s, d, argmax, lda, d_pooled_masked, ldd, hidden, gps, slabs, ld_slab);
+            if (diag == 1) rc = GS_SPW_V(4, 1);                  // DMA + barriers only
+            else if (diag == 2) rc = GS_SPW_V(4, 2);             // compute only
+            else if (diag == 6) rc = GS_SPW_V(4, 6);             // ... without the barrier
+            else if (diag == 14) rc = GS_SPW_V(4, 14);           // ... row reads only
+            else if (diag == 22) rc = GS_SPW_V(4, 22);           // ... FMAs only
+            else rc = GS_SPW_V(4);
         }
+#undef GS_SPW_V
+        if (rc != GS_OK) return rc;
     } else {
         // PF: float4 of a group's row segments per thread (16 s of them over the block's threads)
         if (s * (GS_SPW_FB / 4) <= threads)

@@ -828,8 +828,8 @@ static int dense_fwd_rows_split_impl(const float* X, int64_t ldx, const int32_t*
         const size_t wlds = 2 * (3 * 128 * ST_LDA * 2 + 12 * 256 * 16);
         static bool wattr_set = false;
         static int n_cu = 0;
+        GS_LDS_ATTR(wlds, split_tiled_fwd_wide_kernel);
         if (!wattr_set) {
-            GS_HIP(hipFuncSetAttribute((const void*)split_tiled_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
             int dev = 0;
             hipDeviceProp_t prop;
             GS_HIP(hipGetDevice(&dev));
@@ -853,11 +853,7 @@ static int dense_fwd_rows_split_impl(const float* X, int64_t ldx, const int32_t*
     }
     const int64_t blocks = gs_ceil_div(n_max, 128) * gs_ceil_div(out_dim, 128);
     const size_t lds = 2 * (3 * 128 * ST_LDA * 2 + 12 * 128 * 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GS_HIP(hipFuncSetAttribute((const void*)split_tiled_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    GS_LDS_ATTR(lds, split_tiled_fwd_kernel);
     hipLaunchKernelGGL(split_tiled_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
     GS_LAUNCH_CHECK("split_tiled_fwd_kernel");
     return GS_OK;

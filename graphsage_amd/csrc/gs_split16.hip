@@ -700,11 +700,9 @@ extern "C" int gs_dense_fwd_rows_split16(const void* X2, const int32_t* rexp, co
     const size_t lds = dma ? (size_t)S16_NBUF * (2 * 128 * 64 + 8 * 256 * 16) : (size_t)2 * (2 * 128 * S16_LDA * 2 + 8 * 256 * 16);
     static bool attr_set = false;
     static int n_cu = 0;
+    GS_LDS_ATTR(S16_NBUF * (2 * 128 * 64 + 8 * 256 * 16), split16_dma_fwd_kernel);
+    GS_LDS_ATTR(2 * (2 * 128 * S16_LDA * 2 + 8 * 256 * 16), split16_tiled_fwd_kernel);
     if (!attr_set) {
-        GS_HIP(hipFuncSetAttribute((const void*)split16_dma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   S16_NBUF * (2 * 128 * 64 + 8 * 256 * 16)));
-        GS_HIP(hipFuncSetAttribute((const void*)split16_tiled_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   2 * (2 * 128 * S16_LDA * 2 + 8 * 256 * 16)));
         int dev = 0;
         hipDeviceProp_t prop;
         GS_HIP(hipGetDevice(&dev));

@@ -618,11 +618,7 @@ extern "C" int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C) 
 template <int D, int O, int CW>
 static int launch_tail_cw(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
     const size_t lds = tail_lds_bytes(a.D, a.O, a.C);
-    static bool attr_done = false;
-    if (!attr_done) {
-        GS_HIP(hipFuncSetAttribute((const void*)sage_tail_kernel<D, O, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    GS_LDS_ATTR(160 * 1024, sage_tail_kernel<D, O, CW>);
     const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + 1 main workgroup each
     const int64_t blocks = (int64_t)tail_blocks * ((a.z_ready ? 0 : 2 * O / 64) + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_fwd_bwd: grid too large");

@@ -196,11 +196,7 @@ extern "C" int gs_linkpred_fwd_bwd(const float* Y, int64_t ldy, int64_t B, int32
     hipStream_t st = (hipStream_t)stream;
 #define GS_LP(DJ)                                                                                                         \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            GS_HIP(hipFuncSetAttribute((const void*)linkpred_fwd_bwd_kernel<DJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
+        GS_LDS_ATTR(160 * 1024, linkpred_fwd_bwd_kernel<DJ>);                                                              \
         hipLaunchKernelGGL((linkpred_fwd_bwd_kernel<DJ>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, Y, ldy, B, n_neg, \
                            neg_weight, scale, loss_rows, rr_rows, aff_all, ld_aff, dY, lddy, neg_slabs);                  \
     } while (0)
@@ -382,11 +378,7 @@ static int linkpred_norm_launch(const float* Z, int64_t ldz, int64_t B, int32_t 
     hipStream_t st = (hipStream_t)stream;
 #define GS_LPN(DJ)                                                                                                        \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            GS_HIP(hipFuncSetAttribute((const void*)linkpred_norm_fwd_bwd_kernel<DJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
+        GS_LDS_ATTR(160 * 1024, linkpred_norm_fwd_bwd_kernel<DJ>);                                                         \
         hipLaunchKernelGGL((linkpred_norm_fwd_bwd_kernel<DJ>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, Z, ldz, B,  \
                            n_neg, neg_weight, scale, Y, ldy, loss_rows, rr_rows, aff_all, ld_aff, dZ, lddz, neg_slabs);   \
     } while (0)

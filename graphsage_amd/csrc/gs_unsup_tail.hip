@@ -579,11 +579,7 @@ extern "C" int gs_linkpred_tail_supported(int32_t d_in, int32_t out_dim, int32_t
 
 template <int D, int O>
 static int launch_lp_tail(const LpArgs& L, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        GS_HIP(hipFuncSetAttribute((const void*)sage_lp_tail_kernel<D, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    GS_LDS_ATTR(160 * 1024, sage_lp_tail_kernel<D, O>);
     const int NGH = (L.n_neg + TAIL_ROWS - 1) / TAIL_ROWS;
     const int G = L.t.pair_groups + NGH;
     const int64_t blocks = (int64_t)2 * G + L.t.pair_groups + gs_ceil_div(gather_waves, TAIL_WAVES);

@@ -4,6 +4,7 @@ CSR replicated in each GPU's HBM, ONE RCCL all-reduce of the flat gradient buffe
 has no distributed layer at all (single device, supervised_train.py:55-59).
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -227,6 +228,7 @@ class PeerPushAllReduce(object):
     # on fresh windows -- a workaround; with the cache no mapping is ever re-made.  The epoch / flag state in the window simply
     # continues (all ranks continue in lockstep); a window whose sticky error word is set is dropped from the cache.
     _windows = {}
+    _claimed = {}               # cache key -> weakref of the LIVE hook using that window (one user per window: its epoch / flag state)
 
     def _cache_key(self):
         return (int(self.engine.grads.numel()), self.world_size, self.rank, self.chunks, self.spin_limit, str(self.engine.device))
@@ -239,10 +241,24 @@ class PeerPushAllReduce(object):
         engine = self.engine
         multi = self.world_size > 1
         torch.cuda.set_device(engine.device)
-        cached = PeerPushAllReduce._windows.get(self._cache_key()) if not getattr(self, "_fresh", False) else None
+        key = self._cache_key()
+        owner = PeerPushAllReduce._claimed.get(key)
+        owner = owner() if owner is not None else None
+        if owner is not None and owner is not self and owner._peer and not getattr(self, "_fresh", False):
+            # two hooks alive at once with equal parameter counts would share one window's epoch / flag words across two
+            # engine streams -- a race if both exchange concurrently.  Refuse: close() the other hook first.
+            raise RuntimeError("a live PeerPushAllReduce hook of this process already uses the exchange window for %r; "
+                               "close() it before creating another" % (key,))
+        cached = PeerPushAllReduce._windows.get(key) if not getattr(self, "_fresh", False) else None
+        if cached is not None and self._window_errored(cached):
+            # a sticky error word from an earlier run: every later exchange on it would return early -- never re-use it
+            # (left allocated: a peer may still map it)
+            PeerPushAllReduce._windows.pop(key, None)
+            cached = None
         if (not multi and cached) or (multi and _agree(cached is not None, engine)):
             self._peer = cached                    # every rank still holds its window and its mappings of the peers' windows
             self.reused = True
+            PeerPushAllReduce._claimed[key] = weakref.ref(self)
             return
         self.reused = False
         h = ctypes.c_void_p()
@@ -279,7 +295,19 @@ class PeerPushAllReduce(object):
             if not _agree(err is None, engine):       # nobody launches the exchange unless everybody mapped everybody
                 self.close()
                 raise RuntimeError("peer windows could not be mapped on every rank (this rank: %r)" % (err,))
-        PeerPushAllReduce._windows[self._cache_key()] = self._peer
+        PeerPushAllReduce._windows[key] = self._peer
+        PeerPushAllReduce._claimed[key] = weakref.ref(self)
+
+    @staticmethod
+    def _window_errored(peer):
+        import ctypes
+        from . import ops
+        ep, er = ctypes.c_int64(), ctypes.c_int32()
+        try:
+            ops.call("gs_peer_status", peer, ctypes.byref(ep), ctypes.byref(er))
+        except Exception:
+            return True
+        return int(er.value) != 0
 
     def all_reduce(self, flat, stream=None):
         from . import ops
@@ -308,6 +336,9 @@ class PeerPushAllReduce(object):
     def check(self):
         ep, er = self.status()
         if er:
+            # the error word is sticky: this window is finished -- a later hook of this process must not be handed it
+            if PeerPushAllReduce._windows.get(self._cache_key()) == self._peer:
+                PeerPushAllReduce._windows.pop(self._cache_key(), None)
             raise RuntimeError("peer exchange on rank %d gave up waiting for rank(s) %r (stage bits %d, %d exchanges): the "
                                "gradients of this step are not the sum over ranks"
                                % (self.rank, [r for r in range(self.world_size) if (er >> (8 + r)) & 1], er & 3, ep))
@@ -364,8 +395,12 @@ class PeerPushAllReduce(object):
         if self._peer:
             from . import ops
             peer, self._peer = self._peer, None
+            PeerPushAllReduce._claimed.pop(self._cache_key(), None)
             if PeerPushAllReduce._windows.get(self._cache_key()) != peer:
-                ops.call("gs_peer_destroy", peer)
+                # not (or no longer) in the cache: a failed open frees its window; an ERRORED window stays allocated for
+                # the process's lifetime (a peer may still map it) and is simply never handed out again
+                if not self._window_errored(peer):
+                    ops.call("gs_peer_destroy", peer)
 
 
 class SpinHook(object):

@@ -43,6 +43,9 @@ class Variable(object):
         self.split3 = None
         self.split_dirty = True
         self.split_form = "bf16x3"   # or "f16x2": two fp16 pieces under a column scale (gs_split_rows_f16, the pooling MLP)
+        # one buffer per form, never freed or replaced: captured step graphs hold these pointers and re-cut into them
+        # (Engine._params_updated), so switching Engine.pool_f16 on a live model must not move them
+        self.splits = {}
         self.engine = None  # set by Engine.add_variable
 
     @property
@@ -62,11 +65,12 @@ class Variable(object):
             self.recut(self.engine.stream)
 
     def recut(self, stream):
-        """Bring the cut copy of the value (split3) up to date, in the form its consumer reads."""
-        if self.split_form == "f16x2":
-            ops.split_rows_f16(self.value, out=self.split3, stream=stream)
-        else:
-            ops.split_rows(self.value, out=self.split3, stream=stream)
+        """Bring every cut copy of the value up to date (one per form a consumer has asked for, Engine.split_of)."""
+        for form, buf in self.splits.items():
+            if form == "f16x2":
+                ops.split_rows_f16(self.value, out=buf, stream=stream)
+            else:
+                ops.split_rows(self.value, out=buf, stream=stream)
         self.split_dirty = False
 
     def slab_ptr(self, k):
@@ -112,6 +116,10 @@ class Engine(object):
         self._stream_wide_rows = os.environ.get("GS_STREAM_WIDE_ROWS", "0") == "1"
         self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)
         self._table16 = {}                # constant feature tables cut into two fp16 pieces (table16_of)
+        # feature tables some launch of the step REWRITES (identity features: the trainable leading columns are refreshed behind
+        # every optimizer launch, SampleAndAggregate._init_features): data_ptr of their buffers.  A copy of such a table cut once
+        # (table16_of) would go stale after the first update, so consumers ask is_constant_table() first.
+        self.mutable_tables = set()
         # the pooling MLP on the fp16 matrix pipe with two-piece operands (gs_split16.hip): half the matrix-pipe work of the
         # three-piece bf16 form, same accuracy class; needs a constant feature table (no trainable identity features)
         self.pool_f16 = os.environ.get("GS_POOL_F16", "1") == "1"
@@ -454,21 +462,39 @@ class Engine(object):
         """The current three-piece copy of var.value^T (gs_split_rows).  Made on first use; from then on re-made behind every
         optimizer launch (_params_updated) and -- for values written from the host (Variable.assign sets split_dirty) --
         here.  A dirty flag met while capturing records one redundant re-cut in the graph, never a missing one."""
-        if var.split3 is None or var.split_form != form:
+        if form not in var.splits:
             K, N = var.rows, var.cols
             words = ops.split_rows_f16_words(K, N) if form == "f16x2" else ops.split_rows_words(K, N)
-            var.split3 = torch.empty(words, dtype=torch.int32, device=self.device)
-            var.split_form = form
+            # a NEW buffer per form; the other form's buffer (and the graphs that captured its pointer) stay valid
+            var.splits[form] = torch.empty(words, dtype=torch.int32, device=self.device)
             var.split_dirty = True
             if var not in self._split_vars:
                 self._split_vars.append(var)
+        var.split3, var.split_form = var.splits[form], form
         if var.split_dirty:
             var.recut(self.stream)
         return var.split3
 
+    def is_constant_table(self, X):
+        """No launch of the step rewrites this feature table (see mutable_tables)."""
+        return X.buf.data_ptr() not in self.mutable_tables
+
+    def table16_bytes(self, X):
+        """HBM the two-piece fp16 copy of X takes: [rows][2 pieces][KP] fp16 + one int32 exponent per row."""
+        return X.rows * (2 * 2 * round_up(X.d, 64) + 4)
+
+    def table16_fits(self, X):
+        """The copy is a second table-sized allocation (Reddit: 596 MB, but several GB at GS_POOL_DEDUP_MAX_RATIO = 16 on a
+        10^7-row table): taken only within GS_TABLE16_MAX_GB (default 16; beyond it the three-piece bf16 kernel, which cuts its
+        rows in registers, runs instead)."""
+        return self.table16_bytes(X) <= float(os.environ.get("GS_TABLE16_MAX_GB", "16")) * (1 << 30)
+
     def table16_of(self, X):
         """The two-piece fp16 copy of a CONSTANT feature table (gs_split_table_f16): made once per table (keyed by its buffer), on
         the first -- eager -- execution of a step; (X2, row exponents)."""
+        if not self.is_constant_table(X):
+            raise ops._lib.GraphsageAmdError("table16_of: the table has trainable columns (identity features); a copy cut once "
+                                             "would go stale after the first optimizer step")
         key = (X.ptr, X.rows, X.d, X.ld)
         hit = self._table16.get(key)
         if hit is None:

@@ -176,6 +176,8 @@ class SampleAndAggregate(object):
             torch.cuda.synchronize()
         if self.embeds is not None:
             e.post_update_hooks.append(self._refresh_embeds)
+            # the table's leading columns are rewritten behind every optimizer launch: no cut-once copies of it (Engine.table16_of)
+            e.mutable_tables.add(self.features.buf.data_ptr())
             # the prefetch pipeline gathers step t+1's rows before step t's update: not valid for a trainable table
             self.pipeline = False
 
@@ -445,15 +447,23 @@ class SampleAndAggregate(object):
         e = self.engine
         roots, B, n_roots = self._stage_feed_unsup(feed_dict)
         fused = self.grad_hook is None
+        in_graph = self._dp_in_graph()
 
         def fwd_bwd():
             self._stage_negatives_or_injected(roots, B)
             epilogue = dict(step=1 if fused else 0, clock=1)
             self._forward_unsup(roots, B, n_roots, True, epilogue=epilogue)
             self._backward_unsup(B, n_roots, fuse_adam=fused, epilogue=epilogue)
+            if in_graph and not self._peer_fused():
+                # backward | ncclAllReduce (recorded in the graph) | clip + Adam, as _pipelined_steps_unsup
+                self.grad_hook(self)
+                self._optimize()
 
-        self._run(("utrain" if fused else "utrain_fb", B, self._adj_version()), fwd_bwd)
-        if not fused:
+        # With a capturable hook the whole data-parallel step is this one function: a PeerPushAllReduce hook with fused_step
+        # has ALREADY exchanged, clipped and applied Adam inside _backward_unsup (gs_peer_step) -- running the hook and
+        # _optimize() again behind it would all-reduce the summed gradients a second time and take a second Adam step.
+        self._run(("utrain" if fused else ("utrain_dp" if in_graph else "utrain_fb"), B, self._adj_version()), fwd_bwd)
+        if not fused and not in_graph:
             self.grad_hook(self)
             self._run(("opt",), self._optimize)
         return self._fetch_unsup(B) if fetch else None

@@ -304,3 +304,67 @@ def test_peer_fused_step_single_rank_equals_local_adam(dev, agg):
     for o in outs[1:]:
         assert o[0] == outs[0][0]
         assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+
+
+@pytest.mark.parametrize("hook_kind", ["peer_fused", "peer_three_launches", "rccl"])
+def test_unsup_host_fed_train_step_applies_one_update_per_step_under_capturable_hooks(dev, hook_kind):
+    """SampleAndAggregate.train_step(feed_dict) (unsupervised_train.py:273-274) under a hook that can be recorded in the step
+    graph: the exchange and the optimizer run ONCE per step.  (Round 5's review: with PeerPushAllReduce.fused_step the
+    backward pass already ends in gs_peer_step -- exchange + clip + Adam -- and the trailing hook + _optimize() applied both
+    a second time.)  World of one rank: parameters, Adam state and the step counter equal the hook-free model's, bit for bit."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from graphsage_amd import distributed as gsd
+    from graphsage_amd import engine as eng
+    from test_unsup_gpu import build as build_unsup
+    outs = []
+    for mode in ("local", hook_kind):
+        G, it, ph, sampler, model, ns = build_unsup("mean", True, csr=True, wd=0.01)
+        e = eng.get_engine()
+        hook = None
+        if mode == "rccl":
+            hook = gsd.NativeAllReduce(e, world_size=1, rank=0)
+        elif mode != "local":
+            hook = gsd.PeerPushAllReduce(e)
+            hook.fused_step = mode == "peer_fused"
+            assert hook.self_test()
+        if hook is not None:
+            model.grad_hook = hook
+            assert model._dp_in_graph() and (model._peer_fused() is not None) == (mode == "peer_fused")
+        edges = it.train_edges[:32 * 4]
+        for i in range(4):                      # eager, captured, replayed, replayed
+            b = edges[32 * i: 32 * (i + 1)]
+            model.train_step({ph['batch1']: b[:, 0], ph['batch2']: b[:, 1], ph['batch_size']: 32}, fetch=(i == 3))
+        e.sync()
+        outs.append((e.params.cpu().numpy().copy(), e.adam_v.cpu().numpy().copy(), int(e.step_dev.item())))
+        if hook is not None:
+            assert any(k[0] == "utrain_dp" for k in model._graphs), list(model._graphs)
+            if hasattr(hook, "check"):
+                hook.check()
+            hook.close()
+    assert outs[0][2] == outs[1][2] == 4
+    if hook_kind == "rccl":
+        np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6, atol=1e-8)
+    else:
+        assert np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1])
+
+
+def test_peer_window_has_one_live_user_and_an_errored_window_is_never_reused(dev):
+    """Process-lifetime exchange windows (PeerPushAllReduce._windows) are keyed by shape: a second LIVE hook with the same key
+    is refused (it would share the first one's epoch / flag words across two streams); after close() the window is handed on."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from graphsage_amd import distributed as gsd
+    from graphsage_amd import engine as eng
+    from test_model_gpu import build
+    build(torch.device("cuda:0"), "mean", True, False, csr=True)
+    e = eng.get_engine()
+    a = gsd.PeerPushAllReduce(e)
+    assert a.self_test()
+    with pytest.raises(RuntimeError, match="already uses the exchange window"):
+        gsd.PeerPushAllReduce(e)
+    win = a._peer
+    a.close()
+    b = gsd.PeerPushAllReduce(e)
+    assert b.reused and b._peer == win and b.self_test()
+    b.close()

@@ -158,6 +158,45 @@ def test_identity_features_match_oracle(dev, agg_type, concat, sigmoid, idim, us
     assert float(model.embeds.slabs.abs().max().item()) == 0.0                       # accumulator consumed
 
 
+def test_identity_features_maxpool_distinct_id_mlp_reads_the_fresh_table(dev):
+    """Round 5's review: the default pooling MLP (two fp16 pieces per operand) reads a copy of the feature table cut ONCE
+    (Engine.table16_of); with identity_dim > 0 the table's leading columns are the trainable node_embeddings, rewritten behind
+    every optimizer launch, so from the second step on that copy is stale.  Such a table must take the kernel that cuts the
+    rows it reads (three bf16 pieces).  The distinct-id path is forced (dedup_min_rows = 0; the other identity tests gather
+    < 2048 rows and never reach it); three steps against the oracle on the CURRENT embeddings."""
+    wd, idim = 0.01, 5
+    G, it, ph, sampler, model, ns = build(dev, "maxpool", True, True, wd=wd, identity_dim=idim)
+    model.use_graphs = False
+    e = eng.get_engine()
+    assert e.pool_f16 and e.split_pool and not e.is_constant_table(model.features)
+    with pytest.raises(Exception):
+        e.table16_of(model.features)
+    model.aggregators[0].dedup_min_rows = 0
+    rng = np.random.RandomState(4)
+    batch = rng.choice(it.train_nodes, size=29, replace=False).astype(np.int32)
+    labels = it.label_matrix[batch]
+    feed = {ph['batch']: batch, ph['labels']: labels, ph['batch_size']: len(batch)}
+    for step in (1, 2, 3):
+        perms = [rng.permutation(it.max_degree) for _ in ns]
+        sampler.inject_perms(perms)
+        params = oracle_params(model, "maxpool")
+        emb0 = model.embeds.numpy().copy()
+        feats = np.concatenate([emb0, G.padded_features()], axis=1)
+        loss, preds = model.train_step(feed)
+        assert model.aggregators[0].last_pool_kernel == "split_bf16x3", model.aggregators[0].last_pool_kernel
+        cnt, rows_total = model.aggregators[0].last_unique
+        assert 0 < int(cnt.item()) <= rows_total
+        samples, support = orc.sample(it.adj, batch, ns, perms)
+        res = orc.supervised_fwd_bwd(params, feats, samples, support, labels, model.dims, ns, len(batch), "maxpool",
+                                     True, True, weight_decay=wd, identity_dim=idim)
+        np.testing.assert_allclose(loss, res["loss"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(preds, res["preds"], rtol=1e-4, atol=1e-4)
+        got = device_grads(model, "maxpool")
+        for (name, g), (_, w) in zip(orc.flat_param_items(got, "maxpool"), orc.flat_param_items(res["grads"], "maxpool")):
+            np.testing.assert_allclose(g.reshape(w.shape), w, rtol=1e-4, atol=1e-4 * max(1e-2, np.abs(w).max()),
+                                       err_msg="step %d %s" % (step, name))
+
+
 def test_identity_features_graph_replay(dev):
     """The scatter + refresh launches are part of the captured step: replayed steps == eager steps (up to the
     summation order of the fp32 atomics)."""
