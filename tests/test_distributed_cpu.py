@@ -140,6 +140,9 @@ def _peer_worker(rank, world, port, q):
     scenario = {"name": None}
 
     def fake_call(name, *args):
+        if name == "gs_peer_status":                    # the cached window's sticky error word is read before it is handed on
+            args[1]._obj.value, args[2]._obj.value = 0, 0
+            return 0
         calls.append(name)
         if name == "gs_peer_create":
             if scenario["name"] == "create" and rank == 1:
@@ -167,7 +170,7 @@ def _peer_worker(rank, world, port, q):
             out[name] = ("constructed", list(calls))
             hook.close()
             # process-lifetime windows (round 5): a window that opened on every rank stays allocated and mapped -- close()
-            # detaches only -- and a re-created hook of the same shape re-uses it without a single C call
+            # detaches only -- and a re-created hook of the same shape re-uses it without a single C call (but the status read)
             assert "gs_peer_destroy" not in calls
             n_calls = len(calls)
             again = gsd.PeerPushAllReduce(FakeEngine())
