@@ -15,7 +15,7 @@ ACT_RELU = 1
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
 SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
 GS_PEER_HANDLE_BYTES = 64
-GS_ABI_VERSION = 9      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+GS_ABI_VERSION = 8      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -109,7 +109,6 @@ _PROTOS = {
                                    c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P, c_int32, _P],
     "gs_sage_tail_supported": [c_int32, c_int32, c_int32],
     "gs_sage_tail_fwd_bwd": [_P, _P, c_int32, _P],
-    "gs_sage_fwd_tail": [_P, _P, _P, c_int32, _P],
     "gs_sage_tail_z": [_P, _P, c_int32, _P],
     "gs_sage_tail_dh0": [_P, _P, c_int32, _P],
     "gs_dropout_rows": [_P, c_int64, _P, c_int64, c_int32, _P, _P, c_int64, _P],
@@ -192,15 +191,6 @@ class TailDesc(ctypes.Structure):
                 ("train", c_int32), ("sync", c_void_p), ("z_ready", c_int32), ("gcn", c_int32)]
 
 
-class FwdDesc(ctypes.Structure):
-    """struct gs_fwd_desc (include/graphsage_amd.h)"""
-    _fields_ = [("self", c_void_p), ("ld_self", c_int64), ("self_idx", c_void_p), ("d_self", c_int32),
-                ("agg", c_void_p), ("ld_agg", c_int64), ("d_agg", c_int32), ("n_rows", c_int64),
-                ("W_self", c_void_p), ("ldw_self", c_int64), ("W_neigh", c_void_p), ("ldw_neigh", c_int64),
-                ("out_dim", c_int32), ("act", c_int32), ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int64),
-                ("done", c_void_p)]
-
-
 class LpTailDesc(ctypes.Structure):
     """struct gs_lp_tail_desc (include/graphsage_amd.h)"""
     _fields_ = [("h0", c_void_p), ("ldh", c_int64), ("B", c_int64), ("n_neg", c_int32), ("s", c_int32), ("d_in", c_int32),
@@ -278,7 +268,7 @@ def load(build_if_missing=True):
         fn.restype = c_int
         fn.argtypes = argtypes
     # struct layouts: the library's sizeof() of every descriptor must equal the ctypes mirror's
-    mirrors = [GatherDesc, WgradDesc, VarDesc, FanoutDesc, TailDesc, Dropout, PullDesc, LpTailDesc, FwdDesc]
+    mirrors = [GatherDesc, WgradDesc, VarDesc, FanoutDesc, TailDesc, Dropout, PullDesc, LpTailDesc]
     sizes = (c_int32 * 16)()
     n = lib.gs_abi_struct_sizes(sizes, 16)
     if n != len(mirrors):

@@ -254,15 +254,7 @@ class MeanAggregator(_SageBase):
                     ops.sage_dense_fwd_cogather(self_all.src, self_all.ids, means, None, n_total,
                                                 self.vars['self_weights'].value, self.vars['neigh_weights'].value,
                                                 self.output_dim, self.concat, self.act_code, b, out, jobs, stream=e.stream)
-            self.deferred_fwd = None
-            if getattr(self, "defer_fwd", False) and stream_fwd and not split_fwd:
-                # the caller runs this contraction inside ITS launch (gs_sage_fwd_tail: layer 0 + the fused tail as one
-                # kernel): hand the operands over instead of launching; the gather jobs ride in that launch too
-                self.deferred_fwd = dict(self_m=self_all.src, self_idx=self_all.ids, agg=means, n_rows=n_total,
-                                         W_self=self.vars['self_weights'].value, W_neigh=self.vars['neigh_weights'].value,
-                                         out_dim=self.output_dim, act=self.act_code, bias=b, out=out, jobs=list(side_jobs or ()))
-            else:
-                launch()
+            launch()
             # bench.py re-issues exactly this launch between HIP events (roofline of the step's dominant kernel)
             d_in = self_all.src.d
             jobs_ = list(side_jobs or ())
@@ -428,15 +420,8 @@ class GCNAggregator(_SageBase):
                                      self.act_code, b, out, side_jobs, stream=e.stream)
         elif e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
             # stream form: LDS-free contraction waves (+ the next step's gather jobs) in one launch
-            self.deferred_fwd = None
-            if getattr(self, "defer_fwd", False):
-                # (see MeanAggregator.call_hops: the caller's launch runs this contraction)
-                self.deferred_fwd = dict(self_m=None, self_idx=None, agg=means, n_rows=n_total, W_self=None,
-                                         W_neigh=self.vars['weights'].value, out_dim=self.output_dim, act=self.act_code, bias=b,
-                                         out=out, jobs=list(side_jobs or ()))
-            else:
-                ops.sage_dense_fwd_stream(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim,
-                                          self.act_code, b, out, side_jobs, stream=e.stream)
+            ops.sage_dense_fwd_stream(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
+                                      b, out, side_jobs, stream=e.stream)
         elif side_jobs:
             # horizontally fused launch: these GEMM tiles + the NEXT step's gather-mean waves share the CUs
             ops.sage_dense_fwd_cogather(None, None, means, None, n_total, None, self.vars['weights'].value, self.output_dim,

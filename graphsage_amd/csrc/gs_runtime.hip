@@ -24,7 +24,7 @@ extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
 extern "C" int gs_abi_struct_sizes(int32_t* sizes_out_host, int32_t capacity) {
     const int32_t sizes[] = {(int32_t)sizeof(gs_gather_desc), (int32_t)sizeof(gs_wgrad_desc), (int32_t)sizeof(gs_var_desc),
                              (int32_t)sizeof(gs_fanout_desc), (int32_t)sizeof(gs_tail_desc), (int32_t)sizeof(gs_dropout),
-                             (int32_t)sizeof(gs_pull_desc), (int32_t)sizeof(gs_lp_tail_desc), (int32_t)sizeof(gs_fwd_desc)};
+                             (int32_t)sizeof(gs_pull_desc), (int32_t)sizeof(gs_lp_tail_desc)};
     const int32_t n = (int32_t)(sizeof(sizes) / sizeof(sizes[0]));
     for (int32_t i = 0; i < n && i < capacity; ++i) sizes_out_host[i] = sizes[i];
     return n;

@@ -24,7 +24,6 @@
 // contraction, whose K is split across the waves and summed in a fixed order through LDS (deterministic).
 #include "gs_common.h"
 #include "gs_gather_dev.h"
-#include "gs_stream_dev.h"
 
 #include "gs_tail_dev.h"
 
@@ -38,16 +37,8 @@ extern "C" int gs_debug_tail_timeline(unsigned long long* out_host, int n) {
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
-// FWD = true: the ONE-LAUNCH form of layer 0 + tail (gs_sage_fwd_tail; "persistent step", stage a).  The layer-0 contraction
-// of every hop (aggregators.py:43-64, the work of sage_stream_fwd_kernel) runs as the FIRST class of workgroups of this
-// launch -- two 32 x 64 tiles per 8-wave workgroup, each tile exactly stream_fwd_tile (same K quarters, same summation order:
-// h0 is bit-identical to the two-launch schedule) -- and publishes h0 per 32-row block behind monotonic counters
-// (TailArgs.fdone); the z helpers and the main workgroups of group g start as soon as the <= 8 blocks that hold the group's
-// self and neighbor rows are complete, instead of behind a kernel boundary (drain of the slowest layer-0 wave and of its
-// riders, launch, ramp).  Dispatch order = dependency order: tiles (never wait) < helpers (wait for tiles) < mains (wait for
-// helpers) < riders; every wait is bounded and sets the error word.
-template <int D, int O, int CW, bool FWD = false>
-__global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J, const FwdArgs F) {
+template <int D, int O, int CW>
+__global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
     // Co-scheduled gather: the tail occupies n/16 CUs for ~30 us of mostly waiting; the other ~220 CUs (one 8-wave
     // workgroup each: the launch's LDS size is uniform) stream a share of the NEXT step's gather+mean from HBM meanwhile.
     // Roles by block index: [0, HP G) z HELPERS, [HP G, (HP + 1) G) the G = n/16 MAIN workgroups, then gather riders.
@@ -61,31 +52,17 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     constexpr int HP = 2 * O / 64;
     const int G = tail_blocks;
     const int hp = a.z_ready ? 0 : HP;                   // split form: no helper workgroups in this launch
-    int bid = (int)blockIdx.x;
-    if (FWD) {
-        const int nf = (F.n_tiles + 1) >> 1;             // layer-0 workgroups: two tiles each
-        if (bid < nf) {
-            extern __shared__ __attribute__((aligned(16))) float lds_f[];
-            const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            const int tile = 2 * stream_xcd_swizzle(bid, nf) + (wave >> 2);
-            const bool valid = tile < F.n_tiles;
-            stream_fwd_tile<4, true>(F, valid ? tile : F.n_tiles - 1, wave & 3, lane,
-                                     reinterpret_cast<float (*)[32][64]>(lds_f + (wave >> 2) * (4 * 32 * 64)), valid, a.fdone);
-            return;
-        }
-        bid -= nf;
-    }
-    if (bid >= (hp + 1) * G) {
+    if ((int)blockIdx.x >= (hp + 1) * G) {
         // (a rider wave walking 4 consecutive items with prefetched ids, and 25 loads in flight per lane, were measured:
         // 46 us / no change against 35 us -- with one 8-wave workgroup per CU the riders stream at ~4.6 TB/s either way)
-        run_gather_item<13>(J, ((int64_t)bid - (hp + 1) * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+        run_gather_item<13>(J, ((int64_t)blockIdx.x - (hp + 1) * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
-    if (bid < hp * G) {
-        tail_z_helper<D, O, FWD>(a, bid / HP, bid % HP, true, G);
+    if ((int)blockIdx.x < hp * G) {
+        tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP);
         return;
     }
-    const int grp = bid - hp * G;
+    const int grp = (int)blockIdx.x - hp * G;
     TAIL_STAMP(0);
     constexpr int Z = 2 * O;
     constexpr int ldh = D + 4, ldzs = Z + 4;
@@ -124,19 +101,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // ================= S0: issue this thread's h0 rows and the wave's z-contraction weight slab
-    // (one-launch form: once layer 0 has published the group's rows; read with device-scope loads)
-    uint32_t fgen = 0u;
-    if (FWD) fgen = tail_wait_fwd(a, G, grp);
     f32x4 hself[PASSES], hnb[PASSES][TAIL_NB];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int it = tid + p * TAIL_THREADS;
         const int r = it / D4, c = (it % D4) * 4;
         const int i = min(r0 + r, n - 1);
-        hself[p] = tail_ld4<FWD>(a.h0 + i * ldh0 + c);
+        hself[p] = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
         const float* nb = a.h0 + (n + i * s) * ldh0 + c;
 #pragma unroll
-        for (int u = 0; u < TAIL_NB; ++u) hnb[p][u] = tail_ld4<FWD>(nb + min(u, s - 1) * ldh0);
+        for (int u = 0; u < TAIL_NB; ++u) hnb[p][u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
     }
     // ---------------- phase 0: the relu mask bits of this thread's h0 rows (for phase 8); the rows themselves are only
     // needed by the z helpers
@@ -353,7 +327,6 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     }
     if (!a.train) {
         if (!a.z_ready) tail_sync_done<HP>(a, G, grp, sync_base);
-        if (FWD) tail_fwd_done(a, grp, fgen);
         if (grp == 0 && tid == 0) {
             if (a.c0) *a.c0 += a.d0;
             if (a.c1) *a.c1 += a.d1;
@@ -483,7 +456,6 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     }
     TAIL_STAMP(10);
     if (!a.z_ready) tail_sync_done<HP>(a, G, grp, sync_base);
-    if (FWD) tail_fwd_done(a, grp, fgen);
     if (grp == 0 && tid == 0) {                       // device counters (sampler clock / epoch cursor / optimizer step)
         if (a.c0) *a.c0 += a.d0;
         if (a.c1) *a.c1 += a.d1;
@@ -643,50 +615,25 @@ extern "C" int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C) 
     return ok ? 1 : 0;
 }
 
-static size_t fwd_tail_lds_bytes(int D, int O, int C) { return std::max(tail_lds_bytes(D, O, C), (size_t)2 * 4 * 32 * 64 * sizeof(float)); }
-
 template <int D, int O, int CW>
-static int launch_tail_cw(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st, const FwdArgs* F) {
-    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + 1 main workgroup each
-    int64_t blocks = (int64_t)tail_blocks * ((a.z_ready ? 0 : 2 * O / 64) + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
-    if (F) {
-        // one-launch form: the layer-0 tile workgroups (two tiles each) in front
-        blocks += (F->n_tiles + 1) / 2;
-        GS_REQUIRE(blocks < (1ll << 31), "gs_sage_fwd_tail: grid too large");
-        GS_LDS_ATTR(160 * 1024, sage_tail_kernel<D, O, CW, true>);
-        hipLaunchKernelGGL((sage_tail_kernel<D, O, CW, true>), dim3((unsigned)blocks), dim3(TAIL_THREADS), fwd_tail_lds_bytes(a.D, a.O, a.C),
-                           st, a, tail_blocks, J, *F);
-        GS_LAUNCH_CHECK("sage_tail_kernel<fwd>");
-        return GS_OK;
-    }
+static int launch_tail_cw(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
     const size_t lds = tail_lds_bytes(a.D, a.O, a.C);
     GS_LDS_ATTR(160 * 1024, sage_tail_kernel<D, O, CW>);
+    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + 1 main workgroup each
+    const int64_t blocks = (int64_t)tail_blocks * ((a.z_ready ? 0 : 2 * O / 64) + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_fwd_bwd: grid too large");
-    hipLaunchKernelGGL((sage_tail_kernel<D, O, CW>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J, FwdArgs{});
+    hipLaunchKernelGGL((sage_tail_kernel<D, O, CW>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
     GS_LAUNCH_CHECK("sage_tail_kernel");
     return GS_OK;
 }
 
 template <int D, int O>
-static int launch_tail(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st, const FwdArgs* F = nullptr) {
+static int launch_tail(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
     // C <= 64: one class per lane; 64 < C <= 128 (e.g. PPI's 121 sigmoid labels, example_supervised.sh): two
-    return a.C > 64 ? launch_tail_cw<D, O, 2>(a, J, gather_waves, st, F) : launch_tail_cw<D, O, 1>(a, J, gather_waves, st, F);
+    return a.C > 64 ? launch_tail_cw<D, O, 2>(a, J, gather_waves, st) : launch_tail_cw<D, O, 1>(a, J, gather_waves, st);
 }
-
-static int sage_tail_impl(const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream, const gs_fwd_desc* f);
 
 extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
-    return sage_tail_impl(q, jobs_host, n_jobs, stream, nullptr);
-}
-
-// Layer 0 (every hop) + the fused tail as ONE launch: see sage_tail_kernel<..., FWD = true>.
-extern "C" int gs_sage_fwd_tail(const gs_fwd_desc* f, const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
-    GS_REQUIRE(f && q, "gs_sage_fwd_tail: null descriptor");
-    GS_REQUIRE(q->n > 0 && q->train && !q->z_ready, "gs_sage_fwd_tail: needs a training step (n > 0, train, no split form)");
-    return sage_tail_impl(q, jobs_host, n_jobs, stream, f);
-}
-
-static int sage_tail_impl(const gs_tail_desc* q, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream, const gs_fwd_desc* f) {
     GS_REQUIRE(q, "gs_sage_tail_fwd_bwd: null descriptor");
     if (q->n == 0) return GS_OK;
     GS_REQUIRE(q->n > 0 && q->s > 0, "gs_sage_tail_fwd_bwd: bad sizes");
@@ -743,26 +690,10 @@ static int sage_tail_impl(const gs_tail_desc* q, const gs_gather_desc* jobs_host
         int rc = build_cojobs_s(jobs_host, n_jobs, &J, &gw);
         if (rc != GS_OK) return rc;
     }
-    FwdArgs F = {};
-    const FwdArgs* Fp = nullptr;
-    if (f) {
-        // layer 0 in the same launch: its output IS the tail's h0 (all n + n s rows), published per 32-row block
-        int rc = stream_fwd_args(f->self, f->ld_self, f->self_idx, f->d_self, f->agg, f->ld_agg, f->d_agg, f->n_rows, f->W_self, f->ldw_self,
-                                 f->W_neigh, f->ldw_neigh, f->out_dim, f->act, f->bias, f->out, f->ldo, &F);
-        if (rc != GS_OK) return rc;
-        GS_REQUIRE(f->out == q->h0 && f->ldo == q->ldh && f->n_rows == q->n + q->n * (int64_t)q->s && F.nterms * f->out_dim == D,
-                   "gs_sage_fwd_tail: layer 0 must write the tail's h0 ([n + n s, d_in] at the same address and ld)");
-        GS_REQUIRE(f->done, "gs_sage_fwd_tail: done (ceil((n + n s) / 32) + ceil(n / 16) zero-initialised uint32 words, private to the "
-                            "caller's stream) missing");
-        a.fdone = f->done;
-        a.f_rb = (int32_t)gs_ceil_div(f->n_rows, 32);
-        a.f_trb = F.tiles_n * F.nterms;
-        Fp = &F;
-    }
-    if (D == 256 && O == 128) return launch_tail<256, 128>(a, J, gw, st, Fp);
-    if (D == 256 && O == 64) return launch_tail<256, 64>(a, J, gw, st, Fp);
-    if (D == 128 && O == 128) return launch_tail<128, 128>(a, J, gw, st, Fp);
-    return launch_tail<128, 64>(a, J, gw, st, Fp);
+    if (D == 256 && O == 128) return launch_tail<256, 128>(a, J, gw, st);
+    if (D == 256 && O == 64) return launch_tail<256, 64>(a, J, gw, st);
+    if (D == 128 && O == 128) return launch_tail<128, 128>(a, J, gw, st);
+    return launch_tail<128, 64>(a, J, gw, st);
 }
 
 // Split form, first launch: z = [h_self . W_self | mean(h_neigh) . W_neigh] and the neighbor means of the descriptor (the

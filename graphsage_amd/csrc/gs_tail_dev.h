@@ -38,13 +38,6 @@ struct TailArgs {
     // groups [0, pair_groups) hold 8 PAIRS each -- local rows 0..7 = batch1 rows 8 g .. 8 g + 7, local rows 8..15 = their
     // batch2 partners pairB + 8 g .. -- so that a pair meets in ONE workgroup; groups behind them hold 16 negatives each.
     int32_t pairB, pair_groups;
-    // One-launch form (sage_tail_kernel<..., FWD = true>, gs_sage_fwd_tail): layer 0 runs in the SAME launch and publishes h0
-    // per 32-row block.  fdone: [f_rb] monotonic arrival counters, one per 32-row block of h0 (every layer-0 tile of the block
-    // adds 1: f_trb arrivals per launch), then [G] launch counts, one per 16-row group -- read by the group's helpers and its
-    // main workgroup at their start, advanced by the main workgroup at its end (every reader of the group is done by then:
-    // the main has waited for all its helpers), so a block is complete when counter - (count + 1) * f_trb >= 0.  Nothing is
-    // ever reset.
-    uint32_t* fdone; int32_t f_rb, f_trb;
 };
 
 // Source row of local row r of group g (and whether it exists); rows that do not exist map to a valid row, never stored.
@@ -101,60 +94,13 @@ __device__ __forceinline__ float tail_wave_max(float v) {
 
 #define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
 
-// 16 bytes of an h0 row.  DEV (one-launch form: the row was written by another workgroup of THIS launch): device-scope loads --
-// they bypass this XCD's possibly stale L2 lines of h0, no cache invalidation needed (as the z pick-up).
-template <bool DEV>
-__device__ __forceinline__ f32x4 tail_ld4(const float* p) {
-    if (!DEV) return *reinterpret_cast<const f32x4*>(p);
-    union { unsigned long long u[2]; f32x4 f; } cv;
-    cv.u[0] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cv.u[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return cv.f;
-}
-
-// One-launch form: wait until layer 0 has published every h0 row group g reads -- its <= 16 self rows [16 g, ...) and their s
-// neighbor rows each [n + 16 g s, ...) -- one polling thread per 32-row block (<= 8), then a workgroup barrier.  BOUNDED like
-// the z hand-over: a thread that gives up sets bit 2 of the error word (sync[2 G]) and the workgroup goes on with whatever h0
-// holds; the host raises at its next fetch.  Returns the group's launch count (meaningful in thread 0: tail_fwd_done).
-__device__ __forceinline__ uint32_t tail_wait_fwd(const TailArgs& a, const int G, const int g) {
-    const int n = (int)a.n, s = a.s;
-    const int r_lo = g * TAIL_ROWS, r_hi = min(r_lo + TAIL_ROWS, n);
-    const int b0 = r_lo >> 5, nb_self = ((r_hi - 1) >> 5) - b0 + 1;
-    const int c0 = (n + r_lo * s) >> 5, nb_nei = ((n + r_hi * s - 1) >> 5) - c0 + 1;
-    const int t = threadIdx.x;
-    uint32_t gen = 0u;
-    if (t < nb_self + nb_nei) {
-        const int blk = t < nb_self ? b0 + t : c0 + (t - nb_self);
-        gen = __hip_atomic_load(a.fdone + a.f_rb + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = (gen + 1u) * (uint32_t)a.f_trb;
-        uint32_t spins = 0u;
-        while ((int32_t)(__hip_atomic_load(a.fdone + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) {
-                __hip_atomic_fetch_or(a.sync + 2 * G, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    // (not __syncthreads: that would drain the operand loads the caller already has in flight; the polled value has RETURNED
-    //  to its thread, the h0 loads below are issued behind the barrier and are device-scope)
-    asm volatile("" ::: "memory");
-    lds_barrier();
-    asm volatile("" ::: "memory");
-    return gen;
-}
-// End of a main workgroup of the one-launch form: the group's launch count advances (see TailArgs.fdone).
-__device__ __forceinline__ void tail_fwd_done(const TailArgs& a, const int grp, const uint32_t gen) {
-    if (threadIdx.x == 0) __hip_atomic_store(a.fdone + a.f_rb + grp, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // z helper (see the role comment in sage_tail_kernel): z[16 rows of group g][64 columns part*64 ..] of
 //   z = [h_self . W_self | mean_j(h_neigh_j) . W_neigh]      (aggregators.py:48-58, concat, identity act)
 // 8 waves = 8 K-slices of the slab's term (a 64-column slab lies in ONE term: 64 divides O), partial 16 x 64 tiles
 // summed in wave order through LDS, then published: stores -> device-scope release fence -> arrival counter.
 // The helper whose slab starts the neighbor term also writes the neighbor means (an input of the weight gradients).
-template <int D, int O, bool FWD = false>
-__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part, const bool publish = true, const int G = 0) {
+template <int D, int O>
+__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part, const bool publish = true) {
     constexpr int ldh = D + 4;
     constexpr int D4 = D / 4;
     constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
@@ -177,7 +123,6 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
 #pragma unroll
         for (int u = 0; u < KW; ++u) bz[t][u] = *reinterpret_cast<const f32x2*>(Wp + (4 * u) * ldw + 32 * t);
     const float inv_s = 1.0f / (float)s, inv_s1 = 1.0f / (float)(s + 1);
-    if (FWD) tail_wait_fwd(a, G, g);          // (the weight slice above is already in flight)
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int it = tid + p * TAIL_THREADS;
@@ -186,14 +131,14 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
         const int i = tail_row(a, g, r, valid);
         f32x4 v;
         if (!term && !a.gcn) {
-            v = tail_ld4<FWD>(a.h0 + i * ldh0 + c);
+            v = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
         } else {
             const float* nb = a.h0 + (n + i * s) * ldh0 + c;
             f32x4 hv[TAIL_NB];
             f32x4 hs = zero4;
-            if (a.gcn) hs = tail_ld4<FWD>(a.h0 + i * ldh0 + c);
+            if (a.gcn) hs = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
 #pragma unroll
-            for (int u = 0; u < TAIL_NB; ++u) hv[u] = tail_ld4<FWD>(nb + min(u, s - 1) * ldh0);
+            for (int u = 0; u < TAIL_NB; ++u) hv[u] = *reinterpret_cast<const f32x4*>(nb + min(u, s - 1) * ldh0);
             v = zero4;
 #pragma unroll
             for (int u = 0; u < TAIL_NB; ++u)

@@ -136,9 +136,6 @@ class SampleAndAggregate(object):
         self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
         # the fused tail launches (supervised: gs_sage_tail_fwd_bwd; unsupervised: gs_linkpred_tail); 0 = per-operator schedule
         self.fuse_tail = os.environ.get("GS_FUSE_TAIL", "1") != "0"
-        # ... with layer 0 inside the supervised tail's launch (gs_sage_fwd_tail: its tiles are the launch's first workgroups and
-        # hand h0 over per 32-row block; bit-identical results); 0 = layer 0 as its own launch in front of the tail's
-        self.fuse_fwd_tail = os.environ.get("GS_FUSE_FWD_TAIL", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
         self.use_graphs = True
         self.grad_hook = None
@@ -888,7 +885,7 @@ class SampleAndAggregate(object):
         (tests and A/B runs do) selects / captures another graph instead of silently replaying the old one."""
         e = self.engine
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
-        return (getattr(self, "fuse_tail", True), getattr(self, "fuse_fwd_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
+        return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
                 self.cogather_z, self.cogather_dp_opt, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.split_gemm, e.split_pool, e.pool_f16, str(getattr(self, "pipeline", None)),
                 type(self.grad_hook).__name__, getattr(self.grad_hook, "fused_step", None),

@@ -291,14 +291,6 @@ def split_gather_jobs(jobs, frac):
     return head, [tail]
 
 
-def merge_gather_jobs(a, b):
-    """The gather jobs of two launches that became one (at most 6 per launch: GS_MAX_COJOBS_S)."""
-    out = list(a or ()) + list(b or ())
-    if len(out) > 6:
-        raise _lib.GraphsageAmdError("more than 6 gather jobs in one launch")
-    return out
-
-
 def sage_dense_fwd_cogather(self_m, self_idx, agg, agg_idx, n, W_self, W_neigh, out_dim, concat, act, bias, out,
                             jobs, stream=None):
     """gs_sage_dense_fwd + the gather jobs in ONE horizontally fused launch."""
@@ -518,37 +510,15 @@ def tail_sync_error(sync, n):
     return int(sync[2 * ((n + 15) // 16)].item())
 
 
-def fwd_tail_done_words(n_rows, n):
-    """Size (uint32 words) of gs_fwd_desc.done: one arrival counter per 32-row block of h0 + one launch count per 16-row group."""
-    return (n_rows + 31) // 32 + (n + 15) // 16
-
-
-def fwd_desc(self_m, self_idx, agg, n_rows, W_self, W_neigh, out_dim, act, bias, out, done):
-    """gs_fwd_desc: the arguments of sage_dense_fwd_stream as a descriptor (the layer-0 half of gs_sage_fwd_tail)."""
-    f = _lib.FwdDesc()
-    f._keep = (done, bias)
-    if self_m is not None:
-        f.self, f.ld_self, f.self_idx, f.d_self = self_m.ptr, self_m.ld, ptr(self_idx), self_m.d
-        f.W_self, f.ldw_self = W_self.ptr, W_self.ld
-    f.agg, f.ld_agg, f.d_agg, f.n_rows = agg.ptr, agg.ld, agg.d, n_rows
-    f.W_neigh, f.ldw_neigh = W_neigh.ptr, W_neigh.ld
-    f.out_dim, f.act, f.bias, f.out, f.ldo = out_dim, act, ptr(bias), out.ptr, out.ld
-    assert done.numel() >= (n_rows + 31) // 32
-    f.done = ptr(done)
-    return f
-
-
 def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels, C, sigmoid_loss, means, z, y, logits,
                       preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), jobs=(), stream=None, sync=None,
-                      split=False, jobs_z=(), gcn=False, fwd=None):
+                      split=False, jobs_z=(), gcn=False):
     """gs_sage_tail_fwd_bwd: layer 1 + head (+ their input gradients when dz / d_h0 are given) in ONE launch.
     counters: up to three (device int64 tensor, delta) pairs advanced at the end of the launch.
     sync: int32 device tensor of tail_sync_words(n) words, zero-initialised once and owned by ONE caller / stream
     (kernel-internal hand-over state + an error word, see tail_sync_error); a fresh one is allocated if not given.
     split: two launches instead -- gs_sage_tail_z (lean z-helper kernel carrying the gather jobs `jobs_z`) and then this
-    entry with z_ready (no helpers, no hand-over state) carrying `jobs`; same results bit for bit.
-    fwd: a fwd_desc whose output is h0 -- layer 0 runs in the SAME launch (gs_sage_fwd_tail, bit-identical results)."""
-    assert fwd is None or (not split and dz is not None and d_h0 is not None)
+    entry with z_ready (no helpers, no hand-over state) carrying `jobs`; same results bit for bit."""
     if sync is None and not split:
         import torch
         sync = torch.zeros(tail_sync_words(n), dtype=torch.int32, device=h0.buf.device)
@@ -580,9 +550,6 @@ def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels
         call("gs_sage_tail_z", ctypes.addressof(q), ctypes.addressof(jzarr), len(jz), _s(stream))
     jobs = list(jobs or ())
     jarr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
-    if fwd is not None:
-        call("gs_sage_fwd_tail", ctypes.addressof(fwd), ctypes.addressof(q), ctypes.addressof(jarr), len(jobs), _s(stream))
-        return
     call("gs_sage_tail_fwd_bwd", ctypes.addressof(q), ctypes.addressof(jarr), len(jobs), _s(stream))
 
 

@@ -102,19 +102,10 @@ class SupervisedGraphsage(SampleAndAggregate):
         # anything else takes the per-operator schedule
         contiguous = all(b.data_ptr() == a.data_ptr() + 4 * a.numel() for a, b in zip(samples1[:-1], samples1[1:]))
         self._tail_used = bool(train and contiguous and self._tail_ok())
-        # one-launch form (gs_sage_fwd_tail): layer 0 hands its operands over and runs inside the tail's launch
-        agg0 = self.aggregators[0]
-        agg0.defer_fwd = bool(self._tail_used and self.fuse_fwd_tail and not self.tail_split)
-        agg0.deferred_fwd = None
-        try:
-            out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n,
-                                    aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
-                                    layer0_means=means0, layer0_side_jobs=side_jobs,
-                                    _stop_after_layer=0 if self._tail_used else None)
-        finally:
-            agg0.defer_fwd = False
-        fwd0 = agg0.deferred_fwd
-        agg0.deferred_fwd = None
+        out, _ = self.aggregate(samples1, [self.features], self.dims, self.num_samples, support_sizes1, batch_size=n,
+                                aggregators=self.aggregators, concat=self.concat, model_size=self.model_size,
+                                layer0_means=means0, layer0_side_jobs=side_jobs,
+                                _stop_after_layer=0 if self._tail_used else None)
         self.samples1 = samples1
         if self._tail_used and self._tape[0][0] != "batched":
             raise ops._lib.GraphsageAmdError("fused tail needs the contiguous id buffer (model.sample on ids_buffer)")
@@ -153,19 +144,12 @@ class SupervisedGraphsage(SampleAndAggregate):
             jobs_z, jobs_m = [], tail_jobs
             if self.tail_split and tail_jobs:
                 jobs_z, jobs_m = ops.split_gather_jobs(tail_jobs, self.cogather_tail_z)
-            fwd = None
-            if fwd0 is not None:
-                # layer 0's tiles are the first workgroups of the tail's launch; its gather share rides behind the tail's
-                assert fwd0["out"].ptr == h0.ptr and fwd0["n_rows"] == h0.rows
-                done = e.ws_i32(("fwd_tail_done", self.name, n, h0.rows), ops.fwd_tail_done_words(h0.rows, n))
-                jobs_m = ops.merge_gather_jobs(fwd0.pop("jobs"), jobs_m)
-                fwd = ops.fwd_desc(done=done, **fwd0)
             ops.sage_tail_fwd_bwd(h0, n, s, W_self1, W_neigh1, O1,
                                   self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels, C,
                                   self.sigmoid_loss, self._tail_means, self.agg_out, self.outputs1, self.node_preds,
                                   self.preds, self._dlogits, self._loss_rows, dz=self._tail_dz, d_h0=self._tail_dh0,
                                   counters=counters, jobs=jobs_m, stream=e.stream, sync=self._tail_sync,
-                                  split=self.tail_split, jobs_z=jobs_z, gcn=gcn1, fwd=fwd)
+                                  split=self.tail_split, jobs_z=jobs_z, gcn=gcn1)
         else:
             self.agg_out = out
             self.outputs1 = e.ws_mat("outputs1", n, out.d)
@@ -325,9 +309,8 @@ class SupervisedGraphsage(SampleAndAggregate):
             if err:
                 raise ops._lib.GraphsageAmdError(
                     "fused tail launch: hand-over between its workgroups failed (flags %d: 1 = a row-group workgroup "
-                    "gave up waiting for its helpers, 2 = unexpected arrival count, 4 = a workgroup gave up waiting for the "
-                    "layer-0 tiles of the same launch); results since the last fetch are invalid -- set model.fuse_fwd_tail = "
-                    "False (layer 0 as its own launch) or model.fuse_tail = False (per-operator schedule)" % err)
+                    "gave up waiting for its helpers, 2 = unexpected arrival count); results since the last fetch are "
+                    "invalid -- set model.fuse_tail = False to use the per-operator schedule" % err)
         if hasattr(self.grad_hook, "check"):
             self.grad_hook.check()            # peer-store exchange: a bounded device-side wait that tripped
         loss = float(self.loss_dev.item())

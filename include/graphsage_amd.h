@@ -38,12 +38,12 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 9
+#define GS_ABI_VERSION 8
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
 /* sizeof() of the descriptor structs below, in declaration order (gs_gather_desc, gs_wgrad_desc, gs_var_desc,
- * gs_fanout_desc, gs_tail_desc, gs_dropout, gs_pull_desc, gs_lp_tail_desc, gs_fwd_desc): writes min(count, capacity) values, returns the count.  A
+ * gs_fanout_desc, gs_tail_desc, gs_dropout, gs_pull_desc, gs_lp_tail_desc): writes min(count, capacity) values, returns the count.  A
  * binding compares them with its own struct definitions at load time. */
 int gs_abi_struct_sizes(int32_t* sizes_out_host, int32_t capacity);
 /* Fills CU count, XCD count (8 on MI355X), gcnArchName (>= 64 bytes) of the current device. */
@@ -640,34 +640,6 @@ int gs_sage_tail_dh0(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_h
 /* jobs_host / n_jobs (0..6): gather+mean jobs of the NEXT step co-scheduled in the launch (as gs_sage_dense_fwd_cogather):
  * the tail keeps n/16 CUs busy, the rest of the chip streams the gather meanwhile. */
 int gs_sage_tail_fwd_bwd(const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
-
-/* Layer 0 of a two-layer mean / GCN training step AND its fused tail as ONE launch ("persistent step", stage a):
- *   h0 = act([self . W_self | agg . W_neigh] + bias)  for the rows of ALL hops     (aggregators.py:43-64 / :101-116 -- exactly
- *        gs_sage_dense_fwd_stream: same tiles, same K quarters, same summation order: bit-identical h0)
- *   then everything gs_sage_tail_fwd_bwd does on that h0                            (aggregators.py:43-64, supervised_models.py:85-126)
- * The layer-0 tile workgroups are the first class of workgroups of the tail's launch and publish h0 per 32-row block behind
- * monotonic device counters; the tail's helper / main workgroups of a 16-row group start as soon as the blocks holding the
- * group's rows are complete -- no kernel boundary (drain of the slowest tile wave and of its gather riders, launch, ramp)
- * between the two.  Results are bit-identical to gs_sage_dense_fwd_stream followed by gs_sage_tail_fwd_bwd.
- *   fwd_host:  the arguments of gs_sage_dense_fwd_stream[2] as a struct; out / ldo / n_rows MUST be the tail descriptor's
- *              h0 / ldh / n + n*s; done = ceil(n_rows / 32) + ceil(n / 16) device words, zero-initialised ONCE by the caller and
- *              private to one stream (block arrival counters + per-group launch counts; never reset).
- *   desc_host: as gs_sage_tail_fwd_bwd, train != 0, z_ready == 0; bit 2 (value 4) of the error word desc.sync[2 * ceil(n / 16)]
- *              = a workgroup gave up waiting for layer 0 (bounded wait).
- *   jobs_host: gather+mean jobs of the NEXT step riding behind the tail's workgroups. */
-typedef struct gs_fwd_desc {
-    const float* self; int64_t ld_self; const int32_t* self_idx; int32_t d_self;   /* self == NULL: one term (GCN) */
-    const float* agg; int64_t ld_agg; int32_t d_agg;
-    int64_t n_rows;
-    const float* W_self; int64_t ldw_self;
-    const float* W_neigh; int64_t ldw_neigh;
-    int32_t out_dim, act;
-    const float* bias;
-    float* out; int64_t ldo;
-    uint32_t* done;
-} gs_fwd_desc;
-int gs_sage_fwd_tail(const gs_fwd_desc* fwd_host, const gs_tail_desc* desc_host, const gs_gather_desc* jobs_host, int32_t n_jobs,
-                     void* stream);
 
 /* Inverted dropout tf.nn.dropout(x, keep_prob = 1 - rate) (aggregators.py:46-47,104-105; layers.py:107): kept
  * elements are scaled by 1/keep_prob.  The keep mask is a counter hash of (seed, *clock_dev, site, row0 + row,

@@ -190,24 +190,6 @@ def test_bench_multistep_graphs_equal_single_steps(dev, agg_type):
     assert np.isfinite(outs[0][0])
 
 
-@pytest.mark.parametrize("agg_type", ["mean", "gcn"])
-def test_layer0_inside_the_tail_launch_trains_bit_identically(dev, agg_type):
-    """The one-launch form of layer 0 + fused tail (gs_sage_fwd_tail, the default) against layer 0 as its own launch in front of
-    the tail's (model.fuse_fwd_tail = False): same tiles, same summation orders -> the same bits after 33 steps through 8-step
-    hipGraphs at the benched shapes, with the gather of both launches riding in the one; the hand-over error word stays 0."""
-    outs = []
-    for one in (True, False):
-        G, it, model, order = build(agg_type)
-        model.fuse_fwd_tail = one
-        model.train_steps_device(B, 33, steps_per_launch=8)
-        loss, preds = model._fetch(B)          # raises if a bounded in-kernel wait tripped
-        took = model.aggregators[0].deferred_fwd is None and any("fwd_tail_done" in str(k) for k in model.engine._ws)
-        assert took == one
-        outs.append((loss, preds.copy(), model.engine.params.cpu().numpy().copy()))
-    assert outs[0][0] == outs[1][0] and np.isfinite(outs[0][0])
-    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
-
-
 def test_bench_timed_graph_lengths_equal_single_steps(dev):
     """The graph lengths the bench itself times: `bench.py` on one GPU replays 32 steps per launch, and the driver's command
     (--steps 20) is ONE 20-step graph.  Both give the bits of one-step launches: 32 + 32 + 32 (eager, capture, replay of the

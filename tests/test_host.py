@@ -264,7 +264,7 @@ def test_descriptor_struct_layouts_match_the_library():
     sizes = (ctypes.c_int32 * 16)()
     n = lib.gs_abi_struct_sizes(sizes, 16)
     mirrors = [_lib.GatherDesc, _lib.WgradDesc, _lib.VarDesc, _lib.FanoutDesc, _lib.TailDesc, _lib.Dropout, _lib.PullDesc,
-               _lib.LpTailDesc, _lib.FwdDesc]
+               _lib.LpTailDesc]
     assert n == len(mirrors)
     assert [ctypes.sizeof(c) for c in mirrors] == list(sizes[:n])
     # a drifted mirror is caught by load()

@@ -897,101 +897,6 @@ def test_fused_tail_split_form_is_bit_identical(dev, n, s, D, O, C, sig):
     assert np.abs(outs[1][7]).max() > 0 and np.abs(outs[1][9]).max() > 0
 
 
-@pytest.mark.parametrize("n,s,K,D,O,C,sig,gcn", [(512, 10, 602, 256, 128, 41, False, False),     # the benched step's shapes
-                                                 (512, 10, 256, 256, 128, 64, False, False),     # RMAT's (F = 256)
-                                                 (37, 3, 50, 128, 64, 7, True, False),           # ragged n, K % 8 != 0, one row block
-                                                 (333, 11, 130, 256, 64, 121, True, False),      # s = 11, two class groups
-                                                 (3000, 10, 96, 128, 128, 41, False, False),     # far more workgroups than CUs
-                                                 (512, 10, 602, 256, 128, 41, False, True),      # GCN: one term, one weight matrix
-                                                 (100, 4, 64, 128, 64, 5, False, True)])
-def test_layer0_and_tail_in_one_launch_is_bit_identical(dev, n, s, K, D, O, C, sig, gcn):
-    """gs_sage_fwd_tail (layer 0's tile workgroups as the first class of workgroups of the tail's launch, h0 handed over per
-    32-row block behind monotonic counters) == gs_sage_dense_fwd_stream followed by gs_sage_tail_fwd_bwd, bit for bit, every
-    output incl. h0 itself and the gather jobs riding in the launch; THREE launches on one hand-over buffer (the counters are
-    never reset), NaN in h0 before every launch (each row must come from this launch's tiles), error word 0."""
-    rng = np.random.default_rng(n + K + C)
-    rows, Z = n + n * s, 2 * O
-    N0 = D if gcn else D // 2                      # layer-0 out_dim per term (concat of two terms, or GCN's single term)
-    X = Mat.from_numpy(_asym(rng, (4000, K)), dev, ld_multiple=32)
-    ids = _i32(rng.integers(0, 4000, size=rows), dev)
-    agg = Mat.from_numpy(_asym(rng, (rows, K)), dev, ld_multiple=32)
-    W0s, W0n = Mat.from_numpy(_asym(rng, (K, N0)) * 0.1, dev), Mat.from_numpy(_asym(rng, (K, N0)) * 0.1, dev)
-    if gcn:
-        W1 = Mat.from_numpy(_asym(rng, (D, Z)) * 0.2, dev)
-        Ws, Wn = W1.cols_slice(0, O), W1.cols_slice(O, Z)
-    else:
-        Ws, Wn = Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev), Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev)
-    Wh, bh = Mat.from_numpy(_asym(rng, (Z, C)) * 0.3, dev), torch.from_numpy(_asym(rng, (C,)) * 0.1).to(dev)
-    labn = (rng.random((n, C)) > 0.5).astype(np.float32) if sig else np.eye(C, dtype=np.float32)[rng.integers(0, C, n)]
-    lab = Mat.from_numpy(labn, dev)
-    Xg = Mat.from_numpy(_asym(rng, (5000, 602)), dev, ld_multiple=32)
-    idx = _i32(rng.integers(0, 5000, size=1200 * 25), dev)
-    done = torch.zeros(ops.fwd_tail_done_words(rows, n), dtype=torch.int32, device=dev)
-    sync = torch.zeros(ops.tail_sync_words(n), dtype=torch.int32, device=dev)
-    sync2 = torch.zeros(ops.tail_sync_words(n), dtype=torch.int32, device=dev)
-    outs = []
-    for one_launch in (False, True, True, True):
-        h0 = Mat.zeros(rows, D, dev)
-        h0.buf.fill_(float("nan"))
-        means, z, y = Mat.zeros(n, D, dev), Mat.zeros(n, Z, dev), Mat.zeros(n, Z, dev)
-        lo, pr, dl = Mat.zeros(n, C, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
-        lr, dz, dh0 = torch.zeros(n, device=dev), Mat.zeros(n, Z, dev), Mat.zeros(rows, D, dev)
-        g1, g2 = Mat.zeros(700, 602, dev), Mat.zeros(500, 602, dev)
-        c0 = torch.full((1,), 5, dtype=torch.int64, device=dev)
-        j1 = [ops.gather_job(Xg, idx[:700 * 25], 700, 25, g1)]
-        j2 = [ops.gather_job(Xg, idx[700 * 25:], 500, 25, g2)]
-        _sync()
-        fwd_args = dict(self_m=None if gcn else X, self_idx=None if gcn else ids, agg=agg, n_rows=rows, W_self=None if gcn else W0s,
-                        W_neigh=W0n, out_dim=N0, act=ops.ACT_RELU, bias=None, out=h0)
-        fwd = None
-        if one_launch:
-            fwd = ops.fwd_desc(done=done, **fwd_args)
-        else:
-            ops.sage_dense_fwd_stream(fwd_args["self_m"], fwd_args["self_idx"], agg, rows, fwd_args["W_self"], W0n, N0, ops.ACT_RELU, None,
-                                      h0, j1)
-        ops.sage_tail_fwd_bwd(h0, n, s, Ws, Wn, O, Wh, bh, lab, C, sig, means, z, y, lo, pr, dl, lr, dz=dz, d_h0=dh0,
-                              counters=[(c0, 2)], jobs=(j1 + j2) if one_launch else j2, sync=sync if one_launch else sync2,
-                              gcn=gcn, fwd=fwd)
-        _sync()
-        assert int(c0.item()) == 7 and ops.tail_sync_error(sync, n) == 0 and ops.tail_sync_error(sync2, n) == 0
-        outs.append([m.numpy() for m in (h0, means, z, y, lo, pr, dl, dz, dh0, g1, g2)] + [lr.cpu().numpy()])
-    assert not np.isnan(outs[0][0]).any() and np.abs(outs[0][8]).max() > 0 and np.abs(outs[0][10]).max() > 0
-    for k in (1, 2, 3):
-        for a, b in zip(outs[0], outs[k]):
-            assert np.array_equal(a, b)
-    # the hand-over state after three launches: every block counter = 3 x (tiles per block), every group count = 3
-    dn = done.cpu().numpy()
-    rb = (rows + 31) // 32
-    tiles_per_block = ((N0 + 63) // 64) * (1 if gcn else 2)
-    assert (dn[:rb] == 3 * tiles_per_block).all() and (dn[rb:rb + (n + 15) // 16] == 3).all()
-
-
-def test_one_launch_layer0_tail_bounded_wait_sets_the_error_word(dev):
-    """A hand-over buffer whose launch counts are AHEAD of its block counters (as if layer 0's tiles never arrived): every
-    consumer gives up after its bounded wait, the launch ends, bit 2 of the error word is set -- no hang."""
-    rng = np.random.default_rng(5)
-    n, s, K, D, O, C = 32, 2, 40, 128, 64, 5
-    rows, Z = n + n * s, 2 * O
-    X = Mat.from_numpy(_asym(rng, (rows, K)), dev, ld_multiple=32)
-    agg = Mat.from_numpy(_asym(rng, (rows, K)), dev, ld_multiple=32)
-    W0s, W0n = Mat.from_numpy(_asym(rng, (K, 64)) * 0.1, dev), Mat.from_numpy(_asym(rng, (K, 64)) * 0.1, dev)
-    Ws, Wn = Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev), Mat.from_numpy(_asym(rng, (D, O)) * 0.2, dev)
-    Wh, bh = Mat.from_numpy(_asym(rng, (Z, C)) * 0.3, dev), torch.from_numpy(_asym(rng, (C,)) * 0.1).to(dev)
-    lab = Mat.from_numpy(np.eye(C, dtype=np.float32)[rng.integers(0, C, n)], dev)
-    done = torch.zeros(ops.fwd_tail_done_words(rows, n), dtype=torch.int32, device=dev)
-    done[(rows + 31) // 32:] = 1000                # launch counts far ahead: targets no tile will ever reach
-    sync = torch.zeros(ops.tail_sync_words(n), dtype=torch.int32, device=dev)
-    h0 = Mat.zeros(rows, D, dev)
-    means, z, y = Mat.zeros(n, D, dev), Mat.zeros(n, Z, dev), Mat.zeros(n, Z, dev)
-    lo, pr, dl = Mat.zeros(n, C, dev), Mat.zeros(n, C, dev), Mat.zeros(n, C, dev)
-    lr, dz, dh0 = torch.zeros(n, device=dev), Mat.zeros(n, Z, dev), Mat.zeros(rows, D, dev)
-    _sync()
-    fwd = ops.fwd_desc(X, None, agg, rows, W0s, W0n, 64, ops.ACT_RELU, None, h0, done)
-    ops.sage_tail_fwd_bwd(h0, n, s, Ws, Wn, O, Wh, bh, lab, C, False, means, z, y, lo, pr, dl, lr, dz=dz, d_h0=dh0, sync=sync, fwd=fwd)
-    _sync()
-    assert ops.tail_sync_error(sync, n) & 4
-
-
 @pytest.mark.parametrize("n,s,D,O", [(1044, 10, 256, 128), (37, 3, 128, 64), (3000, 11, 256, 64), (100, 5, 128, 128)])
 def test_last_layer_z_and_dh0_launches(dev, n, s, D, O):
     """gs_sage_tail_z (neighbor mean + both contractions + concat of a last mean layer, aggregators.py:48-58) and its
