@@ -190,6 +190,32 @@ def test_bench_multistep_graphs_equal_single_steps(dev, agg_type):
     assert np.isfinite(outs[0][0])
 
 
+def test_maxpool_two_fp16_pieces_train_like_three_bf16_pieces(dev):
+    """The arithmetic claim behind the default pooling MLP (csrc/gs_split16.hip: two fp16 pieces per operand under power-of-two
+    row / column scales, h h' + h m' + m h', fp32 accumulation) as a test instead of a debug script: the SAME model -- seed,
+    graph, epoch order, initial weights -- trained with the two-piece kernel (Engine.pool_f16) and with the three-piece bf16
+    kernel (no operand bit dropped, six products) agrees in the loss of EVERY one of the first 12 steps to 1e-4 relative and in
+    the predictions to 1e-4 absolute, at the benched shapes (B = 512, 25 x 10, F = 602, hidden 512) through the path bench.py
+    times.  (Both are checked against the oracle in test_bench_path_matches_oracle[maxpool-3] and against fp64 in
+    tests/test_split_gemm_gpu.py; this pins them to each other over a training trajectory.)"""
+    runs = []
+    for f16 in (True, False):
+        G, it, model, order = build("maxpool")
+        e = model.engine
+        e.pool_f16 = f16
+        assert e.split_pool
+        losses, preds = [], None
+        for t in range(12):
+            loss, preds = model.train_step_device(B, fetch=True)
+            losses.append(loss)
+        a0 = model.aggregators[0]
+        assert a0.last_pool_kernel == ("split16" if f16 else "split_bf16x3")
+        runs.append((np.asarray(losses), preds.copy()))
+    assert np.isfinite(runs[0][0]).all() and runs[0][0][-1] < runs[0][0][0]          # it trains
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-4)
+    np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=0, atol=1e-4)
+
+
 def test_bench_timed_graph_lengths_equal_single_steps(dev):
     """The graph lengths the bench itself times: `bench.py` on one GPU replays 32 steps per launch, and the driver's command
     (--steps 20) is ONE 20-step graph.  Both give the bits of one-step launches: 32 + 32 + 32 (eager, capture, replay of the

@@ -106,10 +106,42 @@ def reference_dropout_masks(model, fx, p):
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("name", SUP + SUP_DROPOUT)
 def test_supervised_steps_equal_reference_run(dev, name, fuse):
+    _supervised_steps(name, fuse)
+
+
+def _pool_through_distinct_ids(e, model, form):
+    """Send the max-pool MLP of layer 0 through the path the benched configuration takes -- the step's DISTINCT sampled ids
+    (gs_unique_ids) + the split-MFMA kernel of `form` -- although the fixture gathers far fewer rows than the 2048 the default
+    threshold asks for (GS_POOL_DEDUP_MIN_ROWS / aggregator.dedup_min_rows)."""
+    e.pool_f16 = form == "f16x2"
+    assert e.split_pool
+    model.aggregators[0].dedup_min_rows = 0
+
+
+def _check_pool_kernel(model, form):
+    a0 = model.aggregators[0]
+    assert a0.last_pool_kernel == {"f16x2": "split16", "bf16x3": "split_bf16x3"}[form], a0.last_pool_kernel
+    cnt, rows_total = a0.last_unique
+    assert 0 < int(cnt.item()) <= rows_total
+
+
+@pytest.mark.parametrize("form", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("name", ["sup_maxpool", "sup_maxpool_big"])
+def test_supervised_maxpool_distinct_id_mlp_equals_reference_run(dev, name, form):
+    """The kernel that dominates the benched max-pool step -- the pooling MLP (aggregators.py:176-181, layers.py:104-116) on the
+    step's distinct ids with two fp16 pieces per operand (gs_dense_fwd_rows_split16; `bf16x3`: three bf16 pieces,
+    gs_dense_fwd_rows_split_ws) -- fed the REFERENCE's own run: same comparisons as the default path, at the same 1e-4."""
+    _supervised_steps(name, True, prepare=lambda e, model: _pool_through_distinct_ids(e, model, form),
+                      after_step=lambda model: _check_pool_kernel(model, form))
+
+
+def _supervised_steps(name, fuse, prepare=None, after_step=None):
     fx = Fixture(name)
     c = fx.cfg
     e, ph, adj_info, sampler, model = build_supervised(fx)
     model.fuse_head = model.fuse_sampler = model.fuse_tail = fuse
+    if prepare is not None:
+        prepare(e, model)
     mv = load_weights(model, fx, "init/")
     for s in range(fx.n_steps):
         p = "s%d/" % s
@@ -121,6 +153,8 @@ def test_supervised_steps_equal_reference_run(dev, name, fuse):
             e.inject_dropout_masks(reference_dropout_masks(model, fx, p))
             feed[ph['dropout']] = c["dropout"]                            # supervised_train.py:269
         loss, preds = model.train_step(feed)
+        if after_step is not None:
+            after_step(model)
         if name in ("sup_mean_tail", "sup_gcn_tail"):
             assert bool(getattr(model, "_tail_used", False)) == fuse     # the headline step's fused-tail launch (+ its GCN form)
         for k in range(fx.K):                                           # S1/S2: bit-exact
@@ -168,6 +202,17 @@ def test_evaluation_on_the_test_adjacency_equals_reference(dev, name):
 def test_unsupervised_steps_equal_reference_run(dev, name):
     """models.py:332-405: three sample() calls with their OWN permutations (perm index g * K + k), the reference's
     negatives, loss / MRR / affinities / embeddings / gradients / parameters after Adam."""
+    _unsupervised_steps(name)
+
+
+@pytest.mark.parametrize("form", ["f16x2", "bf16x3"])
+def test_unsupervised_maxpool_distinct_id_mlp_equals_reference_run(dev, form):
+    """As test_supervised_maxpool_distinct_id_mlp_equals_reference_run, for the unsupervised max-pool model (models.py:332-405)."""
+    _unsupervised_steps("unsup_maxpool", prepare=lambda e, model: _pool_through_distinct_ids(e, model, form),
+                        after_step=lambda model: _check_pool_kernel(model, form))
+
+
+def _unsupervised_steps(name, prepare=None, after_step=None):
     fx = Fixture(name)
     c = fx.cfg
     K, n_neg = fx.K, c["neg_sample_size"]
@@ -183,6 +228,8 @@ def test_unsupervised_steps_equal_reference_run(dev, name):
                                aggregator_type=fx.agg, learning_rate=c["learning_rate"], weight_decay=c["weight_decay"],
                                neg_sample_size=n_neg)
     model.use_graphs = False
+    if prepare is not None:
+        prepare(e, model)
     mv = load_weights(model, fx, "init/", supervised=False)
     for s in range(fx.n_steps):
         p = "s%d/" % s
@@ -191,6 +238,8 @@ def test_unsupervised_steps_equal_reference_run(dev, name):
         sampler.inject_perms(fx.perms(p, 3 * K))
         model.inject_negatives(neg)
         loss, ranks, aff_all, mrr, outputs1 = model.train_step({ph['batch1']: b1, ph['batch2']: b2, ph['batch_size']: B})
+        if after_step is not None:
+            after_step(model)
         assert bool(getattr(model, "_lp_tail_used", False)) == (name == "unsup_mean_tail")     # the fused two-launch tail
         roots = np.concatenate([b1, b2, neg])
         assert np.array_equal(model.samples1[0].cpu().numpy(), roots)
