@@ -315,15 +315,9 @@ def main():
         model.grad_hook = gsd.make_grad_hook(e, log=log)
         if rank == 0:
             log("gradient all-reduce: %s" % type(model.grad_hook).__name__)
-    elif os.environ.get("GS_PROBE_DP_PEER"):
-        # diagnostic: the data-parallel schedule that ENDS IN ONE LAUNCH (gs_peer_step: slab sum | peer exchange | clip + Adam) on
-        # ONE GPU -- a world of one rank whose exchange workgroups hold their hand-over for the given microseconds (the peers'
-        # latency, simulated); GS_COGATHER_DP_OPT=<share> lets a share of the gather ride behind them
-        model.grad_hook = gsd.PeerPushAllReduce(e)
-        model.grad_hook.set_probe_wait(int(float(os.environ["GS_PROBE_DP_PEER"])))
     elif os.environ.get("GS_PROBE_DP_SCHEDULE"):
         # diagnostic: the data-parallel step schedule on ONE GPU, the collective replaced by a wave that sleeps for the given
-        # number of microseconds (0 = no-op hook); GS_COGATHER_DP_FORK=0 gives the schedule without the forked gather branch
+        # number of microseconds (0 = no-op hook)
         model.grad_hook = gsd.SpinHook(e, float(os.environ["GS_PROBE_DP_SCHEDULE"]))
     if model.grad_hook is not None:
         dp_info = model.measure_dp_allreduce(log=log if rank == 0 else None) or {}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-call A/B of environment settings over bench configurations:
-#   bash benchmarks/r5_ab_env.sh <outdir> "<cfg name>:<bench args>" ... -- "<VAR=val ...>" ...
+#   bash benchmarks/ab_env.sh <outdir> "<cfg name>:<bench args>" ... -- "<VAR=val ...>" ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$1; shift
 mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-call A/B of two builds of the library over the timed configurations:  bash benchmarks/r5_lib_ab.sh <outdir> <libA.so|""> <libB.so|"">
+# Same-call A/B of two builds of the library over the timed configurations:  bash benchmarks/lib_ab.sh <outdir> <libA.so|""> <libB.so|"">
 # ("" = the in-tree library).  Prints us/step (HIP-event median) per configuration and library.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$1; shift

@@ -6,4 +6,4 @@ mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_bench_parity_gpu.py -x -q -m gpu -k "one_launch or layer0_inside or fused_tail" > $O/pytest_new.log 2>&1
 echo "pytest rc=$?"; tail -5 $O/pytest_new.log
-bash benchmarks/r5_ab_env.sh $1 "head:--steps 96" "rmat:--workload rmat --steps 64" "gcn:--model gcn --steps 64" -- "GS_FUSE_FWD_TAIL=0" "GS_FUSE_FWD_TAIL=1" "GS_FUSE_FWD_TAIL=0" "GS_FUSE_FWD_TAIL=1"
+bash benchmarks/ab_env.sh $1 "head:--steps 96" "rmat:--workload rmat --steps 64" "gcn:--model gcn --steps 64" -- "GS_FUSE_FWD_TAIL=0" "GS_FUSE_FWD_TAIL=1" "GS_FUSE_FWD_TAIL=0" "GS_FUSE_FWD_TAIL=1"

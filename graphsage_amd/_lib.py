@@ -15,7 +15,7 @@ ACT_RELU = 1
 LAW_IID, LAW_REFERENCE, LAW_DISTINCT = 0, 1, 2      # GS_LAW_* (sampling law of the CSR sampler)
 SAMPLER_LAWS = {"iid": LAW_IID, "reference": LAW_REFERENCE, "distinct": LAW_DISTINCT}
 GS_PEER_HANDLE_BYTES = 64
-GS_ABI_VERSION = 8      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
+GS_ABI_VERSION = 9      # must equal GS_ABI_VERSION of include/graphsage_amd.h (struct layouts below mirror that header)
 
 
 class GraphsageAmdError(RuntimeError):
@@ -62,9 +62,6 @@ _PROTOS = {
     "gs_peer_attach": [_P, c_int32, _P, c_int32],
     "gs_peer_attach_local": [_P, _P],
     "gs_peer_allreduce_sum_f32": [_P, _P, c_int64, _P],
-    "gs_peer_set_probe_wait": [_P, c_int32],
-    "gs_peer_step": [_P, _P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
-                     _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P, c_int32, _P],
     "gs_peer_status": [_P, POINTER(c_int64), POINTER(c_int32)],
     "gs_peer_destroy": [_P],
     "gs_sum_scaled": [_P, c_int64, c_float, _P, c_int, _P],
@@ -103,8 +100,6 @@ _PROTOS = {
     "gs_dense_fwd_rows_split16": [_P, _P, _P, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P, c_int64, _P],
     "gs_dense_fwd_rows_split_ws_bytes": [_P],
     "gs_dense_fwd_rows_split_ws": [_P, c_int64, _P, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P, c_int64, _P],
-    "gs_sage_dense_fwd_split": [_P, c_int64, _P, _P, c_int64, c_int32, c_int64, _P, _P, c_int32, c_int, _P, _P, c_int64, _P,
-                                c_int32, _P],
     "gs_flat_reduce_adam_sample": [_P, c_int32, _P, _P, _P, _P, c_int64, c_float, c_int, c_float, c_float, c_float, c_float,
                                    c_float, c_float, _P, c_int32, _P, c_int64, c_float, _P, c_int, _P, _P, c_int32, _P],
     "gs_sage_tail_supported": [c_int32, c_int32, c_int32],

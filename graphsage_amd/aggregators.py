@@ -200,7 +200,7 @@ class MeanAggregator(_SageBase):
         whose inputs are the dense rows [self (n) | neighbors (n s)] of one buffer -- the layer-1 call of every two-layer
         mean model (models.py:321-328).  Returns that buffer as a Mat, or None."""
         if (means is not None or rate > 0 or len(neighs) != 1 or not self.concat or self.bias or self.act_code != ACT_IDENTITY
-                or self_all.ids is not None or neighs[0].ids is not None or os.environ.get("GS_LAYER1_Z", "1") == "0"):
+                or self_all.ids is not None or neighs[0].ids is not None or not getattr(self, "layer1_z", True)):
             return None
         n, s, d = neighs[0].shape3
         a, b = self_all.src, neighs[0].src
@@ -233,20 +233,12 @@ class MeanAggregator(_SageBase):
         n_out = self.output_dim * (2 if self.concat else 1)
         out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
-        stream_fwd = (e.stream_gemm and self.concat and rate == 0 and n_total > 2048 and self.output_dim % 2 == 0
-                      and os.environ.get("GS_STREAM_FWD", "1") == "1")
+        stream_fwd = e.stream_gemm and self.concat and rate == 0 and n_total > 2048 and self.output_dim % 2 == 0
         if side_jobs or stream_fwd:
             # horizontally fused launch: the contraction workgroups + the NEXT step's gather-mean waves share the CUs.
             # Stream form (gs_stream.hip): split-K workgroups without LDS staging, the self rows gathered in the A loads.
-            split_fwd = stream_fwd and e.split_gemm
-
             def launch(jobs=list(side_jobs or ())):
-                if split_fwd:
-                    # the same contraction on the bf16 matrix pipe, operands cut into three bf16 pieces (fp32 accuracy)
-                    ops.sage_dense_fwd_split(self_all.src, self_all.ids, means, n_total, e.split_of(self.vars['self_weights']),
-                                             e.split_of(self.vars['neigh_weights']), self.output_dim, self.act_code, b, out,
-                                             jobs, stream=e.stream)
-                elif stream_fwd:
+                if stream_fwd:
                     ops.sage_dense_fwd_stream(self_all.src, self_all.ids, means, n_total, self.vars['self_weights'].value,
                                               self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, jobs,
                                               stream=e.stream)
@@ -260,11 +252,8 @@ class MeanAggregator(_SageBase):
             jobs_ = list(side_jobs or ())
             self.last_fused_launch = (launch, {
                 "kernel": "%s: [%d x %d|%d] . [%d x %d] x2 (%s) + %d co-scheduled "
-                          "gather+mean jobs of the next step" % ("sage_split_fwd_kernel" if split_fwd else
-                                                                 "sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
-                                                                 n_total, d_in, means.d, d_in, self.output_dim,
-                                                                 "fp32 as 3 bf16 pieces, 6 bf16 MFMAs per product" if split_fwd
-                                                                 else "fp32 MFMA", len(jobs_)),
+                          "gather+mean jobs of the next step" % ("sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
+                                                                 n_total, d_in, means.d, d_in, self.output_dim, "fp32 MFMA", len(jobs_)),
                 "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in jobs_),
                 "gemm_bytes": n_total * (d_in + means.d) * 4 + (d_in + means.d) * self.output_dim * 4 + n_total * n_out * 4,
                 "flops": 2.0 * n_total * (d_in + means.d) * self.output_dim,
@@ -414,11 +403,7 @@ class GCNAggregator(_SageBase):
             means = self.prefetch(self_all, neighs)
         out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
-        if e.stream_gemm and e.split_gemm and n_total > 2048 and rate == 0:
-            # split-MFMA form (gs_split.hip): fp32 operands as three bf16 pieces on the bf16 matrix pipe
-            ops.sage_dense_fwd_split(None, None, means, n_total, None, e.split_of(self.vars['weights']), self.output_dim,
-                                     self.act_code, b, out, side_jobs, stream=e.stream)
-        elif e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
+        if e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
             # stream form: LDS-free contraction waves (+ the next step's gather jobs) in one launch
             ops.sage_dense_fwd_stream(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
                                       b, out, side_jobs, stream=e.stream)
@@ -561,7 +546,7 @@ class _PoolingAggregator(_SageBase):
         dedup = (fused_pool and x_all is not None and x_all.ids is not None and rows_total > dedup_min
                  and x_all.src.rows < (1 << 31)
                  and x_all.src.rows <= int(os.environ.get("GS_POOL_DEDUP_MAX_RATIO", "16")) * rows_total
-                 and getattr(self, "dedup_pool", os.environ.get("GS_POOL_DEDUP", "1") != "0"))
+                 and getattr(self, "dedup_pool", True))
         H = None
         if dedup:
             X, ids, nv_rows = x_all.src, x_all.ids, x_all.src.rows
@@ -649,8 +634,7 @@ class _PoolingAggregator(_SageBase):
         n_out = self.output_dim * (2 if self.concat else 1)
         out = e.ws_mat((self.name, "out", k), n_total, n_out)
         b = self.vars['bias'].value.buf if self.bias else None
-        if (e.stream_gemm and self.concat and n_total > 2048 and self.output_dim % 2 == 0
-                and os.environ.get("GS_STREAM_FWD_POOL", "1") == "1"):
+        if e.stream_gemm and self.concat and n_total > 2048 and self.output_dim % 2 == 0:
             # the stream form of the two contractions (split-K workgroups, no LDS staging, the self rows gathered in the A loads),
             # with each term's own reduction length: 23 instead of 33 us for the Reddit step's layer 0
             ops.sage_dense_fwd_stream2(self_all.src, self_all.ids, pooled, n_total, self.vars['self_weights'].value,

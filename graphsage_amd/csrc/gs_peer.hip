@@ -25,8 +25,6 @@
 // The sum order is the rank order on every rank, so all ranks hold the same bits afterwards (replicas stay identical);
 // for world = 2 it is also bit-identical to RCCL's sum (a + b).
 #include "gs_common.h"
-#include "gs_sample_dev.h"
-#include "gs_gather_dev.h"
 #include <string.h>
 #include <new>
 
@@ -49,8 +47,6 @@ struct PeerArgs {
     int64_t n, L;
     int32_t world, me, W;
     uint32_t spin_limit;
-    uint32_t probe_wait_us;     // diagnostics (gs_peer_set_probe_wait): every exchange workgroup of peer_step_kernel holds its
-                                // hand-over for this long -- a one-GPU stand-in for the peers' latency when the schedule is probed
 };
 
 // Memory ordering, kept to ONE cache maintenance operation per workgroup and hand-over (a system-scope release is a
@@ -168,181 +164,10 @@ __global__ __launch_bounds__(GS_PEER_THREADS) void peer_allreduce_kernel(const P
     if (threadIdx.x == 0) mine.wg_epoch[blockIdx.x] = epoch;
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// The data-parallel step's LAST launch: slab sum | exchange | clip + Adam in ONE kernel (round 5).  The in-graph schedule
-// was backward | gs_flat_reduce_adam (slab sum -> grads) | exchange | gs_adam_step: two launches around the collective, 8 us
-// over the single-GPU step before any exchange time (profiles/r04_dp_schedule.txt).  Here workgroup (p, w)
-//   A'  forms chunk w of slice p of the LOCAL gradient straight from the split-K slabs (+ weight decay), as
-//       flat_reduce_adam_kernel does, and stores it into rank p's window (never through `grads`),
-//   B   sums the copies of chunk w of MY slice in rank order and stores the sum into rank p's window (unchanged),
-//   C'  takes chunk w of rank p's reduced slice, writes it to `grads` and applies clip + Adam to those parameters at once.
-// Behind the world * W exchange workgroups ride the fan-out sampler of a later mini-batch and gather+mean jobs of the next
-// one (as behind flat_reduce_adam_kernel): the exchange workgroups mostly WAIT (flags), the riders use the chip meanwhile.
-// Same sums in the same order as the three-launch schedule: bit-identical parameters.
-#define GS_PEER_MAX_VARS 24
-struct PeerFlatVars {
-    int64_t offset[GS_PEER_MAX_VARS];
-    int64_t size[GS_PEER_MAX_VARS];
-    float* slabs[GS_PEER_MAX_VARS];
-    int32_t n_slabs[GS_PEER_MAX_VARS];
-    int32_t decay[GS_PEER_MAX_VARS];
-    int32_t clear[GS_PEER_MAX_VARS];
-    int32_t n;
-};
-struct PeerStepArgs {
-    float* params; float* m; float* v;
-    float wd, lr, b1, b2, eps, clip, gscale;
-    const uint64_t* step_dev; int32_t step_offset;
-    const float* loss_rows; int64_t loss_n; float loss_scale; float* loss_out; int32_t loss_accumulate;
-};
-
-__global__ __launch_bounds__(GS_PEER_THREADS) void peer_step_kernel(const PeerArgs a, const PeerFlatVars V, const PeerStepArgs S,
-                                                                    const int exch_blocks, const FanoutArgs F, const CoGatherS J) {
-    __shared__ int32_t lvl[2][GS_FANOUT_LDS_SMALL];
-    if ((int)blockIdx.x >= exch_blocks) {
-        const int64_t r = (int64_t)blockIdx.x - exch_blocks;
-        if (r < F.B) sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, lvl);
-        else run_gather_item<8, 25>(J, (r - F.B) * (GS_PEER_THREADS / 64) + (threadIdx.x >> 6), threadIdx.x & 63);
-        return;
-    }
-    const int p = blockIdx.x / a.W, w = blockIdx.x % a.W;
-    const int me = a.me, world = a.world;
-    const PeerWindow mine = a.win[me];
-    const uint32_t epoch = mine.wg_epoch[blockIdx.x] + 1u;
-    if (S.loss_rows && blockIdx.x == 0 && threadIdx.x < 64) {
-        // the step's scalar loss (supervised_models.py:111-118 reduce_mean): one wave, fixed order (as flat_reduce_adam_kernel)
-        float sacc = 0.f;
-        for (int64_t i = threadIdx.x; i < S.loss_n; i += 64) sacc += S.loss_rows[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
-        if (threadIdx.x == 0) S.loss_out[0] = S.loss_accumulate ? S.loss_out[0] + sacc * S.loss_scale : sacc * S.loss_scale;
-    }
-    if (*mine.error != 0u) {                               // sticky (see peer_allreduce_kernel): no update on un-reduced gradients
-        if (threadIdx.x == 0) mine.wg_epoch[blockIdx.x] = epoch;
-        return;
-    }
-    const int par = (int)(epoch & 1u);
-    const int64_t per = ((a.L / 4 + a.W - 1) / a.W) * 4;
-    const int64_t c0 = std::min<int64_t>(a.L, (int64_t)w * per), c1 = std::min<int64_t>(a.L, c0 + per);
-    const int64_t lim = std::max<int64_t>(0, std::min<int64_t>(a.L, a.n - (int64_t)p * a.L));     // the last slice is ragged
-    uint32_t err = 0;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // ---- A'. my local gradient of chunk w of slice p, formed from the slabs, -> rank p's recv[par][me]
-    {
-        float* dst = a.win[p].recv + ((int64_t)par * world + me) * a.L;
-        for (int64_t i = c0 + (int64_t)threadIdx.x * 4; i < c1; i += GS_PEER_THREADS * 4) {
-            f32x4 g = zero4;
-            if (i < lim) {                                  // every variable segment is whole float4s: a quad is all in or all out
-                const int64_t f = (int64_t)p * a.L + i;     // index in the flat buffers
-                int k = 0;
-                while (k + 1 < V.n && f >= V.offset[k + 1]) ++k;
-                const int64_t rel = f - V.offset[k];
-                if (rel < V.size[k]) {
-                    float* sp = V.slabs[k] + rel;
-                    const int ns = V.n_slabs[k];
-                    const int64_t sz = V.size[k];
-                    for (int z0 = 0; z0 < ns; z0 += 24) {   // summation order z = 0, 1, ... as flat_reduce_adam_kernel
-                        f32x4 sv[24];
-#pragma unroll
-                        for (int u = 0; u < 24; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
-#pragma unroll
-                        for (int u = 0; u < 24; ++u)
-                            if (z0 + u < ns) g += sv[u];
-                    }
-                    if (V.clear[k]) *reinterpret_cast<f32x4*>(sp) = zero4;
-                }
-                if (V.decay[k] && S.wd != 0.f) g = gs_wd_add(g, *reinterpret_cast<const f32x4*>(S.params + f), S.wd);
-            }
-            *(f32x4*)(dst + i) = g;
-        }
-        peer_stores_done();
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(a.win[p].rs_flag + ((int64_t)me * a.W + w) * GS_PEER_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // (the parameters and Adam moments of this thread's first quad of phase C' are requested NOW: they depend on nothing the
-    //  exchange produces, and phase C' is otherwise one more dependent round trip behind the last flag)
-    const int64_t i_first = c0 + (int64_t)threadIdx.x * 4;
-    f32x4 pv0 = zero4, mi0 = zero4, vi0 = zero4;
-    if (i_first < c1 && i_first < lim) {
-        const int64_t f = (int64_t)p * a.L + i_first;
-        pv0 = *reinterpret_cast<const f32x4*>(S.params + f);
-        mi0 = *reinterpret_cast<const f32x4*>(S.m + f);
-        vi0 = *reinterpret_cast<const f32x4*>(S.v + f);
-    }
-    // ---- B. chunk w of MY slice has landed from every rank: sum the copies in rank order, store the sum into rank p's full[]
-    {
-        int ok = 1;
-        if (a.probe_wait_us && threadIdx.x == 0) {          // diagnostics: the peers' latency, simulated (one sleeping lane)
-            const unsigned long long until = wall_clock64() + 100ull * a.probe_wait_us;       // 100 MHz
-            while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-        }
-        if ((int)threadIdx.x < world) {
-            ok = peer_wait(mine.rs_flag + ((int64_t)threadIdx.x * a.W + w) * GS_PEER_STRIDE, epoch, a.spin_limit);
-            if (!ok) atomicOr(mine.error, 1u | (256u << threadIdx.x));
-        }
-        if (threadIdx.x < GS_WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        ok = __syncthreads_and(ok);
-        if (!ok) err = 1u;
-    }
-    if (!err) {
-        const float* in = mine.recv + (int64_t)par * world * a.L;
-        float* dst = a.win[p].full + (int64_t)me * a.L;
-        for (int64_t i = c0 + (int64_t)threadIdx.x * 4; i < c1; i += GS_PEER_THREADS * 4) {
-            f32x4 s = *(const f32x4*)(in + i);
-            for (int q = 1; q < world; ++q) {
-                const f32x4 v = *(const f32x4*)(in + (int64_t)q * a.L + i);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-            *(f32x4*)(dst + i) = s;
-        }
-        peer_stores_done();
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(a.win[p].ag_flag + ((int64_t)me * a.W + w) * GS_PEER_STRIDE, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        int ok = 1;
-        if (threadIdx.x == 0) {
-            ok = peer_wait(mine.ag_flag + ((int64_t)p * a.W + w) * GS_PEER_STRIDE, epoch, a.spin_limit);
-            if (!ok) atomicOr(mine.error, 2u | (256u << p));
-        }
-        if (threadIdx.x < GS_WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        ok = __syncthreads_and(ok);
-        if (!ok) err = 2u;
-    }
-    if (!err) {
-        // ---- C'. chunk w of rank p's reduced slice: -> grads, and clip + Adam on its parameters (gs_adam_step's arithmetic)
-        const float lr_t = gs_adam_lr_t(S.lr, S.b1, S.b2, S.step_dev, S.step_offset);
-        const float* src = mine.full + (int64_t)p * a.L;
-        for (int64_t i = c0 + (int64_t)threadIdx.x * 4; i < c1; i += GS_PEER_THREADS * 4) {
-            if (i >= lim) continue;
-            const int64_t f = (int64_t)p * a.L + i;
-            const f32x4 gr = *(const f32x4*)(src + i);
-            f32x4 pv = pv0, mi = mi0, vi = vi0;
-            if (i != i_first) {
-                pv = *reinterpret_cast<const f32x4*>(S.params + f);
-                mi = *reinterpret_cast<const f32x4*>(S.m + f);
-                vi = *reinterpret_cast<const f32x4*>(S.v + f);
-            }
-            *reinterpret_cast<f32x4*>(a.grads + f) = gr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float pe = pv[e], me = mi[e], ve = vi[e];
-                gs_adam_elem(pe, me, ve, gr[e], S.gscale, S.clip, S.b1, S.b2, S.eps, lr_t);
-                pv[e] = pe; mi[e] = me; vi[e] = ve;
-            }
-            *reinterpret_cast<f32x4*>(S.m + f) = mi;
-            *reinterpret_cast<f32x4*>(S.v + f) = vi;
-            *reinterpret_cast<f32x4*>(S.params + f) = pv;
-        }
-    }
-    if (threadIdx.x == 0) mine.wg_epoch[blockIdx.x] = epoch;
-}
-
 struct GsPeer {
     int32_t world, rank, W;
     int64_t n, L, bytes;
     uint32_t spin_limit;
-    uint32_t probe_wait_us;
     char* base[GS_PEER_MAX_WORLD];          // base[rank] = own allocation; others: hipIpcOpenMemHandle / in-process pointers
     bool ipc[GS_PEER_MAX_WORLD];
 };
@@ -457,74 +282,6 @@ extern "C" int gs_peer_allreduce_sum_f32(void* peer, float* buf, int64_t count, 
     hipStream_t s = (hipStream_t)stream;
     peer_allreduce_kernel<<<g->world * g->W, GS_PEER_THREADS, 0, s>>>(a);
     GS_LAUNCH_CHECK("peer_allreduce_kernel");
-    return GS_OK;
-}
-
-// Diagnostics: make every exchange workgroup of gs_peer_step hold its hand-over for `us` microseconds (0 = off): a one-GPU
-// stand-in for the peers' latency when the data-parallel schedule is probed without peers (bench.py GS_PROBE_DP_PEER).
-extern "C" int gs_peer_set_probe_wait(void* peer, int32_t us) {
-    GS_REQUIRE(peer && us >= 0 && us <= 100000, "gs_peer_set_probe_wait: 0 <= us <= 100000");
-    ((GsPeer*)peer)->probe_wait_us = (uint32_t)us;
-    return GS_OK;
-}
-
-extern "C" int gs_peer_step(void* peer, const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m,
-                            float* v, int64_t total, float weight_decay, float lr, float beta1, float beta2, float eps, float clip,
-                            float grad_scale, const uint64_t* step_dev, int32_t step_offset, const float* loss_rows, int64_t loss_n,
-                            float loss_scale, float* loss_out, int loss_accumulate, const gs_fanout_desc* sampler_host,
-                            const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
-    GS_REQUIRE(peer && vars_host && n_vars > 0 && n_vars <= GS_PEER_MAX_VARS, "gs_peer_step: need a window and 1..%d variables", GS_PEER_MAX_VARS);
-    GS_REQUIRE(params && grads && m && v && gs_aligned16(params) && gs_aligned16(grads) && gs_aligned16(m) && gs_aligned16(v) &&
-               total > 0 && total % 4 == 0, "gs_peer_step: bad flat buffers");
-    GS_REQUIRE(!loss_rows || (loss_out && loss_n > 0), "gs_peer_step: loss_out missing");
-    GsPeer* g = (GsPeer*)peer;
-    GS_REQUIRE(total == g->n, "gs_peer_step: the window was created for %lld floats, got %lld", (long long)g->n, (long long)total);
-    GS_REQUIRE(g->L % 4 == 0, "gs_peer_step: slice length must be whole float4s");
-    PeerFlatVars V;
-    memset(&V, 0, sizeof(V));
-    V.n = n_vars;
-    int64_t expect = 0;
-    for (int i = 0; i < n_vars; ++i) {
-        GS_REQUIRE(vars_host[i].offset == expect && vars_host[i].size > 0 && vars_host[i].size % 4 == 0,
-                   "gs_peer_step: variables must tile the flat buffer in order (var %d)", i);
-        GS_REQUIRE(vars_host[i].n_slabs == 0 || (vars_host[i].slabs && gs_aligned16(vars_host[i].slabs)), "gs_peer_step: slabs of var %d missing/misaligned", i);
-        GS_REQUIRE(!vars_host[i].clear || vars_host[i].n_slabs == 1, "gs_peer_step: var %d: clear needs n_slabs == 1", i);
-        V.offset[i] = vars_host[i].offset; V.size[i] = vars_host[i].size; V.slabs[i] = vars_host[i].slabs;
-        V.n_slabs[i] = vars_host[i].n_slabs; V.decay[i] = vars_host[i].decay; V.clear[i] = vars_host[i].clear;
-        expect += vars_host[i].size;
-    }
-    GS_REQUIRE(expect == total, "gs_peer_step: the variables must cover the whole flat buffer (%lld of %lld floats)", (long long)expect, (long long)total);
-    PeerArgs a;
-    memset(&a, 0, sizeof(a));
-    for (int r = 0; r < g->world; ++r) {
-        GS_REQUIRE(g->base[r] != nullptr, "gs_peer_step: rank %d's window is not attached", r);
-        a.win[r] = peer_layout(g->base[r], g->L, g->world, g->W);
-    }
-    a.grads = grads; a.n = g->n; a.L = g->L; a.world = g->world; a.me = g->rank; a.W = g->W; a.spin_limit = g->spin_limit;
-    a.probe_wait_us = g->probe_wait_us;
-    PeerStepArgs S = {params, m, v, weight_decay, lr, beta1, beta2, eps, clip, grad_scale, step_dev, step_offset,
-                      loss_rows, loss_n, loss_scale, loss_out, loss_accumulate};
-    FanoutArgs F = {};
-    int64_t roots = 0;
-    if (sampler_host && sampler_host->B > 0) {
-        int64_t kmax = 0;
-        int rc = gs_fanout_args_desc(sampler_host, &F, &kmax);
-        if (rc != GS_OK) return rc;
-        if (kmax > GS_FANOUT_LDS_SMALL) {
-            gs_set_error("gs_peer_step: per-root fan-out %lld of a kept hop exceeds %d", (long long)kmax, GS_FANOUT_LDS_SMALL);
-            return GS_ENOTSUP;
-        }
-        roots = F.B;
-    }
-    CoGatherS J = {};
-    int64_t waves = 0;
-    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
-    if (rc != GS_OK) return rc;
-    const int exch = g->world * g->W;
-    const int64_t blocks = exch + roots + gs_ceil_div(waves, GS_PEER_THREADS / 64);
-    GS_REQUIRE(blocks < (1ll << 31), "gs_peer_step: grid too large");
-    hipLaunchKernelGGL(peer_step_kernel, dim3((unsigned)blocks), dim3(GS_PEER_THREADS), 0, (hipStream_t)stream, a, V, S, exch, F, J);
-    GS_LAUNCH_CHECK("peer_step_kernel");
     return GS_OK;
 }
 

@@ -98,238 +98,6 @@ extern "C" int gs_split_rows(const float* W, int64_t ldw, int32_t K, int32_t N, 
     return GS_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-struct SplitTerm {
-    const float* A;        // [*, lda] fp32; row i of the term is A[a_idx ? a_idx[i] : i]
-    const int32_t* a_idx;  // nullable row gather (layer 0: the self rows of the feature table)
-    const u32x4* W3;       // gs_split_rows(W [K, N])
-    int32_t lda;
-};
-struct SplitFwdArgs {
-    SplitTerm t[2];
-    int32_t nterms;        // 1, or 2 (concat: term i writes columns [i*N, (i+1)*N))
-    int32_t M, N, K;
-    float* C;
-    int32_t ldc;
-    const float* bias;     // indexed by output column (incl. the concat offset), nullable
-    int32_t act;
-    int32_t tiles_n;       // 64-column tiles per term
-    int32_t n_waves;       // contraction waves = tiles_m * tiles_n * nterms
-};
-
-// One WAVE: C[m0 .. m0+31][n0 .. n0+63] of one term over the whole K.
-//   step s (16 k): lane (r = lane & 31, g = lane >> 5) holds A[row r][16 s + 8 g .. + 7] (two 16-byte loads, cut into pieces
-//   in registers) and, for both 32-column halves, the three pre-cut pieces of W[16 s + 8 g .. + 7][column r] (three 16-byte
-//   loads each: 32 lanes x 16 contiguous bytes); 12 MFMAs.  Both operand streams run D steps ahead of their use (vmcnt
-//   retires loads in order, so a deeper A ring would only wait behind the B loads issued after it).
-template <int D>
-__device__ __forceinline__ void split_fwd_wave(const SplitFwdArgs& g, const int item, const int lane) {
-    constexpr int DA = D, DB = D, U = (D % 2) ? 2 * D : D;     // ring depth; unrolled group (even: the piece buffers alternate)
-    const int l31 = lane & 31, lh = lane >> 5;
-    // The four waves of a workgroup = four ROW tiles of the same (term, column tile): they read the same B fragments at about
-    // the same time, so three of four B loads hit in the CU's L1 -- register-streaming contractions are bound by the L2 -> CU
-    // bandwidth of the operand re-reads (measured: 218 MB per launch at the Reddit shape when every wave streams its own B).
-    const int tiles_m = g.n_waves / (g.nterms * g.tiles_n);
-    const int combo = item / tiles_m, tile_m = item - combo * tiles_m;
-    const int term = combo / g.tiles_n, tile_n = combo - term * g.tiles_n;
-    const int m0 = tile_m * 32, n0 = tile_n * 64;
-    const SplitTerm& T = g.t[term];
-    const int K = g.K, N = g.N;
-    const int S = (K + 15) >> 4;                       // steps; the last one may hold k >= K (A masked, W3 zero-padded)
-    const int KG = 2 * S;
-    const int arow = min(m0 + l31, g.M - 1);
-    const int64_t srow = T.a_idx ? (int64_t)T.a_idx[arow] : (int64_t)arow;
-    const float* ap = T.A + srow * T.lda + 8 * lh;
-    const int c0 = min(n0 + l31, N - 1), c1 = min(n0 + 32 + l31, N - 1);     // clamped: never stored if >= N
-    const char* __restrict__ Wb = (const char*)T.W3;   // uniform base + 32-bit byte offsets (one VALU add per stream and step)
-    const uint32_t plane = (uint32_t)N * 16u;          // bytes between the pieces of a group
-    uint32_t bo0 = ((uint32_t)lh * 3u * (uint32_t)N + (uint32_t)c0) * 16u, bo1 = ((uint32_t)lh * 3u * (uint32_t)N + (uint32_t)c1) * 16u;
-    // the last step is handled apart when K % 16 != 0 (A columns >= K are masked; pad columns up to round_up(K, 4) readable)
-    const int Sfull = (K & 15) ? S - 1 : S;
-    // Two accumulators per column half: the bf16 MFMA adds into its accumulator with truncation, a bias that grows with the
-    // number of additions into a LARGE sum (measured: one accumulator for all six piece products = 228 additions over K = 602
-    // -> 4.7e-6 of the row's rms against 1.9e-6 for the fp32 FMA chain).  The h h products (38 additions) get their own; the
-    // five small products (<= 2^-8 of it) meet in a second one whose truncation is 2^-8 smaller; they are added once at the end.
-    f32x16 acc0, acc1, sml0, sml1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; sml0[e] = 0.f; sml1[e] = 0.f; }
-    f32x4 a[DA][2];
-    u32x4 b[DB][6];
-    int a_left = Sfull - 1, b_left = Sfull - 1;        // pointer advances still allowed (a refill past the end re-reads the
-                                                       // last full step: valid address, value never used)
-    auto load_a = [&](const int slot) {
-#ifdef GS_DIAG_SPLIT_NOA
-        a[slot][0] = f32x4{__int_as_float((int)(uintptr_t)ap), 0.f, 1.f, 2.f}; a[slot][1] = a[slot][0];
-#else
-        a[slot][0] = *reinterpret_cast<const f32x4*>(ap);
-        a[slot][1] = *reinterpret_cast<const f32x4*>(ap + 4);
-#endif
-        ap += a_left > 0 ? 16 : 0;
-        --a_left;
-    };
-    auto load_b = [&](const int slot) {
-#ifdef GS_DIAG_SPLIT_NOB
-        b[slot][0] = b[slot][1] = b[slot][2] = u32x4{bo0, 1u, 2u, 3u}; b[slot][3] = b[slot][4] = b[slot][5] = u32x4{bo1, 1u, 2u, 3u};
-        { const uint32_t adv = b_left > 0 ? 6u * plane : 0u; bo0 += adv; bo1 += adv; --b_left; }
-        return;
-#endif
-        b[slot][0] = *reinterpret_cast<const u32x4*>(Wb + bo0);
-        b[slot][1] = *reinterpret_cast<const u32x4*>(Wb + bo0 + plane);
-        b[slot][2] = *reinterpret_cast<const u32x4*>(Wb + bo0 + 2u * plane);
-        b[slot][3] = *reinterpret_cast<const u32x4*>(Wb + bo1);
-        b[slot][4] = *reinterpret_cast<const u32x4*>(Wb + bo1 + plane);
-        b[slot][5] = *reinterpret_cast<const u32x4*>(Wb + bo1 + 2u * plane);
-        const uint32_t adv = b_left > 0 ? 6u * plane : 0u;     // two groups of 8 k per step
-        bo0 += adv; bo1 += adv;
-        --b_left;
-    };
-    // 12 MFMAs of one step from ready-made A pieces P[0..2] = (h, m, l): small terms first, the two column halves alternate so
-    // that consecutive MFMAs never wait on each other
-    auto mfma12 = [&](const u32x4* P, const u32x4* bb) {
-        sml0 = gs_mfma_bf16(P[0], bb[2], sml0); sml1 = gs_mfma_bf16(P[0], bb[5], sml1);     // h l
-        sml0 = gs_mfma_bf16(P[2], bb[0], sml0); sml1 = gs_mfma_bf16(P[2], bb[3], sml1);     // l h
-        sml0 = gs_mfma_bf16(P[1], bb[1], sml0); sml1 = gs_mfma_bf16(P[1], bb[4], sml1);     // m m
-        sml0 = gs_mfma_bf16(P[0], bb[1], sml0); sml1 = gs_mfma_bf16(P[0], bb[4], sml1);     // h m
-        sml0 = gs_mfma_bf16(P[1], bb[0], sml0); sml1 = gs_mfma_bf16(P[1], bb[3], sml1);     // m h
-        acc0 = gs_mfma_bf16(P[0], bb[0], acc0); acc1 = gs_mfma_bf16(P[0], bb[3], acc1);     // h h
-    };
-    // Software pipeline: while the 12 MFMAs of step s run (384 matrix-pipe cycles), the VALU cuts the A operand of step s + 1
-    // (44 instructions) and the refills of the ring slots step s has freed are issued: one MFMA, then <= 5 other instructions
-    // (an MFMA gap hides 5 single-issue instructions, MI355X_MICROARCH.md).  The scheduler is told the pattern explicitly --
-    // left alone it lumps the 44 VALU in front of the 12 MFMAs.
-    u32x4 P[2][3];
-    if (Sfull > 0) {
-#pragma unroll
-        for (int st = 0; st < DA; ++st) load_a(st);
-#pragma unroll
-        for (int st = 0; st < DB; ++st) load_b(st);
-        gs_split8(a[0][0], a[0][1], P[0][0], P[0][1], P[0][2]);
-        int s = 0;
-#pragma unroll 1
-        for (; s + U < Sfull; s += U) {
-#pragma unroll
-            for (int st = 0; st < U; ++st) {
-                mfma12(P[st & 1], b[st % DB]);
-                load_a(st % DA);                       // slot st was cut one step ago
-                gs_split8(a[(st + 1) % DA][0], a[(st + 1) % DA][1], P[(st + 1) & 1][0], P[(st + 1) & 1][1], P[(st + 1) & 1][2]);
-                load_b(st % DB);                       // (register dependences keep it behind the MFMAs that read the slot)
-#pragma unroll
-                for (int q = 0; q < 12; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);            // four VALU
-                    if (q % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a load behind 8 of the 12
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // the last (possibly partial) group: the rings hold steps s .. s+D-1 and are refilled as long as steps remain
-#pragma unroll
-        for (int st = 0; st < U; ++st) {
-            if (s + st < Sfull) {                      // wave-uniform
-                mfma12(P[st & 1], b[st % DB]);
-                if (s + st + DA < Sfull) load_a(st % DA);
-                if (s + st + 1 < Sfull)
-                    gs_split8(a[(st + 1) % DA][0], a[(st + 1) % DA][1], P[(st + 1) & 1][0], P[(st + 1) & 1][1], P[(st + 1) & 1][2]);
-                if (s + st + DB < Sfull) load_b(st % DB);
-            }
-        }
-    }
-    if (Sfull != S) {
-        const int k0 = 16 * Sfull + 8 * lh;
-        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-        const float* p = T.A + srow * T.lda + k0;
-        if (k0 < K) x0 = *reinterpret_cast<const f32x4*>(p);
-        if (k0 + 4 < K) x1 = *reinterpret_cast<const f32x4*>(p + 4);
-        if (k0 + 1 >= K) x0.y = 0.f;
-        if (k0 + 2 >= K) x0.z = 0.f;
-        if (k0 + 3 >= K) x0.w = 0.f;
-        if (k0 + 5 >= K) x1.y = 0.f;
-        if (k0 + 6 >= K) x1.z = 0.f;
-        if (k0 + 7 >= K) x1.w = 0.f;
-        u32x4 bb[6];
-        const u32x4* q0 = T.W3 + (int64_t)(2 * Sfull + lh) * 3 * N + c0;
-        const u32x4* q1 = T.W3 + (int64_t)(2 * Sfull + lh) * 3 * N + c1;
-        bb[0] = q0[0]; bb[1] = q0[N]; bb[2] = q0[2 * N]; bb[3] = q1[0]; bb[4] = q1[N]; bb[5] = q1[2 * N];
-        gs_split8(x0, x1, P[0][0], P[0][1], P[0][2]);
-        mfma12(P[0], bb);
-    }
-    // bias + activation + store (C/D layout of the 32x32 MFMA: row = (e&3) + 8 (e>>2) + 4 (lane>>5), column = lane & 31)
-    const int col_off = term * N;
-    const int ca = n0 + l31, cb = n0 + 32 + l31;
-    float bias0 = 0.f, bias1 = 0.f;
-    if (g.bias) {
-        if (ca < N) bias0 = g.bias[col_off + ca];
-        if (cb < N) bias1 = g.bias[col_off + cb];
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float v0 = (acc0[e] + sml0[e]) + bias0, v1 = (acc1[e] + sml1[e]) + bias1;
-        if (g.act == GS_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (row < g.M) {
-            float* dst = g.C + (int64_t)row * g.ldc + col_off;
-            if (ca < N) dst[ca] = v0;
-            if (cb < N) dst[cb] = v1;
-        }
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void sage_split_fwd_kernel(const SplitFwdArgs g, const CoGatherS J) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int host_wgs = (g.n_waves + 3) >> 2;
-    if ((int)blockIdx.x < host_wgs) {
-        const int item = (int)blockIdx.x * 4 + wave;
-        if (item < g.n_waves) split_fwd_wave<D>(g, item, lane);
-        return;
-    }
-    run_gather_item(J, ((int64_t)blockIdx.x - host_wgs) * 4 + wave, lane);
-}
-
-extern "C" int gs_sage_dense_fwd_split(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg, int64_t ld_agg,
-                                       int32_t d, int64_t n, const void* W3_self, const void* W3_neigh, int32_t out_dim, int act,
-                                       const float* bias, float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs,
-                                       void* stream) {
-    if (n == 0 && n_jobs == 0) return GS_OK;
-    GS_REQUIRE(agg && W3_neigh && out && d > 0 && out_dim > 0 && n >= 0, "gs_sage_dense_fwd_split: bad args");
-    GS_REQUIRE(!self || W3_self, "gs_sage_dense_fwd_split: W3_self missing");
-    GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_split agg");
-    if (self) GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_split self");
-    const int d4 = ((d + 3) / 4) * 4;
-    GS_REQUIRE(ld_agg >= d4 && (!self || ld_self >= d4), "gs_sage_dense_fwd_split: ld must be >= round_up(d, 4)");
-    GS_REQUIRE(gs_aligned16(W3_neigh) && (!self || gs_aligned16(W3_self)), "gs_sage_dense_fwd_split: W3 must be 16-byte aligned");
-    GS_REQUIRE(n < (1ll << 26) && ldo >= out_dim * (self ? 2 : 1), "gs_sage_dense_fwd_split: bad sizes");
-    GS_REQUIRE(split_rows_bytes(d, out_dim) < (1ll << 32), "gs_sage_dense_fwd_split: W3 must stay below 4 GB");
-    SplitFwdArgs g = {};
-    g.nterms = self ? 2 : 1;
-    if (self) {
-        g.t[0] = SplitTerm{self, self_idx, (const u32x4*)W3_self, (int32_t)ld_self};
-        g.t[1] = SplitTerm{agg, nullptr, (const u32x4*)W3_neigh, (int32_t)ld_agg};
-    } else {
-        g.t[0] = SplitTerm{agg, nullptr, (const u32x4*)W3_neigh, (int32_t)ld_agg};
-    }
-    g.M = (int32_t)n; g.N = out_dim; g.K = d; g.C = out; g.ldc = (int32_t)ldo; g.bias = bias; g.act = act;
-    g.tiles_n = (out_dim + 63) / 64;
-    // a workgroup's four waves = (term, column tile) combinations of the same rows first
-    const int tiles_m = (int)((n + 31) / 32);
-    g.n_waves = tiles_m * g.tiles_n * g.nterms;
-    CoGatherS J = {};
-    int64_t waves = 0;
-    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
-    if (rc != GS_OK) return rc;
-    const int64_t blocks = (g.n_waves + 3) / 4 + gs_ceil_div(waves, 4);
-    GS_REQUIRE(blocks > 0 && blocks < (1ll << 31), "gs_sage_dense_fwd_split: grid too large");
-    // ring depth: 3 steps keep the kernel at <= 256 registers (two waves per SIMD: a contraction wave and a rider, or two
-    // contraction waves); GS_SPLIT_DEPTH=4 is the diagnostics variant (one wave per SIMD)
-    static const int depth = getenv("GS_SPLIT_DEPTH") ? atoi(getenv("GS_SPLIT_DEPTH")) : 3;
-    if (depth >= 4)
-        hipLaunchKernelGGL((sage_split_fwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
-    else
-        hipLaunchKernelGGL((sage_split_fwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, J);
-    GS_LAUNCH_CHECK("sage_split_fwd_kernel");
-    return GS_OK;
-}
-
 // ------------------------------------------------------------------------------------------------ LDS-tiled form
 // out[i] = act(X[idx[i]] . W + bias), i < min(n_max, *n_dev)  -- the pooling MLP of the max-pool aggregator on the step's
 // distinct sampled ids (aggregators.py:176-179 via layers.py:104-116; 51 GF per Reddit step: the one contraction of the path

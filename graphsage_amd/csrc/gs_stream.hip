@@ -247,7 +247,6 @@ struct WgradProb {
     int32_t n, d, out_dim;
     int32_t tiles_m, tiles_n, n_slabs, kchunk;   // kchunk: rows per slab (even)
     int32_t item_start;   // first work item of this problem
-    int32_t wide_rows;    // row-gathered A whose table exceeds 4 GB: 16-byte-unit row offsets (stream_wgrad_body<P, 2>)
 };
 struct WgradArgs {
     WgradProb p[GS_MAX_SGROUP];
@@ -261,9 +260,9 @@ struct WgradArgs {
 // offsets against wave-uniform base pointers (global_load with an SGPR base), advanced with one add per load; a
 // gathered A row costs two v_readlane (SALU) + two VALU.  (The first version -- 64-bit per-lane pointers, a register
 // select ladder for the gather index -- spent ~300 cycles per k-pair outside the 256 MFMA cycles.)
-// GATHERED: 0 = dense A, 1 = row-gathered A addressed with 32-bit BYTE offsets (tables < 4 GB), 2 = row-gathered A of any
-// size: the slice's row offsets are kept in units of 16 bytes (a row starts 16-byte aligned: lda % 4 == 0) and widened per
-// load -- three more VALU per k-pair, which only the tables that need it pay (RMAT: 10^7 rows x 1 KB = 10.2 GB).
+// GATHERED: 0 = dense A, 1 = row-gathered A addressed with 32-bit BYTE offsets (tables < 4 GB; larger tables take the tiled
+// kernel of gs_gemm.hip -- a form with 16-byte-unit row offsets widened per load was measured slower on the one
+// configuration that needs it, RMAT: 95.2 vs 77.3 us/step, benchmarks/variants/README.md).
 template <int P, int GATHERED>
 __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int z, const int f0, const int o0, const int lane,
                                                   const int tl_item) {
@@ -286,7 +285,7 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
     if (GATHERED) {
 #pragma unroll
         for (int jx = 0; jx < IDXR; ++jx)
-            rowoff[jx] = (uint32_t)q.a_idx[min(rb + lane + 64 * jx, re - 1)] * (GATHERED == 2 ? (uint32_t)q.lda / 4u : (uint32_t)q.lda * 4u);
+            rowoff[jx] = (uint32_t)q.a_idx[min(rb + lane + 64 * jx, re - 1)] * ((uint32_t)q.lda * 4u);
     }
     uint32_t hi_mask = lh ? 0xFFFFFFFFu : 0u;
     asm volatile("" : "+v"(hi_mask));                      // opaque: keeps `& hi_mask` an AND
@@ -301,19 +300,14 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
     };
     auto load_stage = [&](const int st) {                  // no arithmetic on the loaded values here: a use would
         uint32_t o0a, o1a;                                 // force a wait right behind the load and empty the ring
-        const char* __restrict__ Ar = Ab;                  // GATHERED == 2: the lane's row base (64-bit)
+        const char* __restrict__ Ar = Ab;
         if (GATHERED) {
             const int l = cur & 63;
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l + 1);   // l even: same register
             const uint32_t t = (hi - lo) & hi_mask;        // (not a select: two SGPR sources would cost two v_mov first)
-            if (GATHERED == 2) {
-                Ar = Ab + ((uint64_t)(lo + t) << 4);
-                o0a = ca0; o1a = ca1;
-            } else {
-                o0a = lo + t + ca0;
-                o1a = lo + t + ca1;
-            }
+            o0a = lo + t + ca0;
+            o1a = lo + t + ca1;
         } else {
             o0a = ao0; o1a = ao1;
             ao0 += strideA; ao1 += strideA;
@@ -349,13 +343,8 @@ __device__ __forceinline__ void stream_wgrad_body(const WgradProb& q, const int 
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)rowoff[0], l + 1);
             const uint32_t t = (hi - lo) & hi_mask;
-            if (GATHERED == 2) {
-                Ar = Ab + ((uint64_t)(lo + t) << 4);
-                o0a = ca0; o1a = ca1;
-            } else {
-                o0a = lo + t + ca0;
-                o1a = lo + t + ca1;
-            }
+            o0a = lo + t + ca0;
+            o1a = lo + t + ca1;
         } else {
             o0a = ao0; o1a = ao1;
             ao0 += strideA; ao1 += strideA;
@@ -443,7 +432,6 @@ __device__ __forceinline__ void stream_wgrad_item(const WgradArgs& G, const int 
     const int tt = local - z * tiles;
     const int tile_m = tt / q.tiles_n, tile_n = tt - tile_m * q.tiles_n;
     if (!q.a_idx) stream_wgrad_body<P, 0>(q, z, tile_m * 64, tile_n * 64, lane, item);
-    else if (q.wide_rows) stream_wgrad_body<P, 2>(q, z, tile_m * 64, tile_n * 64, lane, item);
     else stream_wgrad_body<P, 1>(q, z, tile_m * 64, tile_n * 64, lane, item);
 }
 
@@ -543,10 +531,7 @@ extern "C" int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, in
         // the kernel addresses A and dZ with 32-bit BYTE offsets against their base pointers
         const int64_t a_rows = q.a_idx ? q.a_rows : q.n;
         GS_REQUIRE(!q.a_idx || q.a_rows > 0, "gs_dense_wgrad_grouped_stream: a row-gathered problem must state a_rows");
-        // the kernel addresses dZ and a dense A with 32-bit BYTE offsets; a row-gathered A with 32-bit byte offsets while
-        // its table is < 4 GB and with 32-bit offsets in units of 16 bytes beyond that (64 GB)
-        const bool wide = q.a_idx && (a_rows + 1) * q.lda * 4 >= (1ll << 32);
-        GS_REQUIRE((wide ? (a_rows + 1) * (q.lda / 4) : (a_rows + 1) * q.lda * 4) < (1ll << 32) && (q.n + 1) * q.ldz * 4 < (1ll << 32) &&
+        GS_REQUIRE((a_rows + 1) * q.lda * 4 < (1ll << 32) && (q.n + 1) * q.ldz * 4 < (1ll << 32) &&
                    (int64_t)q.d * q.ld_slab < (1ll << 31),
                    "gs_dense_wgrad_grouped_stream: 32-bit offsets exceeded (A %lld x %lld, dZ %lld x %lld)",
                    (long long)a_rows, (long long)q.lda, (long long)q.n, (long long)q.ldz);
@@ -561,7 +546,6 @@ extern "C" int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, in
         GS_REQUIRE(!q.a_idx || p.kchunk <= 512, "gs_dense_wgrad_grouped_stream: a row-gathered problem needs slices of <= 512 rows "
                    "(n = %lld, n_slabs = %d)", (long long)q.n, q.n_slabs);
         p.item_start = items;
-        p.wide_rows = wide ? 1 : 0;
         items += p.tiles_m * p.tiles_n * q.n_slabs;
     }
     G.n_items = items;

@@ -212,13 +212,10 @@ class PeerPushAllReduce(object):
         multi = dist.is_initialized() and dist.get_world_size() > 1
         self.world_size = dist.get_world_size() if multi else 1
         self.rank = dist.get_rank() if multi else 0
-        self.chunks = int(os.environ.get("GS_PEER_CHUNKS", "0")) if chunks is None else int(chunks)
-        self.spin_limit = int(os.environ.get("GS_PEER_SPIN_LIMIT", "0")) if spin_limit is None else int(spin_limit)
+        self.chunks = 0 if chunks is None else int(chunks)                    # 0: the library's default chunking
+        self.spin_limit = 0 if spin_limit is None else int(spin_limit)        # 0: the library's default bound (2^24 polls)
         self.attempts = 0
         self.failures = []          # this rank's failed self-test attempts (diagnostics)
-        # the step's last launch as ONE kernel: slab sum | exchange | clip + Adam (gs_peer_step) instead of three launches
-        # around the exchange (the models ask through fused_handle()); 0 = the three-launch schedule
-        self.fused_step = os.environ.get("GS_PEER_FUSED_STEP", "1") == "1"
         self._open()
 
     # One window per (shape, rank) for the PROCESS'S LIFETIME: a window is never freed while a peer may still map it, and a
@@ -315,15 +312,6 @@ class PeerPushAllReduce(object):
 
     def __call__(self, model):
         self.all_reduce(self.engine.grads)
-
-    def set_probe_wait(self, us):
-        """Diagnostics: every exchange workgroup of the fused step launch holds its hand-over for `us` microseconds."""
-        from . import ops
-        ops.call("gs_peer_set_probe_wait", self._peer, int(us))
-
-    def fused_handle(self):
-        """The window handle for Engine.finish_backward(peer=...) (gs_peer_step), or None for the three-launch schedule."""
-        return self._peer if self.fused_step else None
 
     def status(self):
         """(exchanges completed on this rank, error word) -- call after the engine stream has been synchronised."""

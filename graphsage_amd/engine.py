@@ -95,25 +95,22 @@ class Engine(object):
         self.post_update_hooks = []
         self.dropout_seed = 123
         self._n_sites = 0
-        # "stream" contraction kernels (gs_stream.hip) for the layer-0 forward and the grouped weight gradients
-        self.stream_gemm = os.environ.get("GS_STREAM_GEMM", "1") == "1"
-        # ... and their split-MFMA form (gs_split.hip): fp32 operands cut into three bf16 pieces, six bf16 MFMAs per product
-        # tile -- fp32 accuracy at 6/16 of the fp32 MFMA's matrix-pipe time
-        # Default: the LDS-tiled pooling MLP (matrix-pipe bound: 564 -> measured below) takes it; the register-streaming layer-0
-        # contraction does not (bound by the L2 -> CU operand traffic in either form: 24.7 vs 24.6 us alone, and the per-step
-        # re-cut of its weights costs two launches)
-        self.split_gemm = os.environ.get("GS_SPLIT_GEMM", "0") == "1"
-        self.split_pool = os.environ.get("GS_SPLIT_POOL", "1") == "1"
-        # split-K policy knobs (tuning hooks, benchmarks/slab_sweep.sh), read ONCE
-        self._wgrad_blocks = int(os.environ.get("GS_WGRAD_BLOCKS", 768))
-        self._wgrad_max_slabs = int(os.environ.get("GS_WGRAD_MAX_SLABS", 32))
-        self._wgrad_big_n = int(os.environ.get("GS_WGRAD_BIG_N", 16384))
-        self._stream_max_slabs = int(os.environ.get("GS_STREAM_MAX_SLABS", 32))
+        # Schedule choices are plain attributes (tests and A/B scripts set them on a live engine; Model._schedule_signature
+        # keys the captured graphs on them); only the few a deployment may want to flip are read from the environment.
+        # "stream" contraction kernels (gs_stream.hip) for the layer-0 forward and the grouped weight gradients; False = the
+        # LDS-tiled family of gs_gemm.hip
+        self.stream_gemm = True
+        # the pooling MLP on the step's distinct ids as a split-MFMA contraction (gs_split16.hip / gs_split.hip); False = fp32 MFMA
+        self.split_pool = True
+        # split-K policy of the weight gradients (measured sweeps: DESIGN.md section 4 / profiles/r02..r05)
+        self._wgrad_blocks = 768          # tiled kernel: ~768 (tile x slice) workgroups per problem
+        self._wgrad_max_slabs = 32
+        self._wgrad_big_n = 16384         # reductions this long take their own 128 x 128-tile launch
+        self._stream_max_slabs = 32
         # contraction waves of ONE round: one per SIMD (4 per CU); the stream weight-gradient launch is cut to fit it (launch_wgrads)
-        self._stream_wave_slots = int(os.environ.get("GS_STREAM_WAVE_SLOTS", 0)) or (
-            4 * torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 1024)
-        self._stream_slice_rows = float(os.environ.get("GS_STREAM_SLICE_ROWS", 256))
-        self._stream_wide_rows = os.environ.get("GS_STREAM_WIDE_ROWS", "0") == "1"
+        self._stream_wave_slots = (4 * torch.cuda.get_device_properties(self.device).multi_processor_count
+                                   if self.device.type == "cuda" else 1024)
+        self._stream_slice_rows = 256.0   # stream kernel: ~one wave per SIMD with >= 256 reduction rows per slice
         self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)
         self._table16 = {}                # constant feature tables cut into two fp16 pieces (table16_of)
         # feature tables some launch of the step REWRITES (identity features: the trainable leading columns are refreshed behind
@@ -285,11 +282,9 @@ class Engine(object):
         ks = int(max(1, min(self._stream_max_slabs, MAX_SLABS - var.n_slabs - reserved, round(n / self._stream_slice_rows))))
         lda, ldz = A.ld, dZ.ld
         if a_idx is not None:
-            # (the kernel also takes tables beyond 4 GB -- 16-byte-unit row offsets, gs_stream.hip GATHERED == 2 -- but the
-            #  one configuration that has one, RMAT with F = 256, is slower on it: 95.2 vs 77.3 us/step, round 5 -- its 8 tiles
-            #  per problem give the stream policy ~400 waves for 1024 SIMDs; GS_STREAM_WIDE_ROWS=1 selects it)
-            limit = (A.rows + 1) * (lda // 4) if self._stream_wide_rows else (A.rows + 1) * lda * 4
-            ok = (n + ks - 1) // ks <= 510 and limit < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
+            # (32-bit BYTE offsets of the gathered rows: tables beyond 4 GB -- RMAT's 10 GB -- take the tiled kernel; a wide-offset
+            #  form of the stream kernel was measured slower there, 95.2 vs 77.3 us/step: benchmarks/variants/README.md)
+            ok = (n + ks - 1) // ks <= 510 and (A.rows + 1) * lda * 4 < 1 << 32 and (n + 1) * ldz * 4 < 1 << 32
         else:
             ok = (n + 1) * max(lda, ldz) * 4 < 1 << 32
         return ok, ks
@@ -404,7 +399,7 @@ class Engine(object):
         return arr
 
     def finish_backward(self, weight_decay, fuse_adam=False, lr=0.0, clip=5.0, grad_scale=1.0, side_jobs=None,
-                        loss=None, step_offset=1, peer=None, peer_jobs=None):
+                        loss=None, step_offset=1):
         """One grouped launch for every queued weight gradient, then ONE launch that sums the slabs into the
         flat gradient buffer (+ weight decay) and, if fuse_adam, applies clip + Adam in the same pass.
         loss = (loss_rows, n, scale, loss_out, accumulate): the step's scalar loss is formed by that launch too;
@@ -419,19 +414,6 @@ class Engine(object):
                 ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
                 1 if lacc else 0)
         rider = getattr(self, "_deferred_sampler", None)
-        if peer is not None:
-            # data-parallel step with the peer-store exchange: slab sum | exchange | clip + Adam are ONE launch (gs_peer_step);
-            # grad_scale = 1 / world; the deferred sampler rides behind the exchange workgroups
-            self._deferred_sampler = None
-            pj = list(peer_jobs or ())        # gather+mean jobs of the next step behind the (mostly waiting) exchange workgroups
-            pjarr = (ops._lib.GatherDesc * max(len(pj), 1))(*pj)
-            ops.call("gs_peer_step", peer, ctypes.addressof(arr), len(self.variables), ops.ptr(self.params), ops.ptr(self.grads),
-                     ops.ptr(self.adam_m), ops.ptr(self.adam_v), self.n_param_floats, float(weight_decay), lr, 0.9, 0.999, 1e-8,
-                     clip, grad_scale, ops.ptr(self.step_dev), int(step_offset), ops.ptr(lr_), ln, float(lscale), ops.ptr(lout),
-                     1 if lacc else 0, ctypes.addressof(rider) if rider is not None else None, ctypes.addressof(pjarr), len(pj),
-                     self.stream)
-            self._params_updated()
-            return
         if rider is not None:
             # a later mini-batch's fan-out sampler rides in this launch (neigh_samplers.fanout under _defer_sampler)
             self._deferred_sampler = None

@@ -115,16 +115,11 @@ class SampleAndAggregate(object):
         self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.5 if self.engine.stream_gemm else 0.7))
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
-        # unsupervised pipeline: share of the gather riding in the last layer's lean launch
-        # data-parallel step ending in gs_peer_step (slab sum | peer exchange | Adam as one launch): share of the next step's
-        # gather riding behind its exchange workgroups, which mostly wait for the peers (0 = off; one GPU cannot measure it:
-        # bench.py GS_PROBE_DP_PEER=<us> probes the schedule with a stand-in wait)
-        self.cogather_dp_opt = float(os.environ.get("GS_COGATHER_DP_OPT", 0.0))
         # unsupervised three-launch form (forward | fused link-prediction tail | weight gradients)
         self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.30))
         self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.25))
         self.cogather_lp_neg = float(os.environ.get("GS_COGATHER_LP_NEG", 0.10))
-        self.cogather_z = float(os.environ.get("GS_COGATHER_Z", 0.04))        # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
+        self.cogather_z = 0.04            # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
         # DIAGNOSTIC (one test pins it bit-identical): the fused tail as two launches (z helpers | row-group workgroups) --
         # no dependency between workgroups of a launch, the safe form under tools that serialise workgroups; +11 us per step
         self.tail_split = os.environ.get("GS_TAIL_SPLIT", "0") == "1"
@@ -133,7 +128,7 @@ class SampleAndAggregate(object):
         #  share in the optimizer launch, one in the last layer's backward launch, a forked gather branch beside the in-graph
         #  all-reduce, the second-stream pipeline, the weight-stationary form of the layer-0 forward.)
         # inside a multi-step graph the sampler of step t+2 rides in step t's optimizer launch (see _pipelined_steps)
-        self.sampler_rides = os.environ.get("GS_SAMPLER_RIDES", "1") != "0"
+        self.sampler_rides = True         # (diagnostic: False = every sampler launch stands alone; one test)
         # the fused tail launches (supervised: gs_sage_tail_fwd_bwd; unsupervised: gs_linkpred_tail); 0 = per-operator schedule
         self.fuse_tail = os.environ.get("GS_FUSE_TAIL", "1") != "0"
         self._graphs, self._graph_outputs, self._warm = {}, {}, set()
@@ -389,12 +384,8 @@ class SampleAndAggregate(object):
         else:
             self.aggregate_backward(self._d_agg_out)
         # every term of the loss is divided by batch_size (:378) -> so is the weight-decay gradient
-        peer = None if fuse_adam else self._peer_fused()
-        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0,
-                          grad_scale=1.0 / self.world_size if peer else 1.0, side_jobs=wgrad_jobs, step_offset=0 if advanced else 1,
-                          peer=peer)
-        if peer and not advanced:
-            e.advance(step=1)          # as _optimize(): the unsupervised DP epilogue leaves the optimizer step counter alone
+        e.finish_backward(self.weight_decay / B, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, side_jobs=wgrad_jobs,
+                          step_offset=0 if advanced else 1)
         if epilogue is not None and not early and not folded:
             self._epilogue_unsup(B, **epilogue)
 
@@ -454,14 +445,13 @@ class SampleAndAggregate(object):
             epilogue = dict(step=1 if fused else 0, clock=1)
             self._forward_unsup(roots, B, n_roots, True, epilogue=epilogue)
             self._backward_unsup(B, n_roots, fuse_adam=fused, epilogue=epilogue)
-            if in_graph and not self._peer_fused():
-                # backward | ncclAllReduce (recorded in the graph) | clip + Adam, as _pipelined_steps_unsup
+            if in_graph:
+                # backward | all-reduce (recorded in the graph) | clip + Adam, as _pipelined_steps_unsup
                 self.grad_hook(self)
                 self._optimize()
 
-        # With a capturable hook the whole data-parallel step is this one function: a PeerPushAllReduce hook with fused_step
-        # has ALREADY exchanged, clipped and applied Adam inside _backward_unsup (gs_peer_step) -- running the hook and
-        # _optimize() again behind it would all-reduce the summed gradients a second time and take a second Adam step.
+        # With a capturable hook the whole data-parallel step is this one function (one hipGraph): the exchange and the
+        # optimizer run exactly once per step.
         self._run(("utrain" if fused else ("utrain_dp" if in_graph else "utrain_fb"), B, self._adj_version()), fwd_bwd)
         if not fused and not in_graph:
             self.grad_hook(self)
@@ -537,14 +527,6 @@ class SampleAndAggregate(object):
         if hasattr(self.grad_hook, "check"):
             self.engine.sync()
             self.grad_hook.check()
-
-    def _peer_fused(self):
-        """Window handle when the data-parallel step ends in ONE launch (slab sum | peer exchange | clip + Adam, gs_peer_step):
-        the in-graph schedule with a PeerPushAllReduce hook whose fused_step is on; None otherwise."""
-        if not self._dp_in_graph():
-            return None
-        fh = getattr(self.grad_hook, "fused_handle", None)
-        return fh() if fh is not None else None
 
     def _dp_in_graph(self):
         """Data-parallel AND the all-reduce hook can be recorded inside the step's hipGraph (NativeAllReduce)."""
@@ -652,7 +634,7 @@ class SampleAndAggregate(object):
                 self._backward_unsup(B, n_roots, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
                 if e._deferred_sampler is not None:
                     raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
-                if in_graph and not self._peer_fused():
+                if in_graph:
                     # backward | ncclAllReduce (recorded in the graph) | clip + Adam
                     self.grad_hook(self)
                     self._optimize()
@@ -887,8 +869,8 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
-                self.cogather_z, self.cogather_dp_opt, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.split_gemm, e.split_pool, e.pool_f16, str(getattr(self, "pipeline", None)),
-                type(self.grad_hook).__name__, getattr(self.grad_hook, "fused_step", None),
+                self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.split_pool, e.pool_f16, str(getattr(self, "pipeline", None)),
+                type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 
     def _run(self, key, fn):

@@ -98,7 +98,7 @@ class UniformNeighborSampler(Layer):
         self.calls_per_sample = 1
         # law "reference": materialise the law's padded table once per adjacency (what minibatch.py:227-245 builds; 119 MB
         # for Reddit at max_degree 128) so that a draw is one lookup -- same ids bit for bit, see padded_table()
-        self.use_table = os.environ.get("GS_SAMPLER_TABLE", "1") != "0"
+        self.use_table = True          # False: the law's padded table stays virtual (evaluated per draw)
 
     def padded_table(self, adj):
         """The reference law's padded table of `adj` ([N+1, max_degree] int32 on the device, gs_build_padded_table), built on

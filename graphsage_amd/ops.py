@@ -390,18 +390,6 @@ def split_table_f16(X, stream=None):
     return X2, rexp
 
 
-def sage_dense_fwd_split(self_m, self_idx, agg, n, W3_self, W3_neigh, out_dim, act, bias, out, jobs, stream=None):
-    """gs_sage_dense_fwd_split: the layer-0 contraction on the bf16 matrix pipe with fp32 accuracy (three-piece operands) +
-    the gather jobs in ONE launch.  W3_*: split_rows() of the weights."""
-    import ctypes
-    jobs = list(jobs or ())
-    arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
-    call("gs_sage_dense_fwd_split", self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0,
-         ptr(self_idx), agg.ptr, agg.ld, agg.d, n, ptr(W3_self), ptr(W3_neigh), out_dim, act, ptr(bias), out.ptr, out.ld,
-         ctypes.addressof(arr), len(jobs), _s(stream))
-    return out
-
-
 def dense_wgrad(A, a_idx, dZ, col0, out_dim, n, n_slabs, slabs, ld_slab, stream=None):
     """slabs: flat fp32 tensor with room for n_slabs * A.d * ld_slab floats."""
     call("gs_dense_wgrad", A.ptr, A.ld, ptr(a_idx), A.d, dZ.ptr, dZ.ld, col0, out_dim, n, n_slabs, ptr(slabs),

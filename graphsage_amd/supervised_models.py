@@ -178,7 +178,7 @@ class SupervisedGraphsage(SampleAndAggregate):
                     first = False
             self._loss_accumulate = not first
 
-    def _backward(self, n, fuse_adam, wgrad_jobs=None, epilogue=None, opt_jobs=None):
+    def _backward(self, n, fuse_adam, wgrad_jobs=None, epilogue=None):
         """Reverse of _forward.  Every weight gradient of the pass is ONE grouped launch; the slab reduction
         (+ weight decay, :104-108) and -- on a single GPU -- clip + Adam (:96-99) are ONE more launch."""
         e = self.engine
@@ -197,13 +197,9 @@ class SupervisedGraphsage(SampleAndAggregate):
                 e.wgrad(a1.vars['neigh_weights'], self._tail_means, None, self._tail_dz, o, n)
             mode, agg0, rows, offsets, outs = self._tape[0]
             agg0.backward_hops(self._tail_dh0, True, embed_sink=None)
-            peer = None if fuse_adam else self._peer_fused()
-            e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0,
-                              grad_scale=1.0 / self.world_size if peer else 1.0, side_jobs=wgrad_jobs,
+            e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, side_jobs=wgrad_jobs,
                               loss=(self._loss_rows, n, 1.0 / n, self.loss_dev, self._loss_accumulate) if epilogue is not None else None,
-                              step_offset=0 if self._tail_step_advanced else 1, peer=peer, peer_jobs=opt_jobs if peer else None)
-            if opt_jobs and not peer:
-                e.launch_gather_jobs(opt_jobs)
+                              step_offset=0 if self._tail_step_advanced else 1)
             return
         if self._head_fused:
             e.wgrad(self.node_pred.vars['weights'], self.outputs1, None, self._dlogits, 0, n)
@@ -223,12 +219,8 @@ class SupervisedGraphsage(SampleAndAggregate):
         self._early_epilogue = early
         advanced = early and bool(epilogue.get("step"))
         self.aggregate_backward(d_out)
-        peer = None if fuse_adam else self._peer_fused()
-        e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0,
-                          grad_scale=1.0 / self.world_size if peer else 1.0, side_jobs=wgrad_jobs, step_offset=0 if advanced else 1,
-                          peer=peer, peer_jobs=opt_jobs if peer else None)
-        if opt_jobs and not peer:
-            e.launch_gather_jobs(opt_jobs)
+        e.finish_backward(self.weight_decay, fuse_adam=fuse_adam, lr=self.learning_rate, clip=5.0, side_jobs=wgrad_jobs,
+                          step_offset=0 if advanced else 1)
         if epilogue is not None and not early:
             self._epilogue(n, **epilogue)
 
@@ -290,7 +282,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             ep = dict(step=1 if (fused or in_graph) else 0, clock=1, cursor=cursor, cursor_delta=n if cursor is not None else 0)
             self._forward(batch_dev, labels_dev, n, train=True, epilogue=ep)
             self._backward(n, fuse_adam=fused, epilogue=ep)
-            if in_graph and not self._peer_fused():
+            if in_graph:
                 self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
                 self._optimize(advanced=True)
 
@@ -410,11 +402,6 @@ class SupervisedGraphsage(SampleAndAggregate):
             self._parity = p
             # the next step's gather is split between this step's two big GEMM launches (layer-0 forward, grouped
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
-            opt_jobs = []
-            if side_jobs and self.cogather_dp_opt > 0 and self._peer_fused():
-                # data-parallel step ending in gs_peer_step: its exchange workgroups mostly wait for the peers -- a share of the
-                # gather rides behind them (taken off the top: the other launches split the rest in their usual proportions)
-                side_jobs, opt_jobs = ops.split_gather_jobs(side_jobs, 1.0 - self.cogather_dp_opt)
             if side_jobs and self.cogather_tail > 0 and self._tail_ok():
                 # the fused tail launch keeps only n/16 CUs busy: the rest of the chip streams a share of the gather
                 f_fwd, f_tail = self.cogather_split3, self.cogather_tail
@@ -425,8 +412,8 @@ class SupervisedGraphsage(SampleAndAggregate):
                 tail_jobs = []
             self._forward(batch_dev, labels_dev, n, train=True, prefetched=pre, side_jobs=fwd_jobs, epilogue=epilogue,
                           tail_jobs=tail_jobs)
-            self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue, opt_jobs=opt_jobs)
-            if in_graph and not self._peer_fused():
+            self._backward(n, fuse_adam=local_adam, wgrad_jobs=wgrad_jobs, epilogue=epilogue)
+            if in_graph:
                 self.grad_hook(self)          # ncclAllReduce on the engine stream, recorded in the graph
                 self._optimize(advanced=True)
 

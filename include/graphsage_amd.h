@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 8
+#define GS_ABI_VERSION 9
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -237,7 +237,7 @@ int gs_sage_dense_fwd_stream2(const float* self, int64_t ld_self, const int32_t*
                               int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);
-/* The same contraction on the bf16 matrix pipe WITHOUT giving up fp32: every fp32 operand x is cut into three bf16 pieces
+/* Contractions on the bf16 matrix pipe WITHOUT giving up fp32: every fp32 operand x is cut into three bf16 pieces
  * x = h + m + l (top / middle / low 8 significant bits: nothing is lost), a product is the sum of piece products -- each formed
  * exactly by v_mfma_f32_32x32x16_bf16 and accumulated in fp32 -- and six of the nine are kept (hh, hm, mh, mm, hl, lh; the
  * dropped ml, lm, ll are <= 3 * 2^-24 |x y|, one fp32 rounding).  Accuracy of an fp32 FMA chain at 6/16 of the fp32 MFMA's
@@ -245,9 +245,6 @@ int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_des
  *   gs_split_rows: W [K, ldw >= N] fp32 -> W3 [G][3][N][8] bf16 (per group of 8 k and piece: the N columns side by side,
  *     16 bytes each -- a B-fragment load of 32 lanes reads 512 contiguous bytes; G = groups up to an even count of 32-k
  *     stages, zero for k >= K: the kernels neither mask nor clamp their B loads); gs_split_rows_bytes gives the size.  Call it after every update of W.
- *   gs_sage_dense_fwd_split: gs_sage_dense_fwd_stream with W3_self / W3_neigh in place of the weights; A operands are read
- *     as fp32 and cut in registers in the shadow of the MFMAs.  One wave per 32 x 64 output tile over the whole K (no LDS,
- *     no barrier, no split-K epilogue); pad columns [d, round_up(d, 4)) of self / agg must be readable.  Deterministic.
  *   gs_dense_fwd_rows_split: gs_dense_fwd_rows_dev in the same arithmetic, LDS-tiled (128 x 128 per workgroup, A rows gathered
  *     through idx and cut once per workgroup): the pooling MLP of the max-pool aggregator on the step's distinct ids.
  */
@@ -292,10 +289,6 @@ int gs_dense_fwd_rows_split16(const void* X2, const int32_t* rexp, const int32_t
                               const void* W2, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo, float* ws,
                               int64_t ws_bytes, void* stream);
 int gs_split_rows(const float* W, int64_t ldw, int32_t K, int32_t N, void* W3, void* stream);
-int gs_sage_dense_fwd_split(const float* self, int64_t ld_self, const int32_t* self_idx, const float* agg, int64_t ld_agg,
-                            int32_t d, int64_t n, const void* W3_self, const void* W3_neigh, int32_t out_dim, int act,
-                            const float* bias, float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs,
-                            void* stream);
 
 /* Input gradient:  dX[n, d] (+)= dZ[:, col0:col0+out_dim] · W[d, out_dim]^T */
 int gs_dense_dgrad(const float* dZ, int64_t ldz, int32_t col0, int32_t out_dim, int64_t n,
@@ -770,21 +763,6 @@ int gs_peer_export(void* peer, void* handle_out_host, int32_t len);
 int gs_peer_attach(void* peer, int32_t peer_rank, const void* handle_host, int32_t len);
 int gs_peer_attach_local(void* peer, void* other_peer);
 int gs_peer_allreduce_sum_f32(void* peer, float* buf, int64_t count, void* stream);
-/* The data-parallel step's last launch: gs_flat_reduce_adam (slab sum + weight decay) | the exchange | gs_adam_step as ONE
- * kernel on the caller's stream (arguments as gs_flat_reduce_adam_sample; the window must have been created for `total`
- * floats and the variables must cover the whole flat buffer): workgroup (p, w) forms chunk w of slice p of the local
- * gradient from the split-K slabs and stores it straight into rank p's window, sums the copies of its own slice in rank
- * order, and applies clip + Adam to the chunk of rank p's reduced slice as it lands (also written to `grads`).  The fan-out
- * sampler of a later mini-batch and gather+mean jobs of the next one ride behind the exchange workgroups, which mostly wait.
- * Same sums in the same order as the three-launch schedule: bit-identical parameters; grad_scale is 1 / world. */
-/* Diagnostics: every exchange workgroup of gs_peer_step holds its hand-over for `us` microseconds (0 = off) -- a one-GPU
- * stand-in for the peers' latency when the data-parallel schedule is probed without peers. */
-int gs_peer_set_probe_wait(void* peer, int32_t us);
-int gs_peer_step(void* peer, const gs_var_desc* vars_host, int32_t n_vars, float* params, float* grads, float* m, float* v,
-                 int64_t total, float weight_decay, float lr, float beta1, float beta2, float eps, float clip, float grad_scale,
-                 const uint64_t* step_dev, int32_t step_offset, const float* loss_rows, int64_t loss_n, float loss_scale,
-                 float* loss_out, int loss_accumulate, const gs_fanout_desc* sampler_host, const gs_gather_desc* jobs_host,
-                 int32_t n_jobs, void* stream);
 int gs_peer_status(void* peer, int64_t* epoch_out_host, int32_t* error_out_host);
 int gs_peer_destroy(void* peer);
 

@@ -275,25 +275,25 @@ def test_bench_gpus_2_launches_its_own_ranks(dev):
 
 
 @pytest.mark.parametrize("agg", ["mean", "maxpool"])
-def test_peer_fused_step_single_rank_equals_local_adam(dev, agg):
-    """The data-parallel step's last launch as ONE kernel (gs_peer_step: slab sum | peer exchange | clip + Adam) with a world of
-    one rank == the three-launch schedule (slab sum | exchange | Adam) == the single-GPU fused optimizer launch, bit for bit,
-    through multi-step hipGraphs with the sampler riding behind the exchange workgroups."""
+def test_peer_exchange_in_graph_single_rank_equals_local_adam(dev, agg):
+    """The in-graph data-parallel schedule (slab sum | exchange | clip + Adam: three launches) with the peer-store exchange and a
+    world of one rank == the single-GPU fused optimizer launch, bit for bit, through multi-step hipGraphs with the sampler riding
+    in the slab-sum launch.  (Round 5's one-launch form of the three, gs_peer_step, lost its measurement -- 129.7 vs 115.4
+    us/step before any peer latency -- and was removed in round 6: benchmarks/variants/README.md.)"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from graphsage_amd import distributed as gsd
     from graphsage_amd import engine as eng
     from test_model_gpu import build
     outs = []
-    for mode in ("local", "peer_fused", "peer_three_launches"):
+    for mode in ("local", "peer"):
         G, it, ph, sampler, model, ns = build(torch.device("cuda:0"), agg, True, False, csr=True, wd=0.01)
         e = eng.get_engine()
         if mode != "local":
             hook = gsd.PeerPushAllReduce(e)
-            hook.fused_step = mode == "peer_fused"
             assert hook.self_test()
             model.grad_hook = hook
-            assert model._dp_in_graph() and (model._peer_fused() is not None) == (mode == "peer_fused")
+            assert model._dp_in_graph()
         model.attach_device_epoch(it.train_nodes[: 8 * B], it.label_matrix)
         model.train_steps_device(B, 7, steps_per_launch=2)
         loss, preds = model._fetch(B)
@@ -306,12 +306,12 @@ def test_peer_fused_step_single_rank_equals_local_adam(dev, agg):
         assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
 
 
-@pytest.mark.parametrize("hook_kind", ["peer_fused", "peer_three_launches", "rccl"])
+@pytest.mark.parametrize("hook_kind", ["peer", "rccl"])
 def test_unsup_host_fed_train_step_applies_one_update_per_step_under_capturable_hooks(dev, hook_kind):
     """SampleAndAggregate.train_step(feed_dict) (unsupervised_train.py:273-274) under a hook that can be recorded in the step
-    graph: the exchange and the optimizer run ONCE per step.  (Round 5's review: with PeerPushAllReduce.fused_step the
-    backward pass already ends in gs_peer_step -- exchange + clip + Adam -- and the trailing hook + _optimize() applied both
-    a second time.)  World of one rank: parameters, Adam state and the step counter equal the hook-free model's, bit for bit."""
+    graph: backward | exchange | clip + Adam are ONE hipGraph and run ONCE per step, as on the device-epoch path.  (Round 5's
+    review found the host-fed path applying the exchange and the optimizer twice under the one-launch peer step, since
+    removed.)  World of one rank: parameters, Adam state and the step counter equal the hook-free model's."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from graphsage_amd import distributed as gsd
@@ -326,11 +326,10 @@ def test_unsup_host_fed_train_step_applies_one_update_per_step_under_capturable_
             hook = gsd.NativeAllReduce(e, world_size=1, rank=0)
         elif mode != "local":
             hook = gsd.PeerPushAllReduce(e)
-            hook.fused_step = mode == "peer_fused"
             assert hook.self_test()
         if hook is not None:
             model.grad_hook = hook
-            assert model._dp_in_graph() and (model._peer_fused() is not None) == (mode == "peer_fused")
+            assert model._dp_in_graph()
         edges = it.train_edges[:32 * 4]
         for i in range(4):                      # eager, captured, replayed, replayed
             b = edges[32 * i: 32 * (i + 1)]
