@@ -39,7 +39,8 @@ def main():
         out["configs"][key] = {"kernel": step_rows[0][0], "avg_us": step_rows[0][3], "share_of_step_kernel_time": step_rows[0][2] / tot,
                                "step_kernel_time_us": tot / steps,
                                "kernels": [{"kernel": r[0], "avg_us": r[3], "calls_per_step": round(r[1] / steps, 2)} for r in step_rows[:8]],
-                               "source": os.path.relpath(path, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))}
+                               # the summary this was read from is committed under profiles/ with the same file name
+                               "source": "profiles/" + os.path.basename(path)}
     p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "graphsage_amd", "_C", "build.stamp")
     out["lib_digest"] = open(p).read().strip() if os.path.exists(p) else None
     json.dump(out, open(out_path, "w"), indent=1)
