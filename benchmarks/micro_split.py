@@ -1,5 +1,5 @@
 """Micro-benchmark: the layer-0 contraction at the Reddit / unsupervised / GCN step shapes -- fp32-MFMA stream kernel
-(gs_sage_dense_fwd_stream) vs the split-MFMA kernel (gs_sage_dense_fwd_split: fp32 operands as three bf16 pieces), alone
+(gs_sage_dense_fwd_stream) vs the LDS-tiled split-MFMA kernel (gs_sage_dense_fwd_tiled3: fp32 operands as three bf16 pieces), alone
 (hot operands, back-to-back launches) and with a share of the next step's gather co-scheduled.
     python benchmarks/micro_split.py"""
 import json
@@ -48,18 +48,32 @@ def main():
         r = {}
         r["split_rows_us"] = timeit(lambda: ops.split_rows(Ws, out=W3s, stream=s), s)
         r["fp32_stream_alone_us"] = timeit(lambda: ops.sage_dense_fwd_stream(X, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s), s)
-        r["split_alone_us"] = timeit(lambda: ops.sage_dense_fwd_split(X, ids_self, means, n, W3s, W3n, D, ops.ACT_RELU, None, out, [], stream=s), s)
+        r["split_alone_us"] = timeit(lambda: ops.sage_dense_fwd_tiled3(X, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s), s)
         r["gather_alone_us"] = timeit(lambda: ops.gather_mean_fwd(X, idx2, roots * s2, s1, out=m2, stream=s), s)
         for frac in (0.15, 0.5, 1.0):
             head, _ = ops.split_gather_jobs(job, frac)
             r["fp32_stream_cogather_%.2f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_stream(X, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, head, stream=s), s)
-            r["split_cogather_%.2f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_split(X, ids_self, means, n, W3s, W3n, D, ops.ACT_RELU, None, out, head, stream=s), s)
+            r["split_cogather_%.2f_us" % frac] = timeit(lambda: ops.sage_dense_fwd_tiled3(X, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, head, stream=s), s)
         # GCN form: one term, N = 256
         Wg = Mat(torch.randn((F, 2 * D), generator=g).to(dev) * 0.05, 2 * D)
         W3g = ops.split_rows(Wg, stream=s)
         r["gcn_fp32_stream_alone_us"] = timeit(lambda: ops.sage_dense_fwd_stream(None, None, means, n, None, Wg, 2 * D, ops.ACT_RELU, None, out, [], stream=s), s)
-        r["gcn_split_alone_us"] = timeit(lambda: ops.sage_dense_fwd_split(None, None, means, n, None, W3g, 2 * D, ops.ACT_RELU, None, out, [], stream=s), s)
+        r["gcn_split_alone_us"] = timeit(lambda: ops.sage_dense_fwd_tiled3(None, None, means, n, None, Wg, 2 * D, ops.ACT_RELU, None, out, [], stream=s), s)
         res[tag] = r
+    # RMAT's layer 0: F = 256 (rows from a small table here: the contraction's own time)
+    F2 = 256
+    X2 = Mat(torch.randn((200000, F2), generator=g).to(dev), F2)
+    n = B * (1 + s2)
+    ids_self = torch.randint(0, 200000, (n,), generator=g, dtype=torch.int32).to(dev)
+    means = Mat.zeros(n, F2, dev, 32)
+    means.buf[:, :F2].normal_()
+    Ws = Mat(torch.randn((F2, D), generator=g).to(dev) * 0.05, D)
+    Wn = Mat(torch.randn((F2, D), generator=g).to(dev) * 0.05, D)
+    W3s, W3n = ops.split_rows(Ws, stream=s), ops.split_rows(Wn, stream=s)
+    out = Mat.zeros(n, 2 * D, dev)
+    res["rmat_f256"] = {
+        "fp32_stream_alone_us": timeit(lambda: ops.sage_dense_fwd_stream(X2, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s), s),
+        "split_alone_us": timeit(lambda: ops.sage_dense_fwd_tiled3(X2, ids_self, means, n, Ws, Wn, D, ops.ACT_RELU, None, out, [], stream=s), s)}
     print(json.dumps(res, indent=1))
 
 

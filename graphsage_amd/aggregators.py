@@ -237,8 +237,15 @@ class MeanAggregator(_SageBase):
         if side_jobs or stream_fwd:
             # horizontally fused launch: the contraction workgroups + the NEXT step's gather-mean waves share the CUs.
             # Stream form (gs_stream.hip): split-K workgroups without LDS staging, the self rows gathered in the A loads.
+            tiled3 = stream_fwd and e.tiled3_fwd and self.output_dim % 4 == 0
+
             def launch(jobs=list(side_jobs or ())):
-                if stream_fwd:
+                if tiled3:
+                    # LDS-tiled, on the bf16 matrix pipe in the three-piece arithmetic (fp32 in and out, cut inside the kernel)
+                    ops.sage_dense_fwd_tiled3(self_all.src, self_all.ids, means, n_total, self.vars['self_weights'].value,
+                                              self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, jobs,
+                                              stream=e.stream)
+                elif stream_fwd:
                     ops.sage_dense_fwd_stream(self_all.src, self_all.ids, means, n_total, self.vars['self_weights'].value,
                                               self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, jobs,
                                               stream=e.stream)
@@ -252,8 +259,11 @@ class MeanAggregator(_SageBase):
             jobs_ = list(side_jobs or ())
             self.last_fused_launch = (launch, {
                 "kernel": "%s: [%d x %d|%d] . [%d x %d] x2 (%s) + %d co-scheduled "
-                          "gather+mean jobs of the next step" % ("sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
-                                                                 n_total, d_in, means.d, d_in, self.output_dim, "fp32 MFMA", len(jobs_)),
+                          "gather+mean jobs of the next step" % ("sage_tiled3_fwd_kernel" if tiled3 else
+                                                                 "sage_stream_fwd_kernel" if stream_fwd else "sage_dense_cogather_kernel",
+                                                                 n_total, d_in, means.d, d_in, self.output_dim,
+                                                                 "fp32 as 3 bf16 pieces, 6 bf16 MFMAs per product" if tiled3 else "fp32 MFMA",
+                                                                 len(jobs_)),
                 "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in jobs_),
                 "gemm_bytes": n_total * (d_in + means.d) * 4 + (d_in + means.d) * self.output_dim * 4 + n_total * n_out * 4,
                 "flops": 2.0 * n_total * (d_in + means.d) * self.output_dim,
@@ -403,7 +413,10 @@ class GCNAggregator(_SageBase):
             means = self.prefetch(self_all, neighs)
         out = e.ws_mat((self.name, "out", k), n_total, self.output_dim)
         b = self.vars['bias'].value.buf if self.bias else None
-        if e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
+        if e.stream_gemm and e.tiled3_fwd and n_total > 2048 and rate == 0 and self.output_dim % 4 == 0:
+            ops.sage_dense_fwd_tiled3(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
+                                      b, out, side_jobs, stream=e.stream)
+        elif e.stream_gemm and n_total > 2048 and rate == 0 and self.output_dim % 2 == 0:
             # stream form: LDS-free contraction waves (+ the next step's gather jobs) in one launch
             ops.sage_dense_fwd_stream(None, None, means, n_total, None, self.vars['weights'].value, self.output_dim, self.act_code,
                                       b, out, side_jobs, stream=e.stream)
@@ -637,8 +650,9 @@ class _PoolingAggregator(_SageBase):
         if e.stream_gemm and self.concat and n_total > 2048 and self.output_dim % 2 == 0:
             # the stream form of the two contractions (split-K workgroups, no LDS staging, the self rows gathered in the A loads),
             # with each term's own reduction length: 23 instead of 33 us for the Reddit step's layer 0
-            ops.sage_dense_fwd_stream2(self_all.src, self_all.ids, pooled, n_total, self.vars['self_weights'].value,
-                                       self.vars['neigh_weights'].value, self.output_dim, self.act_code, b, out, stream=e.stream)
+            (ops.sage_dense_fwd_tiled3 if (e.tiled3_fwd and self.output_dim % 4 == 0) else ops.sage_dense_fwd_stream2)(
+                self_all.src, self_all.ids, pooled, n_total, self.vars['self_weights'].value, self.vars['neigh_weights'].value,
+                self.output_dim, self.act_code, b, out, stream=e.stream)
         else:
             ops.sage_dense_fwd(self_all.src, self_all.ids, pooled, None, n_total, self.vars['self_weights'].value,
                                self.vars['neigh_weights'].value, self.output_dim, self.concat, self.act_code, b, out,

@@ -626,3 +626,334 @@ static int dense_fwd_rows_split_impl(const float* X, int64_t ldx, const int32_t*
     GS_LAUNCH_CHECK("split_tiled_fwd_kernel");
     return GS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ layer-0 forward, LDS-tiled (round 6)
+// out = act([self[self_idx] . W_self | agg . W_neigh] + bias)  for the rows of ALL hops of a layer       (aggregators.py:51-64, :110-116)
+// -- the contraction of gs_sage_dense_fwd_stream (fp32 MFMA, register-streaming: 24.6 us for the Reddit step's 1.74 GF = 45 % of
+// the fp32 matrix pipe's peak; three rounds of tile variants did not move it) on the bf16 matrix pipe in the three-piece
+// arithmetic above: 6 / 16 of the matrix-pipe time, the same fp32 accuracy class, fp32 operands in and out -- NO pre-cut copy of
+// the weights (a re-cut launch behind every optimizer step costs what the kernel wins).  With the pipe out of the way the design is
+// about filling 256 CUs with a 5632-row problem and about who cuts what:
+//   workgroup (8 waves) = 64 rows x 128 columns of ONE term (Reddit: 88 row tiles x 2 terms = 176 workgroups, one round);
+//   stage = 32 k.
+//   A (the (gathered) rows): one float4 per thread and stage through registers, cut ONCE per workgroup (22 VALU per thread) and
+//     written to LDS as pieces ([piece][row][32 k] bf16, 80-byte rows: conflict-free 16-byte fragment reads), three buffers;
+//   B (the weights): raw fp32, global -> LDS by DMA (global_load_lds_dwordx4: a wave instruction = two k rows of the tile's 128
+//     columns; no register, no ds_write), ring of four stages; a wave reads the 8 k of its 32 columns as eight ds_read_b32 and
+//     cuts them itself (44 VALU) -- the eight waves are 2 (K halves of the stage) x 4 (column groups of 32), each over ALL 64
+//     rows, so every B element is cut exactly once per workgroup and an A fragment (pre-cut) is shared by four waves;
+//   a wave contracts ONE 16-k half of every stage for its 64 x 32 tile: 12 MFMAs per stage, two waves per SIMD; the two K halves
+//     of a tile are summed once, through LDS, in the epilogue (fixed order: deterministic);
+//   software pipeline: during stage s a wave issues the MFMAs of stage s from fragments it already holds, reads + cuts the
+//     fragments of stage s + 1, cuts and stores the A pieces of stage s + 2, requests A of stage s + 4 and B of stage s + 3, and
+//     meets the other waves once, at the end; the issue order inside a stage is pinned (a sched_barrier behind every slice).
+// Gather jobs of the next step ride as extra workgroups like in every launch of the step.
+struct Fwd3Term {
+    const float* A;        // [*, lda] fp32; row i of the term is A[a_idx ? a_idx[i] : i]
+    const int32_t* a_idx;  // nullable row gather (layer 0: the self rows of the feature table)
+    const float* W;        // [K, ldw] fp32
+    int32_t lda, ldw, K;
+};
+struct Fwd3Args {
+    Fwd3Term t[2];
+    int32_t nterms;        // 1, or 2 (concat: term i writes columns [i*N, (i+1)*N))
+    int32_t M, N;
+    float* C;
+    int32_t ldc;
+    const float* bias;     // indexed by output column (incl. the concat offset), nullable
+    int32_t act;
+    int32_t tiles_m, tiles_n, n_tiles;     // n_tiles = tiles_m * tiles_n * nterms
+};
+#define F3_BM 64
+#define F3_NA 3            // A-piece buffers
+#define F3_NB 4            // raw B stages in flight
+
+__global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, const CoGatherS J) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_PLANE = F3_BM * ST_LDA * 2;                // bytes
+    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 32 * 128 * 4;
+    constexpr int B_BASE = F3_NA * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= g.n_tiles) {
+        run_gather_item(J, ((int64_t)blockIdx.x - g.n_tiles) * 8 + wave, lane);
+        return;
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    // XCD-aware: block b runs on XCD b % 8; consecutive LOGICAL tiles share an XCD's L2 (a term's W stays resident there)
+    const int nwg = g.n_tiles;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    const int per_term = g.tiles_m * g.tiles_n;
+    const int term = tile / per_term;
+    const int it = tile - term * per_term;
+    const int tile_m = it / g.tiles_n, tile_n = it - tile_m * g.tiles_n;
+    const int m0 = tile_m * F3_BM, n0 = tile_n * 128;
+    const Fwd3Term& T = g.t[term];
+    const int K = T.K, N = g.N, M = g.M;
+    const int stages = (K + 31) >> 5;
+    const int stages2 = (stages + 1) & ~1;                     // an odd stage count is padded with one all-zero stage
+    const int K4 = ((K + 3) >> 2) << 2;                        // readable columns of a row
+    // ---- A: (row tid >> 3, float4 tid & 7) of the 64 x 32 stage tile, through registers
+    const int arow = tid >> 3, aq = tid & 7;
+    const int grow = min(m0 + arow, M - 1);
+    const int64_t srow = T.a_idx ? (int64_t)T.a_idx[grow] : (int64_t)grow;
+    const float* __restrict__ xrow = T.A + srow * T.lda;
+    const int a_wr = (arow * ST_LDA + 4 * aq) * 2;
+    // ---- B: wave w moves chunks 2 w, 2 w + 1 of a stage's 16 (chunk = two k rows x 128 columns = 1 KB, lane-linear in LDS)
+    const int bcol = min(n0 + 4 * l31, N - 4);                 // (columns beyond N: a valid column again, computed and never stored)
+    const float* __restrict__ wcol = T.W + bcol;
+    const int ldw = T.ldw;
+    // A ring of FOUR staging sets: the set stage s + 2 is cut from is re-requested for stage s + 6 at once -- four stages (~2 us)
+    // of cover for a gathered row's trip to HBM.  Requests are hand-written (asm): the compiler does not track them, so it adds no
+    // wait of its own (it answered every use with vmcnt(0) once LDS-DMA requests shared the queue); the counted wait in front of
+    // every stage barrier (F3_BARRIER) is what guarantees them -- see the accounting there.
+    f32x4 ra[4];
+    // (F3_DIAG_*: diagnostics builds only, benchmarks/probes/build_variant.sh -- wrong values, the kernel's time without one component)
+    auto gload_a = [&](const int set, const int s) {           // straight-line request with a clamped (always valid) address
+        const int k = min(32 * s + 4 * aq, K4 - 4);
+#ifdef F3_DIAG_NOGA
+        ra[set] = f32x4{(float)k, 1.f, 2.f, (float)tid};
+#else
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set]) : "v"(xrow + k));
+#endif
+    };
+    auto dma_b = [&](const int s, const int slot) {            // rows beyond K: the last row again (A is zero there)
+#ifndef F3_DIAG_NOGB
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = 2 * wave + i;
+            const int k = min(32 * s + 2 * c + lh, K - 1);
+            __builtin_amdgcn_global_load_lds(wcol + (int64_t)k * ldw, (lds_ptr_t)(smem + B_BASE + slot * B_BYTES + c * 1024), 16, 0, 0);
+        }
+#endif
+    };
+    const int kh = wave >> 2, wn = wave & 3;                   // K half of the stage | 32-column group
+    f32x16 acc[2], sml[2];                                     // [row tile of 32]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; sml[i][e] = 0.f; }
+    // fragments of a stage: TWO register sets -- the MFMAs of stage s run on one while the other receives stage s + 1's
+    u32x4 fa[2][2][3], fb[2][3];
+    const int a_rd = (l31 * ST_LDA + 16 * kh + 8 * lh) * 2;                          // + 32 i rows, + piece plane
+    const int b_rd = B_BASE + ((16 * kh + 8 * lh) * 128 + 32 * wn + l31) * 4;        // + i k rows (512 bytes each)
+    // The stage barrier by hand: "my LDS writes and reads of this stage are done" (lgkmcnt(0)) + "the B stage the next stage reads
+    // has landed" (a COUNTED vmcnt: the younger requests stay in flight across the barrier) + s_barrier.  __syncthreads, and also a
+    // release fence on the local address space (the compiler orders the LDS-DMA writes behind it), would wait for vmcnt(0): every
+    // request of the stages ahead would have to land before any wave may go on -- a stage would cost a memory round trip.
+#define F3_BARRIER(cnt) do { asm volatile("s_waitcnt vmcnt(" #cnt ") lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); \
+                             asm volatile("" ::: "memory"); } while (0)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;                      // LDS byte address of the dynamic segment
+    auto cut_store_a = [&](const int set, const int s, unsigned char* buf) {
+        const int k = 32 * s + 4 * aq;
+        const float x0 = k < K ? ra[set].x : 0.f, x1 = k + 1 < K ? ra[set].y : 0.f;       // selects: zero beyond K (NaN pads must not leak)
+        const float x2 = k + 2 < K ? ra[set].z : 0.f, x3 = k + 3 < K ? ra[set].w : 0.f;
+        uint32_t h0, m0_, l0, h1, m1_, l1;
+        gs_split2(x0, x1, h0, m0_, l0);
+        gs_split2(x2, x3, h1, m1_, l1);
+        // (hand-written stores: behind a C++ store to LDS the compiler waits for EVERY outstanding LDS-DMA -- it cannot tell that
+        //  the B ring and the A-piece buffers never overlap -- i.e. vmcnt(0) once per stage; F3_BARRIER waits for lgkmcnt(0))
+        const uint32_t ad = lds0 + (uint32_t)(buf - smem) + (uint32_t)a_wr;
+        const u32x2 vh = u32x2{h0, h1}, vm = u32x2{m0_, m1_}, vl = u32x2{l0, l1};
+        asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:%4\n\tds_write_b64 %0, %3 offset:%5"
+                     :: "v"(ad), "v"(vh), "v"(vm), "v"(vl), "n"(A_PLANE), "n"(2 * A_PLANE));      // (no "memory": see above)
+    };
+    auto read_cut_frags = [&](const int set, const unsigned char* abuf, const unsigned char* bslot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[set][i][p] = *reinterpret_cast<const u32x4*>(abuf + a_rd + i * (32 * ST_LDA * 2) + p * A_PLANE);
+        float bw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bw[i] = *reinterpret_cast<const float*>(bslot + (b_rd - B_BASE) + i * 512);
+        gs_split8(f32x4{bw[0], bw[1], bw[2], bw[3]}, f32x4{bw[4], bw[5], bw[6], bw[7]}, fb[set][0], fb[set][1], fb[set][2]);
+    };
+    // ---- prologue: ONE round trip -- A of stages 0..5 and B of stages 0..2 requested together; stages 0, 1 cut and stored
+    //      (their sets re-requested for stages 6, 7), the fragments of stage 0 read and cut
+    {
+        f32x4 t0, t1;
+        const int k0 = min(4 * aq, K4 - 4), k1 = min(32 + 4 * aq, K4 - 4);
+#ifdef F3_DIAG_NOGA
+        t0 = t1 = f32x4{(float)k0, 1.f, 2.f, (float)k1};
+#else
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t0) : "v"(xrow + k0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t1) : "v"(xrow + k1));
+#endif
+        gload_a(2, 2); gload_a(3, 3); gload_a(0, 4); gload_a(1, 5);
+        dma_b(0, 0);
+        dma_b(1, 1);
+        dma_b(2, 2);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) :: "memory");
+        const f32x4 s0 = ra[0], s1 = ra[1];
+        ra[0] = t0; cut_store_a(0, 0, smem);
+        ra[1] = t1; cut_store_a(1, 1, smem + A_BYTES);
+        ra[0] = s0; ra[1] = s1;                                // (sets 0, 1 hold stages 4, 5; sets 2, 3 stages 2, 3)
+    }
+    F3_BARRIER(0);
+    read_cut_frags(0, smem, smem + B_BASE);
+    // byte offsets of the A-piece buffers of stage s + 1 | s + 2 (| s: free again at s + 3); B slots are (stage) % 4
+    int oa_nxt = A_BYTES, oa_nn = 2 * A_BYTES, oa_cur = 0;
+    const int stages4 = (stages + 3) & ~3;                     // whole rings: padded with all-zero stages (A is masked beyond K)
+    for (int s = 0; s < stages4; s += 4) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {                       // the register sets are indexed statically
+            const int ss = s + q4;
+            constexpr int dummy_ = 0; (void)dummy_;
+            const int r = q4 & 1;                              // fragment set of this stage
+            const int as = (q4 + 2) & 3;                       // A staging set that holds stage ss + 2
+            const unsigned char* na = smem + oa_nxt;
+            const unsigned char* nb = smem + B_BASE + ((ss + 1) & 3) * B_BYTES + (b_rd - B_BASE);
+            unsigned char* wa = smem + oa_nn;
+#define F3_SB __builtin_amdgcn_sched_barrier(0);
+#ifdef F3_DIAG_NOMFMA
+#define F3_MM(dst, i, pa, pb) asm volatile("" :: "v"(fa[r][i][pa]), "v"(fb[r][pb])); F3_SB
+#else
+#define F3_MM(dst, i, pa, pb) dst[i] = gs_mfma_bf16(fa[r][i][pa], fb[r][pb], dst[i]); F3_SB
+#endif
+#ifdef F3_DIAG_NOLDSR
+#define F3_RA(i, p) fa[r ^ 1][i][p] = u32x4{(unsigned)(p), (unsigned)(uintptr_t)na, 2u, (unsigned)tid}; F3_SB
+#define F3_RW(i) bw[i] = __uint_as_float((unsigned)(uintptr_t)nb + i);
+#else
+#define F3_RA(i, p) fa[r ^ 1][i][p] = *reinterpret_cast<const u32x4*>(na + a_rd + (i) * (32 * ST_LDA * 2) + (p) * A_PLANE); F3_SB
+#define F3_RW(i) bw[i] = *reinterpret_cast<const float*>(nb + (i) * 512);
+#endif
+            float bw[8];
+            uint32_t bh[4], bm[4], bl[4];
+            // One stage of a wave in a PINNED issue order: 12 MFMAs (small terms h l, l h, m m, h m, m h into sml, h h into acc;
+            // the same accumulator every other MFMA), each followed by a slice of the other work.
+            F3_MM(sml, 0, 0, 2)
+            F3_RW(0) F3_RW(1) F3_RW(2) F3_RW(3) F3_RW(4) F3_RW(5) F3_RW(6) F3_RW(7)
+            F3_SB
+            F3_MM(sml, 1, 0, 2) F3_RA(0, 0)
+            F3_MM(acc, 0, 0, 0) F3_RA(0, 1)
+            F3_MM(acc, 1, 0, 0) F3_RA(0, 2)
+            F3_MM(sml, 0, 2, 0) F3_RA(1, 0)
+            gs_split2(bw[0], bw[1], bh[0], bm[0], bl[0]);
+            F3_SB
+            F3_MM(sml, 1, 2, 0) F3_RA(1, 1)
+            gs_split2(bw[2], bw[3], bh[1], bm[1], bl[1]);
+            F3_SB
+            F3_MM(sml, 0, 1, 1) F3_RA(1, 2)
+            gs_split2(bw[4], bw[5], bh[2], bm[2], bl[2]);
+            F3_SB
+            F3_MM(sml, 1, 1, 1)
+            gs_split2(bw[6], bw[7], bh[3], bm[3], bl[3]);
+            fb[r ^ 1][0] = u32x4{bh[0], bh[1], bh[2], bh[3]};
+            fb[r ^ 1][1] = u32x4{bm[0], bm[1], bm[2], bm[3]};
+            fb[r ^ 1][2] = u32x4{bl[0], bl[1], bl[2], bl[3]};
+            F3_SB
+            F3_MM(sml, 0, 0, 1)
+            F3_SB
+            F3_MM(sml, 1, 0, 1)
+#ifndef F3_DIAG_NOLDSW
+            cut_store_a(as, ss + 2, wa);
+#else
+            asm volatile("" :: "v"(ra[as]));
+#endif
+            F3_SB
+            F3_MM(sml, 0, 1, 0)
+            gload_a(as, ss + 6);
+            dma_b(ss + 3, (ss + 3) & 3);
+            F3_SB
+            F3_MM(sml, 1, 1, 0)
+            // What the NEXT stage consumes has landed: its raw B (stage ss + 2, requested during stage ss - 1) and the A set it cuts
+            // (stage ss + 3, requested during stage ss - 3).  A thread's requests retire in order; per stage it issues one A
+            // request and then two B requests, so behind B(ss + 2) lie exactly this stage's three: vmcnt(3).
+            F3_BARRIER(3);
+            F3_SB
+#undef F3_MM
+#undef F3_RA
+#undef F3_RW
+#undef F3_SB
+            const int t = oa_cur; oa_cur = oa_nxt; oa_nxt = oa_nn; oa_nn = t;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests of the last stages
+    __syncthreads();
+    // ---- the two K halves of a tile meet through LDS (free now): waves 4..7 hand their sums to waves 0..3
+    float* red = reinterpret_cast<float*>(smem) + (wave & 3) * (2 * 16 * 64);       // [2 tiles][16 regs][64 lanes] per wave pair
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(i * 16 + e) * 64 + lane] = acc[i][e] + sml[i][e];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    float* otile = reinterpret_cast<float*>(smem) + 4 * (2 * 16 * 64) + wave * (64 * 36);     // [64 rows][32 + 4 pad] per wave
+    const int col_off = term * N;
+    {
+        const int col = n0 + 32 * wn + l31;
+        const float bv = (g.bias && col < N) ? g.bias[col_off + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = ((acc[i][e] + sml[i][e]) + red[(i * 16 + e) * 64 + lane]) + bv;
+                if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                otile[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + l31] = v;     // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+            }
+    }
+    // (wave-private region: the wave's own LDS writes are ordered before its reads by lgkmcnt)
+    const int c4 = (lane & 7) * 4, r0 = lane >> 3;
+    const int colg = n0 + 32 * wn + c4;
+#pragma unroll
+    for (int itr = 0; itr < 8; ++itr) {
+        const int r = 8 * itr + r0;
+        const int row = m0 + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(otile + r * 36 + c4);
+        if (row < M) {
+            float* dst = g.C + (int64_t)row * g.ldc + col_off + colg;
+            if (colg + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+            else {
+                if (colg < N) dst[0] = v.x;
+                if (colg + 1 < N) dst[1] = v.y;
+                if (colg + 2 < N) dst[2] = v.z;
+            }
+        }
+    }
+}
+
+extern "C" int gs_sage_dense_fwd_tiled3(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self, const float* agg,
+                                        int64_t ld_agg, int32_t d_agg, int64_t n, const float* W_self, int64_t ldw_self,
+                                        const float* W_neigh, int64_t ldw_neigh, int32_t out_dim, int act, const float* bias,
+                                        float* out, int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream) {
+    if (n == 0 && n_jobs == 0) return GS_OK;
+    GS_REQUIRE(agg && W_neigh && out && d_agg > 0 && out_dim > 0 && n >= 0 && n < (1ll << 30), "gs_sage_dense_fwd_tiled3: bad args");
+    GS_REQUIRE(!self || (W_self && d_self > 0), "gs_sage_dense_fwd_tiled3: W_self / d_self missing");
+    GS_CHECK_MAT(agg, ld_agg, "gs_sage_dense_fwd_tiled3 agg");
+    GS_CHECK_MAT(W_neigh, ldw_neigh, "gs_sage_dense_fwd_tiled3 W_neigh");
+    if (self) {
+        GS_CHECK_MAT(self, ld_self, "gs_sage_dense_fwd_tiled3 self");
+        GS_CHECK_MAT(W_self, ldw_self, "gs_sage_dense_fwd_tiled3 W_self");
+    }
+    GS_REQUIRE(ld_agg >= ((d_agg + 3) / 4) * 4 && (!self || ld_self >= ((d_self + 3) / 4) * 4), "gs_sage_dense_fwd_tiled3: ld must be >= round_up(d, 4)");
+    GS_REQUIRE(out_dim % 4 == 0 && ldw_neigh >= out_dim && (!self || ldw_self >= out_dim), "gs_sage_dense_fwd_tiled3: out_dim must be a multiple of 4, ldw >= out_dim");
+    GS_REQUIRE(ldo >= out_dim * (self ? 2 : 1) && ldo % 4 == 0 && gs_aligned16(out), "gs_sage_dense_fwd_tiled3: out must be 16-byte aligned, ldo a multiple of 4");
+    GS_REQUIRE(std::max(ld_self, ld_agg) < (1ll << 31) && std::max(ldw_self, ldw_neigh) < (1ll << 31), "gs_sage_dense_fwd_tiled3: 32-bit leading dimensions");
+    Fwd3Args g = {};
+    g.nterms = self ? 2 : 1;
+    if (self) {
+        g.t[0] = Fwd3Term{self, self_idx, W_self, (int32_t)ld_self, (int32_t)ldw_self, d_self};
+        g.t[1] = Fwd3Term{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh, d_agg};
+    } else {
+        g.t[0] = Fwd3Term{agg, nullptr, W_neigh, (int32_t)ld_agg, (int32_t)ldw_neigh, d_agg};
+    }
+    g.M = (int32_t)n; g.N = out_dim; g.C = out; g.ldc = (int32_t)ldo; g.bias = bias; g.act = act;
+    g.tiles_m = (int)gs_ceil_div(n, F3_BM);
+    g.tiles_n = (int)gs_ceil_div(out_dim, 128);
+    g.n_tiles = n > 0 ? g.tiles_m * g.tiles_n * g.nterms : 0;
+    CoGatherS J = {};
+    int64_t waves = 0;
+    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
+    if (rc != GS_OK) return rc;
+    const int64_t blocks = g.n_tiles + gs_ceil_div(waves, 8);
+    GS_REQUIRE(blocks > 0 && blocks < (1ll << 31), "gs_sage_dense_fwd_tiled3: grid too large");
+    const size_t lds = F3_NA * (3 * F3_BM * ST_LDA * 2) + F3_NB * (32 * 128 * 4);
+    GS_LDS_ATTR(lds, sage_tiled3_fwd_kernel);
+    hipLaunchKernelGGL(sage_tiled3_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g, J);
+    GS_LAUNCH_CHECK("sage_tiled3_fwd_kernel");
+    return GS_OK;
+}

@@ -100,6 +100,9 @@ class Engine(object):
         # "stream" contraction kernels (gs_stream.hip) for the layer-0 forward and the grouped weight gradients; False = the
         # LDS-tiled family of gs_gemm.hip
         self.stream_gemm = True
+        # the layer-0 forward LDS-tiled on the bf16 matrix pipe (three-piece arithmetic, gs_sage_dense_fwd_tiled3) instead of the
+        # register-streaming fp32-MFMA kernel
+        self.tiled3_fwd = os.environ.get("GS_TILED3_FWD", "1") == "1"
         # the pooling MLP on the step's distinct ids as a split-MFMA contraction (gs_split16.hip / gs_split.hip); False = fp32 MFMA
         self.split_pool = True
         # split-K policy of the weight gradients (measured sweeps: DESIGN.md section 4 / profiles/r02..r05)

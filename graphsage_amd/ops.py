@@ -328,6 +328,19 @@ def sage_dense_fwd_stream2(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, a
     return out
 
 
+def sage_dense_fwd_tiled3(self_m, self_idx, agg, n, W_self, W_neigh, out_dim, act, bias, out, jobs=(), stream=None):
+    """gs_sage_dense_fwd_tiled3: the layer-0 contraction LDS-tiled on the bf16 matrix pipe (fp32 operands cut into three bf16 pieces
+    INSIDE the kernel: same arguments as sage_dense_fwd_stream2), concat output; self_m None = one term (GCN)."""
+    import ctypes
+    jobs = list(jobs or ())
+    arr = (_lib.GatherDesc * max(len(jobs), 1))(*jobs)
+    call("gs_sage_dense_fwd_tiled3", self_m.ptr if self_m is not None else None, self_m.ld if self_m is not None else 0,
+         ptr(self_idx), self_m.d if self_m is not None else 0, agg.ptr, agg.ld, agg.d, n,
+         W_self.ptr if W_self is not None else None, W_self.ld if W_self is not None else 0, W_neigh.ptr, W_neigh.ld, out_dim, act,
+         ptr(bias), out.ptr, out.ld, ctypes.addressof(arr), len(jobs), _s(stream))
+    return out
+
+
 def split_rows_words(K, N):
     """int32 words of gs_split_rows' output (gs_split_rows_bytes / 4): groups of 8 k up to an even count of 32-k stages."""
     import ctypes

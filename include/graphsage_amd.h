@@ -237,6 +237,18 @@ int gs_sage_dense_fwd_stream2(const float* self, int64_t ld_self, const int32_t*
                               int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);
+/* gs_sage_dense_fwd_tiled3 (ABI 9, round 6): the contraction of gs_sage_dense_fwd_stream2 -- same arguments, fp32 operands in and
+ * out -- on the bf16 matrix pipe in the three-piece arithmetic described below (every fp32 operand = three bf16 pieces, six exact
+ * piece products per element pair, fp32 accumulation: the accuracy of an fp32 FMA chain), LDS-tiled: one 8-wave workgroup per
+ * 64 x 128 output tile of a term, stage = 32 k; the A rows ((gathered) fp32) are cut once per workgroup in registers, the weights
+ * go global -> LDS by DMA as fp32 and are cut by the wave that contracts them (no pre-cut copy, nothing to refresh after an
+ * optimizer step); the two 16-k halves of a stage are contracted by different waves and summed once in the epilogue (fixed order:
+ * deterministic).  Pad columns [d, round_up(d, 4)) of self / agg must be readable (any value: masked); out_dim and ldo multiples
+ * of 4.  self == NULL: one term (GCN).  Gather jobs ride as in gs_sage_dense_fwd_stream. */
+int gs_sage_dense_fwd_tiled3(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self, const float* agg,
+                             int64_t ld_agg, int32_t d_agg, int64_t n, const float* W_self, int64_t ldw_self, const float* W_neigh,
+                             int64_t ldw_neigh, int32_t out_dim, int act, const float* bias, float* out, int64_t ldo,
+                             const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 /* Contractions on the bf16 matrix pipe WITHOUT giving up fp32: every fp32 operand x is cut into three bf16 pieces
  * x = h + m + l (top / middle / low 8 significant bits: nothing is lost), a product is the sum of piece products -- each formed
  * exactly by v_mfma_f32_32x32x16_bf16 and accumulated in fp32 -- and six of the nine are kept (hh, hm, mh, mm, hl, lh; the

@@ -48,6 +48,104 @@ def test_split_rows_pieces_are_exact(dev):
     assert np.all((np.sign(m) == np.sign(h)) | (m == 0)) and np.all((np.sign(l) == np.sign(h)) | (l == 0))
 
 
+CASES = [
+    # n, d, out, two, act, bias, gathered, riders
+    (5632, 602, 128, True, ops.ACT_RELU, False, True, True),        # the Reddit step's layer 0
+    (11484, 602, 128, True, ops.ACT_RELU, False, True, False),      # the unsupervised step's
+    (5632, 256, 128, True, ops.ACT_RELU, False, True, False),       # RMAT's F = 256 (8 whole stages)
+    (5633, 601, 128, True, ops.ACT_IDENTITY, True, False, True),    # ragged rows, 25 valid k in the masked last stage
+    (17000, 608, 64, False, ops.ACT_RELU, True, False, False),      # one term (GCN form), half a column tile, K = 608 exactly
+    (4100, 250, 192, True, ops.ACT_RELU, True, True, False),        # two column tiles per term (the second half empty), K tail
+    (2050, 50, 100, True, ops.ACT_RELU, True, True, False),         # PPI's F = 50 (two stages); N = 100
+    (33, 7, 8, False, ops.ACT_IDENTITY, False, False, False),       # one partial stage, one partial tile
+    (5632, 602, 256, False, ops.ACT_RELU, False, False, False),     # GCN at Reddit's shape (dims 2 x 128)
+]
+
+
+@pytest.mark.parametrize("n,d,out,two,act,bias,gathered,riders", CASES)
+def test_sage_dense_fwd_tiled3(dev, n, d, out, two, act, bias, gathered, riders):
+    """gs_sage_dense_fwd_tiled3 (layer 0 of a mean / GCN step on the bf16 matrix pipe, three-piece operands, LDS-tiled 64 x 128
+    workgroup tiles, aggregators.py:51-64 / :110-116) vs fp64 NumPy: the accuracy of an fp32 FMA chain, NaN in every pad column,
+    gathered / dense self rows, one and two terms, bias + relu / identity, gather jobs riding, bit-identical reruns."""
+    rng = np.random.default_rng(n + d + out)
+    Nn = 6000
+    X = rng.normal(size=(Nn + 1, d)).astype(np.float32); X[Nn] = 0
+    self_m, mean = rng.normal(size=(n, d)).astype(np.float32), rng.normal(size=(n, d)).astype(np.float32)
+    self_ids = rng.integers(0, Nn + 1, size=n).astype(np.int32)
+    if gathered:
+        self_m = X[self_ids]
+    Ws, Wn = (rng.normal(size=(d, out)) * 0.1).astype(np.float32), (rng.normal(size=(d, out)) * 0.1).astype(np.float32)
+    b = (rng.normal(size=((2 if two else 1) * out,)) * 0.1).astype(np.float32) if bias else None
+    Xd = Mat.from_numpy(X, dev, 32)
+    sd, md = Mat.from_numpy(self_m, dev, 32), Mat.from_numpy(mean, dev, 4)      # the means: ld = round_up(d, 4) only
+    for mat in (Xd, sd, md):
+        if mat.ld > d:
+            mat.buf[:, d:] = float("nan")                   # nothing beyond K may leak
+    Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
+    w3s, w3n = ops.split_rows(Wsd), ops.split_rows(Wnd)
+    bd = torch.from_numpy(b).to(dev) if bias else None
+    idx = rng.integers(0, Nn + 1, size=(700, 25)).astype(np.int32)
+    idx_d, sid_d = _i32(idx.reshape(-1), dev), _i32(self_ids, dev)
+    Xclean = Mat.from_numpy(X, dev, 32)                      # the riders' table (NaN pads would enter their float4 sums)
+    outs = []
+    for rep in range(2):
+        outm = Mat.zeros(n, (2 if two else 1) * out, dev)
+        outm.buf.fill_(float("nan"))
+        g_out = Mat.zeros(700, d, dev)
+        jobs = [ops.gather_job(Xclean, idx_d, 700, 25, g_out)] if riders else []
+        if two:
+            ops.sage_dense_fwd_tiled3(Xd if gathered else sd, sid_d if gathered else None, md, n, Wsd, Wnd, out, act, bd, outm, jobs)
+        else:
+            ops.sage_dense_fwd_tiled3(None, None, md, n, None, Wnd, out, act, bd, outm, jobs)
+        torch.cuda.synchronize()
+        outs.append(outm.numpy())
+        if riders:
+            np.testing.assert_allclose(g_out.numpy(), X[idx].mean(axis=1), rtol=1e-4, atol=1e-4)
+    assert np.array_equal(outs[0], outs[1])                  # deterministic
+    want_n = mean.astype(np.float64) @ Wn.astype(np.float64)
+    want = np.concatenate([self_m.astype(np.float64) @ Ws.astype(np.float64), want_n], axis=1) if two else want_n
+    if bias:
+        want = want + b
+    pre = want.copy()
+    if act == ops.ACT_RELU:
+        want = np.maximum(want, 0)
+    got = outs[0].astype(np.float64)
+    assert np.isfinite(got).all()
+    # fp32 accuracy: the error is a few fp32 roundings of the row's scale, like a float32 NumPy matmul's
+    rms = np.sqrt((pre * pre).mean())
+    err = np.abs(got - want).max() / rms
+    f32 = mean @ Wn
+    f32 = np.concatenate([self_m @ Ws, f32], axis=1) if two else f32
+    if bias:
+        f32 = f32 + b
+    if act == ops.ACT_RELU:
+        f32 = np.maximum(f32, 0)
+    err32 = np.abs(f32.astype(np.float64) - want).max() / rms
+    assert err <= max(4 * err32, 4e-7), (err, err32)
+    assert err < 4e-6, err
+
+
+def test_tiled3_fwd_is_as_accurate_as_the_fp32_mfma_kernel(dev):
+    """Same operands through gs_sage_dense_fwd_stream (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains) and through the three-piece
+    tiled form: both errors against fp64 are fp32 rounding noise of the same size."""
+    rng = np.random.default_rng(9)
+    n, d, out = 5632, 602, 128
+    Xs, Mn = rng.normal(size=(n, d)).astype(np.float32), rng.normal(size=(n, d)).astype(np.float32)
+    Ws, Wn = (rng.normal(size=(d, out)) * 0.1).astype(np.float32), (rng.normal(size=(d, out)) * 0.1).astype(np.float32)
+    sd, md = Mat.from_numpy(Xs, dev, 32), Mat.from_numpy(Mn, dev, 32)
+    Wsd, Wnd = Mat.from_numpy(Ws, dev), Mat.from_numpy(Wn, dev)
+    a, b = Mat.zeros(n, 2 * out, dev), Mat.zeros(n, 2 * out, dev)
+    ops.sage_dense_fwd_stream(sd, None, md, n, Wsd, Wnd, out, ops.ACT_IDENTITY, None, a, [])
+    ops.sage_dense_fwd_tiled3(sd, None, md, n, Wsd, Wnd, out, ops.ACT_IDENTITY, None, b, [])
+    torch.cuda.synchronize()
+    want = np.concatenate([Xs.astype(np.float64) @ Ws, Mn.astype(np.float64) @ Wn], axis=1)
+    rms = np.sqrt((want * want).mean())
+    e_fp32 = np.abs(a.numpy() - want).max() / rms
+    e_split = np.abs(b.numpy() - want).max() / rms
+    print("max error / rms vs fp64: fp32 MFMA kernel %.3g, tiled three-piece kernel %.3g" % (e_fp32, e_split))
+    assert e_split <= 2 * e_fp32 and e_split < 4e-6
+
+
 @pytest.mark.parametrize("n_max,count,d,out,act,bias", [
     (6000, 5000, 602, 512, ops.ACT_RELU, True),      # the pooling MLP's shape (fewer rows), device-side row count
     (300, 300, 602, 512, ops.ACT_RELU, True),        # three row tiles, the last one ragged
