@@ -233,7 +233,7 @@ def aux_dominant_profile():
 
 def ref_on_shim_profile():
     """cpu_baseline kind "reference-on-shim": the reference's OWN supervised training step (/root/reference/graphsage/
-    supervised_models.py, unmodified, on tests/tf1_shim) timed by benchmarks/ref_on_shim_cpu.py in the BUILD container -- the
+    supervised_models.py, unmodified, on the TF 1.x stand-in of the test suite) timed by benchmarks/ref_on_shim_cpu.py in the BUILD container -- the
     reference cannot travel to the GPU box, so the committed record is attached (PROFILE-SOURCED), with the torch-CPU port timed
     on the same cores beside it."""
     import glob
