@@ -31,6 +31,10 @@ __device__ __forceinline__ float gs_top16(const float x) { return __uint_as_floa
 
 // two fp32 values -> their three bf16 pieces, packed pairwise.  Truncation, not rounding: every subtraction is exact.
 __device__ __forceinline__ void gs_split2(const float x, const float y, uint32_t& h, uint32_t& m, uint32_t& l) {
+#ifdef GS_DIAG_SPLIT_NOCUT    // diagnostics builds only: wrong values, the kernel's time without the cut
+    h = __float_as_uint(x); m = __float_as_uint(y); l = h;
+    return;
+#endif
     const float rx = x - gs_top16(x), ry = y - gs_top16(y);       // <= 16 significant bits
     const float sx = rx - gs_top16(rx), sy = ry - gs_top16(ry);   // <= 8 significant bits: exact in bf16
     h = gs_hi16_pair(x, y);
@@ -667,6 +671,21 @@ struct Fwd3Args {
 #define F3_BM 64
 #define F3_NA 3            // A-piece buffers
 #define F3_NB 4            // raw B stages in flight
+#ifdef F3_TIMELINE
+// Diagnostics build only (-DF3_TIMELINE, benchmarks/timeline_tiled3.py): shader-clock and wall-clock stamps of waves 0 and 4 of the
+// first 256 workgroups.  [wg][wave 0 | 4][0] entry [1] operands requested [2] prologue barrier passed [3] K loop left [4] K halves
+// summed [5] stores issued [6] wall clock at entry [7] wall clock at exit; [8 + 3 s + 0..2] stage s: MFMAs and slices issued |
+// counted wait over | barrier passed
+__device__ unsigned long long g_f3_tl[256 * 2 * 96];
+extern "C" int gs_debug_f3_timeline(unsigned long long* out_host, int n) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_f3_tl), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define F3_STAMPV(k, v) do { if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 256 && (k) < 96) g_f3_tl[(blockIdx.x * 2 + (wave >> 2)) * 96 + (k)] = (v); } while (0)
+#define F3_STAMP(k) F3_STAMPV(k, clock64())
+#else
+#define F3_STAMP(k) do { } while (0)
+#define F3_STAMPV(k, v) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, const CoGatherS J) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -680,6 +699,8 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
         return;
     }
     const int l31 = lane & 31, lh = lane >> 5;
+    F3_STAMP(0);
+    F3_STAMPV(6, wall_clock64());
     // XCD-aware: block b runs on XCD b % 8; consecutive LOGICAL tiles share an XCD's L2 (a term's W stays resident there)
     const int nwg = g.n_tiles;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
@@ -772,6 +793,9 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
     };
     // ---- prologue: ONE round trip -- A of stages 0..5 and B of stages 0..2 requested together; stages 0, 1 cut and stored
     //      (their sets re-requested for stages 6, 7), the fragments of stage 0 read and cut
+    dma_b(0, 0);                                               // (the weights do not wait for the row ids)
+    dma_b(1, 1);
+    dma_b(2, 2);
     {
         f32x4 t0, t1;
         const int k0 = min(4 * aq, K4 - 4), k1 = min(32 + 4 * aq, K4 - 4);
@@ -782,9 +806,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t1) : "v"(xrow + k1));
 #endif
         gload_a(2, 2); gload_a(3, 3); gload_a(0, 4); gload_a(1, 5);
-        dma_b(0, 0);
-        dma_b(1, 1);
-        dma_b(2, 2);
+        F3_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) :: "memory");
         const f32x4 s0 = ra[0], s1 = ra[1];
         ra[0] = t0; cut_store_a(0, 0, smem);
@@ -792,6 +814,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
         ra[0] = s0; ra[1] = s1;                                // (sets 0, 1 hold stages 4, 5; sets 2, 3 stages 2, 3)
     }
     F3_BARRIER(0);
+    F3_STAMP(2);
     read_cut_frags(0, smem, smem + B_BASE);
     // byte offsets of the A-piece buffers of stage s + 1 | s + 2 (| s: free again at s + 3); B slots are (stage) % 4
     int oa_nxt = A_BYTES, oa_nn = 2 * A_BYTES, oa_cur = 0;
@@ -854,14 +877,23 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
 #endif
             F3_SB
             F3_MM(sml, 0, 1, 0)
-            gload_a(as, ss + 6);
             dma_b(ss + 3, (ss + 3) & 3);
+            gload_a(as, ss + 6);
             F3_SB
             F3_MM(sml, 1, 1, 0)
+            F3_STAMP(8 + 3 * ss);
             // What the NEXT stage consumes has landed: its raw B (stage ss + 2, requested during stage ss - 1) and the A set it cuts
-            // (stage ss + 3, requested during stage ss - 3).  A thread's requests retire in order; per stage it issues one A
-            // request and then two B requests, so behind B(ss + 2) lie exactly this stage's three: vmcnt(3).
-            F3_BARRIER(3);
+            // (stage ss + 3, requested during stage ss - 3).  A thread's requests retire IN ORDER; per stage it issues its two B
+            // requests and THEN its A request, so behind B(ss + 2) lie A(ss + 5) of the same stage and this stage's three:
+            // vmcnt(4).  (With the A request in front of the B requests the wait for B(ss + 2) was also a wait for A(ss + 5),
+            // issued one stage before -- the four-stage A ring covered one stage of an HBM round trip: ~500 cycles of every stage
+            // were spent in this wait.)
+#ifdef F3_TIMELINE
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            F3_STAMP(9 + 3 * ss);
+#endif
+            F3_BARRIER(4);
+            F3_STAMP(10 + 3 * ss);
             F3_SB
 #undef F3_MM
 #undef F3_RA
@@ -870,6 +902,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
             const int t = oa_cur; oa_cur = oa_nxt; oa_nxt = oa_nn; oa_nn = t;
         }
     }
+    F3_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests of the last stages
     __syncthreads();
     // ---- the two K halves of a tile meet through LDS (free now): waves 4..7 hand their sums to waves 0..3
@@ -881,17 +914,26 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
             for (int e = 0; e < 16; ++e) red[(i * 16 + e) * 64 + lane] = acc[i][e] + sml[i][e];
     }
     __syncthreads();
+    F3_STAMP(4);
     if (kh == 1) return;
     float* otile = reinterpret_cast<float*>(smem) + 4 * (2 * 16 * 64) + wave * (64 * 36);     // [64 rows][32 + 4 pad] per wave
     const int col_off = term * N;
     {
         const int col = n0 + 32 * wn + l31;
         const float bv = (g.bias && col < N) ? g.bias[col_off + col] : 0.f;
+        // (the partner's 32 sums FIRST, all of them in flight: read and written in one loop the compiler kept every read behind
+        //  the previous write -- `red` and `otile` might overlap for all it knows -- 32 LDS round trips in a row, 3800 cycles)
+        float pr[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pr[i][e] = red[(i * 16 + e) * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float v = ((acc[i][e] + sml[i][e]) + red[(i * 16 + e) * 64 + lane]) + bv;
+                float v = ((acc[i][e] + sml[i][e]) + pr[i][e]) + bv;
                 if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
                 otile[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + l31] = v;     // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
             }
@@ -914,6 +956,8 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
             }
         }
     }
+    F3_STAMP(5);
+    F3_STAMPV(7, wall_clock64());
 }
 
 extern "C" int gs_sage_dense_fwd_tiled3(const float* self, int64_t ld_self, const int32_t* self_idx, int32_t d_self, const float* agg,

@@ -116,7 +116,7 @@ class SampleAndAggregate(object):
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
         self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
         # unsupervised three-launch form (forward | fused link-prediction tail | weight gradients)
-        self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.30))
+        self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.20))      # 0.30 with the stream forward (round 5); the tiled forward holds a CU per workgroup: 176.2 vs 179.5 us/step
         self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.25))
         self.cogather_lp_neg = float(os.environ.get("GS_COGATHER_LP_NEG", 0.10))
         self.cogather_z = 0.04            # measured: 0 | 0.04 | 0.08 | 0.12 -> 201.5 | 199.1 | 202.9 | 209.4 us
