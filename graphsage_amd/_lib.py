@@ -90,6 +90,7 @@ _PROTOS = {
     "gs_sage_dense_fwd_stream2": [_P, c_int64, _P, c_int32, _P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int, _P,
                                   _P, c_int64, _P, c_int32, _P],
     "gs_dense_wgrad_grouped_stream": [_P, c_int32, _P, c_int32, _P],
+    "gs_dense_wgrad_grouped_tiled3": [_P, c_int32, _P, c_int32, _P],
     "gs_sage_dense_fwd_tiled3": [_P, c_int64, _P, c_int32, _P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int, _P,
                                  _P, c_int64, _P, c_int32, _P],
     "gs_split_rows_bytes": [c_int32, c_int32, _P],

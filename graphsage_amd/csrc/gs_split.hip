@@ -20,6 +20,7 @@
 #include "gs_common.h"
 #include "gs_gather_dev.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -999,5 +1000,316 @@ extern "C" int gs_sage_dense_fwd_tiled3(const float* self, int64_t ld_self, cons
     GS_LDS_ATTR(lds, sage_tiled3_fwd_kernel);
     hipLaunchKernelGGL(sage_tiled3_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g, J);
     GS_LAUNCH_CHECK("sage_tiled3_fwd_kernel");
+    return GS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients, LDS-tiled
+// gs_dense_wgrad_grouped_tiled3: every weight gradient of a backward pass, dW = A[a_idx]^T . dZ[:, col0 : col0 + out_dim], in the
+// three-piece arithmetic above -- the grouped launch of gs_dense_wgrad_grouped_stream (same descriptors, same split-K slabs, same
+// riders), LDS-tiled like sage_tiled3_fwd_kernel.  Both operands are row-contiguous over the REDUCTION index (k = a batch row), the
+// matrix pipe wants 8 consecutive k per lane: both go global -> LDS raw (fp32, LDS-DMA, no register, no ds_write) as [32 k][64 m] and
+// [32 k][128 n] stage tiles, and a wave reads the 8 k of ITS column as eight ds_read_b32 (lanes side by side: conflict-free) and cuts
+// them in registers -- the transposition costs nothing but the cut itself.
+//   workgroup (8 waves) = one (64 m x 128 n tile, reduction slice) of one problem; the waves are 2 (k halves of a stage) x 4 (column
+//   groups of 32), each over both 32-row blocks of m: per stage and wave 24 ds_read_b32, 12 two-element cuts, 12 MFMAs;
+//   ring of W3_NS stage slots (24 KB each) filled W3_NS - 1 stages ahead, ONE barrier per stage behind a counted vmcnt;
+//   a gathered problem's row ids (<= 1024 per slice) are read once into LDS; 64-bit row addresses (tables beyond 4 GB are fine);
+//   rows beyond the slice are masked in the B fragment (the clamped row is read, its dZ values are zeroed before the cut).
+#define W3_NS 4
+#define W3_MAXROWS 1024
+#define W3_MAXP 12
+struct Wg3Prob {
+    const float* A;        // [*, lda]: row r of the reduction is A[a_idx ? a_idx[r] : r]
+    const int32_t* a_idx;  // nullable row gather
+    const float* dZ;       // [n, ldz], already offset by col0
+    float* slabs;          // [n_slabs][d][ld_slab]
+    int32_t lda, ldz, ld_slab, zcols;      // zcols: readable columns of a dZ row from the offset pointer (multiple of 4)
+    int32_t n, d, out_dim;
+    int32_t tiles_m, tiles_n, n_slabs, kchunk;   // kchunk: rows per slice, a multiple of 32
+    int32_t item_start;
+};
+struct Wg3Args {
+    Wg3Prob p[W3_MAXP];
+    int32_t n, n_items;
+};
+
+__global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, const CoGatherS J) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_BYTES = 32 * 64 * 4, B_BYTES = 32 * 128 * 4, S_BYTES = A_BYTES + B_BYTES;
+    constexpr int IDX_BASE = W3_NS * S_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= G.n_items) {
+        run_gather_item(J, ((int64_t)blockIdx.x - G.n_items) * 8 + wave, lane);
+        return;
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    // XCD-aware: block b runs on XCD b % 8; consecutive LOGICAL items (the m tiles of one slice: the same dZ rows) share an L2
+    const int nwg = G.n_items;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, lcl = blockIdx.x >> 3;
+    const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lcl;
+    int pi = 0;
+    while (pi + 1 < G.n && item >= G.p[pi + 1].item_start) ++pi;
+    const Wg3Prob& q = G.p[pi];
+    const int local = item - q.item_start;
+    const int tiles = q.tiles_m * q.tiles_n;
+    const int z = local / tiles;
+    const int tt = local - z * tiles;
+    const int tile_m = tt / q.tiles_n, tile_n = tt - tile_m * q.tiles_n;
+    const int m0 = tile_m * 64, n0 = tile_n * 128;
+    const int rb = z * q.kchunk, re = min(rb + q.kchunk, q.n);
+    const int len = max(re - rb, 0);                           // (an empty slice still writes its slab: zeros)
+    const int rlast = max(re, 1) - 1;                          // every row read is clamped to a valid one
+    const int stages = (len + 31) >> 5;
+    const int stages4 = (stages + 3) & ~3;
+    // the slice's source rows (<= W3_MAXROWS), once: the row ids of a gathered problem, else the rows themselves -- one code path
+    int32_t* idxs = reinterpret_cast<int32_t*>(smem + IDX_BASE);
+#pragma unroll
+    for (int t = tid; t < W3_MAXROWS; t += 512) {
+        const int rr = min(rb + t, rlast);
+        idxs[t] = q.a_idx ? q.a_idx[rr] : rr;
+    }
+    __syncthreads();
+    // ---- requests: wave w moves A chunk w (4 k rows x 64 m = 1 KB, lane-linear in LDS) and B chunks 2 w, 2 w + 1 (2 k rows x 128 n)
+    const int akk = 4 * wave + (lane >> 4);
+    const float* __restrict__ acol = q.A + min(m0 + 4 * (lane & 15), q.lda - 4);       // (columns beyond the row: a valid chunk again,
+    const float* __restrict__ zcol = q.dZ + min(n0 + 4 * l31, q.zcols - 4);            //  computed and never stored)
+    const int lda = q.lda, ldz = q.ldz;
+    auto a_row = [&](const int s) -> int64_t {                 // source row of this lane's A request of stage s
+        return (int64_t)idxs[min(32 * s + akk, W3_MAXROWS - 1)];
+    };
+    auto dma = [&](const int s, const int slot, const int64_t arow) {
+        unsigned char* base = smem + slot * S_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = 2 * wave + i;
+            const int r = min(rb + 32 * s + 2 * c + lh, rlast);
+            __builtin_amdgcn_global_load_lds(zcol + (int64_t)r * ldz, (lds_ptr_t)(base + A_BYTES + c * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds(acol + arow * lda, (lds_ptr_t)(base + wave * 1024), 16, 0, 0);
+    };
+    const int kh = wave >> 2, wn = wave & 3;                   // k half of the stage | 32-column group
+    f32x16 acc[2], sml[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; sml[i][e] = 0.f; }
+    u32x4 fa[2][2][3], fb[2][3];
+    const int kfrag = 16 * kh + 8 * lh;                        // first of this lane's 8 k inside a stage
+    const int a_rd = (kfrag * 64 + l31) * 4;                   // + i k rows (256 bytes each), + 128 for the second m block
+    const int b_rd = A_BYTES + (kfrag * 128 + 32 * wn + l31) * 4;      // + i k rows (512 bytes each)
+    // stage barrier by hand, see sage_tiled3_fwd_kernel: counted vmcnt (younger requests stay in flight) + lgkmcnt(0) + s_barrier
+#define W3_WAIT_STR2(x) #x
+#define W3_WAIT_STR(x) W3_WAIT_STR2(x)
+#define W3_BARRIER() do { asm volatile("s_waitcnt vmcnt(" W3_WAIT_STR(W3_INFLIGHT) ") lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); \
+                          asm volatile("" ::: "memory"); } while (0)
+    auto read_cut_frags = [&](const int set, const unsigned char* slot, const int s) {
+        float bw[8], aw[2][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bw[i] = *reinterpret_cast<const float*>(slot + b_rd + i * 512);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) aw[j][i] = *reinterpret_cast<const float*>(slot + a_rd + j * 128 + i * 256);
+        const int lim = len - 32 * s - kfrag;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bw[i] = i < lim ? bw[i] : 0.f;
+        gs_split8(f32x4{bw[0], bw[1], bw[2], bw[3]}, f32x4{bw[4], bw[5], bw[6], bw[7]}, fb[set][0], fb[set][1], fb[set][2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            gs_split8(f32x4{aw[j][0], aw[j][1], aw[j][2], aw[j][3]}, f32x4{aw[j][4], aw[j][5], aw[j][6], aw[j][7]},
+                      fa[set][j][0], fa[set][j][1], fa[set][j][2]);
+    };
+    // ---- prologue: stages 0 .. W3_NS - 2 requested together; stage 0's fragments read and cut
+#pragma unroll
+    for (int s = 0; s < W3_NS - 1; ++s) dma(s, s, a_row(s));
+    int64_t arow_nxt = a_row(W3_NS - 1);
+#if W3_NS == 4
+#define W3_INFLIGHT 3
+#elif W3_NS == 5
+#define W3_INFLIGHT 6
+#else
+#define W3_INFLIGHT 9
+#endif
+    W3_BARRIER();                                              // stages 0 and 1 have landed (everyone's share of them)
+    read_cut_frags(0, smem, 0);
+    int slot_rd = 1, slot_wr = W3_NS - 1;                      // slot of stage ss + 1 | of stage ss + W3_NS - 1
+    // The stages whose look-ahead reads lie wholly inside the slice run WITHOUT the row mask (a branch inside a stage would break the
+    // pinned issue order: the compiler sinks the cuts behind it); the last ones (and the zero padding of the ring) run the masked copy.
+    auto run = [&](auto masked, const int s_begin, const int s_end) {
+    for (int s = s_begin; s < s_end; s += 4) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int ss = s + q4;
+            const int r = q4 & 1;
+            const unsigned char* nb = smem + slot_rd * S_BYTES;
+#define W3_SB __builtin_amdgcn_sched_barrier(0);
+#define W3_MM(dst, i, pa, pb) dst[i] = gs_mfma_bf16(fa[r][i][pa], fb[r][pb], dst[i]); W3_SB
+#define W3_RB(i) bw[i] = *reinterpret_cast<const float*>(nb + b_rd + (i) * 512);
+#define W3_RA(j, i) aw[j][i] = *reinterpret_cast<const float*>(nb + a_rd + (j) * 128 + (i) * 256);
+            float bw[8], aw[2][8];
+            uint32_t ph[4], pm[4], pl[4];
+            // One stage of a wave in a PINNED issue order: 12 MFMAs of stage ss on one fragment set, each followed by a slice of
+            // the work for stage ss + 1 (24 reads, 12 cuts into the other set) and of the requests for stage ss + W3_NS - 1.
+            W3_MM(sml, 0, 0, 2)
+            W3_RB(0) W3_RB(1) W3_RB(2) W3_RB(3) W3_RB(4) W3_RB(5) W3_RB(6) W3_RB(7)
+            W3_RA(0, 0) W3_RA(0, 1) W3_RA(0, 2) W3_RA(0, 3) W3_RA(0, 4) W3_RA(0, 5) W3_RA(0, 6) W3_RA(0, 7)
+            W3_SB
+            W3_MM(sml, 1, 0, 2)
+            W3_RA(1, 0) W3_RA(1, 1) W3_RA(1, 2) W3_RA(1, 3) W3_RA(1, 4) W3_RA(1, 5) W3_RA(1, 6) W3_RA(1, 7)
+            W3_SB
+            W3_MM(acc, 0, 0, 0)
+            if constexpr (decltype(masked)::value) {           // the slice ends inside stage ss + 1, or before it
+                const int lim = len - 32 * (ss + 1) - kfrag;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bw[i] = i < lim ? bw[i] : 0.f;
+            }
+            gs_split2(bw[0], bw[1], ph[0], pm[0], pl[0]);
+            W3_SB
+            W3_MM(acc, 1, 0, 0)
+            gs_split2(bw[2], bw[3], ph[1], pm[1], pl[1]);
+            W3_SB
+            W3_MM(sml, 0, 2, 0)
+            gs_split2(bw[4], bw[5], ph[2], pm[2], pl[2]);
+            W3_SB
+            W3_MM(sml, 1, 2, 0)
+            gs_split2(bw[6], bw[7], ph[3], pm[3], pl[3]);
+            fb[r ^ 1][0] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+            fb[r ^ 1][1] = u32x4{pm[0], pm[1], pm[2], pm[3]};
+            fb[r ^ 1][2] = u32x4{pl[0], pl[1], pl[2], pl[3]};
+            W3_SB
+            W3_MM(sml, 0, 1, 1)
+            gs_split2(aw[0][0], aw[0][1], ph[0], pm[0], pl[0]);
+            gs_split2(aw[0][2], aw[0][3], ph[1], pm[1], pl[1]);
+            W3_SB
+            W3_MM(sml, 1, 1, 1)
+            gs_split2(aw[0][4], aw[0][5], ph[2], pm[2], pl[2]);
+            gs_split2(aw[0][6], aw[0][7], ph[3], pm[3], pl[3]);
+            fa[r ^ 1][0][0] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+            fa[r ^ 1][0][1] = u32x4{pm[0], pm[1], pm[2], pm[3]};
+            fa[r ^ 1][0][2] = u32x4{pl[0], pl[1], pl[2], pl[3]};
+            W3_SB
+            W3_MM(sml, 0, 0, 1)
+            gs_split2(aw[1][0], aw[1][1], ph[0], pm[0], pl[0]);
+            gs_split2(aw[1][2], aw[1][3], ph[1], pm[1], pl[1]);
+            W3_SB
+            W3_MM(sml, 1, 0, 1)
+            gs_split2(aw[1][4], aw[1][5], ph[2], pm[2], pl[2]);
+            gs_split2(aw[1][6], aw[1][7], ph[3], pm[3], pl[3]);
+            fa[r ^ 1][1][0] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+            fa[r ^ 1][1][1] = u32x4{pm[0], pm[1], pm[2], pm[3]};
+            fa[r ^ 1][1][2] = u32x4{pl[0], pl[1], pl[2], pl[3]};
+            W3_SB
+            W3_MM(sml, 0, 1, 0)
+            dma(ss + W3_NS - 1, slot_wr, arow_nxt);            // into the slot stage ss - 1 was read from (during stage ss - 2)
+            W3_SB
+            W3_MM(sml, 1, 1, 0)
+            arow_nxt = a_row(ss + W3_NS);
+            // stage ss + 2 (what the next stage reads) has landed: behind it only the W3_NS - 3 younger stages' requests, 3 each
+            W3_BARRIER();
+            W3_SB
+#undef W3_MM
+#undef W3_RB
+#undef W3_RA
+#undef W3_SB
+            slot_rd = slot_rd + 1 == W3_NS ? 0 : slot_rd + 1;
+            slot_wr = slot_wr + 1 == W3_NS ? 0 : slot_wr + 1;
+        }
+    }
+    };
+    const int s_plain = max((len >> 5) - 1, 0) & ~3;           // stages ss < s_plain read a full stage ss + 1
+    run(std::false_type{}, 0, s_plain);
+    run(std::true_type{}, s_plain, stages4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead requests of the last stages
+    __syncthreads();
+    // ---- the two k halves of a tile meet through LDS (free now): waves 4..7 hand their sums to waves 0..3 (fixed order)
+    float* red = reinterpret_cast<float*>(smem) + (wave & 3) * (2 * 16 * 64);
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(i * 16 + e) * 64 + lane] = acc[i][e] + sml[i][e];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    float* otile = reinterpret_cast<float*>(smem) + 4 * (2 * 16 * 64) + wave * (64 * 36);
+    {
+        float pr[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pr[i][e] = red[(i * 16 + e) * 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                otile[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + l31] = (acc[i][e] + sml[i][e]) + pr[i][e];
+    }
+    float* __restrict__ S = q.slabs + (int64_t)z * q.d * q.ld_slab;
+    const bool vec = (q.ld_slab & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 15u) == 0;
+    const int c4 = (lane & 7) * 4, r0 = lane >> 3;
+    const int colg = n0 + 32 * wn + c4;
+    const int N = q.out_dim;
+#pragma unroll
+    for (int itr = 0; itr < 8; ++itr) {
+        const int rr = 8 * itr + r0;
+        const int row = m0 + rr;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(otile + rr * 36 + c4);
+        if (row < q.d) {
+            float* dst = S + (int64_t)row * q.ld_slab + colg;
+            if (vec && colg + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+            else {
+                if (colg < N) dst[0] = v.x;
+                if (colg + 1 < N) dst[1] = v.y;
+                if (colg + 2 < N) dst[2] = v.z;
+                if (colg + 3 < N) dst[3] = v.w;
+            }
+        }
+    }
+#undef W3_BARRIER
+#undef W3_INFLIGHT
+}
+
+extern "C" int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                             int32_t n_jobs, void* stream) {
+    GS_REQUIRE(descs_host && n_desc > 0 && n_desc <= W3_MAXP, "gs_dense_wgrad_grouped_tiled3: 1..%d problems", W3_MAXP);
+    Wg3Args G = {};
+    G.n = n_desc;
+    int64_t items = 0;
+    for (int i = 0; i < n_desc; ++i) {
+        const gs_wgrad_desc& q = descs_host[i];
+        GS_CHECK_MAT(q.A, q.lda, "gs_dense_wgrad_grouped_tiled3 A");
+        GS_CHECK_MAT(q.dZ, q.ldz, "gs_dense_wgrad_grouped_tiled3 dZ");
+        GS_REQUIRE(q.slabs && q.d > 0 && q.out_dim > 0 && q.n > 0 && q.n_slabs > 0 && q.col0 >= 0 && q.col0 % 4 == 0,
+                   "gs_dense_wgrad_grouped_tiled3: bad sizes");
+        GS_REQUIRE(q.lda >= q.d && q.ldz >= q.col0 + q.out_dim && q.ld_slab >= q.out_dim, "gs_dense_wgrad_grouped_tiled3: ld too small");
+        GS_REQUIRE(q.n < (1ll << 31) - 64 * 1024 && q.lda < (1ll << 31) && q.ldz < (1ll << 31) && (int64_t)q.d * q.ld_slab < (1ll << 31),
+                   "gs_dense_wgrad_grouped_tiled3: 32-bit sizes exceeded");
+        Wg3Prob& p = G.p[i];
+        p.A = q.A; p.a_idx = q.a_idx; p.dZ = q.dZ + q.col0; p.slabs = q.slabs;
+        p.lda = (int32_t)q.lda; p.ldz = (int32_t)q.ldz; p.ld_slab = (int32_t)q.ld_slab; p.zcols = (int32_t)(q.ldz - q.col0);
+        p.n = (int32_t)q.n; p.d = q.d; p.out_dim = q.out_dim;
+        p.tiles_m = (int)gs_ceil_div(q.d, 64);
+        p.tiles_n = (int)gs_ceil_div(q.out_dim, 128);
+        p.n_slabs = q.n_slabs;
+        p.kchunk = (int32_t)(gs_ceil_div(gs_ceil_div(q.n, q.n_slabs), 32) * 32);
+        GS_REQUIRE(!q.a_idx || p.kchunk <= W3_MAXROWS, "gs_dense_wgrad_grouped_tiled3: a row-gathered problem needs slices of <= %d rows "
+                   "(n = %lld, n_slabs = %d)", W3_MAXROWS, (long long)q.n, q.n_slabs);
+        p.item_start = (int32_t)items;
+        items += (int64_t)p.tiles_m * p.tiles_n * q.n_slabs;
+    }
+    GS_REQUIRE(items < (1ll << 30), "gs_dense_wgrad_grouped_tiled3: too many work items");
+    G.n_items = (int32_t)items;
+    CoGatherS J = {};
+    int64_t waves = 0;
+    int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
+    if (rc != GS_OK) return rc;
+    const int64_t blocks = items + gs_ceil_div(waves, 8);
+    GS_REQUIRE(blocks < (1ll << 31), "gs_dense_wgrad_grouped_tiled3: grid too large");
+    const size_t lds = W3_NS * (32 * 64 * 4 + 32 * 128 * 4) + W3_MAXROWS * 4;
+    GS_LDS_ATTR(lds, wgrad_tiled3_kernel);
+    hipLaunchKernelGGL(wgrad_tiled3_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, G, J);
+    GS_LAUNCH_CHECK("wgrad_tiled3_kernel");
     return GS_OK;
 }

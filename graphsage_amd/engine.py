@@ -114,6 +114,11 @@ class Engine(object):
         self._stream_wave_slots = (4 * torch.cuda.get_device_properties(self.device).multi_processor_count
                                    if self.device.type == "cuda" else 1024)
         self._stream_slice_rows = 256.0   # stream kernel: ~one wave per SIMD with >= 256 reduction rows per slice
+        # the grouped weight gradients LDS-tiled on the bf16 matrix pipe (three-piece arithmetic, gs_dense_wgrad_grouped_tiled3): one
+        # 8-wave workgroup per (64 x 128 tile, slice), cut so that the launch is ONE round of workgroups (one per CU)
+        self.tiled3_wgrad = os.environ.get("GS_TILED3_WGRAD", "1") == "1"
+        self._tiled3_wg_slots = (torch.cuda.get_device_properties(self.device).multi_processor_count
+                                 if self.device.type == "cuda" else 256)
         self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)
         self._table16 = {}                # constant feature tables cut into two fp16 pieces (table16_of)
         # feature tables some launch of the step REWRITES (identity features: the trainable leading columns are refreshed behind
@@ -314,6 +319,39 @@ class Engine(object):
             out.append(k2)
         return out
 
+    def _tiled3_slabs(self):
+        """Slab counts for gs_dense_wgrad_grouped_tiled3, or None when a problem cannot take it.  A workgroup holds its CU for its
+        slice's 32-row stages, so the launch is cut into ONE round: the smallest stage count L per workgroup with
+        sum(tiles x ceil(stages / L)) <= CUs (the Reddit step: 11 slices of 512 rows for the two 602 x 128 layer-0 problems, 1 for
+        the 512-row layer-1 / head problems = 233 workgroups; 12 + 2 would be 265 = two rounds: 37 vs 22 us alone,
+        benchmarks/micro_wgrad.py).  A slice holds at most 1024 rows (its row ids live in LDS)."""
+        if len(self._pending) > 12:
+            return None
+        probs, reserved = [], {}
+        for v, A, ai, dZ, _, n, _ in self._pending:
+            tiles = ((v.rows + 63) // 64) * ((v.cols + 127) // 128)
+            cap = MAX_SLABS - v.n_slabs - reserved.get(id(v), 0)
+            kmin = (n + 1023) // 1024
+            if cap < kmin:
+                return None
+            probs.append((tiles, (n + 31) // 32, kmin, cap, id(v)))
+            reserved[id(v)] = reserved.get(id(v), 0) + kmin      # (what the later problems of the variable can still count on)
+        slots = self._tiled3_wg_slots
+        total = sum(t * st for t, st, _, _, _ in probs)
+        L = max(4, (total + slots - 1) // slots)
+        while True:
+            ks = [int(max(kmin, min(cap, (st + L - 1) // L))) for t, st, kmin, cap, _ in probs]
+            if sum(t * k for (t, _, _, _, _), k in zip(probs, ks)) <= slots or L >= 32:
+                break
+            L += 1
+        used = {}
+        for (t, st, kmin, cap, vid), k in zip(probs, ks):       # several problems of one variable share its arena
+            used[vid] = used.get(vid, 0) + k
+        for v in {id(p[0]): p[0] for p in self._pending}.values():
+            if v.n_slabs + used.get(id(v), 0) > MAX_SLABS:
+                return None
+        return ks
+
     def _assign_slabs(self, ks_list):
         """Pending problems -> gs_wgrad_desc list with slabs assigned behind what each variable already holds.  ks_list: the
         slab count of every pending problem, decided by launch_wgrads (stream policy, or None = tiled policy)."""
@@ -365,6 +403,18 @@ class Engine(object):
         # problem, in order, against the slabs the earlier problems of the same variable will have taken (`reserved`), and
         # those counts are the ones assigned -- so a variable whose arena is nearly full cannot shrink a gathered problem's
         # slab count below what the eligibility check saw.
+        if self.stream_gemm and self.tiled3_wgrad:
+            ks3 = self._tiled3_slabs()
+            if ks3 is not None:
+                pending = self._assign_slabs(ks3)
+                jobs = list(side_jobs or ())
+                arr = (ops._lib.WgradDesc * len(pending))(*pending)
+                jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
+                ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr), len(pending), ctypes.addressof(jarr), len(jobs),
+                         self.stream)
+                self.last_wgrad_kernel = "tiled3"
+                return
+        self.last_wgrad_kernel = "stream/tiled"
         stream, ks_list, reserved = self.stream_gemm, [], {}
         for v, A, ai, dZ, _, n, _ in self._pending:
             ok, ks = self._stream_slabs(v, A, ai, dZ, n, reserved=reserved.get(id(v), 0))

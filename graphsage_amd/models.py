@@ -869,7 +869,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
-                self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.tiled3_fwd, e.split_pool, e.pool_f16, str(getattr(self, "pipeline", None)),
+                self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.tiled3_fwd, e.tiled3_wgrad, e.split_pool, e.pool_f16, str(getattr(self, "pipeline", None)),
                 type(self.grad_hook).__name__,
                 id(self.grad_hook), law)
 

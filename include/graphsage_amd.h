@@ -237,6 +237,14 @@ int gs_sage_dense_fwd_stream2(const float* self, int64_t ld_self, const int32_t*
                               int64_t ldo, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
 int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);
+/* gs_dense_wgrad_grouped_tiled3 (ABI 9, round 6): gs_dense_wgrad_grouped_stream -- same descriptors, same split-K slabs, same
+ * co-scheduled gather jobs -- in the three-piece bf16 arithmetic of gs_sage_dense_fwd_tiled3 (fp32 in and out, the accuracy of an
+ * fp32 FMA chain), LDS-tiled: one 8-wave workgroup per (64 x 128 tile of dW, reduction slice), both operands moved HBM -> LDS raw
+ * by LDS-DMA and cut by the waves that read them.  <= 12 problems; a slice is round_up(ceil(n / n_slabs), 32) rows and must not
+ * exceed 1024; row addresses are 64-bit (tables beyond 4 GB are fine: a_rows is not needed).  A slab whose slice is empty is
+ * written as zeros.  Replaces the TF-op group of aggregators.py:51-58's gradient (tf.gradients of the two matmuls). */
+int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                  int32_t n_jobs, void* stream);
 /* gs_sage_dense_fwd_tiled3 (ABI 9, round 6): the contraction of gs_sage_dense_fwd_stream2 -- same arguments, fp32 operands in and
  * out -- on the bf16 matrix pipe in the three-piece arithmetic described below (every fp32 operand = three bf16 pieces, six exact
  * piece products per element pair, fp32 accumulation: the accuracy of an fp32 FMA chain), LDS-tiled: one 8-wave workgroup per

@@ -1048,10 +1048,14 @@ def test_sage_dense_fwd_stream2_terms_of_different_length(dev, n, d_self, d_agg,
     assert_close_rownorm(outm.numpy(), want)
 
 
-@pytest.mark.parametrize("slices0", [22, 11, 45])
-def test_dense_wgrad_grouped_stream(dev, slices0):
-    """gs_dense_wgrad_grouped_stream: the weight gradients of a mean step (layer 0: 602x128 x2 over 5632 rows, layer 1:
-    256x128 x2 over 512 rows, head 256x41, bias 1x41, odd slice lengths) as split-K slabs + a co-scheduled gather job."""
+@pytest.mark.parametrize("entry", ["gs_dense_wgrad_grouped_stream", "gs_dense_wgrad_grouped_tiled3"])
+@pytest.mark.parametrize("slices0", [22, 11, 45, 6])
+def test_dense_wgrad_grouped_stream(dev, slices0, entry):
+    """gs_dense_wgrad_grouped_stream / _tiled3: the weight gradients of a mean step (layer 0: 602x128 x2 over 5632 rows, layer 1:
+    256x128 x2 over 512 rows, head 256x41, bias 1x41, odd slice lengths) as split-K slabs + a co-scheduled gather job.
+    (tiled3 at 45 slices: 128-row slices, the 45th slab's slice is EMPTY and must come out as zeros.)"""
+    if entry.endswith("stream") and slices0 == 6:
+        pytest.skip("the stream kernel keeps a gathered slice's <= 512 row offsets in registers")
     import ctypes
     from graphsage_amd import _lib
     rng = np.random.default_rng(77)
@@ -1073,7 +1077,7 @@ def test_dense_wgrad_grouped_stream(dev, slices0):
             Ad = Mat.from_numpy(A, dev)
         Zd = Mat.from_numpy(dZ, dev)
         ld_slab = (o + 3) & ~3
-        sl = torch.zeros(ns * d * ld_slab, device=dev)
+        sl = torch.full((ns * d * ld_slab,), float("nan"), device=dev)      # every slab element inside [d, o] must be WRITTEN
         keep += [Ad, Zd, sl]
         descs[i].A, descs[i].a_idx, descs[i].dZ, descs[i].slabs = Ad.ptr, ops.ptr(idx_dev) if aidx is not None else None, Zd.ptr, sl.data_ptr()
         descs[i].lda, descs[i].ldz, descs[i].ld_slab, descs[i].n = Ad.ld, Zd.ld, ld_slab, n
@@ -1087,7 +1091,7 @@ def test_dense_wgrad_grouped_stream(dev, slices0):
     Xd, idx_d = Mat.from_numpy(X, dev, 32), _i32(idx.reshape(-1), dev)   # descriptors hold raw pointers: keep the tensors
     job = ops.gather_job(Xd, idx_d, 300, 10, g_out)
     jarr = (_lib.GatherDesc * 1)(job)
-    ops.call("gs_dense_wgrad_grouped_stream", ctypes.addressof(descs), len(probs), ctypes.addressof(jarr), 1, ops.current_stream())
+    ops.call(entry, ctypes.addressof(descs), len(probs), ctypes.addressof(jarr), 1, ops.current_stream())
     _sync()
     for (sl, ns, d, ld_slab, o), w in zip(slabs, want):
         got = sl.cpu().numpy().reshape(ns, d, ld_slab)[:, :, :o].astype(np.float64).sum(axis=0)

@@ -146,6 +146,85 @@ def test_tiled3_fwd_is_as_accurate_as_the_fp32_mfma_kernel(dev):
     assert e_split <= 2 * e_fp32 and e_split < 4e-6
 
 
+def _wgrad_desc(A, a_idx, dZ, col0, out, n, d, ns, dev, a_rows=0):
+    from graphsage_amd import _lib
+    ld_slab = (out + 3) & ~3
+    sl = torch.full((ns * d * ld_slab,), float("nan"), device=dev)
+    q = _lib.WgradDesc()
+    q.A, q.a_idx, q.dZ, q.slabs = A.ptr, ops.ptr(a_idx), dZ.ptr, sl.data_ptr()
+    q.lda, q.ldz, q.ld_slab, q.n = A.ld, dZ.ld, ld_slab, n
+    q.d, q.col0, q.out_dim, q.n_slabs, q.a_rows = d, col0, out, ns, a_rows
+    return q, sl, ld_slab
+
+
+def test_tiled3_wgrad_is_as_accurate_as_the_fp32_mfma_kernel(dev):
+    """Same operands through gs_dense_wgrad_grouped_stream (fp32 MFMA) and gs_dense_wgrad_grouped_tiled3 (three bf16 pieces): both
+    errors against fp64 are fp32 rounding noise of the same size; NaN in the operands' pad columns reaches no output."""
+    import ctypes
+    from graphsage_amd import _lib
+    rng = np.random.default_rng(19)
+    n, d, out = 5632, 602, 128
+    A = rng.normal(size=(n, d)).astype(np.float32)
+    dZ = (rng.normal(size=(n, 2 * out)) * 0.1).astype(np.float32)
+    Ad, Zd = Mat.from_numpy(A, dev, 32), Mat.from_numpy(dZ, dev, 32)
+    Ad.buf[:, d:] = float("nan")
+    want = A.astype(np.float64).T @ dZ[:, out:].astype(np.float64)
+    errs = {}
+    jn = (_lib.GatherDesc * 1)()
+    for entry, ns in (("gs_dense_wgrad_grouped_stream", 22), ("gs_dense_wgrad_grouped_tiled3", 11)):
+        q, sl, ld_slab = _wgrad_desc(Ad, None, Zd, out, out, n, d, ns, dev)
+        arr = (_lib.WgradDesc * 1)(q)
+        ops.call(entry, ctypes.addressof(arr), 1, ctypes.addressof(jn), 0, ops.current_stream())
+        torch.cuda.synchronize()
+        got = sl.cpu().numpy().reshape(ns, d, ld_slab)[:, :, :out].astype(np.float64).sum(axis=0)
+        assert np.isfinite(got).all(), entry
+        errs[entry] = np.abs(got - want).max() / np.sqrt((want * want).mean())
+    print("max error / rms vs fp64:", errs)
+    assert errs["gs_dense_wgrad_grouped_tiled3"] <= 2 * errs["gs_dense_wgrad_grouped_stream"] and errs["gs_dense_wgrad_grouped_tiled3"] < 4e-6
+
+
+@pytest.mark.parametrize("n,d,out,col0,ns,gathered", [
+    (5632, 602, 128, 128, 11, True),        # the Reddit step's layer-0 self term: 512-row slices, ragged last m tile
+    (11484, 602, 128, 0, 12, True),         # the unsupervised step's: 960-row slices, the last one 924 rows (a partial last stage)
+    (1000, 50, 256, 0, 1, False),           # PPI's F = 50 (one m tile, columns clamped), two n tiles, one 1000-row slice (1024 > n)
+    (77, 256, 41, 0, 2, False),             # head-shaped: 41 columns, 64-row slices, the second one 13 rows
+    (33, 1, 7, 4, 1, False),                # a bias gradient: A = ones [n, 1] (lda 4), 7 columns at an offset
+    (300, 130, 200, 0, 3, True)])           # three m tiles (the last 2 rows), two n tiles (the last 72 columns), 128-row slices (44 in the last)
+def test_dense_wgrad_grouped_tiled3_shapes(dev, n, d, out, col0, ns, gathered):
+    """gs_dense_wgrad_grouped_tiled3 on ragged shapes vs fp64: every slab element inside [d, out] written, nothing outside it."""
+    import ctypes
+    from graphsage_amd import _lib
+    rng = np.random.default_rng(n + d + out)
+    rows = 4000 if gathered else n
+    T = np.ones((rows, 1), np.float32) if d == 1 else rng.normal(size=(rows, d)).astype(np.float32)
+    aidx = rng.integers(0, rows, size=n).astype(np.int32) if gathered else None
+    A = T[aidx] if gathered else T
+    dZ = (rng.normal(size=(n, col0 + out)) * 0.1).astype(np.float32)
+    Td, Zd = Mat.from_numpy(T, dev), Mat.from_numpy(dZ, dev)
+    if Td.ld > d:
+        Td.buf[:, d:] = float("nan")
+    if Zd.ld > col0 + out:
+        Zd.buf[:, col0 + out:] = float("nan")
+    idx_d = _i32(aidx, dev) if gathered else None
+    q, sl, ld_slab = _wgrad_desc(Td, idx_d, Zd, col0, out, n, d, ns, dev)
+    arr = (_lib.WgradDesc * 1)(q)
+    jn = (_lib.GatherDesc * 1)()
+    ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr), 1, ctypes.addressof(jn), 0, ops.current_stream())
+    torch.cuda.synchronize()
+    raw = sl.cpu().numpy().reshape(ns, d, ld_slab)
+    assert np.isfinite(raw[:, :, :out]).all()
+    assert np.isnan(raw[:, :, out:]).all()               # pad columns of a slab row are not touched
+    want = A.astype(np.float64).T @ dZ[:, col0:].astype(np.float64)
+    got = raw[:, :, :out].astype(np.float64).sum(axis=0)
+    rms = np.sqrt((want * want).mean()) + 1e-30
+    assert np.abs(got - want).max() / rms < 1e-5, np.abs(got - want).max() / rms
+    # deterministic
+    sl2 = sl.clone()
+    ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr), 1, ctypes.addressof(jn), 0, ops.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(sl), torch.nan_to_num(sl2))
+
+
 @pytest.mark.parametrize("n_max,count,d,out,act,bias", [
     (6000, 5000, 602, 512, ops.ACT_RELU, True),      # the pooling MLP's shape (fewer rows), device-side row count
     (300, 300, 602, 512, ops.ACT_RELU, True),        # three row tiles, the last one ragged
