@@ -1007,15 +1007,22 @@ extern "C" int gs_sage_dense_fwd_tiled3(const float* self, int64_t ld_self, cons
 // gs_dense_wgrad_grouped_tiled3: every weight gradient of a backward pass, dW = A[a_idx]^T . dZ[:, col0 : col0 + out_dim], in the
 // three-piece arithmetic above -- the grouped launch of gs_dense_wgrad_grouped_stream (same descriptors, same split-K slabs, same
 // riders), LDS-tiled like sage_tiled3_fwd_kernel.  Both operands are row-contiguous over the REDUCTION index (k = a batch row), the
-// matrix pipe wants 8 consecutive k per lane: both go global -> LDS raw (fp32, LDS-DMA, no register, no ds_write) as [32 k][64 m] and
-// [32 k][128 n] stage tiles, and a wave reads the 8 k of ITS column as eight ds_read_b32 (lanes side by side: conflict-free) and cuts
+// matrix pipe wants 8 consecutive k per lane: both go global -> LDS raw (fp32, LDS-DMA, no register, no ds_write) as [16 k][64 m] and
+// [16 k][128 n] stage tiles, and a wave reads the 8 k of ITS column as eight ds_read_b32 (lanes side by side: conflict-free) and cuts
 // them in registers -- the transposition costs nothing but the cut itself.
-//   workgroup (8 waves) = one (64 m x 128 n tile, reduction slice) of one problem; the waves are 2 (k halves of a stage) x 4 (column
-//   groups of 32), each over both 32-row blocks of m: per stage and wave 24 ds_read_b32, 12 two-element cuts, 12 MFMAs;
-//   ring of W3_NS stage slots (24 KB each) filled W3_NS - 1 stages ahead, ONE barrier per stage behind a counted vmcnt;
-//   a gathered problem's row ids (<= 1024 per slice) are read once into LDS; 64-bit row addresses (tables beyond 4 GB are fine);
-//   rows beyond the slice are masked in the B fragment (the clamped row is read, its dZ values are zeroed before the cut).
+//   workgroup (FOUR waves) = one (64 m x 128 n tile, reduction slice) of one problem; wave w owns the 32-column group w over both
+//   32-row blocks of m: per 16-k stage and wave 24 ds_read_b32, 12 two-element cuts, 12 MFMAs;
+//   ring of W3_NS stage slots (12 KB each) filled W3_NS - 1 stages ahead, ONE barrier per stage behind a counted vmcnt;
+//   a slice's source rows (<= 1024: the row ids of a gathered problem) are read once into LDS; 64-bit row addresses (tables beyond
+//   4 GB are fine); rows beyond the slice are masked in the B fragment (the clamped row is read, its dZ values are zeroed).
+// Why four waves and 16-k stages: a launch has ONE workgroup shape -- threads, registers AND dynamic LDS -- for all its roles, so the
+// riders (next step's gather, no LDS of their own) inherit the hosts' allocation.  At 8 waves / 100 KB (first version: 21.7 us
+// alone, but +5 us per step) no rider workgroup fits on a CU beside a host; at 4 waves / 52 KB / < 170 VGPRs a host shares its CU
+// with two rider workgroups (8 rider waves per CU -- what the stream kernel's launch gives them).
+#ifndef W3_NS
 #define W3_NS 4
+#endif
+#define W3_KS 16           // k per stage
 #define W3_MAXROWS 1024
 #define W3_MAXP 12
 struct Wg3Prob {
@@ -1033,14 +1040,14 @@ struct Wg3Args {
     int32_t n, n_items;
 };
 
-__global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, const CoGatherS J) {
+__global__ __launch_bounds__(256) void wgrad_tiled3_kernel(const Wg3Args G, const CoGatherS J) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int A_BYTES = 32 * 64 * 4, B_BYTES = 32 * 128 * 4, S_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = W3_KS * 64 * 4, B_BYTES = W3_KS * 128 * 4, S_BYTES = A_BYTES + B_BYTES;
     constexpr int IDX_BASE = W3_NS * S_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= G.n_items) {
-        run_gather_item(J, ((int64_t)blockIdx.x - G.n_items) * 8 + wave, lane);
+        run_gather_item(J, ((int64_t)blockIdx.x - G.n_items) * 4 + wave, lane);
         return;
     }
     const int l31 = lane & 31, lh = lane >> 5;
@@ -1060,12 +1067,12 @@ __global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, cons
     const int rb = z * q.kchunk, re = min(rb + q.kchunk, q.n);
     const int len = max(re - rb, 0);                           // (an empty slice still writes its slab: zeros)
     const int rlast = max(re, 1) - 1;                          // every row read is clamped to a valid one
-    const int stages = (len + 31) >> 5;
+    const int stages = (len + W3_KS - 1) / W3_KS;
     const int stages4 = (stages + 3) & ~3;
     // the slice's source rows (<= W3_MAXROWS), once: the row ids of a gathered problem, else the rows themselves -- one code path
     int32_t* idxs = reinterpret_cast<int32_t*>(smem + IDX_BASE);
 #pragma unroll
-    for (int t = tid; t < W3_MAXROWS; t += 512) {
+    for (int t = tid; t < W3_MAXROWS; t += 256) {
         const int rr = min(rb + t, rlast);
         idxs[t] = q.a_idx ? q.a_idx[rr] : rr;
     }
@@ -1076,29 +1083,38 @@ __global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, cons
     const float* __restrict__ zcol = q.dZ + min(n0 + 4 * l31, q.zcols - 4);            //  computed and never stored)
     const int lda = q.lda, ldz = q.ldz;
     auto a_row = [&](const int s) -> int64_t {                 // source row of this lane's A request of stage s
-        return (int64_t)idxs[min(32 * s + akk, W3_MAXROWS - 1)];
+        return (int64_t)idxs[min(W3_KS * s + akk, W3_MAXROWS - 1)];
     };
     auto dma = [&](const int s, const int slot, const int64_t arow) {
         unsigned char* base = smem + slot * S_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = 2 * wave + i;
-            const int r = min(rb + 32 * s + 2 * c + lh, rlast);
+            const int r = min(rb + W3_KS * s + 2 * c + lh, rlast);
             __builtin_amdgcn_global_load_lds(zcol + (int64_t)r * ldz, (lds_ptr_t)(base + A_BYTES + c * 1024), 16, 0, 0);
         }
         __builtin_amdgcn_global_load_lds(acol + arow * lda, (lds_ptr_t)(base + wave * 1024), 16, 0, 0);
     };
-    const int kh = wave >> 2, wn = wave & 3;                   // k half of the stage | 32-column group
+    const int wn = wave;                                       // 32-column group
     f32x16 acc[2], sml[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; sml[i][e] = 0.f; }
     u32x4 fa[2][2][3], fb[2][3];
-    const int kfrag = 16 * kh + 8 * lh;                        // first of this lane's 8 k inside a stage
+    const int kfrag = 8 * lh;                                  // first of this lane's 8 k inside a stage
     const int a_rd = (kfrag * 64 + l31) * 4;                   // + i k rows (256 bytes each), + 128 for the second m block
     const int b_rd = A_BYTES + (kfrag * 128 + 32 * wn + l31) * 4;      // + i k rows (512 bytes each)
     // stage barrier by hand, see sage_tiled3_fwd_kernel: counted vmcnt (younger requests stay in flight) + lgkmcnt(0) + s_barrier
+#if W3_NS == 4
+#define W3_INFLIGHT 3
+#elif W3_NS == 5
+#define W3_INFLIGHT 6
+#elif W3_NS == 6
+#define W3_INFLIGHT 9
+#else
+#define W3_INFLIGHT 15
+#endif
 #define W3_WAIT_STR2(x) #x
 #define W3_WAIT_STR(x) W3_WAIT_STR2(x)
 #define W3_BARRIER() do { asm volatile("s_waitcnt vmcnt(" W3_WAIT_STR(W3_INFLIGHT) ") lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); \
@@ -1111,7 +1127,7 @@ __global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, cons
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) aw[j][i] = *reinterpret_cast<const float*>(slot + a_rd + j * 128 + i * 256);
-        const int lim = len - 32 * s - kfrag;
+        const int lim = len - W3_KS * s - kfrag;
 #pragma unroll
         for (int i = 0; i < 8; ++i) bw[i] = i < lim ? bw[i] : 0.f;
         gs_split8(f32x4{bw[0], bw[1], bw[2], bw[3]}, f32x4{bw[4], bw[5], bw[6], bw[7]}, fb[set][0], fb[set][1], fb[set][2]);
@@ -1124,13 +1140,6 @@ __global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, cons
 #pragma unroll
     for (int s = 0; s < W3_NS - 1; ++s) dma(s, s, a_row(s));
     int64_t arow_nxt = a_row(W3_NS - 1);
-#if W3_NS == 4
-#define W3_INFLIGHT 3
-#elif W3_NS == 5
-#define W3_INFLIGHT 6
-#else
-#define W3_INFLIGHT 9
-#endif
     W3_BARRIER();                                              // stages 0 and 1 have landed (everyone's share of them)
     read_cut_frags(0, smem, 0);
     int slot_rd = 1, slot_wr = W3_NS - 1;                      // slot of stage ss + 1 | of stage ss + W3_NS - 1
@@ -1160,7 +1169,7 @@ __global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, cons
             W3_SB
             W3_MM(acc, 0, 0, 0)
             if constexpr (decltype(masked)::value) {           // the slice ends inside stage ss + 1, or before it
-                const int lim = len - 32 * (ss + 1) - kfrag;
+                const int lim = len - W3_KS * (ss + 1) - kfrag;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bw[i] = i < lim ? bw[i] : 0.f;
             }
@@ -1217,35 +1226,19 @@ __global__ __launch_bounds__(512) void wgrad_tiled3_kernel(const Wg3Args G, cons
         }
     }
     };
-    const int s_plain = max((len >> 5) - 1, 0) & ~3;           // stages ss < s_plain read a full stage ss + 1
+    const int s_plain = max(len / W3_KS - 1, 0) & ~3;          // stages ss < s_plain read a full stage ss + 1
     run(std::false_type{}, 0, s_plain);
     run(std::true_type{}, s_plain, stages4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead requests of the last stages
     __syncthreads();
-    // ---- the two k halves of a tile meet through LDS (free now): waves 4..7 hand their sums to waves 0..3 (fixed order)
-    float* red = reinterpret_cast<float*>(smem) + (wave & 3) * (2 * 16 * 64);
-    if (kh == 1) {
+    // ---- the wave's 64 x 32 tile -> its slab, through a wave-private LDS staging tile (16-byte row segments)
+    float* otile = reinterpret_cast<float*>(smem) + wave * (64 * 36);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[(i * 16 + e) * 64 + lane] = acc[i][e] + sml[i][e];
-    }
-    __syncthreads();
-    if (kh == 1) return;
-    float* otile = reinterpret_cast<float*>(smem) + 4 * (2 * 16 * 64) + wave * (64 * 36);
-    {
-        float pr[2][16];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) pr[i][e] = red[(i * 16 + e) * 64 + lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                otile[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + l31] = (acc[i][e] + sml[i][e]) + pr[i][e];
-    }
+        for (int e = 0; e < 16; ++e)
+            otile[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + l31] = acc[i][e] + sml[i][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (wave-private region: the wave's own writes before its reads)
     float* __restrict__ S = q.slabs + (int64_t)z * q.d * q.ld_slab;
     const bool vec = (q.ld_slab & 3) == 0 && (reinterpret_cast<uintptr_t>(S) & 15u) == 0;
     const int c4 = (lane & 7) * 4, r0 = lane >> 3;
@@ -1305,11 +1298,11 @@ extern "C" int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, in
     int64_t waves = 0;
     int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
     if (rc != GS_OK) return rc;
-    const int64_t blocks = items + gs_ceil_div(waves, 8);
+    const int64_t blocks = items + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_dense_wgrad_grouped_tiled3: grid too large");
-    const size_t lds = W3_NS * (32 * 64 * 4 + 32 * 128 * 4) + W3_MAXROWS * 4;
+    const size_t lds = W3_NS * (W3_KS * 64 * 4 + W3_KS * 128 * 4) + W3_MAXROWS * 4;
     GS_LDS_ATTR(lds, wgrad_tiled3_kernel);
-    hipLaunchKernelGGL(wgrad_tiled3_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, G, J);
+    hipLaunchKernelGGL(wgrad_tiled3_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G, J);
     GS_LAUNCH_CHECK("wgrad_tiled3_kernel");
     return GS_OK;
 }
