@@ -670,8 +670,10 @@ struct Fwd3Args {
     int32_t tiles_m, tiles_n, n_tiles;     // n_tiles = tiles_m * tiles_n * nterms
 };
 #define F3_BM 64
-#define F3_NA 3            // A-piece buffers
+#define F3_NA 2            // A-piece buffers (stage s + 1 being read, stage s + 2 being written)
 #define F3_NB 4            // raw B stages in flight
+#define F3_KS 16           // k per stage
+#define F3_LDA 24          // bf16 per LDS row of an A plane: 16 + 8 pad (48 bytes: 16 lanes of a 16-byte fragment read cover all banks)
 #ifdef F3_TIMELINE
 // Diagnostics build only (-DF3_TIMELINE, benchmarks/timeline_tiled3.py): shader-clock and wall-clock stamps of waves 0 and 4 of the
 // first 256 workgroups.  [wg][wave 0 | 4][0] entry [1] operands requested [2] prologue barrier passed [3] K loop left [4] K halves
@@ -688,15 +690,15 @@ extern "C" int gs_debug_f3_timeline(unsigned long long* out_host, int n) {
 #define F3_STAMPV(k, v) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, const CoGatherS J) {
+__global__ __launch_bounds__(256) void sage_tiled3_fwd_kernel(const Fwd3Args g, const CoGatherS J) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int A_PLANE = F3_BM * ST_LDA * 2;                // bytes
-    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 32 * 128 * 4;
+    constexpr int A_PLANE = F3_BM * F3_LDA * 2;                // bytes
+    constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = F3_KS * 128 * 4;
     constexpr int B_BASE = F3_NA * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= g.n_tiles) {
-        run_gather_item(J, ((int64_t)blockIdx.x - g.n_tiles) * 8 + wave, lane);
+        run_gather_item(J, ((int64_t)blockIdx.x - g.n_tiles) * 4 + wave, lane);
         return;
     }
     const int l31 = lane & 31, lh = lane >> 5;
@@ -713,16 +715,15 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
     const int m0 = tile_m * F3_BM, n0 = tile_n * 128;
     const Fwd3Term& T = g.t[term];
     const int K = T.K, N = g.N, M = g.M;
-    const int stages = (K + 31) >> 5;
-    const int stages2 = (stages + 1) & ~1;                     // an odd stage count is padded with one all-zero stage
+    const int stages = (K + F3_KS - 1) / F3_KS;
     const int K4 = ((K + 3) >> 2) << 2;                        // readable columns of a row
-    // ---- A: (row tid >> 3, float4 tid & 7) of the 64 x 32 stage tile, through registers
-    const int arow = tid >> 3, aq = tid & 7;
+    // ---- A: (row tid >> 2, float4 tid & 3) of the 64 x 16 stage tile, through registers
+    const int arow = tid >> 2, aq = tid & 3;
     const int grow = min(m0 + arow, M - 1);
     const int64_t srow = T.a_idx ? (int64_t)T.a_idx[grow] : (int64_t)grow;
     const float* __restrict__ xrow = T.A + srow * T.lda;
-    const int a_wr = (arow * ST_LDA + 4 * aq) * 2;
-    // ---- B: wave w moves chunks 2 w, 2 w + 1 of a stage's 16 (chunk = two k rows x 128 columns = 1 KB, lane-linear in LDS)
+    const int a_wr = (arow * F3_LDA + 4 * aq) * 2;
+    // ---- B: wave w moves chunks 2 w, 2 w + 1 of a stage's 8 (chunk = two k rows x 128 columns = 1 KB, lane-linear in LDS)
     const int bcol = min(n0 + 4 * l31, N - 4);                 // (columns beyond N: a valid column again, computed and never stored)
     const float* __restrict__ wcol = T.W + bcol;
     const int ldw = T.ldw;
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
     f32x4 ra[4];
     // (F3_DIAG_*: diagnostics builds only, benchmarks/probes/build_variant.sh -- wrong values, the kernel's time without one component)
     auto gload_a = [&](const int set, const int s) {           // straight-line request with a clamped (always valid) address
-        const int k = min(32 * s + 4 * aq, K4 - 4);
+        const int k = min(F3_KS * s + 4 * aq, K4 - 4);
 #ifdef F3_DIAG_NOGA
         ra[set] = f32x4{(float)k, 1.f, 2.f, (float)tid};
 #else
@@ -745,12 +746,12 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = 2 * wave + i;
-            const int k = min(32 * s + 2 * c + lh, K - 1);
+            const int k = min(F3_KS * s + 2 * c + lh, K - 1);
             __builtin_amdgcn_global_load_lds(wcol + (int64_t)k * ldw, (lds_ptr_t)(smem + B_BASE + slot * B_BYTES + c * 1024), 16, 0, 0);
         }
 #endif
     };
-    const int kh = wave >> 2, wn = wave & 3;                   // K half of the stage | 32-column group
+    const int wn = wave;                                       // 32-column group
     f32x16 acc[2], sml[2];                                     // [row tile of 32]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -758,8 +759,8 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
         for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; sml[i][e] = 0.f; }
     // fragments of a stage: TWO register sets -- the MFMAs of stage s run on one while the other receives stage s + 1's
     u32x4 fa[2][2][3], fb[2][3];
-    const int a_rd = (l31 * ST_LDA + 16 * kh + 8 * lh) * 2;                          // + 32 i rows, + piece plane
-    const int b_rd = B_BASE + ((16 * kh + 8 * lh) * 128 + 32 * wn + l31) * 4;        // + i k rows (512 bytes each)
+    const int a_rd = (l31 * F3_LDA + 8 * lh) * 2;                                    // + 32 i rows, + piece plane
+    const int b_rd = B_BASE + ((8 * lh) * 128 + 32 * wn + l31) * 4;                  // + i k rows (512 bytes each)
     // The stage barrier by hand: "my LDS writes and reads of this stage are done" (lgkmcnt(0)) + "the B stage the next stage reads
     // has landed" (a COUNTED vmcnt: the younger requests stay in flight across the barrier) + s_barrier.  __syncthreads, and also a
     // release fence on the local address space (the compiler orders the LDS-DMA writes behind it), would wait for vmcnt(0): every
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;                      // LDS byte address of the dynamic segment
     auto cut_store_a = [&](const int set, const int s, unsigned char* buf) {
-        const int k = 32 * s + 4 * aq;
+        const int k = F3_KS * s + 4 * aq;
         const float x0 = k < K ? ra[set].x : 0.f, x1 = k + 1 < K ? ra[set].y : 0.f;       // selects: zero beyond K (NaN pads must not leak)
         const float x2 = k + 2 < K ? ra[set].z : 0.f, x3 = k + 3 < K ? ra[set].w : 0.f;
         uint32_t h0, m0_, l0, h1, m1_, l1;
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) fa[set][i][p] = *reinterpret_cast<const u32x4*>(abuf + a_rd + i * (32 * ST_LDA * 2) + p * A_PLANE);
+            for (int p = 0; p < 3; ++p) fa[set][i][p] = *reinterpret_cast<const u32x4*>(abuf + a_rd + i * (32 * F3_LDA * 2) + p * A_PLANE);
         float bw[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) bw[i] = *reinterpret_cast<const float*>(bslot + (b_rd - B_BASE) + i * 512);
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
     dma_b(2, 2);
     {
         f32x4 t0, t1;
-        const int k0 = min(4 * aq, K4 - 4), k1 = min(32 + 4 * aq, K4 - 4);
+        const int k0 = min(4 * aq, K4 - 4), k1 = min(F3_KS + 4 * aq, K4 - 4);
 #ifdef F3_DIAG_NOGA
         t0 = t1 = f32x4{(float)k0, 1.f, 2.f, (float)k1};
 #else
@@ -817,8 +818,9 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
     F3_BARRIER(0);
     F3_STAMP(2);
     read_cut_frags(0, smem, smem + B_BASE);
-    // byte offsets of the A-piece buffers of stage s + 1 | s + 2 (| s: free again at s + 3); B slots are (stage) % 4
-    int oa_nxt = A_BYTES, oa_nn = 2 * A_BYTES, oa_cur = 0;
+    // byte offsets of the A-piece buffers of stage s + 1 | s + 2 (= the one stage s was read from, during stage s - 1: every wave
+    // has passed a barrier since); B slots are (stage) % 4
+    int oa_nxt = A_BYTES, oa_nn = 0;
     const int stages4 = (stages + 3) & ~3;                     // whole rings: padded with all-zero stages (A is masked beyond K)
     for (int s = 0; s < stages4; s += 4) {
 #pragma unroll
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
 #define F3_RA(i, p) fa[r ^ 1][i][p] = u32x4{(unsigned)(p), (unsigned)(uintptr_t)na, 2u, (unsigned)tid}; F3_SB
 #define F3_RW(i) bw[i] = __uint_as_float((unsigned)(uintptr_t)nb + i);
 #else
-#define F3_RA(i, p) fa[r ^ 1][i][p] = *reinterpret_cast<const u32x4*>(na + a_rd + (i) * (32 * ST_LDA * 2) + (p) * A_PLANE); F3_SB
+#define F3_RA(i, p) fa[r ^ 1][i][p] = *reinterpret_cast<const u32x4*>(na + a_rd + (i) * (32 * F3_LDA * 2) + (p) * A_PLANE); F3_SB
 #define F3_RW(i) bw[i] = *reinterpret_cast<const float*>(nb + (i) * 512);
 #endif
             float bw[8];
@@ -900,46 +902,29 @@ __global__ __launch_bounds__(512) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
 #undef F3_RA
 #undef F3_RW
 #undef F3_SB
-            const int t = oa_cur; oa_cur = oa_nxt; oa_nxt = oa_nn; oa_nn = t;
+            const int t = oa_nxt; oa_nxt = oa_nn; oa_nn = t;
         }
     }
     F3_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests of the last stages
     __syncthreads();
-    // ---- the two K halves of a tile meet through LDS (free now): waves 4..7 hand their sums to waves 0..3
-    float* red = reinterpret_cast<float*>(smem) + (wave & 3) * (2 * 16 * 64);       // [2 tiles][16 regs][64 lanes] per wave pair
-    if (kh == 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) red[(i * 16 + e) * 64 + lane] = acc[i][e] + sml[i][e];
-    }
-    __syncthreads();
     F3_STAMP(4);
-    if (kh == 1) return;
-    float* otile = reinterpret_cast<float*>(smem) + 4 * (2 * 16 * 64) + wave * (64 * 36);     // [64 rows][32 + 4 pad] per wave
+    // ---- the wave's 64 x 32 tile: bias + activation, then through a wave-private LDS staging tile to 16-byte row segments
+    float* otile = reinterpret_cast<float*>(smem) + wave * (64 * 36);     // [64 rows][32 + 4 pad] per wave
     const int col_off = term * N;
     {
         const int col = n0 + 32 * wn + l31;
         const float bv = (g.bias && col < N) ? g.bias[col_off + col] : 0.f;
-        // (the partner's 32 sums FIRST, all of them in flight: read and written in one loop the compiler kept every read behind
-        //  the previous write -- `red` and `otile` might overlap for all it knows -- 32 LDS round trips in a row, 3800 cycles)
-        float pr[2][16];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) pr[i][e] = red[(i * 16 + e) * 64 + lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float v = ((acc[i][e] + sml[i][e]) + pr[i][e]) + bv;
+                float v = (acc[i][e] + sml[i][e]) + bv;
                 if (g.act == GS_ACT_RELU) v = fmaxf(v, 0.f);
                 otile[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + l31] = v;     // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
             }
     }
-    // (wave-private region: the wave's own LDS writes are ordered before its reads by lgkmcnt)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (wave-private region: the wave's own LDS writes before its reads)
     const int c4 = (lane & 7) * 4, r0 = lane >> 3;
     const int colg = n0 + 32 * wn + c4;
 #pragma unroll
@@ -994,11 +979,11 @@ extern "C" int gs_sage_dense_fwd_tiled3(const float* self, int64_t ld_self, cons
     int64_t waves = 0;
     int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
     if (rc != GS_OK) return rc;
-    const int64_t blocks = g.n_tiles + gs_ceil_div(waves, 8);
+    const int64_t blocks = g.n_tiles + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks > 0 && blocks < (1ll << 31), "gs_sage_dense_fwd_tiled3: grid too large");
-    const size_t lds = F3_NA * (3 * F3_BM * ST_LDA * 2) + F3_NB * (32 * 128 * 4);
+    const size_t lds = F3_NA * (3 * F3_BM * F3_LDA * 2) + F3_NB * (F3_KS * 128 * 4);
     GS_LDS_ATTR(lds, sage_tiled3_fwd_kernel);
-    hipLaunchKernelGGL(sage_tiled3_fwd_kernel, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g, J);
+    hipLaunchKernelGGL(sage_tiled3_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g, J);
     GS_LAUNCH_CHECK("sage_tiled3_fwd_kernel");
     return GS_OK;
 }
