@@ -117,6 +117,7 @@ class Engine(object):
         # the grouped weight gradients LDS-tiled on the bf16 matrix pipe (three-piece arithmetic, gs_dense_wgrad_grouped_tiled3): one
         # 8-wave workgroup per (64 x 128 tile, slice), cut so that the launch is ONE round of workgroups (one per CU)
         self.tiled3_wgrad = os.environ.get("GS_TILED3_WGRAD", "1") == "1"
+        self.last_wgrad_kernel = None     # "tiled3" | "stream/tiled": what the last grouped weight-gradient launch took (tests)
         self._tiled3_wg_slots = (torch.cuda.get_device_properties(self.device).multi_processor_count
                                  if self.device.type == "cuda" else 256)
         self._injected_keep = {}          # dropout site -> injected keep bits (parity tests)

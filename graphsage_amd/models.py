@@ -110,11 +110,14 @@ class SampleAndAggregate(object):
         self.row_offset = 0
         # shares of the prefetch gather carried by the step's launches (sweeps in DESIGN.md).  Two-launch form (layer-0
         # forward | weight gradients): 0.7 | 0.3 with the LDS-tiled kernels, 0.5 | 0.5 with the stream kernels.
-        # Three-launch form of the supervised mean model (layer-0 forward | fused tail | weight gradients): 0.15 | 0.5 |
-        # 0.35 -- the tail keeps only 32 CUs busy, the rest of the chip streams the gather.
+        # Three-launch form of the supervised mean model (layer-0 forward | fused tail | weight gradients): 0.25 | 0.40 |
+        # 0.35 since round 6 -- the four-wave tiled forward and weight-gradient workgroups leave room for two rider workgroups on
+        # their own CUs (profiles/r06_tiled3_wgrad_ab.txt: headline 97.7 us/step; 0.15 | 0.5 | 0.35 with the stream kernels, where
+        # the tail -- 32 busy CUs -- was the best host).
         self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.5 if self.engine.stream_gemm else 0.7))
-        self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.15))
-        self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", 0.5 if self.engine.stream_gemm else 0.0))
+        tiled = self.engine.stream_gemm and self.engine.tiled3_fwd and self.engine.tiled3_wgrad
+        self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.25 if tiled else 0.15))
+        self.cogather_tail = float(os.environ.get("GS_COGATHER_TAIL", (0.40 if tiled else 0.5) if self.engine.stream_gemm else 0.0))
         # unsupervised three-launch form (forward | fused link-prediction tail | weight gradients)
         self.cogather_lp_fwd = float(os.environ.get("GS_COGATHER_LP_FWD", 0.20))      # 0.30 with the stream forward (round 5); the tiled forward holds a CU per workgroup: 176.2 vs 179.5 us/step
         self.cogather_lp_tail = float(os.environ.get("GS_COGATHER_LP_TAIL", 0.25))
