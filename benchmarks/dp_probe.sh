@@ -2,7 +2,7 @@
 # Probe of the data-parallel step SCHEDULE on one GPU (a stand-in wait in the collective's place), one gpurun call:
 #   GS_PROBE_DP_SCHEDULE=<us>  the in-graph schedule: slab sum (+ sampler) | sleeping wave (the collective) | clip + Adam
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=${1:-$R/gpurun_out/dp_probe}
+O=${1:-$R/gpurun_out/dp_probe}; shift
 mkdir -p $O
 cd $R
 i=0
