@@ -1,4 +1,4 @@
-"""profiles/r05_aux_dominant.json from the rocprofv3 --kernel-trace summaries of the aux configurations (benchmarks/rocpd_stats.py
+"""profiles/rNN_aux_dominant.json from the rocprofv3 --kernel-trace summaries of the aux configurations (benchmarks/rocpd_stats.py
 markdown): per configuration the step's kernels by time, the dominant one first -- read by bench.py (aux.*.roofline.dominant_kernel).
     python benchmarks/aux_dominant.py out.json graphsage_maxpool=profiles/r05_maxpool_kernel_stats.md unsupervised=... rmat=... gcn=..."""
 import json

@@ -639,19 +639,22 @@ static int dense_fwd_rows_split_impl(const float* X, int64_t ldx, const int32_t*
 // arithmetic above: 6 / 16 of the matrix-pipe time, the same fp32 accuracy class, fp32 operands in and out -- NO pre-cut copy of
 // the weights (a re-cut launch behind every optimizer step costs what the kernel wins).  With the pipe out of the way the design is
 // about filling 256 CUs with a 5632-row problem and about who cuts what:
-//   workgroup (8 waves) = 64 rows x 128 columns of ONE term (Reddit: 88 row tiles x 2 terms = 176 workgroups, one round);
-//   stage = 32 k.
+//   workgroup (FOUR waves) = 64 rows x 128 columns of ONE term (Reddit: 88 row tiles x 2 terms = 176 workgroups, one round);
+//   stage = 16 k.
 //   A (the (gathered) rows): one float4 per thread and stage through registers, cut ONCE per workgroup (22 VALU per thread) and
-//     written to LDS as pieces ([piece][row][32 k] bf16, 80-byte rows: conflict-free 16-byte fragment reads), three buffers;
+//     written to LDS as pieces ([piece][row][16 k] bf16, 48-byte rows: conflict-free 16-byte fragment reads), two buffers;
 //   B (the weights): raw fp32, global -> LDS by DMA (global_load_lds_dwordx4: a wave instruction = two k rows of the tile's 128
-//     columns; no register, no ds_write), ring of four stages; a wave reads the 8 k of its 32 columns as eight ds_read_b32 and
-//     cuts them itself (44 VALU) -- the eight waves are 2 (K halves of the stage) x 4 (column groups of 32), each over ALL 64
-//     rows, so every B element is cut exactly once per workgroup and an A fragment (pre-cut) is shared by four waves;
-//   a wave contracts ONE 16-k half of every stage for its 64 x 32 tile: 12 MFMAs per stage, two waves per SIMD; the two K halves
-//     of a tile are summed once, through LDS, in the epilogue (fixed order: deterministic);
+//     columns; no register, no ds_write), ring of four stages; wave w reads the 8 k of ITS 32 columns as eight ds_read_b32 and
+//     cuts them itself (44 VALU): every B element is cut exactly once per workgroup, an A fragment (pre-cut) is shared by the
+//     four waves;
+//   a wave contracts every stage for its 64 x 32 tile: 12 MFMAs per stage, one wave per SIMD;
 //   software pipeline: during stage s a wave issues the MFMAs of stage s from fragments it already holds, reads + cuts the
-//     fragments of stage s + 1, cuts and stores the A pieces of stage s + 2, requests A of stage s + 4 and B of stage s + 3, and
+//     fragments of stage s + 1, cuts and stores the A pieces of stage s + 2, requests A of stage s + 6 and B of stage s + 3, and
 //     meets the other waves once, at the end; the issue order inside a stage is pinned (a sched_barrier behind every slice).
+// Why four waves and 50 KB: the riders (next step's gather) inherit the launch's workgroup shape -- threads, registers AND dynamic
+// LDS.  The first version (8 waves = 2 K halves x 4 column groups, 32-k stages, 111 KB) was 2.6 us faster ALONE (20.2 vs 22.8 us)
+// and left no room for a rider workgroup on a host's CU; this one shares its CU with two (profiles/r06_tiled3_wgrad_ab.txt:
+// with half of the gather riding 31.1 vs 38.9 us; unsupervised step 157.7 vs 167.2 us).
 // Gather jobs of the next step ride as extra workgroups like in every launch of the step.
 struct Fwd3Term {
     const float* A;        // [*, lda] fp32; row i of the term is A[a_idx ? a_idx[i] : i]
