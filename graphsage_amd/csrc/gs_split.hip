@@ -672,6 +672,10 @@ struct Fwd3Args {
     int32_t act;
     int32_t tiles_m, tiles_n, n_tiles;     // n_tiles = tiles_m * tiles_n * nterms
 };
+// independent 16-byte loads a RIDER wave of the two tiled launches keeps in flight (gs_gather_dev.h: run_gather_item)
+#ifndef T3_RIDER_U
+#define T3_RIDER_U 8
+#endif
 #define F3_BM 64
 #define F3_NA 2            // A-piece buffers (stage s + 1 being read, stage s + 2 being written)
 #define F3_NB 4            // raw B stages in flight
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(256) void sage_tiled3_fwd_kernel(const Fwd3Args g, 
     constexpr int B_BASE = F3_NA * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= g.n_tiles) {
-        run_gather_item(J, ((int64_t)blockIdx.x - g.n_tiles) * 4 + wave, lane);
+        run_gather_item<T3_RIDER_U>(J, ((int64_t)blockIdx.x - g.n_tiles) * 4 + wave, lane);
         return;
     }
     const int l31 = lane & 31, lh = lane >> 5;
@@ -1035,7 +1039,7 @@ __global__ __launch_bounds__(256) void wgrad_tiled3_kernel(const Wg3Args G, cons
     constexpr int IDX_BASE = W3_NS * S_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= G.n_items) {
-        run_gather_item(J, ((int64_t)blockIdx.x - G.n_items) * 4 + wave, lane);
+        run_gather_item<T3_RIDER_U>(J, ((int64_t)blockIdx.x - G.n_items) * 4 + wave, lane);
         return;
     }
     const int l31 = lane & 31, lh = lane >> 5;
