@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 KNOWN_CAL_BYTES = 232966 * 608 * 4
-STEP_KERNELS = ["sage_stream_fwd_kernel", "sage_tail_kernel", "stream_wgrad_kernel", "flat_reduce_adam_kernel", "sample_fanout_kernel"]
+STEP_KERNELS = ["sage_tiled3_fwd_kernel", "sage_stream_fwd_kernel", "sage_tail_kernel", "wgrad_tiled3_kernel", "stream_wgrad_kernel", "flat_reduce_adam_kernel", "sample_fanout_kernel"]
 
 
 def per_kernel(db, counter):
