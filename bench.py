@@ -566,6 +566,16 @@ def main():
                     "gather_share_of_step": info["gather_share"]},
             "mfma": {"algorithmic_flops_per_launch": info["flops"], "achieved": info["flops"] / (us * 1e-6) / 1e12,
                      "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": info["flops"] / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}}
+        pp = info.get("piece_products", 1)
+        if pp > 1:
+            # the kernel computes in fp32-equivalent arithmetic on the bf16 pipe: `frac` above prices the algorithmic fp32 flops
+            # against the fp32 MFMA peak (what an fp32 kernel could reach at best); these price what is ISSUED against its own pipe
+            m = result["roofline_step_kernel"]["mfma"]
+            m["basis"] = "algorithmic fp32 flops / fp32 MFMA peak (the kernel itself issues bf16 MFMAs: see pipe_*)"
+            m["pipe"] = "bf16 (fp32 operands as three bf16 pieces, %d MFMAs per product tile)" % pp
+            m["pipe_flops_issued_per_launch"] = pp * info["flops"]
+            m["pipe_peak"] = MFMA_16BIT_PEAK_TF
+            m["pipe_frac"] = pp * info["flops"] / (us * 1e-6) / 1e12 / MFMA_16BIT_PEAK_TF
 
     if args.model in ("graphsage_maxpool", "graphsage_meanpool") and not args.unsupervised:
         # pooling aggregators: the dominant kernel is the MLP contraction over every gathered neighbor row

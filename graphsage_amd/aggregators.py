@@ -267,6 +267,7 @@ class MeanAggregator(_SageBase):
                 "gather_bytes": sum(j.n * j.s * j.d * 4 + j.n * j.s * 4 + j.n * j.d * 4 for j in jobs_),
                 "gemm_bytes": n_total * (d_in + means.d) * 4 + (d_in + means.d) * self.output_dim * 4 + n_total * n_out * 4,
                 "flops": 2.0 * n_total * (d_in + means.d) * self.output_dim,
+                "piece_products": 6 if tiled3 else 1,       # MFMAs issued per fp32 product tile (bf16 pipe) | fp32 pipe
                 "gather_share": sum(j.n * j.s for j in jobs_) / float(max(1, sum(nv.shape3[0] * nv.shape3[1] for nv in neighs)))})
         else:
             ops.sage_dense_fwd(self_in.src, self_in.ids, means, None, n_total, self.vars['self_weights'].value,

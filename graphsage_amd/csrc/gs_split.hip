@@ -1279,8 +1279,9 @@ extern "C" int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, in
         p.tiles_n = (int)gs_ceil_div(q.out_dim, 128);
         p.n_slabs = q.n_slabs;
         p.kchunk = (int32_t)(gs_ceil_div(gs_ceil_div(q.n, q.n_slabs), 32) * 32);
-        GS_REQUIRE(!q.a_idx || p.kchunk <= W3_MAXROWS, "gs_dense_wgrad_grouped_tiled3: a row-gathered problem needs slices of <= %d rows "
-                   "(n = %lld, n_slabs = %d)", W3_MAXROWS, (long long)q.n, q.n_slabs);
+        // (every problem: the kernel reads a slice's source rows -- ids or the rows themselves -- from its LDS row list)
+        GS_REQUIRE(p.kchunk <= W3_MAXROWS, "gs_dense_wgrad_grouped_tiled3: a slice holds at most %d rows (n = %lld, n_slabs = %d)",
+                   W3_MAXROWS, (long long)q.n, q.n_slabs);
         p.item_start = (int32_t)items;
         items += (int64_t)p.tiles_m * p.tiles_n * q.n_slabs;
     }

@@ -241,7 +241,7 @@ int gs_dense_wgrad_grouped_stream(const gs_wgrad_desc* descs_host, int32_t n_des
  * co-scheduled gather jobs -- in the three-piece bf16 arithmetic of gs_sage_dense_fwd_tiled3 (fp32 in and out, the accuracy of an
  * fp32 FMA chain), LDS-tiled: one 8-wave workgroup per (64 x 128 tile of dW, reduction slice), both operands moved HBM -> LDS raw
  * by LDS-DMA and cut by the waves that read them.  <= 12 problems; a slice is round_up(ceil(n / n_slabs), 32) rows and must not
- * exceed 1024; row addresses are 64-bit (tables beyond 4 GB are fine: a_rows is not needed).  A slab whose slice is empty is
+ * exceed 1024 (any problem, gathered or dense); row addresses are 64-bit (tables beyond 4 GB are fine: a_rows is not needed).  A slab whose slice is empty is
  * written as zeros.  Replaces the TF-op group of aggregators.py:51-58's gradient (tf.gradients of the two matmuls). */
 int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
                                   int32_t n_jobs, void* stream);

@@ -225,6 +225,24 @@ def test_dense_wgrad_grouped_tiled3_shapes(dev, n, d, out, col0, ns, gathered):
     assert torch.equal(torch.nan_to_num(sl), torch.nan_to_num(sl2))
 
 
+def test_dense_wgrad_grouped_tiled3_refuses_slices_beyond_its_row_list(dev):
+    """A slice's source rows live in a 1024-entry LDS list -- for dense problems too: longer slices are refused, not mis-addressed."""
+    import ctypes
+    from graphsage_amd import _lib
+    n, d, out = 4100, 64, 64
+    Ad, Zd = Mat.zeros(n, d, dev), Mat.zeros(n, out, dev)
+    jn = (_lib.GatherDesc * 1)()
+    q, sl, _ = _wgrad_desc(Ad, None, Zd, 0, out, n, d, 4, dev)             # 4 slices of 1056 rows
+    arr = (_lib.WgradDesc * 1)(q)
+    with pytest.raises(_lib.GraphsageAmdError, match="at most 1024 rows"):
+        ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr), 1, ctypes.addressof(jn), 0, ops.current_stream())
+    q, sl, _ = _wgrad_desc(Ad, None, Zd, 0, out, n, d, 5, dev)             # 5 slices of 832 rows: fine
+    arr = (_lib.WgradDesc * 1)(q)
+    ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr), 1, ctypes.addressof(jn), 0, ops.current_stream())
+    torch.cuda.synchronize()
+    assert float(sl.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n_max,count,d,out,act,bias", [
     (6000, 5000, 602, 512, ops.ACT_RELU, True),      # the pooling MLP's shape (fewer rows), device-side row count
     (300, 300, 602, 512, ops.ACT_RELU, True),        # three row tiles, the last one ragged
