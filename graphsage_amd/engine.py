@@ -321,33 +321,22 @@ class Engine(object):
         return out
 
     def _tiled3_slabs(self):
-        """Slab counts for gs_dense_wgrad_grouped_tiled3, or None when a problem cannot take it.  A workgroup holds its CU for its
-        slice's 32-row stages, so the launch is cut into ONE round: the smallest stage count L per workgroup with
-        sum(tiles x ceil(stages / L)) <= CUs (the Reddit step: 11 slices of 512 rows for the two 602 x 128 layer-0 problems, 1 for
-        the 512-row layer-1 / head problems = 233 workgroups; 12 + 2 would be 265 = two rounds: 37 vs 22 us alone,
-        benchmarks/micro_wgrad.py).  A slice holds at most 1024 rows (its row ids live in LDS)."""
+        """Slab counts for gs_dense_wgrad_grouped_tiled3 (tiled3_slab_policy over the pending problems), or None when a problem
+        cannot take it."""
         if len(self._pending) > 12:
             return None
         probs, reserved = [], {}
         for v, A, ai, dZ, _, n, _ in self._pending:
             tiles = ((v.rows + 63) // 64) * ((v.cols + 127) // 128)
             cap = MAX_SLABS - v.n_slabs - reserved.get(id(v), 0)
-            kmin = (n + 1023) // 1024
-            if cap < kmin:
+            if cap < (n + 1023) // 1024:
                 return None
-            probs.append((tiles, (n + 31) // 32, kmin, cap, id(v)))
-            reserved[id(v)] = reserved.get(id(v), 0) + kmin      # (what the later problems of the variable can still count on)
-        slots = self._tiled3_wg_slots
-        total = sum(t * st for t, st, _, _, _ in probs)
-        L = max(4, (total + slots - 1) // slots)
-        while True:
-            ks = [int(max(kmin, min(cap, (st + L - 1) // L))) for t, st, kmin, cap, _ in probs]
-            if sum(t * k for (t, _, _, _, _), k in zip(probs, ks)) <= slots or L >= 32:
-                break
-            L += 1
+            probs.append((tiles, n, cap))
+            reserved[id(v)] = reserved.get(id(v), 0) + (n + 1023) // 1024    # (what the later problems of the variable can count on)
+        ks = tiled3_slab_policy(probs, self._tiled3_wg_slots)
         used = {}
-        for (t, st, kmin, cap, vid), k in zip(probs, ks):       # several problems of one variable share its arena
-            used[vid] = used.get(vid, 0) + k
+        for (v, *_), k in zip(self._pending, ks):               # several problems of one variable share its arena
+            used[id(v)] = used.get(id(v), 0) + k
         for v in {id(p[0]): p[0] for p in self._pending}.values():
             if v.n_slabs + used.get(id(v), 0) > MAX_SLABS:
                 return None
@@ -566,6 +555,24 @@ class Engine(object):
 
 
 _default_engine = None
+
+
+def tiled3_slab_policy(probs, slots):
+    """Split-K slab counts for ONE launch of gs_dense_wgrad_grouped_tiled3.  probs: (tiles, reduction rows, slab capacity) per
+    problem; slots: workgroups of one round (one per CU).  A workgroup holds its CU for its slice's 32-row stages, so the launch is
+    cut into ONE round: the smallest stage count L per workgroup with sum(tiles x ceil(stages / L)) <= slots -- the Reddit step: 11
+    slices of 512 rows for the two 602 x 128 layer-0 problems, 1 for the 512-row layer-1 / head problems = 233 workgroups (12 + 2
+    would be 265 = two rounds: 32 vs 24 us alone, benchmarks/micro_wgrad.py).  A slice holds at most 1024 rows (its row list lives
+    in LDS), so L <= 32 and launches beyond slots x 32 stages take more than one round."""
+    st = [(n + 31) // 32 for _, n, _ in probs]
+    kmin = [(n + 1023) // 1024 for _, n, _ in probs]
+    total = sum(t * s_ for (t, _, _), s_ in zip(probs, st))
+    L = max(4, (total + slots - 1) // slots)
+    while True:
+        ks = [int(max(km, min(cap, (s_ + L - 1) // L))) for (t, _, cap), s_, km in zip(probs, st, kmin)]
+        if sum(t * k for (t, _, _), k in zip(probs, ks)) <= slots or L >= 32:
+            return ks
+        L += 1
 
 
 def get_engine():

@@ -280,3 +280,24 @@ def test_descriptor_struct_layouts_match_the_library():
     finally:
         _lib.WgradDesc = fields
         _lib._lib = saved
+
+
+def test_tiled3_slab_policy_cuts_a_pass_into_one_round():
+    """engine.tiled3_slab_policy (host logic of gs_dense_wgrad_grouped_tiled3's launch): one round of workgroups where the pass fits,
+    slices of <= 1024 rows always, slab capacity respected."""
+    from graphsage_amd.engine import tiled3_slab_policy
+    # the Reddit step: two 602 x 128 problems over 5632 rows (10 tiles each), layer 1 (4 tiles x 2), head (4), bias (1) over 512 rows
+    probs = [(10, 5632, 64), (10, 5632, 64), (4, 512, 64), (4, 512, 64), (4, 512, 64), (1, 512, 64)]
+    ks = tiled3_slab_policy(probs, 256)
+    assert ks == [11, 11, 1, 1, 1, 1] and sum(t * k for (t, _, _), k in zip(probs, ks)) == 233
+    # the unsupervised step: 11,484 rows -> 12 slices of 960 rows (<= 1024), one round
+    ks = tiled3_slab_policy([(10, 11484, 64), (10, 11484, 64), (4, 1044, 64), (4, 1044, 64)], 256)
+    assert ks[0] == ks[1] == 12 and all((n + k - 1) // k <= 1024 for (_, n, _), k in zip([(10, 11484, 64)] * 2, ks[:2]))
+    assert sum(t * k for t, k in zip((10, 10, 4, 4), ks)) <= 256
+    # more work than one round of 1024-row slices holds: the row limit wins over the round
+    ks = tiled3_slab_policy([(40, 16000, 64)], 256)
+    assert ks == [16] and (16000 + 15) // 16 <= 1024
+    # a nearly full slab arena caps the count (the caller has checked cap >= ceil(n / 1024))
+    assert tiled3_slab_policy([(10, 5632, 6), (10, 5632, 64)], 256) [0] == 6
+    # tiny problems: one slice each
+    assert tiled3_slab_policy([(1, 33, 64), (1, 7, 64)], 256) == [1, 1]
