@@ -96,7 +96,10 @@ def test_bench_path_matches_oracle(dev, agg_type, steps):
         before = np_params(model, agg_type)
         loss, preds = model.train_step_device(B, fetch=True)
         # the kernels bench.py times: the LDS-tiled three-piece weight gradients (and layer-0 forward) -- not a fallback
-        assert model.engine.tiled3_fwd and model.engine.last_wgrad_kernel == "tiled3", model.engine.last_wgrad_kernel
+        # (GS_TILED3_FWD=0 / GS_TILED3_WGRAD=0, the documented opt-outs, run this same test through the stream kernels)
+        import os
+        if os.environ.get("GS_TILED3_FWD", "1") == "1" and os.environ.get("GS_TILED3_WGRAD", "1") == "1":
+            assert model.engine.tiled3_fwd and model.engine.last_wgrad_kernel == "tiled3", model.engine.last_wgrad_kernel
         # ---- S1/S2: the ids the device drew == the CPU restatement of the counter hash (bit exact)
         batch = order[t * B:(t + 1) * B]
         got = [s.cpu().numpy() for s in model.samples1]
