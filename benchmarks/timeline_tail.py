@@ -23,10 +23,21 @@ def main():
     model.train_steps_device(T.B, 25, steps_per_launch=8)
     torch.cuda.synchronize()
     lib = _lib.load()
-    buf = (ctypes.c_ulonglong * (64 * 16))()
-    assert lib.gs_debug_tail_timeline(buf, 64 * 16) == 0
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)[:32, :11]
-    t = (t - t[:, 0].min()) * 0.01
+    NW = 64 * 16 + 256 * 8
+    buf = (ctypes.c_ulonglong * NW)()
+    assert lib.gs_debug_tail_timeline(buf, NW) == 0
+    raw = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+    t = raw[:64 * 16].reshape(64, 16)[:32, :11]
+    hp = raw[64 * 16:].reshape(256, 8)[:128, :6]
+    t00 = min(t[:, 0].min(), hp[:, 0].min())
+    hp = (hp - t00) * 0.01
+    print("z helpers (128 workgroups), us after the launch's first stamp:")
+    for k, name in enumerate(["entry", "operands landed, A rows in LDS", "MFMAs + partial tiles in LDS", "z stores issued",
+                              "z stores acknowledged (all waves)", "arrival counter incremented (returned)"]):
+        print("  %-42s min %5.2f  median %5.2f  max %5.2f" % (name, hp[:, k].min(), np.median(hp[:, k]), hp[:, k].max()))
+    for term, sl in (("self-term slabs", [i for i in range(128) if i % 4 < 2]), ("neighbor-term slabs", [i for i in range(128) if i % 4 >= 2])):
+        print("  %-20s operands landed median %5.2f, counter done median %5.2f" % (term, np.median(hp[sl, 1]), np.median(hp[sl, 5])))
+    t = (t - t00) * 0.01
     print("riders: split3 %.2f tail %.2f; block start %.1f..%.1f us, end %.1f..%.1f us" % (
         model.cogather_split3, model.cogather_tail, t[:, 0].min(), t[:, 0].max(), t[:, 10].min(), t[:, 10].max()))
     d = np.diff(t, axis=1)

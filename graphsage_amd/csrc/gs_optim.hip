@@ -164,16 +164,36 @@ extern "C" int gs_sumsq_scaled(const float* x, int64_t count, float scale, float
 // ---------------------------------------------------------------------------------------------------
 // Flat gradient finalisation (+ optional fused clip/Adam): one launch over the whole parameter buffer.
 #define GS_MAX_VARS 24
+__device__ __forceinline__ int64_t gs_readfirstlane_i64(const int64_t x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// One variable of the flat buffer in units of float4 (every offset / size is a multiple of 4 floats, the buffer is below 2^31
+// float4): 32 bytes, ONE scalar load for a wave-uniform index.
+struct FlatVar {
+    float* slabs;
+    int64_t size;                     // floats: the slab stride
+    int32_t qoff, qsize;              // float4 units
+    int32_t n_slabs;
+    int16_t decay, clear;
+};
 struct FlatVars {
-    int64_t offset[GS_MAX_VARS];
-    int64_t size[GS_MAX_VARS];
-    float* slabs[GS_MAX_VARS];
-    int32_t n_slabs[GS_MAX_VARS];
-    int32_t decay[GS_MAX_VARS];
-    int32_t clear[GS_MAX_VARS];
+    int32_t qoff[GS_MAX_VARS];        // the offsets once more, side by side (INT32_MAX beyond n): the variable search is one batch of loads
+    FlatVar v[GS_MAX_VARS];
     int32_t n;
 };
 
+#ifdef GS_TIMELINE
+// Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_optim.py): wall-clock stamps (100 MHz) of the optimizer workgroups
+// [entry, descriptors known, slabs landed, stores issued] and of the first rider workgroups [entry, end].
+__device__ unsigned long long g_opt_timeline[1024 * 4];
+extern "C" int gs_debug_opt_timeline(unsigned long long* out_host, int n) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_opt_timeline), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define OPT_STAMP(slot, k) do { if (threadIdx.x == 0 && (slot) < 1024) g_opt_timeline[(slot) * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define OPT_STAMP(slot, k) do { } while (0)
+#endif
 __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const FlatVars V, float* __restrict__ params,
                                                                float* __restrict__ grads, float* __restrict__ m,
                                                                float* __restrict__ v, int64_t total4, float wd,
@@ -188,26 +208,46 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
     // round trips of almost no work, hidden under this launch instead of heading a step as its own 7 us launch.
     __shared__ int32_t lvl[2][GS_FANOUT_LDS_SMALL];
     if ((int)blockIdx.x >= opt_blocks) {
-        const int64_t r = (int64_t)blockIdx.x - opt_blocks;
+        int64_t r = (int64_t)blockIdx.x - opt_blocks;
+        OPT_STAMP(512 + (int)r, 0);
+        if (loss_rows) {
+            // the step's scalar loss (supervised_models.py:111-118 reduce_mean): one wave of a workgroup of its own, fixed order
+            // (as the first wave of optimizer workgroup 0 it put a round trip ahead of that workgroup's own)
+            if (r == 0) {
+                if (threadIdx.x < 64) {
+                    float sacc = 0.f;
+                    for (int64_t i = threadIdx.x; i < loss_n; i += 64) sacc += loss_rows[i];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+                    if (threadIdx.x == 0) loss_out[0] = loss_accumulate ? loss_out[0] + sacc * loss_scale : sacc * loss_scale;
+                }
+                return;
+            }
+            --r;
+        }
         if (r < F.B) sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, lvl);
         else run_gather_item<8, 25>(J, (r - F.B) * (GS_OPT_THREADS / 64) + (threadIdx.x >> 6), threadIdx.x & 63);   // ... and gather+mean waves of the next mini-batch
+        OPT_STAMP(512 + (int)r + (loss_rows ? 1 : 0), 1);
         return;
     }
+    OPT_STAMP((int)blockIdx.x, 0);
+    // The launch is one float4 per thread and latency-bound; its dependent chain is [kernel arguments + every variable offset] ->
+    // [the wave's variable descriptor + the step counter] -> [slabs, parameter, Adam state] -> stores.  (A per-lane variable index
+    // made offset, size, slab pointer, clear and decay flags five dependent vector loads of the argument block; a scalar search
+    // loop was as many dependent scalar loads: 2.1 us between a workgroup's entry and its slab requests, benchmarks/timeline_optim.py.)
+    uint64_t t_dev = 0ull;
+    if (fuse_adam && step_dev) t_dev = *step_dev;
     float lr_t = 0.f;
-    if (fuse_adam) lr_t = gs_adam_lr_t(lr, b1, b2, step_dev, step_offset);
-    if (loss_rows && blockIdx.x == 0 && threadIdx.x < 64) {
-        // the step's scalar loss (supervised_models.py:111-118 reduce_mean): one wave, fixed order
-        float sacc = 0.f;
-        for (int64_t i = threadIdx.x; i < loss_n; i += 64) sacc += loss_rows[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
-        if (threadIdx.x == 0) loss_out[0] = loss_accumulate ? loss_out[0] + sacc * loss_scale : sacc * loss_scale;
-    }
+    bool have_lr = false;
+    auto bias_correction = [&]() {
+        if (fuse_adam && !have_lr) {
+            const float t = (float)(t_dev + (uint64_t)step_offset);
+            lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));      // gs_adam_lr_t
+            have_lr = true;
+        }
+    };
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)opt_blocks * blockDim.x) {
         const int64_t i = q * 4;  // every segment offset/size is a multiple of 4 floats
-        int k = 0;
-        while (k + 1 < V.n && i >= V.offset[k + 1]) ++k;
-        const int64_t rel = i - V.offset[k];
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         // parameter and Adam state first: their loads share the round trip of the slab loads below
         f32x4 p = *reinterpret_cast<const f32x4*>(params + i);
@@ -216,25 +256,54 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
             mi = *reinterpret_cast<const f32x4*>(m + i);
             vi = *reinterpret_cast<const f32x4*>(v + i);
         }
-        if (rel < V.size[k]) {
-            float* sp = V.slabs[k] + rel;
-            const int ns = V.n_slabs[k];
-            const int64_t sz = V.size[k];
-            // 24 slab loads in flight per thread (the launch is one float4 per thread and latency-bound: the 22 slabs of
-            // a Reddit step are ONE memory round trip; with 4 in flight they were 6-8); summation order stays z = 0, 1, ...
-            for (int z0 = 0; z0 < ns; z0 += 24) {
-                f32x4 sv[24];
+        // the variable(s) of this WAVE's 64 float4 (wave-uniform indices: scalar loads).  The variables tile the flat buffer in
+        // order (checked on the host); a wave almost always lies inside one.
+        const int q_lo = __builtin_amdgcn_readfirstlane((int)q);   // the first active lane holds the wave's smallest index
+        const int q_hi = q_lo + 63;
+        int klo = 0, khi = 0;
 #pragma unroll
-                for (int u = 0; u < 24; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
-#pragma unroll
-                for (int u = 0; u < 24; ++u)
-                    if (z0 + u < ns) g += sv[u];
-            }
-            if (V.clear[k]) *reinterpret_cast<f32x4*>(sp) = f32x4{0.f, 0.f, 0.f, 0.f};   // atomic accumulator: consume
+        for (int j = 1; j < GS_MAX_VARS; ++j) {
+            klo += q_lo >= V.qoff[j] ? 1 : 0;
+            khi += q_hi >= V.qoff[j] ? 1 : 0;
         }
-        if (V.decay[k] && wd != 0.f) g = gs_wd_add(g, p, wd);
+        bool decay = false;
+        OPT_STAMP((int)blockIdx.x, 1);
+        for (int k = klo; k <= khi; ++k) {
+            FlatVar d;                                             // (two 16-byte scalar loads, not a lazy load per field)
+            {
+                typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4* src = reinterpret_cast<const i32x4*>(&V.v[k]);
+                i32x4* dst = reinterpret_cast<i32x4*>(&d);
+                dst[0] = src[0];
+                dst[1] = src[1];
+            }
+            const int64_t sz = d.size;
+            const int relq = (int)q - d.qoff;
+            if (relq >= 0 && relq < d.qsize) {
+                float* sp = d.slabs + 4 * (int64_t)relq;
+                const int ns = d.n_slabs;
+                // 24 slab loads in flight per thread (the 22 slabs of a Reddit step are ONE memory round trip; with 4 in flight
+                // they were 6-8); summation order stays z = 0, 1, ...
+                for (int z0 = 0; z0 < ns; z0 += 24) {
+                    f32x4 sv[24];
+#pragma unroll
+                    for (int u = 0; u < 24; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
+#pragma unroll
+                    for (int u = 0; u < 24; ++u)
+                        if (z0 + u < ns) g += sv[u];
+                }
+                if (d.clear) *reinterpret_cast<f32x4*>(sp) = f32x4{0.f, 0.f, 0.f, 0.f};   // atomic accumulator: consume
+                decay = d.decay != 0;
+            }
+        }
+#ifdef GS_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        OPT_STAMP((int)blockIdx.x, 2);
+        if (decay && wd != 0.f) g = gs_wd_add(g, p, wd);
         *reinterpret_cast<f32x4*>(grads + i) = g;
         if (fuse_adam) {
+            bias_correction();
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pe = p[e], me = mi[e], ve = vi[e];
@@ -245,6 +314,7 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
             *reinterpret_cast<f32x4*>(v + i) = vi;
             *reinterpret_cast<f32x4*>(params + i) = p;
         }
+        OPT_STAMP((int)blockIdx.x, 3);
     }
 }
 
@@ -260,18 +330,22 @@ static int flat_reduce_adam_impl(const gs_var_desc* vars_host, int32_t n_vars, f
     GS_REQUIRE(!fuse_adam || (m && v), "gs_flat_reduce_adam: Adam state missing");
     FlatVars V = {};
     V.n = n_vars;
+    for (int i = 0; i < GS_MAX_VARS; ++i) V.qoff[i] = INT32_MAX;
     int64_t expect = 0;
     for (int i = 0; i < n_vars; ++i) {
         GS_REQUIRE(vars_host[i].offset == expect && vars_host[i].size > 0 && vars_host[i].size % 4 == 0,
                    "gs_flat_reduce_adam: variables must tile the flat buffer in order (var %d)", i);
         GS_REQUIRE(vars_host[i].n_slabs == 0 || (vars_host[i].slabs && gs_aligned16(vars_host[i].slabs)),
                    "gs_flat_reduce_adam: slabs of var %d missing/misaligned", i);
-        V.offset[i] = vars_host[i].offset;
-        V.size[i] = vars_host[i].size;
-        V.slabs[i] = vars_host[i].slabs;
-        V.n_slabs[i] = vars_host[i].n_slabs;
-        V.decay[i] = vars_host[i].decay;
-        V.clear[i] = vars_host[i].clear;
+        GS_REQUIRE((vars_host[i].offset + vars_host[i].size) / 4 < INT32_MAX, "gs_flat_reduce_adam: flat buffer beyond 2^31 float4");
+        V.qoff[i] = (int32_t)(vars_host[i].offset / 4);
+        V.v[i].qoff = (int32_t)(vars_host[i].offset / 4);
+        V.v[i].qsize = (int32_t)(vars_host[i].size / 4);
+        V.v[i].size = vars_host[i].size;
+        V.v[i].slabs = vars_host[i].slabs;
+        V.v[i].n_slabs = vars_host[i].n_slabs;
+        V.v[i].decay = vars_host[i].decay ? 1 : 0;
+        V.v[i].clear = vars_host[i].clear ? 1 : 0;
         GS_REQUIRE(!vars_host[i].clear || vars_host[i].n_slabs == 1, "gs_flat_reduce_adam: var %d: clear needs n_slabs == 1", i);
         expect += vars_host[i].size;
     }
@@ -286,8 +360,9 @@ static int flat_reduce_adam_impl(const gs_var_desc* vars_host, int32_t n_vars, f
     int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
     if (rc != GS_OK) return rc;
     const int64_t rider_blocks = gs_ceil_div(waves, GS_OPT_THREADS / 64);
-    GS_REQUIRE(blocks + roots + rider_blocks < (1ll << 31), "gs_flat_reduce_adam: grid too large");
-    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3((unsigned)(blocks + roots + rider_blocks)), dim3(GS_OPT_THREADS), 0, (hipStream_t)stream, V,
+    const int loss_block = loss_rows ? 1 : 0;
+    GS_REQUIRE(blocks + loss_block + roots + rider_blocks < (1ll << 31), "gs_flat_reduce_adam: grid too large");
+    hipLaunchKernelGGL(flat_reduce_adam_kernel, dim3((unsigned)(blocks + loss_block + roots + rider_blocks)), dim3(GS_OPT_THREADS), 0, (hipStream_t)stream, V,
                        params, grads, m, v, total4, weight_decay, fuse_adam, lr, beta1, beta2, eps, clip, grad_scale, step_dev,
                        step_offset, loss_rows, loss_n, loss_scale, loss_out, loss_accumulate, blocks, F, J);
     GS_LAUNCH_CHECK("flat_reduce_adam_kernel");

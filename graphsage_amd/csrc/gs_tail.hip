@@ -25,18 +25,19 @@
 #include "gs_common.h"
 #include "gs_gather_dev.h"
 
-#include "gs_tail_dev.h"
-
 #ifdef GS_TIMELINE
-// Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_tail.py): wall-clock stamp (100 MHz) per phase boundary.
-__device__ unsigned long long g_tail_timeline[64 * 16];
+// Diagnostics build only (-DGS_TIMELINE, benchmarks/timeline_tail.py): wall-clock stamp (100 MHz) per phase boundary of the main
+// workgroups (rows [0, 64)) and of the z helpers (rows [64, 64 + 256), 8 stamps each).
+__device__ unsigned long long g_tail_timeline[64 * 16 + 256 * 8];
 extern "C" int gs_debug_tail_timeline(unsigned long long* out_host, int n) {
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_tail_timeline), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
 }
 #define TAIL_STAMP(k) do { if (threadIdx.x == 0 && grp < 64) g_tail_timeline[grp * 16 + (k)] = wall_clock64(); } while (0)
+#define TAIL_HELPER_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_tail_timeline[64 * 16 + blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
+#include "gs_tail_dev.h"
 template <int D, int O, int CW>
 __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
     // Co-scheduled gather: the tail occupies n/16 CUs for ~30 us of mostly waiting; the other ~220 CUs (one 8-wave
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         return;
     }
     if ((int)blockIdx.x < hp * G) {
-        tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP);
+        tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP, G);
         return;
     }
     const int grp = (int)blockIdx.x - hp * G;
@@ -165,7 +166,6 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
             b7[sl][m][1] = *reinterpret_cast<const f32x4*>(B0 + 16 * ldw + 16 * m);
         }
     };
-    load_b7(0);
     // phase 5 (d_y, NT form): rows n0 .. n0+31 of W_head, K = Cp32 <= 64 CW -> up to 4 CW macro steps x 2 tiles
     f32x4 bh5[4 * CW][2];
     {
@@ -181,39 +181,26 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     }
     // (two class groups: the wider logits / d_y operands take the registers of the second input-gradient slab, which is
     // requested after the loss phase instead -- phases 5-6 cover its round trip)
-    if (DPW > 1 && CW == 1) load_b7(DPW - 1);
     TAIL_STAMP(2);
 
-    // ---------------- phase 1: pick up z from the helpers
-    // The wait is BOUNDED (~0.3 s): if the helpers of this launch never arrive (a tool that serialises workgroups, a
-    // dispatch order that starves them) the workgroup sets the error flag and goes on with whatever z holds -- the step's
-    // numbers are then garbage but the stream does not hang, and the host raises on the flag at its next fetch.
-    uint32_t sync_base = 0u;
-    if (tid == 0 && !a.z_ready) {
-        sync_base = __hip_atomic_load(a.sync + G + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0u;
-        while (__hip_atomic_load(a.sync + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sync_base < (uint32_t)HP) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) {
-                __hip_atomic_fetch_or(a.sync + 2 * G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    {
-        // device-scope loads (they bypass this XCD's possibly stale L2 lines of z; no cache invalidation needed)
-        constexpr int Z2 = (2 * O) / 2;
+    // ---------------- phase 1: pick up z: the helpers' granules (fused form), or the z rows an earlier launch wrote (split form)
+    uint32_t z_tag = 0u;
+    if (!a.z_ready) {
+        // (two class groups: the wider head operands leave registers for half the granules at a time)
+        z_tag = tail_pick_up_z<Z, (CW > 1 && TAIL_ROWS * Z / TAIL_THREADS >= 8) ? TAIL_ROWS * Z / TAIL_THREADS / 2 : TAIL_ROWS * Z / TAIL_THREADS>(a, G, grp, Zs, ldzs);
+    } else {
+        constexpr int Z2 = Z / 2;
 #pragma unroll
         for (int p = 0; p < TAIL_ROWS * Z2 / TAIL_THREADS; ++p) {
             const int it = tid + p * TAIL_THREADS;
             const int r = it / Z2, c = (it % Z2) * 2;
-            union { f32x2 f; unsigned long long u; } cv;
-            cv.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.z + min(r0 + r, n - 1) * (int)a.ldz + c),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *reinterpret_cast<f32x2*>(Zs + r * (2 * O + 4) + c) = cv.f;
+            *reinterpret_cast<f32x2*>(Zs + r * ldzs + c) = *reinterpret_cast<const f32x2*>(a.z + min(r0 + r, n - 1) * (int)a.ldz + c);
         }
     }
+    // the input-gradient weight slabs (256 KB per workgroup) are requested BEHIND the z pick-up: loads return in order, so ahead
+    // of it they stood between the polls and their data (3 us of this CU's 64 B/clk fill path); phases 2-6 cover them
+    load_b7(0);
+    if (DPW > 1 && CW == 1) load_b7(DPW - 1);
     lds_barrier();
     TAIL_STAMP(3);
 
@@ -234,7 +221,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         for (int m = 0; m < Z / 64; ++m) {
             const float y = v[m] * inv;
             Zs[row * ldzs + lane + 64 * m] = y;
-            if (r0 + row < n) a.y[(r0 + row) * (int)a.ldy + lane + 64 * m] = y;
+            if (r0 + row < n) {
+                a.y[(r0 + row) * (int)a.ldy + lane + 64 * m] = y;
+                if (!a.z_ready) a.z[(r0 + row) * (int)a.ldz + lane + 64 * m] = v[m];    // (the granules are kernel-internal)
+            }
         }
         if (lane == 0) invs[row] = inv;
     }
@@ -326,7 +316,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         if (valid && lane == 0) a.loss_rows[i] = loss;
     }
     if (!a.train) {
-        if (!a.z_ready) tail_sync_done<HP>(a, G, grp, sync_base);
+        if (!a.z_ready) tail_epoch_done(a, G, grp, z_tag);
         if (grp == 0 && tid == 0) {
             if (a.c0) *a.c0 += a.d0;
             if (a.c1) *a.c1 += a.d1;
@@ -455,7 +445,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     }
     TAIL_STAMP(10);
-    if (!a.z_ready) tail_sync_done<HP>(a, G, grp, sync_base);
+    if (!a.z_ready) tail_epoch_done(a, G, grp, z_tag);
     if (grp == 0 && tid == 0) {                       // device counters (sampler clock / epoch cursor / optimizer step)
         if (a.c0) *a.c0 += a.d0;
         if (a.c1) *a.c1 += a.d1;
@@ -474,7 +464,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void sage_tail_z_kernel(const Tail
         run_gather_item<8>(J, ((int64_t)blockIdx.x - HP * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
-    tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP, false);
+    tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP, G, false);
 }
 
 static size_t tail_z_lds_bytes(int D) { return ((size_t)TAIL_ROWS * (D + 4) + (size_t)TAIL_WAVES * TAIL_ROWS * 64) * sizeof(float); }
@@ -680,8 +670,9 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     a.gcn = q->gcn ? 1 : 0;
     GS_REQUIRE(!q->gcn || (q->W_neigh == q->W_self + O && q->ldwn == q->ldws),
                "gs_sage_tail_fwd_bwd: gcn form takes ONE weight matrix (W_neigh == W_self + out_dim, same ld)");
-    GS_REQUIRE(q->sync || q->z_ready, "gs_sage_tail_fwd_bwd: sync (2 * ceil(n / 16) + 2 zero-initialised uint32 words, private "
-                                      "to the caller's stream) missing");
+    GS_REQUIRE(q->sync || q->z_ready, "gs_sage_tail_fwd_bwd: sync (2 G + 2 + 64 G out_dim zero-initialised uint32 words, G = ceil(n / 16), "
+                                      "private to the caller's stream) missing");
+    GS_REQUIRE(!q->sync || (reinterpret_cast<uintptr_t>(q->sync) & 7u) == 0, "gs_sage_tail_fwd_bwd: sync must be 8-byte aligned");
     a.sync = q->sync;
     hipStream_t st = (hipStream_t)stream;
     CoGatherS J = {};

@@ -22,10 +22,15 @@ struct TailArgs {
     float* d_h0; int64_t lddh;
     uint64_t* c0; uint64_t d0; uint64_t* c1; uint64_t d1; uint64_t* c2; uint64_t d2;
     int32_t train;
-    // hand-over state of the z helpers, G = ceil(n / 16) groups: [0, G) monotonic arrival counters (helpers add 1),
-    // [G, 2G) arrivals already consumed by earlier launches (written only by the group's main workgroup), [2G] error
-    // flags (bit 0: a main workgroup gave up waiting, bit 1: a group saw a number of arrivals other than HP).  Nothing
-    // is ever reset, so a launch does not depend on a reset store of the previous one.
+    // hand-over state of the z helpers, G = ceil(n / 16) groups.
+    //   gs_linkpred_tail (counter form): [0, G) monotonic arrival counters (helpers add 1), [G, 2G) arrivals already consumed by
+    //   earlier launches (written only by the group's main workgroup), [2G] error flags (bit 0: a main workgroup gave up
+    //   waiting, bit 1: a group saw a number of arrivals other than HP).
+    //   gs_sage_tail_fwd_bwd (granule form): [G, 2G) the group's launch EPOCH (written only by the group's main workgroup, at its
+    //   end), [2G] error flags (bit 0), and from word 2G + 2 on G x 16 x 2 O eight-byte granules {z element, tag}: a helper
+    //   writes every element of its slab as ONE 8-byte device-scope store tagged epoch + 1, the main workgroup polls the
+    //   granules themselves -- no flag, no drained store queue, no second round trip behind a flag.
+    // Nothing is ever reset, so a launch does not depend on a reset store of the previous one.
     uint32_t* sync;
     // split form: z (and the neighbor means) were written by a PREVIOUS launch (sage_tail_z_kernel): this launch has no
     // helper workgroups, waits for nothing and touches no hand-over state
@@ -93,6 +98,9 @@ __device__ __forceinline__ float tail_wave_max(float v) {
 }
 
 #define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
+#ifndef TAIL_HELPER_STAMP
+#define TAIL_HELPER_STAMP(k) do { } while (0)
+#endif
 
 // z helper (see the role comment in sage_tail_kernel): z[16 rows of group g][64 columns part*64 ..] of
 //   z = [h_self . W_self | mean_j(h_neigh_j) . W_neigh]      (aggregators.py:48-58, concat, identity act)
@@ -100,7 +108,7 @@ __device__ __forceinline__ float tail_wave_max(float v) {
 // summed in wave order through LDS, then published: stores -> device-scope release fence -> arrival counter.
 // The helper whose slab starts the neighbor term also writes the neighbor means (an input of the weight gradients).
 template <int D, int O>
-__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part, const bool publish = true) {
+__device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, const int part, const int G, const bool publish = true) {
     constexpr int ldh = D + 4;
     constexpr int D4 = D / 4;
     constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;
@@ -109,6 +117,7 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     float* As = lds;                                             // [16][ldh]  the term's A rows
     float* Pz = lds + TAIL_ROWS * ldh;                           // [8 waves][16][64] partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    TAIL_HELPER_STAMP(0);
     const int j = lane & 15, q = lane >> 4;
     const int n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
     const int col_base = part * 64;
@@ -123,6 +132,11 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
 #pragma unroll
         for (int u = 0; u < KW; ++u) bz[t][u] = *reinterpret_cast<const f32x2*>(Wp + (4 * u) * ldw + 32 * t);
     const float inv_s = 1.0f / (float)s, inv_s1 = 1.0f / (float)(s + 1);
+    // the tag of this launch's granules: the group's epoch + 1 (the epoch word is written by the group's main workgroup at the
+    // END of a launch, i.e. after it has consumed every granule of this helper: a kernel boundary lies between that store and
+    // this load)
+    uint32_t tag = 0u;
+    if (publish) tag = a.sync[G + g] + 1u;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int it = tid + p * TAIL_THREADS;
@@ -150,6 +164,7 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
         *reinterpret_cast<f32x4*>(As + r * ldh + c) = valid ? v : zero4;
     }
     lds_barrier();
+    TAIL_HELPER_STAMP(1);
     {
         const float* A = As + j * ldh + 4 * wave * KW + q;
 #pragma unroll
@@ -167,6 +182,7 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
         }
     }
     lds_barrier();
+    TAIL_HELPER_STAMP(2);
 #pragma unroll
     for (int p = 0; p < TAIL_ROWS * 32 / TAIL_THREADS; ++p) {     // (row, column pair) items: 16 x 32
         const int it = tid + p * TAIL_THREADS;
@@ -174,21 +190,70 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
         f32x2 v = *reinterpret_cast<const f32x2*>(Pz + r * 64 + c2);
 #pragma unroll
         for (int w = 1; w < TAIL_WAVES; ++w) v += *reinterpret_cast<const f32x2*>(Pz + (w * TAIL_ROWS + r) * 64 + c2);
-        // published with device-scope (write-through) stores: a release FENCE would write back the XCD's whole L2,
-        // dirty gather output of the riders included (measured: z arrived 17 us late)
-        bool zvalid;
-        const int zi = tail_row(a, g, r, zvalid);
-        if (zvalid) {
-            union { f32x2 f; unsigned long long u; } cv;
-            cv.f = v;
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.z + zi * (int)a.ldz + col_base + c2), cv.u,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (publish) {
+            // Published as GRANULES: {element, tag} in ONE 8-byte device-scope (write-through) store each -- the data is its own
+            // flag (an 8-byte store is single-copy atomic), every row of the group (the main workgroup polls all 16 x 2 O
+            // granules; rows that do not exist carry zeros).  (A release FENCE would write back the XCD's whole L2, dirty gather
+            // output of the riders included -- z arrived 17 us late; z stores + drained queue + arrival counter + the main
+            // workgroup's poll + its z loads were 5 dependent round trips, 5-6 us behind the helpers' last MFMA.)
+            unsigned long long* zg = reinterpret_cast<unsigned long long*>(a.sync + 2 * G + 2) +
+                                     ((int64_t)g * TAIL_ROWS + r) * (2 * O) + col_base + c2;
+            union { float f; uint32_t u; } c0v, c1v;
+            c0v.f = v.x; c1v.f = v.y;
+            __hip_atomic_store(zg, ((unsigned long long)tag << 32) | c0v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zg + 1, ((unsigned long long)tag << 32) | c1v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            bool zvalid;                                             // split form: the kernel boundary is the hand-over
+            const int zi = tail_row(a, g, r, zvalid);
+            if (zvalid) *reinterpret_cast<f32x2*>(a.z + zi * (int)a.ldz + col_base + c2) = v;
         }
     }
-    if (!publish) return;                                        // split form: the kernel boundary is the hand-over
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores are acknowledged ...
-    __syncthreads();                                             // ... and everybody else's
-    if (tid == 0) __hip_atomic_fetch_add(a.sync + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TAIL_HELPER_STAMP(3);
+}
+
+// Main workgroup: this launch's z rows of group g from the helpers' granules into Zs [16][ldzs] (every thread polls its own
+// 16 x Z / TAIL_THREADS granules with device-scope loads until all carry the launch's tag).  BOUNDED: if a helper of this launch
+// never arrives (a tool that serialises workgroups, a dispatch order that starves it) the error flag is set and the workgroup
+// goes on with whatever the granules hold -- the step's numbers are then garbage, but the stream does not hang, and the host
+// raises on the flag at its next fetch.  Returns the tag (the group's new epoch, stored by tail_sync_done).
+template <int Z, int CH>
+__device__ __forceinline__ uint32_t tail_pick_up_z(const TailArgs& a, const int G, const int grp, float* Zs, const int ldzs) {
+    constexpr int NG = TAIL_ROWS * Z / TAIL_THREADS;             // granules per thread (8 for Z = 256), polled CH at a time
+    static_assert(NG % CH == 0, "chunk");
+    const uint32_t tag = a.sync[G + grp] + 1u;                   // (written by this workgroup's predecessor: a kernel boundary ago)
+    const unsigned long long* zg = reinterpret_cast<const unsigned long long*>(a.sync + 2 * G + 2) + (int64_t)grp * TAIL_ROWS * Z;
+    bool ok = true;
+#pragma unroll
+    for (int p0 = 0; p0 < NG; p0 += CH) {
+        unsigned long long gr[CH];
+        uint32_t spins = 0u;
+        bool all;
+        do {
+#pragma unroll
+            for (int p = 0; p < CH; ++p)
+                gr[p] = __hip_atomic_load(zg + threadIdx.x + (p0 + p) * TAIL_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            all = true;
+#pragma unroll
+            for (int p = 0; p < CH; ++p) all = all && (uint32_t)(gr[p] >> 32) == tag;
+            if (all) break;
+            __builtin_amdgcn_s_sleep(8);
+        } while (++spins < (1u << 18));
+        ok = ok && all;
+#pragma unroll
+        for (int p = 0; p < CH; ++p) {
+            const int it = threadIdx.x + (p0 + p) * TAIL_THREADS;
+            union { uint32_t u; float f; } cv;
+            cv.u = (uint32_t)gr[p];
+            Zs[(it / Z) * ldzs + it % Z] = cv.f;
+        }
+    }
+    if (!ok) __hip_atomic_fetch_or(a.sync + 2 * G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return tag;
+}
+
+// End of a main workgroup of the granule form: the group's epoch advances (the next launch's tag differs).
+__device__ __forceinline__ void tail_epoch_done(const TailArgs& a, const int G, const int grp, const uint32_t tag) {
+    if (threadIdx.x == 0) a.sync[G + grp] = tag;
 }
 
 // z helper of a whole TERM (gs_unsup_tail.hip): all O columns of z's self half (term 0) or neighbor-mean half (term 1) of

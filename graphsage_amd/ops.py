@@ -501,9 +501,11 @@ def sage_tail_supported(d_in, out_dim, C):
     return bool(_lib.load().gs_sage_tail_supported(int(d_in), int(out_dim), int(C)))
 
 
-def tail_sync_words(n):
-    """Size (uint32 words) of the hand-over buffer gs_sage_tail_fwd_bwd needs for n batch rows."""
-    return 2 * ((n + 15) // 16) + 2
+def tail_sync_words(n, out_dim=128):
+    """Size (uint32 words) of the hand-over buffer gs_sage_tail_fwd_bwd needs for n batch rows: epochs, the error word and
+    16 x 2*out_dim eight-byte granules per 16-row group (gs_tail_desc.sync).  A buffer serves ONE n."""
+    G = (n + 15) // 16
+    return 2 * G + 2 + 64 * G * out_dim
 
 
 def tail_sync_error(sync, n):
@@ -522,9 +524,9 @@ def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels
     entry with z_ready (no helpers, no hand-over state) carrying `jobs`; same results bit for bit."""
     if sync is None and not split:
         import torch
-        sync = torch.zeros(tail_sync_words(n), dtype=torch.int32, device=h0.buf.device)
+        sync = torch.zeros(tail_sync_words(n, out_dim), dtype=torch.int32, device=h0.buf.device)
         torch.cuda.synchronize()
-    assert split or sync.numel() >= tail_sync_words(n)
+    assert split or sync.numel() >= tail_sync_words(n, out_dim)
     q = _lib.TailDesc()
     q._keep = sync
     q.sync = ptr(sync) if not split else None

@@ -129,7 +129,8 @@ class SupervisedGraphsage(SampleAndAggregate):
             counters = []
             self._tail_step_advanced = False
             # hand-over state of the launch's helper workgroups: private to this model (its engine stream)
-            self._tail_sync = e.ws_i32(("tail_sync", self.name), ops.tail_sync_words(n))
+            # (one buffer per batch size: its layout depends on n, and stale granules of another layout must never be met)
+            self._tail_sync = e.ws_i32(("tail_sync", self.name, n, O1), ops.tail_sync_words(n, O1))
             self._tail_sync_n = n
             if epilogue:
                 if epilogue.get("step"):

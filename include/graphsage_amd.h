@@ -38,7 +38,7 @@ extern "C" {
 #define GS_ACT_IDENTITY 0
 #define GS_ACT_RELU 1
 
-#define GS_ABI_VERSION 9
+#define GS_ABI_VERSION 10
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -584,12 +584,12 @@ typedef struct gs_tail_desc {
     uint64_t* c1; uint64_t d1;
     uint64_t* c2; uint64_t d2;
     int32_t s, d_in, out_dim, C, sigmoid, train;
-    uint32_t* sync;        /* [2 * ceil(n / 16) + 2] device words, zero-initialised ONCE by the caller and private to one
-                              stream (in-kernel hand-over of the layer-1 pre-activations from the helper workgroups to the
-                              row-group workgroups): monotonic arrival counters, consumed counts, and at index
-                              2 * ceil(n / 16) an error word the caller should check when it fetches results (bit 0: a
-                              row-group workgroup gave up waiting (bounded wait), bit 1: unexpected arrival count).
-                              May be NULL when z_ready != 0. */
+    uint32_t* sync;        /* [2 * G + 2 + 64 * G * out_dim] device words, G = ceil(n / 16), 8-byte aligned, zero-initialised ONCE by
+                              the caller, private to one stream and to ONE n (ABI 10; in-kernel hand-over of the layer-1
+                              pre-activations from the helper workgroups to the row-group workgroups): words [G, 2 G) = the
+                              groups' launch epochs, word 2 G = an error word the caller should check when it fetches results
+                              (bit 0: a row-group workgroup gave up waiting -- the wait is bounded), and from word 2 G + 2 on
+                              G x 16 x 2*out_dim eight-byte granules {z element, epoch tag}.  May be NULL when z_ready != 0. */
     int32_t z_ready;       /* != 0: z and means were written by gs_sage_tail_z on this stream (split form): the launch has no
                               helper workgroups, no in-kernel hand-over and needs no sync buffer */
     int32_t gcn;           /* != 0: GCNAggregator form of layer 1 (aggregators.py:101-116; gs_sage_tail_fwd_bwd and gs_sage_tail_z):
