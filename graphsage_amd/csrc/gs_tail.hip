@@ -38,7 +38,10 @@ extern "C" int gs_debug_tail_timeline(unsigned long long* out_host, int n) {
 #define TAIL_STAMP(k) do { } while (0)
 #endif
 #include "gs_tail_dev.h"
-template <int D, int O, int CW>
+// (diagnostics / A-B: GS_TAIL_HALVES=0 in the environment keeps one main workgroup per group)
+static const bool g_tail_halves = [] { const char* e = getenv("GS_TAIL_HALVES"); return !(e && e[0] == '0'); }();
+
+template <int D, int O, int CW, int NH>
 __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs a, const int tail_blocks, const CoGatherS J) {
     // Co-scheduled gather: the tail occupies n/16 CUs for ~30 us of mostly waiting; the other ~220 CUs (one 8-wave
     // workgroup each: the launch's LDS size is uniform) stream a share of the NEXT step's gather+mean from HBM meanwhile.
@@ -50,29 +53,38 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     // prefetches every later phase's operands and then picks z up.  Helpers never wait for anything and have the lower
     // block indices (dispatched first), so a waiting main workgroup never keeps a helper off the chip for good; all
     // (HP + 1) G workgroups are resident at once for n <= 816 (one 8-wave workgroup per CU).
+    // NH = 2 (training launches, D = 256): TWO main workgroups per group.  Both pick z up and run the small head phases
+    // redundantly (identical values; half 0 stores them); the input-gradient contraction, the relu masks and the d_h0 stores --
+    // 8 of a main workgroup's 12 us behind the pick-up, all of them bound by ONE CU's matrix pipe and store path -- are split by
+    // COLUMNS: half h owns columns [128 h, 128 h + 128) of d_self and of d_means (both terms of a column stay together: the GCN
+    // form adds them).
     constexpr int HP = 2 * O / 64;
     const int G = tail_blocks;
     const int hp = a.z_ready ? 0 : HP;                   // split form: no helper workgroups in this launch
-    if ((int)blockIdx.x >= (hp + 1) * G) {
+    if ((int)blockIdx.x >= (hp + NH) * G) {
         // (a rider wave walking 4 consecutive items with prefetched ids, and 25 loads in flight per lane, were measured:
         // 46 us / no change against 35 us -- with one 8-wave workgroup per CU the riders stream at ~4.6 TB/s either way)
-        run_gather_item<13>(J, ((int64_t)blockIdx.x - (hp + 1) * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+        run_gather_item<13>(J, ((int64_t)blockIdx.x - (hp + NH) * G) * TAIL_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
     if ((int)blockIdx.x < hp * G) {
         tail_z_helper<D, O>(a, (int)blockIdx.x / HP, (int)blockIdx.x % HP, G);
         return;
     }
-    const int grp = (int)blockIdx.x - hp * G;
+    const int mb = (int)blockIdx.x - hp * G;
+    const int half = NH > 1 ? mb / G : 0;                // workgroup-uniform
+    const int grp = mb - half * G;
     TAIL_STAMP(0);
     constexpr int Z = 2 * O;
     constexpr int ldh = D + 4, ldzs = Z + 4;
     constexpr int D4 = D / 4;
-    constexpr int PASSES = TAIL_ROWS * D4 / TAIL_THREADS;        // (row, float4 column) items per thread: D / 128
+    static_assert(NH == 1 || (NH == 2 && D == 256), "two main workgroups per group: D = 256 only");
+    constexpr int D4H = D4 / NH;                                  // float4 columns of a row this workgroup owns
+    constexpr int PASSES = TAIL_ROWS * D4H / TAIL_THREADS;        // (row, float4 column) items per thread: D / 128 / NH
     constexpr int ZSLABS = Z / 32;                                // 32-column slabs of z / d_y  (<= 8: one per wave)
     constexpr int DSLABS = 2 * D / 32;                            // 32-column slabs of [d_self | d_means]
-    constexpr int DPW = DSLABS / TAIL_WAVES;                      // ... per wave (1 or 2)
-    constexpr int KZ = D / 4;                                     // k-steps (4 k each) of the z contraction
+    constexpr int DPW = DSLABS / TAIL_WAVES / NH;                 // ... per wave of this workgroup (1 or 2)
+
     constexpr int M7 = O / 16;                                    // macro steps (16 k each) of the input-gradient contraction
     constexpr int ldi = 2 * D + 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int it = tid + p * TAIL_THREADS;
-        const int r = it / D4, c = (it % D4) * 4;
+        const int r = it / D4H, c = (half * D4H + it % D4H) * 4;
         const int i = min(r0 + r, n - 1);
         hself[p] = *reinterpret_cast<const f32x4*>(a.h0 + i * ldh0 + c);
         const float* nb = a.h0 + (n + i * s) * ldh0 + c;
@@ -155,8 +167,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     }
     // phase 7 ([d_self | d_means], NT form): DPW slabs of 32 weight rows, K = O
     f32x4 b7[DPW][M7][2];
+    // first of the 32 columns of [d_self | d_means] (in [0, 2D)) of this wave's slab sl
+    auto slab_col0 = [&](const int sl) -> int {
+        if (NH == 1) return (wave + sl * TAIL_WAVES) * 32;
+        return (wave >> 2) * D + half * (D / 2) + (wave & 3) * 32;     // waves 0-3: d_self, 4-7: d_means, this half's 128 columns
+    };
     auto load_b7 = [&](const int sl) {
-        const int col0 = (wave + sl * TAIL_WAVES) * 32;          // in [0, 2D)
+        const int col0 = slab_col0(sl);
         const int term = col0 >= D ? 1 : 0;
         const int ldw = (int)(term ? a.ldwn : a.ldws);
         const float* B0 = (term ? a.Wn : a.Ws) + (col0 - term * D + j) * ldw + 4 * q;
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         for (int m = 0; m < Z / 64; ++m) {
             const float y = v[m] * inv;
             Zs[row * ldzs + lane + 64 * m] = y;
-            if (r0 + row < n) {
+            if (r0 + row < n && half == 0) {
                 a.y[(r0 + row) * (int)a.ldy + lane + 64 * m] = y;
                 if (!a.z_ready) a.z[(r0 + row) * (int)a.ldz + lane + 64 * m] = v[m];    // (the granules are kernel-internal)
             }
@@ -307,17 +324,17 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
             const int c = lane + 64 * m;
             const float gv = (valid && in[m]) ? gl[m] : 0.f;
             if (c < Cp32) DLs[row * ldc + c] = gv;
-            if (valid && c < Cp4) {
+            if (valid && c < Cp4 && half == 0) {
                 if (a.logits) a.logits[i * (int)a.ldlo + c] = in[m] ? x[m] : 0.f;
                 if (a.preds) a.preds[i * (int)a.ldp + c] = in[m] ? pr[m] : 0.f;
                 a.dlogits[i * (int)a.lddl + c] = gv;
             }
         }
-        if (valid && lane == 0) a.loss_rows[i] = loss;
+        if (valid && lane == 0 && half == 0) a.loss_rows[i] = loss;
     }
     if (!a.train) {
-        if (!a.z_ready) tail_epoch_done(a, G, grp, z_tag);
-        if (grp == 0 && tid == 0) {
+        if (!a.z_ready) tail_epoch_done<NH>(a, G, grp, z_tag);
+        if (grp == 0 && half == 0 && tid == 0) {
             if (a.c0) *a.c0 += a.d0;
             if (a.c1) *a.c1 += a.d1;
             if (a.c2) *a.c2 += a.d2;
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         for (int m = 0; m < Z / 64; ++m) {
             const float g = clamped ? dy[m] * inv : inv * (dy[m] - yv[m] * dot);
             DZs[row * ldzs + lane + 64 * m] = g;
-            if (r0 + row < n) a.dz[(r0 + row) * (int)a.lddz + lane + 64 * m] = g;
+            if (r0 + row < n && half == 0) a.dz[(r0 + row) * (int)a.lddz + lane + 64 * m] = g;
         }
     }
     lds_barrier();
@@ -383,7 +400,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
     float* DIN = Hs;                                   // [16][2D + 8]   (Hs | Ms are dead since phase 1)
 #pragma unroll
     for (int sl = 0; sl < DPW; ++sl) {
-        const int col0 = (wave + sl * TAIL_WAVES) * 32;
+        const int col0 = slab_col0(sl);
         const int term = col0 >= D ? 1 : 0;
         const float* A = DZs + term * O + j * ldzs + 4 * q;
         f32x4 acc0 = zero4, acc1 = zero4;
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int it = tid + p * TAIL_THREADS;
-            const int r = it / D4, c = (it % D4) * 4;
+            const int r = it / D4H, c = (half * D4H + it % D4H) * 4;
             const int i = r0 + r;
             if (i < n) {
                 f32x4 g_self = *reinterpret_cast<const f32x4*>(DIN + r * ldi + c);
@@ -445,8 +462,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void sage_tail_kernel(const TailArgs 
         }
     }
     TAIL_STAMP(10);
-    if (!a.z_ready) tail_epoch_done(a, G, grp, z_tag);
-    if (grp == 0 && tid == 0) {                       // device counters (sampler clock / epoch cursor / optimizer step)
+    if (!a.z_ready) tail_epoch_done<NH>(a, G, grp, z_tag);
+    if (grp == 0 && half == 0 && tid == 0) {                       // device counters (sampler clock / epoch cursor / optimizer step)
         if (a.c0) *a.c0 += a.d0;
         if (a.c1) *a.c1 += a.d1;
         if (a.c2) *a.c2 += a.d2;
@@ -605,16 +622,26 @@ extern "C" int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C) 
     return ok ? 1 : 0;
 }
 
-template <int D, int O, int CW>
-static int launch_tail_cw(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
+template <int D, int O, int CW, int NH>
+static int launch_tail_nh(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
     const size_t lds = tail_lds_bytes(a.D, a.O, a.C);
-    GS_LDS_ATTR(160 * 1024, sage_tail_kernel<D, O, CW>);
-    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + 1 main workgroup each
-    const int64_t blocks = (int64_t)tail_blocks * ((a.z_ready ? 0 : 2 * O / 64) + 1) + gs_ceil_div(gather_waves, TAIL_WAVES);
+    GS_LDS_ATTR(160 * 1024, sage_tail_kernel<D, O, CW, NH>);
+    const int tail_blocks = (int)gs_ceil_div(a.n, TAIL_ROWS);       // groups of 16 rows: (2 O / 64) z helpers + NH main workgroups each
+    const int64_t blocks = (int64_t)tail_blocks * ((a.z_ready ? 0 : 2 * O / 64) + NH) + gs_ceil_div(gather_waves, TAIL_WAVES);
     GS_REQUIRE(blocks < (1ll << 31), "gs_sage_tail_fwd_bwd: grid too large");
-    hipLaunchKernelGGL((sage_tail_kernel<D, O, CW>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
+    hipLaunchKernelGGL((sage_tail_kernel<D, O, CW, NH>), dim3((unsigned)blocks), dim3(TAIL_THREADS), lds, st, a, tail_blocks, J);
     GS_LAUNCH_CHECK("sage_tail_kernel");
     return GS_OK;
+}
+
+// Training launches over 256 input columns run two main workgroups per group (see sage_tail_kernel); forward-only launches
+// (the second workgroup would have nothing of its own) and D = 128 (one input-gradient slab per wave already) run one.
+template <int D, int O, int CW>
+static int launch_tail_cw(const TailArgs& a, const CoGatherS& J, int64_t gather_waves, hipStream_t st) {
+    if constexpr (D == 256) {
+        if (a.train && g_tail_halves) return launch_tail_nh<D, O, CW, 2>(a, J, gather_waves, st);
+    }
+    return launch_tail_nh<D, O, CW, 1>(a, J, gather_waves, st);
 }
 
 template <int D, int O>

@@ -251,9 +251,19 @@ __device__ __forceinline__ uint32_t tail_pick_up_z(const TailArgs& a, const int 
     return tag;
 }
 
-// End of a main workgroup of the granule form: the group's epoch advances (the next launch's tag differs).
+// End of a main workgroup of the granule form: the group's epoch advances (the next launch's tag differs).  With NH main
+// workgroups per group the LAST of them to finish stores it (word grp of the buffer counts finished main workgroups, NH per
+// launch, never reset): each of them has read the epoch by then, whatever order they were dispatched in.
+template <int NH>
 __device__ __forceinline__ void tail_epoch_done(const TailArgs& a, const int G, const int grp, const uint32_t tag) {
-    if (threadIdx.x == 0) a.sync[G + grp] = tag;
+    if (threadIdx.x == 0) {
+        if (NH == 1) {
+            a.sync[G + grp] = tag;
+        } else {
+            const uint32_t old = __hip_atomic_fetch_add(a.sync + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((old + 1u) % (uint32_t)NH == 0u) a.sync[G + grp] = tag;
+        }
+    }
 }
 
 // z helper of a whole TERM (gs_unsup_tail.hip): all O columns of z's self half (term 0) or neighbor-mean half (term 1) of

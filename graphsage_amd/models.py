@@ -114,6 +114,14 @@ class SampleAndAggregate(object):
         # 0.35 since round 6 -- the four-wave tiled forward and weight-gradient workgroups leave room for two rider workgroups on
         # their own CUs (profiles/r06_tiled3_wgrad_ab.txt: headline 97.7 us/step; 0.15 | 0.5 | 0.35 with the stream kernels, where
         # the tail -- 32 busy CUs -- was the best host).
+        # Round 6, two main workgroups per group in the fused tail (training launches over 256 input columns, gs_tail.hip): the
+        # tail's own chain is 19 us instead of 26, and what it hosts for free is a fixed AMOUNT of gather (~64 MB: 64 + 128 idle
+        # CUs for 19 / 11 us), not a fixed share -- rider_shares() sets (forward | tail | weight gradients) from the step's gather
+        # bytes: 0.40 | 0.20 | 0.40 for the Reddit step (321 MB: 98.3 -> 94.0 us/step), 0.125 | 0.75 | 0.125 for RMAT
+        # (79 MB: 67.4 -> 59.9); profiles/r06_tail_halves_ab.txt.  GS_COGATHER_TAIL / GS_COGATHER_SPLIT3 pin fixed shares.
+        self.tail_halves = os.environ.get("GS_TAIL_HALVES", "1") != "0"
+        self.cogather_auto = ("GS_COGATHER_TAIL" not in os.environ and "GS_COGATHER_SPLIT3" not in os.environ)
+        self.tail_free_bytes = 64e6
         self.cogather_split = float(os.environ.get("GS_COGATHER_SPLIT", 0.5 if self.engine.stream_gemm else 0.7))
         tiled = self.engine.stream_gemm and self.engine.tiled3_fwd and self.engine.tiled3_wgrad
         self.cogather_split3 = float(os.environ.get("GS_COGATHER_SPLIT3", 0.25 if tiled else 0.15))
@@ -221,6 +229,17 @@ class SampleAndAggregate(object):
     _OUT_ATTRS = ("samples1", "outputs_all", "outputs1", "agg_out", "_loss_rows", "_rr_rows", "aff_all", "_d_agg_out",
                   "_loss_accumulate", "_tape", "_lp_tail_used", "_tail_h0", "_tail_means", "_tail_dh0", "_lp_sync",
                   "_lp_sync_shape", "_epilogue_folded")
+
+    def rider_shares(self, jobs, tail_d_in):
+        """(forward share, tail share) of the next step's gather for the three-launch form (the weight gradients carry the
+        rest).  Fixed shares unless the fused tail runs two main workgroups per group (tail_d_in == 256); then the tail takes
+        what it hosts for free (tail_free_bytes) and the two contraction launches halve the rest."""
+        tiled = self.engine.stream_gemm and self.engine.tiled3_fwd and self.engine.tiled3_wgrad
+        if not (self.cogather_auto and self.tail_halves and tiled and tail_d_in == 256 and not self.tail_split):
+            return self.cogather_split3, self.cogather_tail
+        total = float(sum(j.n * j.s * j.d * 4 for j in jobs))
+        f_tail = min(0.75, max(0.10, self.tail_free_bytes / max(total, 1.0)))
+        return 0.5 * (1.0 - f_tail), f_tail
 
     def _roots(self, B, parity=None):
         """[batch1 (B) | batch2 (B) | negatives] = the head of the contiguous id buffer."""
@@ -872,6 +891,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
+                self.cogather_auto, self.tail_halves, self.tail_free_bytes,
                 self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.tiled3_fwd, e.tiled3_wgrad, e.split_pool, e.pool_f16, str(getattr(self, "pipeline", None)),
                 type(self.grad_hook).__name__,
                 id(self.grad_hook), law)

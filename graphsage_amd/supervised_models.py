@@ -405,7 +405,7 @@ class SupervisedGraphsage(SampleAndAggregate):
             # weight gradient): both are latency-bound, so the HBM-bound gather waves back-fill their idle slots
             if side_jobs and self.cogather_tail > 0 and self._tail_ok():
                 # the fused tail launch keeps only n/16 CUs busy: the rest of the chip streams a share of the gather
-                f_fwd, f_tail = self.cogather_split3, self.cogather_tail
+                f_fwd, f_tail = self.rider_shares(side_jobs, self.dims[1] if self.aggregator_type == "gcn" else 2 * self.dims[1])
                 fwd_jobs, rest = ops.split_gather_jobs(side_jobs, f_fwd)
                 tail_jobs, wgrad_jobs = ops.split_gather_jobs(rest, min(1.0, f_tail / max(1e-6, 1.0 - f_fwd)))
             else:
