@@ -91,6 +91,7 @@ _PROTOS = {
                                   _P, c_int64, _P, c_int32, _P],
     "gs_dense_wgrad_grouped_stream": [_P, c_int32, _P, c_int32, _P],
     "gs_dense_wgrad_grouped_tiled3": [_P, c_int32, _P, c_int32, _P],
+    "gs_dense_wgrad_grouped_tiled3_sample": [_P, c_int32, _P, c_int32, _P, _P],
     "gs_sage_dense_fwd_tiled3": [_P, c_int64, _P, c_int32, _P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int, _P,
                                  _P, c_int64, _P, c_int32, _P],
     "gs_split_rows_bytes": [c_int32, c_int32, _P],
@@ -186,7 +187,8 @@ class TailDesc(ctypes.Structure):
                 ("dz", c_void_p), ("lddz", c_int64), ("d_h0", c_void_p), ("lddh", c_int64),
                 ("c0", c_void_p), ("d0", c_uint64), ("c1", c_void_p), ("d1", c_uint64), ("c2", c_void_p), ("d2", c_uint64),
                 ("s", c_int32), ("d_in", c_int32), ("out_dim", c_int32), ("C", c_int32), ("sigmoid", c_int32),
-                ("train", c_int32), ("sync", c_void_p), ("z_ready", c_int32), ("gcn", c_int32)]
+                ("train", c_int32), ("sync", c_void_p), ("z_ready", c_int32), ("gcn", c_int32),
+                ("ids_copy_src", c_void_p), ("ids_copy_dst", c_void_p), ("ids_copy_n", c_int64)]
 
 
 class LpTailDesc(ctypes.Structure):

@@ -285,7 +285,12 @@ class MeanAggregator(_SageBase):
         n_out = o * (2 if self.concat else 1)
         dz = self._dz(d_out, out, n_total, n_out, pre_masked)
         col_n = o if self.concat else 0
-        e.wgrad(self.vars['self_weights'], self_in.src, self_in.ids, dz, 0, n_total)
+        # (wgrad_ids: the step's private copy of these ids, made by the fused tail launch when a later step's sampler rides in
+        #  the weight-gradient launch and refills the id buffer meanwhile -- SupervisedGraphsage._forward)
+        wg_ids = getattr(self, "wgrad_ids", None)
+        self.wgrad_ids = None
+        e.wgrad(self.vars['self_weights'], self_in.src, wg_ids if (wg_ids is not None and self_in.ids is not None) else self_in.ids,
+                dz, 0, n_total)
         e.wgrad(self.vars['neigh_weights'], means, None, dz, col_n, n_total)
         if self.bias:
             e.bgrad(self.vars['bias'], dz, n_total, n_out)

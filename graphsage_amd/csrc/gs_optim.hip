@@ -207,6 +207,7 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
     // Workgroups beyond opt_blocks run the fan-out SAMPLER of a later mini-batch (one root each): five dependent memory
     // round trips of almost no work, hidden under this launch instead of heading a step as its own 7 us launch.
     __shared__ int32_t lvl[2][GS_FANOUT_LDS_SMALL];
+    __shared__ int32_t law_cols[GS_MAX_HOPS][GS_LAW_COLS];
     if ((int)blockIdx.x >= opt_blocks) {
         int64_t r = (int64_t)blockIdx.x - opt_blocks;
         OPT_STAMP(512 + (int)r, 0);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
             }
             --r;
         }
-        if (r < F.B) sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, lvl);
+        if (r < F.B) sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, lvl, law_cols);
         else run_gather_item<8, 25>(J, (r - F.B) * (GS_OPT_THREADS / 64) + (threadIdx.x >> 6), threadIdx.x & 63);   // ... and gather+mean waves of the next mini-batch
         OPT_STAMP(512 + (int)r + (loss_rows ? 1 : 0), 1);
         return;

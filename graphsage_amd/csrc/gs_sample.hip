@@ -168,7 +168,8 @@ extern "C" int gs_stage_batch(const int32_t* order, int64_t n_order, const uint6
 // called hop by hop (same counter-based hash of (seed, step, hop, global row, j)).
 __global__ __launch_bounds__(256) void sample_fanout_kernel(const FanoutArgs a) {
     __shared__ int32_t lvl[2][GS_FANOUT_LDS];
-    sample_fanout_root<GS_FANOUT_LDS>(a, blockIdx.x, lvl);
+    __shared__ int32_t law_cols[GS_MAX_HOPS][GS_LAW_COLS];
+    sample_fanout_root<GS_FANOUT_LDS>(a, blockIdx.x, lvl, law_cols);
 }
 
 extern "C" int gs_sample_fanout_csr(const int64_t* rowptr, const int32_t* col, int64_t n_nodes, int32_t pad_id,

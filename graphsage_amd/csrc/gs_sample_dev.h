@@ -142,11 +142,21 @@ struct FanoutArgs {
 
 #define GS_LAW_COLS 128      // per-call columns kept in LDS up to this fan-out (larger fan-outs compute them per slot)
 
-// One workgroup (any size) per root `i`; lvl = two LDS fan-out buffers of CAP ints each.
+// One workgroup (any size) per root `i`; lvl = two LDS fan-out buffers of CAP ints each, law_cols = LDS for the calls' columns
+// (both handed in by the caller: a launch that carries the sampler as a rider gives it a piece of ITS LDS allocation).
+#define GS_FANOUT_LDS_INTS(CAP) (2 * (CAP) + GS_MAX_HOPS * GS_LAW_COLS)
 template <int CAP>
-__device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const int64_t i, int32_t (*lvl)[CAP]) {
+__device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const int64_t i, int32_t (*lvl)[CAP],
+                                                   int32_t (*law_cols)[GS_LAW_COLS]) {
     const int tid = threadIdx.x, nthr = blockDim.x;
-    __shared__ int32_t law_cols[GS_LAW_COLS];
+    // workgroup barrier that orders LDS only: what crosses it here (lvl, law_cols) lives in LDS, and __syncthreads() would also
+    // drain the global loads / stores in flight -- a round trip per barrier in a chain that is nothing but round trips
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    const uint64_t st = a.step + (a.step_dev ? *a.step_dev : 0ull);
     int32_t root = 0;
     if (a.pairs) {
         if (tid == 0) {
@@ -177,37 +187,48 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
         }
     } else if (a.order) {
         const uint64_t c = a.cursor ? *a.cursor : 0ull;
-        root = a.order[(int64_t)((c + (uint64_t)i) % (uint64_t)a.n_order)];
-        if (tid == 0) a.ids_all[a.offsets[0] + i] = root;
-        if (a.label_table) {
-            const int Cp = (a.C + 3) & ~3;
-            for (int k = tid; k < Cp; k += nthr)
-                a.labels_out[i * a.ldo + k] = k < a.C ? a.label_table[(int64_t)root * a.ldt + k] : 0.f;
-        }
+        root = a.order[(int64_t)((c + (uint64_t)i) % (uint64_t)a.n_order)];        // (requested; first used below the columns)
     } else {
         root = a.ids_all[a.offsets[0] + i];
     }
+    const uint32_t seg = a.law.law == GS_LAW_REFERENCE ? (uint32_t)(i >= a.seg1) + (uint32_t)(i >= a.seg2) : 0u;
+    auto hop_key = [&](const int h) -> uint64_t {
+        return gs_mix64(a.seed ^ (st * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(a.hop0 + seg * (uint32_t)a.n_hops + h) << 56));
+    };
+    // GS_LAW_REFERENCE: every hop's call columns once per workgroup instead of once per slot, all hops up front -- they depend on
+    // the sampler clock only, so the permutation arithmetic runs under the root's round trip instead of between the hops'
+    if (a.law.law == GS_LAW_REFERENCE) {
+        for (int h = 0; h < a.n_hops; ++h) {
+            const int s = a.fan[h];
+            if (s <= GS_LAW_COLS) {
+                const uint64_t key = hop_key(h);
+                for (int jj = tid; jj < s; jj += nthr) law_cols[h][jj] = (int32_t)gs_call_column(key, (uint32_t)jj, (uint32_t)a.law.max_degree);
+            }
+        }
+    }
+    if (a.order && !a.pairs && tid == 0) a.ids_all[a.offsets[0] + i] = root;
+    // The root's label row is only REQUESTED here (one element per thread when the row fits the workgroup) and stored behind
+    // the hops: storing it at once put its round trip in front of the first hop's -- the chain this workgroup is, and as a rider
+    // of the optimizer launch the thing that launch waits for (benchmarks/timeline_optim.py: riders 7-9 us, optimizer 5.3).
+    const int Cp_lab = (a.C + 3) & ~3;
+    const bool lab_late = a.order && !a.pairs && a.label_table && Cp_lab <= nthr;
+    float lab_v = 0.f;
+    if (lab_late && tid < a.C) lab_v = a.label_table[(int64_t)root * a.ldt + tid];
+    if (a.order && !a.pairs && a.label_table && !lab_late) {
+        for (int k = tid; k < Cp_lab; k += nthr)
+            a.labels_out[i * a.ldo + k] = k < a.C ? a.label_table[(int64_t)root * a.ldt + k] : 0.f;
+    }
     if (tid == 0) lvl[0][0] = root;
-    __syncthreads();
-    const uint64_t st = a.step + (a.step_dev ? *a.step_dev : 0ull);
+    lds_sync();
     int64_t count_prev = 1;
     for (int h = 0; h < a.n_hops; ++h) {
         const int s = a.fan[h];
         const int64_t count = count_prev * s;
-        const uint32_t seg = a.law.law == GS_LAW_REFERENCE ? (uint32_t)(i >= a.seg1) + (uint32_t)(i >= a.seg2) : 0u;
-        const uint64_t key = gs_mix64(a.seed ^ (st * 0x9E3779B97F4A7C15ull) ^
-                                      ((uint64_t)(a.hop0 + seg * (uint32_t)a.n_hops + h) << 56));
+        const uint64_t key = hop_key(h);
         const int32_t* prev = lvl[h & 1];
         int32_t* next = lvl[(h + 1) & 1];
         const bool keep = (h + 1 < a.n_hops);  // the last hop is only written to global memory
-        const int32_t* cols = nullptr;
-        if (a.law.law == GS_LAW_REFERENCE && s <= GS_LAW_COLS) {
-            // the call's s columns once per workgroup instead of once per slot (the previous hop's readers are past the
-            // barrier that ended that hop)
-            for (int jj = tid; jj < s; jj += nthr) law_cols[jj] = (int32_t)gs_call_column(key, (uint32_t)jj, (uint32_t)a.law.max_degree);
-            __syncthreads();
-            cols = law_cols;
-        }
+        const int32_t* cols = (a.law.law == GS_LAW_REFERENCE && s <= GS_LAW_COLS) ? law_cols[h] : nullptr;
         for (int64_t t = tid; t < count; t += nthr) {
             const int64_t pl = t / s;  // parent slot in the previous level
             const uint32_t j = (uint32_t)(t - pl * s);
@@ -230,9 +251,10 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
             if (keep) next[t] = pick;
             a.ids_all[a.offsets[h + 1] + i * count + t] = pick;
         }
-        __syncthreads();
+        lds_sync();
         count_prev = count;
     }
+    if (lab_late && tid < Cp_lab) a.labels_out[i * a.ldo + tid] = lab_v;
 }
 
 // host: validate (law, max_degree) against the fan-outs of the calls it will serve

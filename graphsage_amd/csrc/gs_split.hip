@@ -19,6 +19,7 @@
 //                             split-K epilogue; gather jobs of the next step ride as extra workgroups like before.
 #include "gs_common.h"
 #include "gs_gather_dev.h"
+#include "gs_sample_dev.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1032,14 +1033,24 @@ struct Wg3Args {
     int32_t n, n_items;
 };
 
-__global__ __launch_bounds__(256) void wgrad_tiled3_kernel(const Wg3Args G, const CoGatherS J) {
+__global__ __launch_bounds__(256) void wgrad_tiled3_kernel(const Wg3Args G, const FanoutArgs F, const CoGatherS J) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int A_BYTES = W3_KS * 64 * 4, B_BYTES = W3_KS * 128 * 4, S_BYTES = A_BYTES + B_BYTES;
     constexpr int IDX_BASE = W3_NS * S_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= G.n_items) {
-        run_gather_item<T3_RIDER_U>(J, ((int64_t)blockIdx.x - G.n_items) * 4 + wave, lane);
+        // Riders behind the contraction workgroups: first the fan-out SAMPLER of a later mini-batch, one root per workgroup (five
+        // dependent round trips of almost no work: as a rider of the optimizer launch it was what that launch waited for -- 8 us
+        // against the optimizer's own 5.5 -- here it ends long before the contraction does); then gather+mean waves.
+        const int64_t r = (int64_t)blockIdx.x - G.n_items;
+        if (r < F.B) {
+            int32_t* ints = reinterpret_cast<int32_t*>(smem);      // (a rider's share of the launch's LDS allocation)
+            sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, reinterpret_cast<int32_t (*)[GS_FANOUT_LDS_SMALL]>(ints),
+                                                    reinterpret_cast<int32_t (*)[GS_LAW_COLS]>(ints + 2 * GS_FANOUT_LDS_SMALL));
+            return;
+        }
+        run_gather_item<T3_RIDER_U>(J, (r - F.B) * 4 + wave, lane);
         return;
     }
     const int l31 = lane & 31, lh = lane >> 5;
@@ -1256,8 +1267,8 @@ __global__ __launch_bounds__(256) void wgrad_tiled3_kernel(const Wg3Args G, cons
 #undef W3_INFLIGHT
 }
 
-extern "C" int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
-                                             int32_t n_jobs, void* stream) {
+static int wgrad_grouped_tiled3_impl(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                     int32_t n_jobs, const FanoutArgs* sampler, void* stream) {
     GS_REQUIRE(descs_host && n_desc > 0 && n_desc <= W3_MAXP, "gs_dense_wgrad_grouped_tiled3: 1..%d problems", W3_MAXP);
     Wg3Args G = {};
     G.n = n_desc;
@@ -1291,11 +1302,42 @@ extern "C" int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, in
     int64_t waves = 0;
     int rc = build_cojobs_s(jobs_host, n_jobs, &J, &waves);
     if (rc != GS_OK) return rc;
-    const int64_t blocks = items + gs_ceil_div(waves, 4);
+    FanoutArgs F = {};
+    if (sampler) F = *sampler;
+    const int64_t blocks = items + F.B + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_dense_wgrad_grouped_tiled3: grid too large");
     const size_t lds = W3_NS * (W3_KS * 64 * 4 + W3_KS * 128 * 4) + W3_MAXROWS * 4;
+    static_assert(GS_FANOUT_LDS_INTS(GS_FANOUT_LDS_SMALL) * 4 <= W3_NS * (W3_KS * 64 * 4 + W3_KS * 128 * 4), "sampler rider LDS");
     GS_LDS_ATTR(lds, wgrad_tiled3_kernel);
-    hipLaunchKernelGGL(wgrad_tiled3_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G, J);
+    hipLaunchKernelGGL(wgrad_tiled3_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G, F, J);
     GS_LAUNCH_CHECK("wgrad_tiled3_kernel");
     return GS_OK;
+}
+
+extern "C" int gs_dense_wgrad_grouped_tiled3(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                             int32_t n_jobs, void* stream) {
+    return wgrad_grouped_tiled3_impl(descs_host, n_desc, jobs_host, n_jobs, nullptr, stream);
+}
+
+// ... with the fan-out sampler of a later mini-batch riding in the launch (gs_fanout_desc as gs_sample_fanout_desc takes it).
+// The caller guarantees that nothing this launch READS is written by that sampler: the row ids of a gathered problem must not be
+// the id buffer the sampler fills (gs_tail_desc.ids_copy_* makes the private copy the weight gradients read instead).
+extern "C" int gs_dense_wgrad_grouped_tiled3_sample(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                                    int32_t n_jobs, const gs_fanout_desc* sampler_host, void* stream) {
+    if (!sampler_host) return wgrad_grouped_tiled3_impl(descs_host, n_desc, jobs_host, n_jobs, nullptr, stream);
+    FanoutArgs F = {};
+    int64_t kmax = 0;
+    if (gs_fanout_args_desc(sampler_host, &F, &kmax) != GS_OK) return GS_EINVAL;
+    if (kmax > GS_FANOUT_LDS_SMALL) {
+        gs_set_error("gs_dense_wgrad_grouped_tiled3_sample: per-root fan-out %lld of a kept hop exceeds %d", (long long)kmax, GS_FANOUT_LDS_SMALL);
+        return GS_ENOTSUP;
+    }
+    int64_t last = sampler_host->B;                                // the id buffer's extent: [roots | hop 1 | ... | hop n_hops]
+    for (int h = 0; h < sampler_host->n_hops; ++h) last *= sampler_host->fan[h];
+    const int32_t* lo = sampler_host->ids_all;
+    const int32_t* hi = sampler_host->ids_all + sampler_host->offsets[sampler_host->n_hops] + last;
+    for (int i = 0; i < n_desc; ++i)
+        GS_REQUIRE(!descs_host[i].a_idx || descs_host[i].a_idx + descs_host[i].n <= lo || descs_host[i].a_idx >= hi,
+                   "gs_dense_wgrad_grouped_tiled3_sample: problem %d gathers through the id buffer the riding sampler writes", i);
+    return wgrad_grouped_tiled3_impl(descs_host, n_desc, jobs_host, n_jobs, &F, stream);
 }

@@ -695,6 +695,8 @@ extern "C" int gs_sage_tail_fwd_bwd(const gs_tail_desc* q, const gs_gather_desc*
     a.train = q->train ? 1 : 0;
     a.z_ready = q->z_ready ? 1 : 0;
     a.gcn = q->gcn ? 1 : 0;
+    GS_REQUIRE(q->ids_copy_n >= 0 && (q->ids_copy_n == 0 || (q->ids_copy_src && q->ids_copy_dst)), "gs_sage_tail_fwd_bwd: ids_copy pointers missing");
+    if (!q->z_ready) { a.ids_copy_src = q->ids_copy_src; a.ids_copy_dst = q->ids_copy_dst; a.ids_copy_n = q->ids_copy_n; }
     GS_REQUIRE(!q->gcn || (q->W_neigh == q->W_self + O && q->ldwn == q->ldws),
                "gs_sage_tail_fwd_bwd: gcn form takes ONE weight matrix (W_neigh == W_self + out_dim, same ld)");
     GS_REQUIRE(q->sync || q->z_ready, "gs_sage_tail_fwd_bwd: sync (2 G + 2 + 64 G out_dim zero-initialised uint32 words, G = ceil(n / 16), "
@@ -744,6 +746,8 @@ extern "C" int gs_sage_tail_z(const gs_tail_desc* q, const gs_gather_desc* jobs_
     a.means = q->means; a.ldm = q->ldm; a.z = q->z; a.ldz = q->ldz;
     a.z_ready = 1;
     a.gcn = q->gcn ? 1 : 0;
+    GS_REQUIRE(q->ids_copy_n >= 0 && (q->ids_copy_n == 0 || (q->ids_copy_src && q->ids_copy_dst)), "gs_sage_tail_z: ids_copy pointers missing");
+    a.ids_copy_src = q->ids_copy_src; a.ids_copy_dst = q->ids_copy_dst; a.ids_copy_n = q->ids_copy_n;
     hipStream_t st = (hipStream_t)stream;
     CoGatherS J = {};
     int64_t gw = 0;

@@ -43,6 +43,8 @@ struct TailArgs {
     // groups [0, pair_groups) hold 8 PAIRS each -- local rows 0..7 = batch1 rows 8 g .. 8 g + 7, local rows 8..15 = their
     // batch2 partners pairB + 8 g .. -- so that a pair meets in ONE workgroup; groups behind them hold 16 negatives each.
     int32_t pairB, pair_groups;
+    // optional: ids_copy_dst[0 : ids_copy_n) = ids_copy_src[...], written by the launch's z-helper workgroups (gs_tail_desc)
+    const int32_t* ids_copy_src; int32_t* ids_copy_dst; int64_t ids_copy_n;
 };
 
 // Source row of local row r of group g (and whether it exists); rows that do not exist map to a valid row, never stored.
@@ -86,15 +88,38 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Wave-wide sum / max, the result in every lane, on the DPP path: an xor butterfly over 1, 2, 4, 8 inside each row of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror and row_mirror read the SAME partner value as lane ^ 1, ^ 2, ^ 4,
+// ^ 8: after two steps a quad is uniform, after three an 8-lane group is), then the four row results, read with v_readlane, as
+// (r0 + r1) + (r2 + r3).  A fixed order, the same in every lane and every launch (deterministic) -- but not the order of the
+// __shfl_xor loop it replaces (that one started at lane ^ 32): sums differ from it in the last bit.  The __shfl_xor form
+// compiles to six dependent ds_bpermute_b32 (~130 cycles each), and a main workgroup of the fused tail runs twelve reductions
+// in its dependent chain: 1.9 -> 1.3 us for the loss phase, 0.9 -> 0.6 for l2-normalise' (benchmarks/timeline_tail.py).
+template <int CTRL>
+__device__ __forceinline__ float tail_dpp(const float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float tail_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += tail_dpp<0xB1>(v);
+    v += tail_dpp<0x4E>(v);
+    v += tail_dpp<0x141>(v);
+    v += tail_dpp<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float tail_wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, tail_dpp<0xB1>(v));
+    v = fmaxf(v, tail_dpp<0x4E>(v));
+    v = fmaxf(v, tail_dpp<0x141>(v));
+    v = fmaxf(v, tail_dpp<0x140>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 #define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
@@ -118,6 +143,11 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     float* Pz = lds + TAIL_ROWS * ldh;                           // [8 waves][16][64] partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TAIL_HELPER_STAMP(0);
+    if (a.ids_copy_n > 0) {                                      // (see gs_tail_desc.ids_copy_src: a few KB, spread over the helpers)
+        constexpr int HPc = 2 * O / 64;
+        for (int64_t t = ((int64_t)g * HPc + part) * TAIL_THREADS + tid; t < a.ids_copy_n; t += (int64_t)G * HPc * TAIL_THREADS)
+            a.ids_copy_dst[t] = a.ids_copy_src[t];
+    }
     const int j = lane & 15, q = lane >> 4;
     const int n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
     const int col_base = part * 64;

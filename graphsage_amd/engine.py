@@ -132,6 +132,8 @@ class Engine(object):
         self._split_vars = []             # variables with a three-piece bf16 copy, re-cut behind every optimizer launch
         self._defer_sampler = False       # neigh_samplers.fanout: hand the launch to the next optimizer launch instead
         self._deferred_sampler = None
+        self._sampler_to_wgrad = False    # ... to the weight-gradient launch instead (set by the model around a step's launches)
+        self.last_wgrad_sampler = False
 
     # -------------------------------------------------------------------------------- variables
     def add_variable(self, name, init, decay=False, scatter=False):
@@ -400,9 +402,18 @@ class Engine(object):
                 jobs = list(side_jobs or ())
                 arr = (ops._lib.WgradDesc * len(pending))(*pending)
                 jarr = (ops._lib.GatherDesc * max(len(jobs), 1))(*jobs)
-                ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr), len(pending), ctypes.addressof(jarr), len(jobs),
-                         self.stream)
+                rider = self._deferred_sampler if getattr(self, "_sampler_to_wgrad", False) else None
+                if rider is not None:
+                    # a later mini-batch's fan-out sampler rides in THIS launch (the caller has made sure that no problem gathers
+                    # through the id buffer it fills; the library checks)
+                    self._deferred_sampler = None
+                    ops.call("gs_dense_wgrad_grouped_tiled3_sample", ctypes.addressof(arr), len(pending), ctypes.addressof(jarr),
+                             len(jobs), ctypes.addressof(rider), self.stream)
+                else:
+                    ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr), len(pending), ctypes.addressof(jarr), len(jobs),
+                             self.stream)
                 self.last_wgrad_kernel = "tiled3"
+                self.last_wgrad_sampler = rider is not None
                 return
         self.last_wgrad_kernel = "stream/tiled"
         stream, ks_list, reserved = self.stream_gemm, [], {}

@@ -119,6 +119,15 @@ class SampleAndAggregate(object):
         # CUs for 19 / 11 us), not a fixed share -- rider_shares() sets (forward | tail | weight gradients) from the step's gather
         # bytes: 0.40 | 0.20 | 0.40 for the Reddit step (321 MB: 98.3 -> 94.0 us/step), 0.125 | 0.75 | 0.125 for RMAT
         # (79 MB: 67.4 -> 59.9); profiles/r06_tail_halves_ab.txt.  GS_COGATHER_TAIL / GS_COGATHER_SPLIT3 pin fixed shares.
+        # the sampler of the step after the next rides in the weight-gradient launch instead of the optimizer launch (supervised
+        # fused-tail models on the tiled kernels; the tail launch makes the private id copy the weight gradients then read):
+        # the optimizer launch waited 8 us for the sampler's chain against 5.5 us of its own
+        # ... when the step's gather is small: the 512 one-root sampler workgroups hold rider slots of that launch for their
+        # 8 us each, which costs a launch that carries 130 MB of gather more than the optimizer launch gains (same-call A/B:
+        # RMAT, 79 MB per step: 60.0 -> 58.8 us/step; Reddit, 321 MB: 94.7 -> 95.1, GCN 95.9 -> 98.4)
+        self.sampler_in_wgrad = os.environ.get("GS_SAMPLER_IN_WGRAD", "1") != "0"
+        self.sampler_in_wgrad_max_bytes = 150e6
+        self._wgrad_sampler_seen = None
         self.tail_halves = os.environ.get("GS_TAIL_HALVES", "1") != "0"
         self.cogather_auto = ("GS_COGATHER_TAIL" not in os.environ and "GS_COGATHER_SPLIT3" not in os.environ)
         self.tail_free_bytes = 64e6
@@ -891,7 +900,7 @@ class SampleAndAggregate(object):
         law = tuple((s.law, s.max_degree, s.seed) for s in self._samplers())
         return (getattr(self, "fuse_tail", True), getattr(self, "fuse_head", True), getattr(self, "fuse_sampler", True),
                 self.sampler_rides, self.cogather_split, self.cogather_split3, self.cogather_tail, self.tail_split,
-                self.cogather_auto, self.tail_halves, self.tail_free_bytes,
+                self.cogather_auto, self.tail_halves, self.tail_free_bytes, self.sampler_in_wgrad, self.sampler_in_wgrad_max_bytes,
                 self.cogather_z, self.cogather_lp_fwd, self.cogather_lp_tail, self.cogather_lp_neg, e.stream_gemm, e.tiled3_fwd, e.tiled3_wgrad, e.split_pool, e.pool_f16, str(getattr(self, "pipeline", None)),
                 type(self.grad_hook).__name__,
                 id(self.grad_hook), law)

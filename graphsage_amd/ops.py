@@ -515,13 +515,15 @@ def tail_sync_error(sync, n):
 
 def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels, C, sigmoid_loss, means, z, y, logits,
                       preds, dlogits, loss_rows, dz=None, d_h0=None, counters=(), jobs=(), stream=None, sync=None,
-                      split=False, jobs_z=(), gcn=False):
+                      split=False, jobs_z=(), gcn=False, ids_copy=None):
     """gs_sage_tail_fwd_bwd: layer 1 + head (+ their input gradients when dz / d_h0 are given) in ONE launch.
     counters: up to three (device int64 tensor, delta) pairs advanced at the end of the launch.
     sync: int32 device tensor of tail_sync_words(n) words, zero-initialised once and owned by ONE caller / stream
     (kernel-internal hand-over state + an error word, see tail_sync_error); a fresh one is allocated if not given.
     split: two launches instead -- gs_sage_tail_z (lean z-helper kernel carrying the gather jobs `jobs_z`) and then this
-    entry with z_ready (no helpers, no hand-over state) carrying `jobs`; same results bit for bit."""
+    entry with z_ready (no helpers, no hand-over state) carrying `jobs`; same results bit for bit.
+    ids_copy: (src int32 tensor, dst int32 tensor, count) -- the launch's helper workgroups copy the step's node ids into the
+    private buffer the weight gradients gather through (gs_tail_desc.ids_copy_*)."""
     if sync is None and not split:
         import torch
         sync = torch.zeros(tail_sync_words(n, out_dim), dtype=torch.int32, device=h0.buf.device)
@@ -547,6 +549,8 @@ def sage_tail_fwd_bwd(h0, n, s, W_self, W_neigh, out_dim, W_head, b_head, labels
     (q.c0, q.d0), (q.c1, q.d1), (q.c2, q.d2) = cs[:3]
     q.s, q.d_in, q.out_dim, q.C, q.sigmoid, q.train = s, h0.d, out_dim, C, 1 if sigmoid_loss else 0, 1 if train else 0
     q.gcn = 1 if gcn else 0          # GCNAggregator layer 1: W_self / W_neigh are the two column halves of ONE weight matrix
+    if ids_copy is not None:
+        q.ids_copy_src, q.ids_copy_dst, q.ids_copy_n = ptr(ids_copy[0]), ptr(ids_copy[1]), int(ids_copy[2])
     if split:
         jz = list(jobs_z or ())
         jzarr = (_lib.GatherDesc * max(len(jz), 1))(*jz)

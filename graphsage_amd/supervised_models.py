@@ -145,12 +145,21 @@ class SupervisedGraphsage(SampleAndAggregate):
             jobs_z, jobs_m = [], tail_jobs
             if self.tail_split and tail_jobs:
                 jobs_z, jobs_m = ops.split_gather_jobs(tail_jobs, self.cogather_tail_z)
+            ids_copy = None
+            agg0 = self.aggregators[0]
+            agg0.wgrad_ids = None
+            if getattr(e, "_sampler_to_wgrad", False) and self.aggregator_type == "mean" and agg0._saved and agg0._saved[-1][5] is not None \
+                    and agg0._saved[-1][5].ids is not None:
+                src = agg0._saved[-1][5].ids                     # the rows layer 0's self term gathered: [roots | hop-1 ids]
+                dst = e.ws_i32(("wgrad_ids", self.name, n), src.numel())
+                ids_copy = (src, dst, src.numel())
+                agg0.wgrad_ids = dst[:src.numel()]
             ops.sage_tail_fwd_bwd(h0, n, s, W_self1, W_neigh1, O1,
                                   self.node_pred.vars['weights'].value, self.node_pred.vars['bias'].value.buf, labels, C,
                                   self.sigmoid_loss, self._tail_means, self.agg_out, self.outputs1, self.node_preds,
                                   self.preds, self._dlogits, self._loss_rows, dz=self._tail_dz, d_h0=self._tail_dh0,
                                   counters=counters, jobs=jobs_m, stream=e.stream, sync=self._tail_sync,
-                                  split=self.tail_split, jobs_z=jobs_z, gcn=gcn1)
+                                  split=self.tail_split, jobs_z=jobs_z, gcn=gcn1, ids_copy=ids_copy)
         else:
             self.agg_out = out
             self.outputs1 = e.ws_mat("outputs1", n, out.d)
@@ -456,8 +465,17 @@ class SupervisedGraphsage(SampleAndAggregate):
                         if e._deferred_sampler is None:
                             raise ops._lib.GraphsageAmdError("sampler did not take the one-launch fan-out path")
                     self._prefetched[(n, q)] = (batch_q, labels_q, (samples, support, means_q))
-                    compute(p, side_jobs=jobs, epilogue=dict(step=1 if fused else 0, clock=1, cursor=self._cursor,
-                                                             cursor_delta=n))
+                    # (fused-tail models: that sampler leaves with the weight-gradient launch -- Engine.launch_wgrads -- and
+                    #  the tail launch copies this step's ids for the weight gradients, whose id buffer the sampler refills)
+                    e._sampler_to_wgrad = bool(self.sampler_in_wgrad and e._deferred_sampler is not None and self._tail_ok()
+                                               and sum(jb.n * jb.s * jb.d * 4 for jb in jobs) <= self.sampler_in_wgrad_max_bytes)
+                    try:
+                        compute(p, side_jobs=jobs, epilogue=dict(step=1 if fused else 0, clock=1, cursor=self._cursor,
+                                                                 cursor_delta=n))
+                    finally:
+                        if e._sampler_to_wgrad:
+                            self._wgrad_sampler_seen = bool(e.last_wgrad_sampler)   # (tests: did the sampler leave with that launch?)
+                        e._sampler_to_wgrad = False
                     if e._deferred_sampler is not None:
                         raise ops._lib.GraphsageAmdError("deferred sampler was not consumed by the optimizer launch")
                 p = 1 - p

@@ -551,6 +551,13 @@ int gs_flat_reduce_adam_sample(const gs_var_desc* vars_host, int32_t n_vars, flo
                                float eps, float clip, float grad_scale, const uint64_t* step_dev, int32_t step_offset,
                                const float* loss_rows, int64_t loss_n, float loss_scale, float* loss_out, int loss_accumulate,
                                const gs_fanout_desc* sampler_host, const gs_gather_desc* jobs_host, int32_t n_jobs, void* stream);
+/* gs_dense_wgrad_grouped_tiled3 with the fan-out sampler of a LATER mini-batch riding in the launch (ABI 10; sampler_host as gs_sample_fanout_desc takes
+ * it, nullable; per-root id count of every kept hop <= 512, else GS_ENOTSUP).  The sampler is a chain of dependent round trips:
+ * as a rider of the optimizer launch (gs_flat_reduce_adam_sample) it is what that launch waits for, here it ends long before
+ * the contraction.  No problem may gather its rows (a_idx) through the id buffer that sampler fills -- GS_EINVAL; the private
+ * copy gs_tail_desc.ids_copy_* makes is what the step's weight gradients read instead.  Same draws as the standalone launch. */
+int gs_dense_wgrad_grouped_tiled3_sample(const gs_wgrad_desc* descs_host, int32_t n_desc, const gs_gather_desc* jobs_host,
+                                         int32_t n_jobs, const gs_fanout_desc* sampler_host, void* stream);
 
 /* Fused tail of the supervised two-layer GraphSAGE-mean model: layer 1 (MeanAggregator._call on the layer-0 outputs,
  * aggregators.py:43-64, identity act: last layer, models.py:307-310), l2_normalize + Dense head + loss/preds
@@ -596,6 +603,9 @@ typedef struct gs_tail_desc {
                               ONE weight matrix W [d_in, 2*out_dim] passed as W_self = W, W_neigh = W + out_dim (same ld); both
                               column halves of z contract the mean over {neighbors} U {self} = (sum_j h_neigh_j + h_self)/(s+1),
                               which `means` receives; d_h0 rows (self and neighbors) = relu'(h0) * (dz . W^T) / (s + 1) */
+    const int32_t* ids_copy_src; /* optional (ids_copy_n > 0; ABI 10): the launch's helper workgroups also copy ids_copy_n int32 from */
+    int32_t* ids_copy_dst;       /* src to dst (gs_sage_tail_fwd_bwd without z_ready, or gs_sage_tail_z): the private copy of the step's */
+    int64_t ids_copy_n;          /* node ids that the weight gradients gather through when the NEXT-next step's sampler rides in their launch */
 } gs_tail_desc;
 int gs_sage_tail_supported(int32_t d_in, int32_t out_dim, int32_t C);
 

@@ -195,6 +195,29 @@ def test_bench_multistep_graphs_equal_single_steps(dev, agg_type):
     assert np.isfinite(outs[0][0])
 
 
+@pytest.mark.parametrize("agg", ["mean", "gcn"])
+def test_sampler_riding_in_the_weight_gradient_launch_is_bit_identical(dev, agg):
+    """Small-gather steps (RMAT) let the sampler of the step after next ride in the weight-gradient launch instead of the
+    optimizer launch (gs_dense_wgrad_grouped_tiled3_sample): the fused tail launch copies the step's node ids, the weight
+    gradients gather through the copy, the sampler refills the id buffer meanwhile.  Same draws, same steps, bit for bit, as
+    with the sampler in the optimizer launch -- at the benched shapes, 8 steps per hipGraph launch."""
+    outs = []
+    for in_wgrad in (True, False):
+        G, it, model, order = build(agg)
+        model.sampler_in_wgrad = in_wgrad
+        model.sampler_in_wgrad_max_bytes = 1e15                          # (the Reddit-sized gather is above the default bound)
+        model.train_steps_device(B, 33, steps_per_launch=8)
+        loss, preds = model._fetch(B)
+        if model.engine.tiled3_wgrad and model.engine.stream_gemm:
+            assert model.engine.last_wgrad_kernel == "tiled3"
+        outs.append((loss, preds.copy(), model.engine.params.cpu().numpy().copy(), model._wgrad_sampler_seen))
+    if outs[0][3] is not None:
+        assert outs[0][3] and not outs[1][3]                              # the first leg did take the new launch
+    assert outs[0][0] == outs[1][0] and np.isfinite(outs[0][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+
+
 def test_maxpool_two_fp16_pieces_train_like_three_bf16_pieces(dev):
     """The arithmetic claim behind the default pooling MLP (csrc/gs_split16.hip: two fp16 pieces per operand under power-of-two
     row / column scales, h h' + h m' + m h', fp32 accumulation) as a test instead of a debug script: the SAME model -- seed,
