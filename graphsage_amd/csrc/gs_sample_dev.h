@@ -159,31 +159,36 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
     const uint64_t st = a.step + (a.step_dev ? *a.step_dev : 0ull);
     int32_t root = 0;
     if (a.pairs) {
-        if (tid == 0) {
-            const uint64_t c = a.cursor ? *a.cursor : 0ull;
-            if (i < 2 * a.n_pair_roots) {
+        const uint64_t c = a.cursor ? *a.cursor : 0ull;
+        if (i < 2 * a.n_pair_roots) {
+            if (tid == 0) {
                 const int side = i >= a.n_pair_roots ? 1 : 0;
                 const int64_t e = (int64_t)((c + (uint64_t)(i - side * a.n_pair_roots)) % (uint64_t)a.n_pairs);
                 root = a.pairs[2 * e + side];
-            } else {
-                const uint64_t t = (uint64_t)(i - 2 * a.n_pair_roots);
-                const uint64_t stc = a.step + (a.step_dev ? *a.step_dev : 0ull);
-                const uint64_t nkey = gs_mix64(a.neg_seed ^ (stc * 0x9E3779B97F4A7C15ull) ^ (0xFFull << 56));
-                // keyed by the GLOBAL slot: data-parallel ranks draw different negatives
-                const uint32_t r = (uint32_t)(gs_mix64(nkey + t + (uint64_t)a.root_offset) >> 32);
-                int64_t lo = 0, hi = a.n_cdf - 1;  // first index with cdf[idx] > r
-                if (a.guide) {
-                    const uint32_t b = r >> (32 - a.guide_bits);
-                    lo = a.guide[b];
-                    hi = min((int64_t)a.guide[b + 1], a.n_cdf - 1);
-                }
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (a.cdf[mid] > r) hi = mid; else lo = mid + 1;
-                }
-                root = (int32_t)lo;
+                a.ids_all[a.offsets[0] + i] = root;
             }
-            a.ids_all[a.offsets[0] + i] = root;
+        } else if (tid < 64) {
+            // a negative: the first node whose cdf exceeds the draw.  The guide table leaves an interval of a few entries: the
+            // first wave reads it in ONE round trip and counts the entries <= r (the cdf is non-decreasing: lo + that count is
+            // where the binary search ends); longer intervals are halved first.  (One lane bisecting was one dependent round
+            // trip per step: the 20 negatives' workgroups ended 4-5 us after the 1024 pair roots' and with them the launch.)
+            const uint64_t t = (uint64_t)(i - 2 * a.n_pair_roots);
+            const uint64_t nkey = gs_mix64(a.neg_seed ^ (st * 0x9E3779B97F4A7C15ull) ^ (0xFFull << 56));
+            // keyed by the GLOBAL slot: data-parallel ranks draw different negatives
+            const uint32_t r = (uint32_t)(gs_mix64(nkey + t + (uint64_t)a.root_offset) >> 32);
+            int64_t lo = 0, hi = a.n_cdf - 1;  // first index with cdf[idx] > r
+            if (a.guide) {
+                const uint32_t b = r >> (32 - a.guide_bits);
+                lo = a.guide[b];
+                hi = min((int64_t)a.guide[b + 1], a.n_cdf - 1);
+            }
+            while (hi - lo > 64) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (a.cdf[mid] > r) hi = mid; else lo = mid + 1;
+            }
+            const bool le = (int64_t)tid < hi - lo && a.cdf[lo + tid] <= r;
+            root = (int32_t)(lo + (int64_t)__popcll(__ballot(le)));
+            if (tid == 0) a.ids_all[a.offsets[0] + i] = root;
         }
     } else if (a.order) {
         const uint64_t c = a.cursor ? *a.cursor : 0ull;

@@ -335,7 +335,7 @@ class Engine(object):
                 return None
             probs.append((tiles, n, cap))
             reserved[id(v)] = reserved.get(id(v), 0) + (n + 1023) // 1024    # (what the later problems of the variable can count on)
-        ks = tiled3_slab_policy(probs, self._tiled3_wg_slots)
+        ks = tiled3_slab_policy(probs, self._tiled3_wg_slots, int(os.environ.get("GS_T3_MAX_SLABS", TILED3_MAX_SLABS)))
         used = {}
         for (v, *_), k in zip(self._pending, ks):               # several problems of one variable share its arena
             used[id(v)] = used.get(id(v), 0) + k
@@ -568,7 +568,10 @@ class Engine(object):
 _default_engine = None
 
 
-def tiled3_slab_policy(probs, slots):
+TILED3_MAX_SLABS = 24
+
+
+def tiled3_slab_policy(probs, slots, max_slabs=TILED3_MAX_SLABS):
     """Split-K slab counts for ONE launch of gs_dense_wgrad_grouped_tiled3.  probs: (tiles, reduction rows, slab capacity) per
     problem; slots: workgroups of one round (one per CU).  A workgroup holds its CU for its slice's 32-row stages, so the launch is
     cut into ONE round: the smallest stage count L per workgroup with sum(tiles x ceil(stages / L)) <= slots -- the Reddit step: 11
@@ -579,8 +582,10 @@ def tiled3_slab_policy(probs, slots):
     kmin = [(n + 1023) // 1024 for _, n, _ in probs]
     total = sum(t * s_ for (t, _, _), s_ in zip(probs, st))
     L = max(4, (total + slots - 1) // slots)
+    # (at most 24 slabs where the slice limit allows: the optimizer launch sums a variable's slabs 24 loads at a time, a 25th is
+    #  a second memory round trip of that launch -- RMAT's two 256 x 128 problems took 26)
     while True:
-        ks = [int(max(km, min(cap, (s_ + L - 1) // L))) for (t, _, cap), s_, km in zip(probs, st, kmin)]
+        ks = [int(max(km, min(cap, max_slabs, (s_ + L - 1) // L))) for (t, _, cap), s_, km in zip(probs, st, kmin)]
         if sum(t * k for (t, _, _), k in zip(probs, ks)) <= slots or L >= 32:
             return ks
         L += 1

@@ -301,3 +301,6 @@ def test_tiled3_slab_policy_cuts_a_pass_into_one_round():
     assert tiled3_slab_policy([(10, 5632, 6), (10, 5632, 64)], 256) [0] == 6
     # tiny problems: one slice each
     assert tiled3_slab_policy([(1, 33, 64), (1, 7, 64)], 256) == [1, 1]
+    # the RMAT step (F = 256: 4 tiles per layer-0 problem): at most 24 slabs -- what the optimizer launch sums in ONE round trip
+    ks = tiled3_slab_policy([(4, 5632, 64), (4, 5632, 64), (4, 512, 64), (4, 512, 64), (2, 512, 64), (1, 512, 64)], 256)
+    assert max(ks) <= 24 and ks[0] == ks[1] == 24
