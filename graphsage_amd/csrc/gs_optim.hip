@@ -164,6 +164,9 @@ extern "C" int gs_sumsq_scaled(const float* x, int64_t count, float scale, float
 // ---------------------------------------------------------------------------------------------------
 // Flat gradient finalisation (+ optional fused clip/Adam): one launch over the whole parameter buffer.
 #define GS_MAX_VARS 24
+#ifndef GS_OPT_SLAB_BATCH
+#define GS_OPT_SLAB_BATCH 24          // slab loads in flight per thread (engine.TILED3_MAX_SLABS: a variable's slabs are one round trip)
+#endif
 __device__ __forceinline__ int64_t gs_readfirstlane_i64(const int64_t x) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
     return (int64_t)(((uint64_t)hi << 32) | lo);
@@ -285,12 +288,12 @@ __global__ __launch_bounds__(GS_OPT_THREADS) void flat_reduce_adam_kernel(const 
                 const int ns = d.n_slabs;
                 // 24 slab loads in flight per thread (the 22 slabs of a Reddit step are ONE memory round trip; with 4 in flight
                 // they were 6-8); summation order stays z = 0, 1, ...
-                for (int z0 = 0; z0 < ns; z0 += 24) {
-                    f32x4 sv[24];
+                for (int z0 = 0; z0 < ns; z0 += GS_OPT_SLAB_BATCH) {
+                    f32x4 sv[GS_OPT_SLAB_BATCH];
 #pragma unroll
-                    for (int u = 0; u < 24; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
+                    for (int u = 0; u < GS_OPT_SLAB_BATCH; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sp + (int64_t)min(z0 + u, ns - 1) * sz);
 #pragma unroll
-                    for (int u = 0; u < 24; ++u)
+                    for (int u = 0; u < GS_OPT_SLAB_BATCH; ++u)
                         if (z0 + u < ns) g += sv[u];
                 }
                 if (d.clear) *reinterpret_cast<f32x4*>(sp) = f32x4{0.f, 0.f, 0.f, 0.f};   // atomic accumulator: consume

@@ -145,16 +145,25 @@ struct FanoutArgs {
 // One workgroup (any size) per root `i`; lvl = two LDS fan-out buffers of CAP ints each, law_cols = LDS for the calls' columns
 // (both handed in by the caller: a launch that carries the sampler as a rider gives it a piece of ITS LDS allocation).
 #define GS_FANOUT_LDS_INTS(CAP) (2 * (CAP) + GS_MAX_HOPS * GS_LAW_COLS)
-template <int CAP>
+// PER_WAVE: one WAVE per root instead of one workgroup (a launch that carries the sampler as a rider packs four roots into a
+// rider workgroup's slot: the chain is as long, the slots it holds are a quarter); lvl / law_cols are then the wave's own.
+template <int CAP, bool PER_WAVE = false>
 __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const int64_t i, int32_t (*lvl)[CAP],
                                                    int32_t (*law_cols)[GS_LAW_COLS]) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = PER_WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nthr = PER_WAVE ? 64 : (int)blockDim.x;
     // workgroup barrier that orders LDS only: what crosses it here (lvl, law_cols) lives in LDS, and __syncthreads() would also
-    // drain the global loads / stores in flight -- a round trip per barrier in a chain that is nothing but round trips
+    // drain the global loads / stores in flight -- a round trip per barrier in a chain that is nothing but round trips.  (One
+    // wave: its LDS operations execute in order; only the compiler has to keep them there.)
     auto lds_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        if (PER_WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
     };
     const uint64_t st = a.step + (a.step_dev ? *a.step_dev : 0ull);
     int32_t root = 0;
@@ -234,27 +243,44 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
         int32_t* next = lvl[(h + 1) & 1];
         const bool keep = (h + 1 < a.n_hops);  // the last hop is only written to global memory
         const int32_t* cols = (a.law.law == GS_LAW_REFERENCE && s <= GS_LAW_COLS) ? law_cols[h] : nullptr;
-        for (int64_t t = tid; t < count; t += nthr) {
-            const int64_t pl = t / s;  // parent slot in the previous level
-            const uint32_t j = (uint32_t)(t - pl * s);
-            const int32_t id = prev[pl];
-            int32_t pick = a.pad_id;
-            if (a.table) {
-                if (id >= 0 && (int64_t)id <= a.n_nodes) {             // row n_nodes = the all-pad row
-                    const uint32_t M = (uint32_t)a.law.max_degree;
-                    const uint32_t c = cols ? (uint32_t)cols[j] : gs_call_column(key, j, M);
-                    pick = a.table[(int64_t)id * M + c];
+        // U slots per thread and pass: their lookups are requested together, the stores follow (one slot at a time, the store of
+        // slot t stood between the lookups of t and t + nthr: a wave walking a 250-slot hop paid four round trips for one)
+        constexpr int U = PER_WAVE ? 4 : 1;
+        for (int64_t t0 = tid; t0 < count; t0 += (int64_t)U * nthr) {
+            int32_t picks[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t t = t0 + (int64_t)u * nthr;
+                int32_t pick = a.pad_id;
+                if (t < count) {
+                    const int64_t pl = t / s;  // parent slot in the previous level
+                    const uint32_t j = (uint32_t)(t - pl * s);
+                    const int32_t id = prev[pl];
+                    if (a.table) {
+                        if (id >= 0 && (int64_t)id <= a.n_nodes) {             // row n_nodes = the all-pad row
+                            const uint32_t M = (uint32_t)a.law.max_degree;
+                            const uint32_t c = cols ? (uint32_t)cols[j] : gs_call_column(key, j, M);
+                            pick = a.table[(int64_t)id * M + c];
+                        }
+                    } else if (id >= 0 && (int64_t)id < a.n_nodes) {
+                        const int64_t b = a.rowptr[id];
+                        const int32_t deg = (int32_t)(a.rowptr[id + 1] - b);
+                        if (deg > 0) {
+                            const int64_t grow = (a.root_offset + i) * count_prev + pl;  // global row at this hop
+                            pick = a.col[b + (int64_t)gs_draw(a.law, a.seed, key, grow, j, s, id, (uint32_t)deg, cols)];
+                        }
+                    }
                 }
-            } else if (id >= 0 && (int64_t)id < a.n_nodes) {
-                const int64_t b = a.rowptr[id];
-                const int32_t deg = (int32_t)(a.rowptr[id + 1] - b);
-                if (deg > 0) {
-                    const int64_t grow = (a.root_offset + i) * count_prev + pl;  // global row at this hop
-                    pick = a.col[b + (int64_t)gs_draw(a.law, a.seed, key, grow, j, s, id, (uint32_t)deg, cols)];
+                picks[u] = pick;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t t = t0 + (int64_t)u * nthr;
+                if (t < count) {
+                    if (keep) next[t] = picks[u];
+                    a.ids_all[a.offsets[h + 1] + i * count + t] = picks[u];
                 }
             }
-            if (keep) next[t] = pick;
-            a.ids_all[a.offsets[h + 1] + i * count + t] = pick;
         }
         lds_sync();
         count_prev = count;

@@ -1044,13 +1044,18 @@ __global__ __launch_bounds__(256) void wgrad_tiled3_kernel(const Wg3Args G, cons
         // dependent round trips of almost no work: as a rider of the optimizer launch it was what that launch waited for -- 8 us
         // against the optimizer's own 5.5 -- here it ends long before the contraction does); then gather+mean waves.
         const int64_t r = (int64_t)blockIdx.x - G.n_items;
-        if (r < F.B) {
-            int32_t* ints = reinterpret_cast<int32_t*>(smem);      // (a rider's share of the launch's LDS allocation)
-            sample_fanout_root<GS_FANOUT_LDS_SMALL>(F, r, reinterpret_cast<int32_t (*)[GS_FANOUT_LDS_SMALL]>(ints),
-                                                    reinterpret_cast<int32_t (*)[GS_LAW_COLS]>(ints + 2 * GS_FANOUT_LDS_SMALL));
+        const int64_t sblocks = (F.B + 3) >> 2;                     // one root per WAVE: four per rider slot
+        if (r < sblocks) {
+            const int64_t root = 4 * r + wave;
+            if (root < F.B) {
+                int32_t* ints = reinterpret_cast<int32_t*>(smem) + wave * GS_FANOUT_LDS_INTS(GS_FANOUT_LDS_SMALL);   // (the wave's
+                sample_fanout_root<GS_FANOUT_LDS_SMALL, true>(F, root,                                              //  share of the launch's LDS)
+                                                              reinterpret_cast<int32_t (*)[GS_FANOUT_LDS_SMALL]>(ints),
+                                                              reinterpret_cast<int32_t (*)[GS_LAW_COLS]>(ints + 2 * GS_FANOUT_LDS_SMALL));
+            }
             return;
         }
-        run_gather_item<T3_RIDER_U>(J, (r - F.B) * 4 + wave, lane);
+        run_gather_item<T3_RIDER_U>(J, (r - sblocks) * 4 + wave, lane);
         return;
     }
     const int l31 = lane & 31, lh = lane >> 5;
@@ -1304,10 +1309,10 @@ static int wgrad_grouped_tiled3_impl(const gs_wgrad_desc* descs_host, int32_t n_
     if (rc != GS_OK) return rc;
     FanoutArgs F = {};
     if (sampler) F = *sampler;
-    const int64_t blocks = items + F.B + gs_ceil_div(waves, 4);
+    const int64_t blocks = items + gs_ceil_div(F.B, 4) + gs_ceil_div(waves, 4);
     GS_REQUIRE(blocks < (1ll << 31), "gs_dense_wgrad_grouped_tiled3: grid too large");
     const size_t lds = W3_NS * (W3_KS * 64 * 4 + W3_KS * 128 * 4) + W3_MAXROWS * 4;
-    static_assert(GS_FANOUT_LDS_INTS(GS_FANOUT_LDS_SMALL) * 4 <= W3_NS * (W3_KS * 64 * 4 + W3_KS * 128 * 4), "sampler rider LDS");
+    static_assert(4 * GS_FANOUT_LDS_INTS(GS_FANOUT_LDS_SMALL) * 4 <= W3_NS * (W3_KS * 64 * 4 + W3_KS * 128 * 4), "sampler rider LDS");
     GS_LDS_ATTR(lds, wgrad_tiled3_kernel);
     hipLaunchKernelGGL(wgrad_tiled3_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, G, F, J);
     GS_LAUNCH_CHECK("wgrad_tiled3_kernel");

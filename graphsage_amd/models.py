@@ -122,11 +122,12 @@ class SampleAndAggregate(object):
         # the sampler of the step after the next rides in the weight-gradient launch instead of the optimizer launch (supervised
         # fused-tail models on the tiled kernels; the tail launch makes the private id copy the weight gradients then read):
         # the optimizer launch waited 8 us for the sampler's chain against 5.5 us of its own
-        # ... when the step's gather is small: the 512 one-root sampler workgroups hold rider slots of that launch for their
-        # 8 us each, which costs a launch that carries 130 MB of gather more than the optimizer launch gains (same-call A/B:
-        # RMAT, 79 MB per step: 60.0 -> 58.8 us/step; Reddit, 321 MB: 94.7 -> 95.1, GCN 95.9 -> 98.4)
+        # One root per WAVE there (128 rider slots for 512 roots; with one root per workgroup the sampler held 512 slots of that
+        # launch for 8 us each and cost a Reddit-sized step more than the optimizer launch gained: 94.7 -> 95.1 us/step).  Same-call
+        # A/B with the per-wave form (profiles/r06_tail_halves_ab.txt): Reddit 95.0 -> 92.0, GCN 96.1 -> 95.8, RMAT 59.4 -> 57.8.
+        # GS_SAMPLER_IN_WGRAD_MAX_MB bounds the step's gather bytes for which it is taken (diagnostics; default: always).
         self.sampler_in_wgrad = os.environ.get("GS_SAMPLER_IN_WGRAD", "1") != "0"
-        self.sampler_in_wgrad_max_bytes = 150e6
+        self.sampler_in_wgrad_max_bytes = float(os.environ.get("GS_SAMPLER_IN_WGRAD_MAX_MB", 1e9)) * 1e6
         self._wgrad_sampler_seen = None
         self.tail_halves = os.environ.get("GS_TAIL_HALVES", "1") != "0"
         self.cogather_auto = ("GS_COGATHER_TAIL" not in os.environ and "GS_COGATHER_SPLIT3" not in os.environ)
