@@ -160,9 +160,13 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         } else {
+#ifdef GS_SAMPLER_FULL_BARRIER    // diagnostics
+            __syncthreads();
+#else
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
         }
     };
     const uint64_t st = a.step + (a.step_dev ? *a.step_dev : 0ull);
@@ -221,14 +225,11 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
         }
     }
     if (a.order && !a.pairs && tid == 0) a.ids_all[a.offsets[0] + i] = root;
-    // The root's label row is only REQUESTED here (one element per thread when the row fits the workgroup) and stored behind
-    // the hops: storing it at once put its round trip in front of the first hop's -- the chain this workgroup is, and as a rider
-    // of the optimizer launch the thing that launch waits for (benchmarks/timeline_optim.py: riders 7-9 us, optimizer 5.3).
-    const int Cp_lab = (a.C + 3) & ~3;
-    const bool lab_late = a.order && !a.pairs && a.label_table && Cp_lab <= nthr;
-    float lab_v = 0.f;
-    if (lab_late && tid < a.C) lab_v = a.label_table[(int64_t)root * a.ldt + tid];
-    if (a.order && !a.pairs && a.label_table && !lab_late) {
+    // the root's label row (stored at once: a form that only requested it here and stored it behind the hops measured a 0.3 us
+    // shorter chain, and 200-step training runs with it differed from each other in 1-5 % of the runs -- never without it,
+    // profiles/r06_determinism.txt; the mechanism was not found, the form is gone)
+    if (a.order && !a.pairs && a.label_table) {
+        const int Cp_lab = (a.C + 3) & ~3;
         for (int k = tid; k < Cp_lab; k += nthr)
             a.labels_out[i * a.ldo + k] = k < a.C ? a.label_table[(int64_t)root * a.ldt + k] : 0.f;
     }
@@ -285,7 +286,6 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
         lds_sync();
         count_prev = count;
     }
-    if (lab_late && tid < Cp_lab) a.labels_out[i * a.ldo + tid] = lab_v;
 }
 
 // host: validate (law, max_degree) against the fan-outs of the calls it will serve

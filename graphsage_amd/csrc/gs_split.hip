@@ -1044,8 +1044,13 @@ __global__ __launch_bounds__(256) void wgrad_tiled3_kernel(const Wg3Args G, cons
         // dependent round trips of almost no work: as a rider of the optimizer launch it was what that launch waited for -- 8 us
         // against the optimizer's own 5.5 -- here it ends long before the contraction does); then gather+mean waves.
         const int64_t r = (int64_t)blockIdx.x - G.n_items;
+#ifdef W3_NO_SAMPLER              // diagnostics switch
+        const int64_t sblocks = 0;
+        if (false) {
+#else
         const int64_t sblocks = (F.B + 3) >> 2;                     // one root per WAVE: four per rider slot
         if (r < sblocks) {
+#endif
             const int64_t root = 4 * r + wave;
             if (root < F.B) {
                 int32_t* ints = reinterpret_cast<int32_t*>(smem) + wave * GS_FANOUT_LDS_INTS(GS_FANOUT_LDS_SMALL);   // (the wave's

@@ -99,6 +99,19 @@ template <int CTRL>
 __device__ __forceinline__ float tail_dpp(const float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+#ifdef TAIL_REDUCE_SHFL           // diagnostics: the ds_bpermute butterfly in the SAME order (1, 2, 4, 8, then the rows)
+__device__ __forceinline__ float tail_wave_sum(float v) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+    const float r0 = __shfl(v, 0, 64), r1 = __shfl(v, 16, 64), r2 = __shfl(v, 32, 64), r3 = __shfl(v, 48, 64);
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float tail_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+#else
 __device__ __forceinline__ float tail_wave_sum(float v) {
     v += tail_dpp<0xB1>(v);
     v += tail_dpp<0x4E>(v);
@@ -121,6 +134,7 @@ __device__ __forceinline__ float tail_wave_max(float v) {
     const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+#endif
 
 #define TAIL_NB 11   // neighbor rows per batch row held in registers (s <= TAIL_NB)
 #ifndef TAIL_HELPER_STAMP
@@ -143,11 +157,13 @@ __device__ __forceinline__ void tail_z_helper(const TailArgs& a, const int g, co
     float* Pz = lds + TAIL_ROWS * ldh;                           // [8 waves][16][64] partial tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TAIL_HELPER_STAMP(0);
+#ifndef TAIL_NO_IDS_COPY          // (diagnostics switch)
     if (a.ids_copy_n > 0) {                                      // (see gs_tail_desc.ids_copy_src: a few KB, spread over the helpers)
         constexpr int HPc = 2 * O / 64;
         for (int64_t t = ((int64_t)g * HPc + part) * TAIL_THREADS + tid; t < a.ids_copy_n; t += (int64_t)G * HPc * TAIL_THREADS)
             a.ids_copy_dst[t] = a.ids_copy_src[t];
     }
+#endif
     const int j = lane & 15, q = lane >> 4;
     const int n = (int)a.n, s = a.s, ldh0 = (int)a.ldh;
     const int col_base = part * 64;

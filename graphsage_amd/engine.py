@@ -106,6 +106,7 @@ class Engine(object):
         # the pooling MLP on the step's distinct ids as a split-MFMA contraction (gs_split16.hip / gs_split.hip); False = fp32 MFMA
         self.split_pool = True
         # split-K policy of the weight gradients (measured sweeps: DESIGN.md section 4 / profiles/r02..r05)
+        self.tiled3_max_slabs = TILED3_MAX_SLABS   # (sweep: RMAT 57.6 us/step at 24, 59.2 at 20, 60.6 at 16, 64.0 at 12; Reddit 94.6 at 11, 99.1 at 8)
         self._wgrad_blocks = 768          # tiled kernel: ~768 (tile x slice) workgroups per problem
         self._wgrad_max_slabs = 32
         self._wgrad_big_n = 16384         # reductions this long take their own 128 x 128-tile launch
@@ -335,7 +336,7 @@ class Engine(object):
                 return None
             probs.append((tiles, n, cap))
             reserved[id(v)] = reserved.get(id(v), 0) + (n + 1023) // 1024    # (what the later problems of the variable can count on)
-        ks = tiled3_slab_policy(probs, self._tiled3_wg_slots, int(os.environ.get("GS_T3_MAX_SLABS", TILED3_MAX_SLABS)))
+        ks = tiled3_slab_policy(probs, self._tiled3_wg_slots, self.tiled3_max_slabs)
         used = {}
         for (v, *_), k in zip(self._pending, ks):               # several problems of one variable share its arena
             used[id(v)] = used.get(id(v), 0) + k

@@ -472,3 +472,80 @@ def test_split_pieces_f16_reconstruct_to_one_rounding(dev):
     assert np.array_equal(ce, e)
     recw = (body[:, 0] + body[:, 1]).transpose(0, 2, 1).reshape(KP, N)[:K] * np.exp2(-ce.astype(np.float64))[None, :]
     assert np.all(np.abs(recw - W.astype(np.float64)) <= tol.T * 1.0001)
+
+
+def test_sampler_riding_in_the_tiled3_weight_gradient_launch_draws_what_the_standalone_launch_draws(dev):
+    """gs_dense_wgrad_grouped_tiled3_sample under stress: the fan-out sampler (reference law on the materialised table, batch +
+    label staging, one root per WAVE of a rider workgroup) riding behind the Reddit step's two layer-0 problems and a gather
+    job, 400 launches with a moving cursor / clock while a second stream keeps the chip busy.  Every launch: ids and labels
+    bit-equal to gs_sample_fanout_desc at the same cursor / clock, slabs bit-equal to the launch without a rider; a problem
+    that gathers through the id buffer the sampler fills is refused."""
+    import ctypes
+    from graphsage_amd import _lib
+    rng = np.random.default_rng(5)
+    N, B, fans, C, M = 30000, 512, (10, 25), 41, 128
+    deg = rng.integers(1, 200, size=N)
+    rowptr_np = np.zeros(N + 1, np.int64)
+    rowptr_np[1:] = np.cumsum(deg)
+    col_np = rng.integers(0, N, size=int(rowptr_np[-1])).astype(np.int32)
+    rowptr, col = torch.from_numpy(rowptr_np).to(dev), torch.from_numpy(col_np).to(dev)
+    table = ops.build_padded_table(rowptr, col, N, N, M, 77)
+    order = torch.from_numpy(rng.permutation(N).astype(np.int32)).to(dev)
+    labels = Mat.from_numpy(rng.normal(size=(N + 1, C)).astype(np.float32), dev)
+    offsets = [0, B, B + B * fans[0], B + B * fans[0] + B * fans[0] * fans[1]]
+    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+    clock = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def desc(ids, lab):
+        return ops.fanout_desc(rowptr, col, N, N, list(fans), offsets, ids, B, 123, step_dev=clock, order=order, cursor_dev=cursor,
+                               label_table=labels, labels_out=lab, law=1,                     # GS_LAW_REFERENCE
+                               max_degree=M, padded_table=table)
+
+    ids_a, ids_b = (torch.full((offsets[-1],), -7, dtype=torch.int32, device=dev) for _ in range(2))
+    lab_a, lab_b = Mat.zeros(B, C, dev), Mat.zeros(B, C, dev)
+    qa, qb = desc(ids_a, lab_a), desc(ids_b, lab_b)
+    # the Reddit step's layer-0 problems (gathered self term through a PRIVATE id vector, dense neighbor term) + a gather job
+    n, d, out = 5632, 602, 128
+    X = Mat.from_numpy(rng.normal(size=(N + 1, d)).astype(np.float32), dev, 32)
+    means = Mat.from_numpy(rng.normal(size=(n, d)).astype(np.float32), dev, 32)
+    dZ = Mat.from_numpy((rng.normal(size=(n, 2 * out)) * 0.1).astype(np.float32), dev, 32)
+    aidx = torch.from_numpy(rng.integers(0, N, size=n).astype(np.int32)).to(dev)
+    gidx = torch.from_numpy(rng.integers(0, N, size=2048 * 25).astype(np.int32)).to(dev)
+    gout = Mat.zeros(2048, d, dev, 32)
+    jobs = (_lib.GatherDesc * 1)(ops.gather_job(X, gidx, 2048, 25, gout))
+
+    def problems():
+        q0, s0, _ = _wgrad_desc(X, aidx, dZ, 0, out, n, d, 11, dev)
+        q1, s1, _ = _wgrad_desc(means, None, dZ, out, out, n, d, 11, dev)
+        return (_lib.WgradDesc * 2)(q0, q1), (s0, s1)
+
+    arr_ref, slabs_ref = problems()
+    ops.call("gs_dense_wgrad_grouped_tiled3", ctypes.addressof(arr_ref), 2, ctypes.addressof(jobs), 1, ops.current_stream())
+    torch.cuda.synchronize()
+    want_slabs = [s.clone() for s in slabs_ref]
+    side = torch.cuda.Stream()
+    arr, slabs = problems()
+    for it in range(400):
+        cursor.fill_(int(rng.integers(0, N)))
+        clock.fill_(it)
+        for s in slabs:
+            s.fill_(float("nan"))
+        ids_b.fill_(-7)
+        torch.cuda.synchronize()
+        if it % 3 == 0:
+            with torch.cuda.stream(side):                                    # concurrent work on another stream
+                ops.gather_mean_fwd(X, gidx, 2048, 25, out=Mat.zeros(2048, d, dev, 32), stream=side.cuda_stream)
+        ops.sample_fanout_desc(qa)
+        ops.call("gs_dense_wgrad_grouped_tiled3_sample", ctypes.addressof(arr), 2, ctypes.addressof(jobs), 1, ctypes.addressof(qb),
+                 ops.current_stream())
+        torch.cuda.synchronize()
+        assert torch.equal(ids_a, ids_b), "launch %d: ids differ at %d slots" % (it, int((ids_a != ids_b).sum()))
+        assert torch.equal(lab_a.buf, lab_b.buf), "launch %d: labels differ" % it
+        for got, want in zip(slabs, want_slabs):
+            assert torch.equal(got, want), "launch %d: slabs differ" % it
+    # a gathered problem whose row ids ARE the sampler's id buffer is refused
+    qbad, _, _ = _wgrad_desc(X, ids_b[:n], dZ, 0, out, n, d, 11, dev)
+    bad = (_lib.WgradDesc * 1)(qbad)
+    with pytest.raises(_lib.GraphsageAmdError):
+        ops.call("gs_dense_wgrad_grouped_tiled3_sample", ctypes.addressof(bad), 1, ctypes.addressof(jobs), 1, ctypes.addressof(qb),
+                 ops.current_stream())
