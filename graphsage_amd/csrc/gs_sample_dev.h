@@ -228,10 +228,17 @@ __device__ __forceinline__ void sample_fanout_root(const FanoutArgs& a, const in
     // the root's label row (stored at once: a form that only requested it here and stored it behind the hops measured a 0.3 us
     // shorter chain, and 200-step training runs with it differed from each other in 1-5 % of the runs -- never without it,
     // profiles/r06_determinism.txt; the mechanism was not found, the form is gone)
+    // A workgroup gives the row to its LAST wave (when it fits one): that wave's load -> store round trip then runs beside the
+    // first hop's, which only occupies the first wave, instead of in front of it.
     if (a.order && !a.pairs && a.label_table) {
         const int Cp_lab = (a.C + 3) & ~3;
-        for (int k = tid; k < Cp_lab; k += nthr)
-            a.labels_out[i * a.ldo + k] = k < a.C ? a.label_table[(int64_t)root * a.ldt + k] : 0.f;
+        if (!PER_WAVE && nthr >= 128 && Cp_lab <= 64) {
+            const int k = tid - (nthr - 64);
+            if (k >= 0 && k < Cp_lab) a.labels_out[i * a.ldo + k] = k < a.C ? a.label_table[(int64_t)root * a.ldt + k] : 0.f;
+        } else {
+            for (int k = tid; k < Cp_lab; k += nthr)
+                a.labels_out[i * a.ldo + k] = k < a.C ? a.label_table[(int64_t)root * a.ldt + k] : 0.f;
+        }
     }
     if (tid == 0) lvl[0][0] = root;
     lds_sync();
