@@ -218,6 +218,23 @@ def test_sampler_riding_in_the_weight_gradient_launch_is_bit_identical(dev, agg)
     assert np.array_equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("agg", ["mean", "gcn"])
+def test_training_runs_repeat_bit_for_bit(dev, agg):
+    """Run-to-run determinism of the schedule bench.py times (8 steps per hipGraph launch, riders in every launch, the in-kernel
+    hand-over of the fused tail with two main workgroups per group): the same model trained twice from the same seeds ends with
+    the same bits after 264 steps.  (The statistical form of this check -- hundreds of processes, millions of steps -- is
+    benchmarks/determinism.sh / race_hunt.py; what it found is in profiles/r06_determinism.txt.)"""
+    outs = []
+    for _ in range(2):
+        G, it, model, order = build(agg)
+        model.train_steps_device(B, 264, steps_per_launch=8)
+        loss, preds = model._fetch(B)
+        outs.append((loss, preds.copy(), model.engine.params.cpu().numpy().copy()))
+    assert outs[0][0] == outs[1][0] and np.isfinite(outs[0][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+
+
 def test_maxpool_two_fp16_pieces_train_like_three_bf16_pieces(dev):
     """The arithmetic claim behind the default pooling MLP (csrc/gs_split16.hip: two fp16 pieces per operand under power-of-two
     row / column scales, h h' + h m' + m h', fp32 accumulation) as a test instead of a debug script: the SAME model -- seed,
